@@ -1,0 +1,139 @@
+"""Import the REAL reference hot-path modules under stubs (build container only).
+
+Test infrastructure.  ``/root/reference`` exists only in the build container,
+so this module is used exclusively by ``tests/golden/make_golden.py`` (to emit
+golden vectors from the reference itself) and by the CPU-only test
+``tests/test_oracle_vs_reference.py`` (skipped when the reference is absent).
+Nothing here travels to the GPU box in a usable form and nothing in the
+product path imports it.
+
+Recipe: ``fme`` cannot be imported normally here
+(python 3.10 < 3.11, torch_harmonics / dacite / tensorly / tltorch / xarray
+missing), so we (1) alias ``typing.Self``; (2) register empty namespace
+packages whose ``__path__`` points into the reference tree so no package
+``__init__`` runs; (3) stub the missing third-party modules - the
+torch-harmonics quadrature/Legendre entry points are served by this oracle's
+restatement, which the reference's own goldens then validate; (4) import the
+real ``fme.sht_fix`` and ``fme.ace.models.modulus.sfnonet``.
+"""
+
+import importlib
+import os
+import sys
+import types
+import typing
+
+REF = os.environ.get("ACE_REFERENCE_ROOT", "/root/reference")
+
+
+def available() -> bool:
+    return os.path.isdir(os.path.join(REF, "fme"))
+
+
+def _ns(name, path=None):
+    m = types.ModuleType(name)
+    if path is not None:
+        m.__path__ = [path]
+    sys.modules[name] = m
+    return m
+
+
+_loaded = None
+
+
+def load():
+    """Returns a namespace with the reference classes (RealSHT, InverseRealSHT, SFNO)."""
+    global _loaded
+    if _loaded is not None:
+        return _loaded
+    if not available():
+        raise RuntimeError("reference tree not present")
+    import numpy as np
+    import torch
+    import typing_extensions
+
+    if not hasattr(typing, "Self"):
+        typing.Self = typing_extensions.Self
+
+    from . import legendre as _leg
+    from . import quadrature as _quad
+
+    # (2) skeleton packages
+    for pkg in [
+        "fme", "fme.core", "fme.core.models", "fme.core.distributed", "fme.core.benchmark",
+        "fme.ace", "fme.ace.models", "fme.ace.models.modulus",
+    ]:
+        _ns(pkg, os.path.join(REF, *pkg.split(".")))
+
+    # (3) third-party stubs
+    th = _ns("torch_harmonics", "/nonexistent")
+    thq = _ns("torch_harmonics.quadrature")
+    thl = _ns("torch_harmonics.legendre")
+    thd = _ns("torch_harmonics.distributed")
+
+    def _as_t(f):
+        def g(n, a=-1.0, b=1.0):
+            x, w = f(n, a, b)
+            return torch.as_tensor(np.ascontiguousarray(x)), torch.as_tensor(np.ascontiguousarray(w))
+        return g
+
+    thq.legendre_gauss_weights = _as_t(_quad.legendre_gauss_weights)
+    thq.lobatto_weights = _as_t(_quad.lobatto_weights)
+    thq.clenshaw_curtiss_weights = _as_t(_quad.clenshaw_curtiss_weights)
+
+    def _precompute_legpoly(mmax, lmax, t, norm="ortho", inverse=False, csphase=True):
+        return _leg.precompute_legpoly(mmax, lmax, np.asarray(t), norm=norm, inverse=inverse, csphase=csphase)
+
+    thl._precompute_legpoly = _precompute_legpoly
+
+    class _Never(torch.nn.Module):
+        pass
+
+    thd.DistributedRealSHT = _Never
+    thd.DistributedInverseRealSHT = type("DistributedInverseRealSHT", (_Never,), {})
+    th.quadrature, th.legendre, th.distributed = thq, thl, thd
+    th.RealFFT2 = type("RealFFT2", (_Never,), {})
+    th.InverseRealFFT2 = type("InverseRealFFT2", (_Never,), {})
+
+    tl = _ns("tensorly")
+    tl.set_backend = lambda *_a, **_k: None
+    tl.ndim = lambda t: t.ndim
+    tl.einsum = torch.einsum
+    _ns("tltorch", "/nonexistent")
+    _ns("tltorch.factorized_tensors", "/nonexistent")
+    core = _ns("tltorch.factorized_tensors.core")
+    core.FactorizedTensor = type("FactorizedTensor", (), {})
+
+    bench = _ns("fme.core.benchmark.benchmark")
+
+    class BenchmarkABC:
+        pass
+
+    bench.BenchmarkABC = BenchmarkABC
+    bench.register_benchmark = lambda name: (lambda cls: cls)
+
+    timer = _ns("fme.core.benchmark.timer")
+    timer.Timer = type("Timer", (), {})
+    timer.NullTimer = type("NullTimer", (), {})
+    timer.CUDATimer = type("CUDATimer", (), {})
+
+    dev = _ns("fme.core.device")
+    dev.get_device = lambda: torch.device("cpu")
+    dev.using_gpu = lambda: False
+
+    ty = _ns("fme.core.typing_")
+    ty.TensorDict = dict
+    ty.TensorMapping = typing.Mapping
+
+    # (4) the real reference modules
+    sht_fix = importlib.import_module("fme.sht_fix")
+    sfnonet = importlib.import_module("fme.ace.models.modulus.sfnonet")
+
+    ns = types.SimpleNamespace(
+        RealSHT=sht_fix.RealSHT,
+        InverseRealSHT=sht_fix.InverseRealSHT,
+        SFNO=sfnonet.SphericalFourierNeuralOperatorNet,
+        SpectralConvS2=importlib.import_module("fme.ace.models.modulus.s2convolutions").SpectralConvS2,
+    )
+    _loaded = ns
+    return ns

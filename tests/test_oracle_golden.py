@@ -1,0 +1,108 @@
+"""The CPU oracle against every golden the reference holds for this path
+ and against vectors emitted by the reference itself
+(tests/golden/make_golden.py).  Tolerances are torch.testing.assert_close
+defaults for fp32 (rtol 1.3e-6, atol 1e-5), the reference's own bar
+(fme/core/testing/regression.py:8-16)."""
+
+import dataclasses
+import os
+
+import pytest
+import torch
+
+import oracle
+from oracle import stepper as ostep
+from oracle.sfno import SFNOConfig, SFNOOracle, init_state
+
+
+def _load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+def checksum(t):
+    return float(t.double().abs().sum())
+
+
+def test_sht_regression(golden_dir):
+    x = _load(golden_dir, "gen_sht_input.pt")["x"]
+    g = _load(golden_dir, "ref_sht-regression.pt")["output"]
+    out = oracle.RealSHT(9, 18)(x)  # default grid = lobatto, lmax = nlat-1
+    assert out.shape == g.shape == (1, 8, 10)
+    torch.testing.assert_close(out, g)
+
+
+def test_inverse_sht_regression(golden_dir):
+    x = _load(golden_dir, "gen_sht_input.pt")["x"]
+    g = _load(golden_dir, "ref_inverse_sht-regression.pt")["output"]
+    out = oracle.InverseRealSHT(9, 18)(oracle.RealSHT(9, 18)(x))
+    torch.testing.assert_close(out, g)
+
+
+@pytest.mark.parametrize("grid", ["equiangular", "legendre-gauss"])
+@pytest.mark.parametrize("constant", [1.0, 0.42])
+def test_constant_field(grid, constant):
+    # fme/test_harmonics.py:10-25
+    field = torch.full((6, 12), constant)
+    coeffs = oracle.RealSHT(6, 12, grid=grid)(field).ravel()
+    assert abs(coeffs[0]) > 1e-3
+    assert torch.all(coeffs[1:].abs() < 1e-6)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_roundtrip_idempotent(seed):
+    # fme/test_harmonics.py:35-42
+    torch.manual_seed(seed)
+    f = torch.randn(6, 12)
+    sht = oracle.RealSHT(6, 12, grid="legendre-gauss")
+    isht = oracle.InverseRealSHT(6, 12, grid="legendre-gauss")
+    p = isht(sht(f))
+    assert torch.all(torch.isclose(p, isht(sht(p)), atol=1e-6))
+
+
+def test_sht_180x360_vs_reference(golden_dir):
+    d = _load(golden_dir, "gen_sht_180x360.pt")
+    x = torch.randn(3, 180, 360, generator=torch.Generator().manual_seed(d["seed"]))
+    assert checksum(x) == pytest.approx(d["x_checksum"], rel=1e-12)
+    sht = oracle.RealSHT(180, 360, lmax=180, mmax=181, grid="legendre-gauss")
+    isht = oracle.InverseRealSHT(180, 360, lmax=180, mmax=181, grid="legendre-gauss")
+    c = sht(x)
+    torch.testing.assert_close(c, d["coeffs"])
+    torch.testing.assert_close(isht(c), d["roundtrip"])
+
+
+def test_modulus_sfnonet_golden(golden_dir):
+    d = _load(golden_dir, "gen_modulus_sfnonet_case.pt")
+    g = _load(golden_dir, "ref_modulus_sfnonet_output.pt")
+    net = SFNOOracle(SFNOConfig(**d["cfg"]), d["state"])
+    y = net(d["x"])
+    torch.testing.assert_close(y, g)
+    torch.testing.assert_close(y, d["y"])
+
+
+def test_stepper_predict_golden(golden_dir):
+    d = _load(golden_dir, "gen_stepper_case.pt")
+    g = _load(golden_dir, "ref_stepper_predict_regression.pt")
+    net = SFNOOracle(SFNOConfig(**d["cfg"]), d["state"])
+    names = ["a", "b", "c"]
+    means = {k: torch.tensor(d["mean"]) for k in names}
+    stds = {k: torch.tensor(d["std"]) for k in names}
+    outs = ostep.predict(net, {"b": d["b"][:, :1]}, {"a": d["a"]}, 2, d["in_names"], d["out_names"], means, stds)
+    ob = torch.stack([o["b"] for o in outs], 1)
+    oc = torch.stack([o["c"] for o in outs], 1)
+    torch.testing.assert_close(ob, g["output.b"])
+    torch.testing.assert_close(oc, g["output.c"])
+    torch.testing.assert_close(ob[:, -1:], g["next_state.b"])
+
+
+@pytest.mark.parametrize("name", ["gen_sfno_dhconv_12x24.pt", "gen_sfno_dhconv_equiangular_9x18.pt",
+                                  "gen_sfno_dhconv_180x360_c8.pt"])
+def test_dhconv_nets_vs_reference(golden_dir, name):
+    d = _load(golden_dir, name)
+    cfg = SFNOConfig(**{**d["cfg"], "img_shape": tuple(d["cfg"]["img_shape"])})
+    state = init_state(cfg, seed=d["seed"])
+    assert sum(checksum(v) for v in state.values()) == pytest.approx(d["state_checksum"], rel=1e-12)
+    x = torch.randn(d["batch"], cfg.in_chans, *cfg.img_shape, generator=torch.Generator().manual_seed(d["seed"] + 1000))
+    assert checksum(x) == pytest.approx(d["x_checksum"], rel=1e-12)
+    y = SFNOOracle(cfg, state)(x)
+    torch.testing.assert_close(y, d["y"])
+    assert dataclasses.asdict(cfg)["operator_type"] == "dhconv"
