@@ -1,0 +1,19 @@
+"""ace_amd - MI355X-native SFNO rollout engine behind the fme.ace stepper / module-registry API.
+
+Only the hot path named by BASELINE.json's north_star lives here: the SFNO forward
+step (hand-written gfx950 HIP behind a C ABI, ace_amd/csrc + include/ace_sfno.h) and the
+host-side mirror of the reference interfaces that call it (module registry, SFNO
+builder, packer/normaliser, single-module step, stepper loop).  There is no CPU
+fallback: without the built HIP library the ops raise.
+"""
+
+from .registry import Module, ModuleConfig, ModuleSelector, Registry  # noqa: F401
+from .dataset_info import DatasetInfo  # noqa: F401
+from .sht import InverseRealSHT, RealSHT  # noqa: F401
+from .sfno import SphericalFourierNeuralOperatorBuilder, SphericalFourierNeuralOperatorNet  # noqa: F401
+from .packer import Packer  # noqa: F401
+from .normalizer import StandardNormalizer  # noqa: F401
+from .step import SingleModuleStep, SingleModuleStepConfig, StepArgs, StepOutput  # noqa: F401
+from .stepper import Stepper  # noqa: F401
+
+__version__ = "0.1.0"

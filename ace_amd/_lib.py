@@ -1,0 +1,112 @@
+"""ctypes binding of libace_sfno.so (include/ace_sfno.h).
+
+The product path has no CPU or eager-torch fallback: if the HIP library is
+missing this module raises, loudly, at first use."""
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libace_sfno.so")
+
+ACE_OK, ACE_ERR_INVALID, ACE_ERR_RUNTIME, ACE_ERR_STATE = 0, -1, -2, -3
+
+
+class AceSfnoConfig(ctypes.Structure):
+    """struct ace_sfno_config (include/ace_sfno.h)."""
+
+    _fields_ = [
+        ("in_chans", c_int), ("out_chans", c_int), ("nlat", c_int), ("nlon", c_int),
+        ("embed_dim", c_int), ("num_layers", c_int), ("scale_factor", c_int),
+        ("hard_thresholding_fraction", c_float), ("operator_type", c_int),
+        ("normalization_layer", c_int), ("activation_function", c_int), ("use_mlp", c_int),
+        ("mlp_ratio", c_float), ("encoder_layers", c_int), ("pos_embed", c_int), ("big_skip", c_int),
+        ("data_grid", c_int), ("max_batch", c_int),
+    ]
+
+
+# every symbol include/ace_sfno.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "ace_last_error": (c_char_p, []),
+    "ace_version": (c_int, []),
+    "ace_sht_plan_create": (c_int, [c_int, c_int, c_int, c_int, c_char_p, POINTER(c_void_p)]),
+    "ace_sht_plan_destroy": (None, [c_void_p]),
+    "ace_sht_plan_dims": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "ace_sht_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ace_sht_inverse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ace_sht_tables_host": (c_int, [c_int, c_int, c_int, c_int, c_char_p, c_int, c_void_p]),
+    "ace_conv1x1": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p]),
+    "ace_instance_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_long, c_void_p]),
+    "ace_sfno_create": (c_int, [POINTER(AceSfnoConfig), POINTER(c_void_p)]),
+    "ace_sfno_destroy": (None, [c_void_p]),
+    "ace_sfno_set_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_long, c_void_p]),
+    "ace_sfno_num_weights": (c_int, [c_void_p]),
+    "ace_sfno_weight_name": (c_char_p, [c_void_p, c_int]),
+    "ace_sfno_weight_numel": (c_long, [c_void_p, c_int]),
+    "ace_sfno_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ace_sfno_num_stages": (c_int, []),
+    "ace_sfno_stage_name": (c_char_p, [c_int]),
+    "ace_sfno_forward_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, POINTER(c_float), POINTER(c_int)]),
+    "ace_sfno_set_taps": (c_int, [c_void_p, c_int]),
+    "ace_sfno_get_tap": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "ace_sfno_forward_graph": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ace_pack_normalize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p]),
+    "ace_unpack_denormalize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p]),
+}
+
+_lib = None
+
+
+class AceLibraryMissing(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library; raises AceLibraryMissing if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AceLibraryMissing(
+                f"{LIB_PATH} not found: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'` or `python -m ace_amd.build`). "
+                "ace_amd has no CPU fallback."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(rc: int) -> None:
+    """Map the C status to the exception the reference would raise at this boundary."""
+    if rc == ACE_OK:
+        return
+    msg = lib().ace_last_error().decode()
+    if rc == ACE_ERR_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def ptr(t) -> int:
+    """Device pointer of a contiguous CUDA/HIP float32 tensor (or None)."""
+    if t is None:
+        return None
+    import torch
+
+    if not t.is_cuda:
+        raise RuntimeError("ace_amd kernels need tensors on an MI355X (got a CPU tensor); there is no CPU fallback")
+    if t.dtype != torch.float32 and t.dtype != torch.complex64:
+        raise TypeError(f"expected float32/complex64 tensor, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,678 @@
+// C ABI of libace_sfno.so (include/ace_sfno.h): SHT plans, building blocks and the
+// SFNO forward schedule.  Host code only; the kernels live in kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/ace_sfno.h"
+#include "kernels.h"
+#include "tables.h"
+
+using namespace ace;
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing: never abort, return a code and keep a thread-local message
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e__ = (expr);                                                                           \
+        if (e__ != hipSuccess)                                                                             \
+            return fail(ACE_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e__));              \
+    } while (0)
+#define ACE_TRY(expr)                \
+    do {                             \
+        int rc__ = (expr);           \
+        if (rc__ != ACE_OK) return rc__; \
+    } while (0)
+
+extern "C" const char* ace_last_error(void) { return g_err.c_str(); }
+extern "C" int ace_version(void) { return 100; }
+
+struct DevBuf {
+    float* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count, bool zero = true) {
+        release();
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(float));
+        if (e != hipSuccess) { p = nullptr; return e; }
+        n = count;
+        if (zero) e = hipMemset(p, 0, count * sizeof(float));
+        return e;
+    }
+    hipError_t ensure(size_t count) { return count <= n ? hipSuccess : alloc(count); }
+    hipError_t upload(const std::vector<float>& h) {
+        hipError_t e = alloc(h.size(), false);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// SHT plan
+// ---------------------------------------------------------------------------------------------
+struct ace_sht_plan {
+    int nlat = 0, nlon = 0, lmax = 0, mmax = 0, Hp = 0, Lp = 0, Kfp = 0;
+    Grid grid = GRID_LEGENDRE_GAUSS;
+    DevBuf wt, pt, fc, fs, gc, gs;
+    DevBuf X, D;  // scratch of the standalone transforms (plan-owned, grown on demand)
+};
+
+static int plan_build(int nlat, int nlon, int lmax, int mmax, Grid g, std::unique_ptr<ace_sht_plan>& out) {
+    ShtTables t;
+    std::string err = build_sht_tables(nlat, nlon, lmax, mmax, g, t);
+    if (!err.empty()) return fail(ACE_ERR_INVALID, err);
+    auto p = std::make_unique<ace_sht_plan>();
+    p->nlat = t.nlat; p->nlon = t.nlon; p->lmax = t.lmax; p->mmax = t.mmax;
+    p->Hp = t.Hp; p->Lp = t.Lp; p->Kfp = t.Kfp; p->grid = g;
+    HIP_TRY(p->wt.upload(t.wt));
+    HIP_TRY(p->pt.upload(t.pt));
+    HIP_TRY(p->fc.upload(t.fc));
+    HIP_TRY(p->fs.upload(t.fs));
+    HIP_TRY(p->gc.upload(t.gc));
+    HIP_TRY(p->gs.upload(t.gs));
+    out = std::move(p);
+    return ACE_OK;
+}
+
+// X[m][k][b][ri][c] <- longitude DFT of x (Bt, C, H, W), optional per-(b,c) affine on load
+static int run_dft_forward(const ace_sht_plan& pl, const float* x, const float* sc, const float* sh, float* X, int Bt,
+                           int C, hipStream_t s) {
+    DftArgs a;
+    a.x = x; a.spec_out = X; a.tc = pl.fc.p; a.ts = pl.fs.p; a.ldt = pl.Kfp; a.sc = sc; a.sh = sh;
+    a.Bt = Bt; a.C = C; a.H = pl.nlat; a.W = pl.nlon; a.Mm = pl.mmax;
+    HIP_TRY(launch_dft_forward(a, s));
+    return ACE_OK;
+}
+static int run_dft_inverse(const ace_sht_plan& pl, const float* X, const float* bias, float* y, int Bt, int C,
+                           hipStream_t s) {
+    DftArgs a;
+    a.spec = X; a.y = y; a.tc = pl.gc.p; a.ts = pl.gs.p; a.ldt = pl.Kfp; a.bias = bias;
+    a.Bt = Bt; a.C = C; a.H = pl.nlat; a.W = pl.nlon; a.Mm = pl.mmax;
+    HIP_TRY(launch_dft_inverse(a, s));
+    return ACE_OK;
+}
+// D[l][m][n2] = sum_k wt[m][l][k] X[m][k][n2]   (sht_fix.py:134-138), batched over m, rows l >= m only
+static int run_legendre_forward(const ace_sht_plan& pl, const float* X, float* D, long N2, hipStream_t s) {
+    GemmArgs g;
+    g.A = pl.wt.p; g.lda = pl.Hp; g.sA = (long)pl.lmax * pl.Hp;
+    g.B = X; g.ldb = N2; g.sB = (long)pl.nlat * N2;
+    g.C = D; g.ldc = (long)pl.mmax * N2; g.sC = N2;
+    g.M = pl.lmax; g.N = (int)N2; g.K = pl.nlat; g.nbatch = pl.mmax;
+    g.tri = TRI_ROWS_GE_BATCH;
+    HIP_TRY(launch_gemm(g, s));
+    return ACE_OK;
+}
+// X[m][k][n2] = sum_{l>=m} pt[m][k][l] E[l][m][n2]   (sht_fix.py:208-219), batched over m
+static int run_legendre_inverse(const ace_sht_plan& pl, const float* E, float* X, long N2, hipStream_t s) {
+    GemmArgs g;
+    g.A = pl.pt.p; g.lda = pl.Lp; g.sA = (long)pl.nlat * pl.Lp;
+    g.B = E; g.ldb = (long)pl.mmax * N2; g.sB = N2;
+    g.C = X; g.ldc = N2; g.sC = (long)pl.nlat * N2;
+    g.M = pl.nlat; g.N = (int)N2; g.K = pl.lmax; g.nbatch = pl.mmax;
+    g.tri = TRI_K_GE_BATCH;
+    HIP_TRY(launch_gemm(g, s));
+    return ACE_OK;
+}
+
+extern "C" int ace_sht_plan_create(int nlat, int nlon, int lmax, int mmax, const char* grid, ace_sht_plan** plan) {
+    if (!plan || !grid) return fail(ACE_ERR_INVALID, "null argument");
+    Grid g;
+    if (std::string(grid) == "healpix") return fail(ACE_ERR_INVALID, "'healpix' grid not supported");
+    if (!parse_grid(grid, &g)) return fail(ACE_ERR_INVALID, "Unknown quadrature mode");
+    std::unique_ptr<ace_sht_plan> p;
+    ACE_TRY(plan_build(nlat, nlon, lmax, mmax, g, p));
+    *plan = p.release();
+    return ACE_OK;
+}
+extern "C" void ace_sht_plan_destroy(ace_sht_plan* plan) { delete plan; }
+extern "C" int ace_sht_plan_dims(const ace_sht_plan* p, int* nlat, int* nlon, int* lmax, int* mmax) {
+    if (!p) return fail(ACE_ERR_INVALID, "null plan");
+    if (nlat) *nlat = p->nlat;
+    if (nlon) *nlon = p->nlon;
+    if (lmax) *lmax = p->lmax;
+    if (mmax) *mmax = p->mmax;
+    return ACE_OK;
+}
+
+extern "C" int ace_sht_forward(ace_sht_plan* p, const float* x, float* coeffs, int n, void* stream) {
+    if (!p || !x || !coeffs || n <= 0) return fail(ACE_ERR_INVALID, "ace_sht_forward: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long N2 = 2L * n;
+    HIP_TRY(p->X.ensure((size_t)p->mmax * p->nlat * N2));
+    HIP_TRY(p->D.ensure((size_t)p->lmax * p->mmax * N2));
+    // coefficients with l < m are never written by the triangular Legendre stage: they are zero
+    HIP_TRY(hipMemsetAsync(p->D.p, 0, (size_t)p->lmax * p->mmax * N2 * sizeof(float), s));
+    ACE_TRY(run_dft_forward(*p, x, nullptr, nullptr, p->X.p, 1, n, s));
+    ACE_TRY(run_legendre_forward(*p, p->X.p, p->D.p, N2, s));
+    HIP_TRY(launch_spec_to_ref(p->D.p, coeffs, 1, n, p->lmax, p->mmax, s));
+    return ACE_OK;
+}
+extern "C" int ace_sht_inverse(ace_sht_plan* p, const float* coeffs, float* x, int n, void* stream) {
+    if (!p || !x || !coeffs || n <= 0) return fail(ACE_ERR_INVALID, "ace_sht_inverse: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long N2 = 2L * n;
+    HIP_TRY(p->X.ensure((size_t)p->mmax * p->nlat * N2));
+    HIP_TRY(p->D.ensure((size_t)p->lmax * p->mmax * N2));
+    HIP_TRY(launch_ref_to_spec(coeffs, p->D.p, 1, n, p->lmax, p->mmax, s));
+    ACE_TRY(run_legendre_inverse(*p, p->D.p, p->X.p, N2, s));
+    ACE_TRY(run_dft_inverse(*p, p->X.p, nullptr, x, 1, n, s));
+    return ACE_OK;
+}
+
+extern "C" int ace_sht_tables_host(int nlat, int nlon, int lmax, int mmax, const char* grid, int which,
+                                   void* out_host) {
+    if (!grid || !out_host) return fail(ACE_ERR_INVALID, "null argument");
+    Grid g;
+    if (!parse_grid(grid, &g)) return fail(ACE_ERR_INVALID, "Unknown quadrature mode");
+    if (which == 2 || which == 3) {
+        std::vector<double> x, w;
+        quadrature(g, nlat, x, w);
+        std::memcpy(out_host, (which == 2 ? x : w).data(), sizeof(double) * nlat);
+        return ACE_OK;
+    }
+    ShtTables t;
+    std::string err = build_sht_tables(nlat, nlon, lmax, mmax, g, t);
+    if (!err.empty()) return fail(ACE_ERR_INVALID, err);
+    float* o = static_cast<float*>(out_host);
+    for (int m = 0; m < t.mmax; ++m)
+        for (int l = 0; l < t.lmax; ++l)
+            for (int k = 0; k < t.nlat; ++k) {
+                const size_t dst = ((size_t)m * t.lmax + l) * t.nlat + k;
+                if (which == 0) o[dst] = t.wt[((size_t)m * t.lmax + l) * t.Hp + k];
+                else if (which == 1) o[dst] = t.pt[((size_t)m * t.nlat + k) * t.Lp + l];
+                else return fail(ACE_ERR_INVALID, "unknown table id");
+            }
+    return ACE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// building blocks
+// ---------------------------------------------------------------------------------------------
+extern "C" int ace_conv1x1(const float* x, const float* weight, const float* bias, float* y, int n, int cin, int cout,
+                           long hw, int act, void* stream) {
+    if (!x || !weight || !y || n <= 0 || cin <= 0 || cout <= 0 || hw <= 0)
+        return fail(ACE_ERR_INVALID, "ace_conv1x1: bad argument");
+    GemmArgs g;
+    g.A = weight; g.lda = cin; g.sA = 0;
+    g.B = x; g.ldb = hw; g.sB = (long)cin * hw;
+    g.C = y; g.ldc = hw; g.sC = (long)cout * hw;
+    g.bias = bias; g.M = cout; g.N = (int)hw; g.K = cin; g.nbatch = n; g.act = act;
+    HIP_TRY(launch_gemm(g, static_cast<hipStream_t>(stream)));
+    return ACE_OK;
+}
+
+extern "C" int ace_instance_norm(const float* x, const float* gamma, const float* beta, float eps, float* y, int n,
+                                 int c, long hw, void* stream) {
+    if (!x || !y || n <= 0 || c <= 0 || hw <= 0) return fail(ACE_ERR_INVALID, "ace_instance_norm: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* st = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st), sizeof(float) * 2 * n * c));
+    hipError_t e = launch_instnorm_stats(x, gamma, beta, eps, n, c, hw, st, st + (size_t)n * c, s);
+    if (e == hipSuccess) e = launch_rowaffine_add(x, st, st + (size_t)n * c, nullptr, nullptr, nullptr, y, (long)n * c, hw, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(st);
+    HIP_TRY(e);
+    return ACE_OK;
+}
+
+extern "C" int ace_pack_normalize(const float* const* srcs, const long* strides, const float* mean, const float* std_,
+                                  float* dst, int batch, int nch, long hw, void* stream) {
+    if (!srcs || !strides || !mean || !std_ || !dst) return fail(ACE_ERR_INVALID, "ace_pack_normalize: null argument");
+    HIP_TRY(launch_pack_normalize(srcs, strides, mean, std_, dst, batch, nch, hw, static_cast<hipStream_t>(stream)));
+    return ACE_OK;
+}
+extern "C" int ace_unpack_denormalize(const float* src, const float* mean, const float* std_, float* const* dsts,
+                                      const long* strides, int batch, int nch, long hw, void* stream) {
+    if (!src || !strides || !mean || !std_ || !dsts)
+        return fail(ACE_ERR_INVALID, "ace_unpack_denormalize: null argument");
+    HIP_TRY(launch_unpack_denormalize(src, mean, std_, dsts, strides, batch, nch, hw, static_cast<hipStream_t>(stream)));
+    return ACE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the network
+// ---------------------------------------------------------------------------------------------
+struct Weight {
+    std::string name;
+    long numel = 0;
+    DevBuf buf;    // library copy in the reference's layout
+    bool set = false;
+    int block = -1;
+    bool is_filter = false;
+};
+
+struct GraphKey {
+    const float* in; float* out; int batch;
+    bool operator<(const GraphKey& o) const { return std::tie(in, out, batch) < std::tie(o.in, o.out, o.batch); }
+};
+
+struct ace_sfno {
+    ace_sfno_config cfg;
+    int H = 0, W = 0, C = 0, L = 0, Mm = 0, hid = 0, Bmax = 1;
+    long HW = 0;
+    std::unique_ptr<ace_sht_plan> plan_lg, plan_data_own;
+    ace_sht_plan* plan_data = nullptr;  // == plan_lg.get() when data_grid is legendre-gauss
+    std::vector<std::unique_ptr<Weight>> weights;
+    std::map<std::string, int> index;
+    std::vector<DevBuf> wx;  // per block: dhconv weight expanded to real [L][2C][2C]
+    // workspace
+    DevBuf h0, h1, Y, T, R, U, X, D, E, stats;
+    bool taps_on = false;
+    std::vector<DevBuf> taps;
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    hipStream_t capture_stream = nullptr;
+
+    const float* w(const std::string& name) const {
+        auto it = index.find(name);
+        return it == index.end() ? nullptr : weights[it->second]->buf.p;
+    }
+};
+
+static void add_weight(ace_sfno* n, const std::string& name, long numel, int block = -1, bool is_filter = false) {
+    auto w = std::make_unique<Weight>();
+    w->name = name; w->numel = numel; w->block = block; w->is_filter = is_filter;
+    n->index[name] = (int)n->weights.size();
+    n->weights.push_back(std::move(w));
+}
+
+extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
+    if (!cfg || !out) return fail(ACE_ERR_INVALID, "null argument");
+    const ace_sfno_config& c = *cfg;
+    if (c.scale_factor != 1) return fail(ACE_ERR_INVALID, "scale_factor != 1 is not supported");
+    if (c.in_chans <= 0 || c.out_chans <= 0 || c.embed_dim <= 0 || c.num_layers <= 0 || c.nlat < 2 || c.nlon < 2)
+        return fail(ACE_ERR_INVALID, "non-positive dimension in ace_sfno_config");
+    if (c.operator_type != 0 && c.operator_type != 1) return fail(ACE_ERR_INVALID, "Unsupported operator type");
+    if (c.normalization_layer != 0 && c.normalization_layer != 1)
+        return fail(ACE_ERR_INVALID, "normalization_layer must be 'none' or 'instance_norm'");
+    if (c.activation_function < 1 || c.activation_function > 3)
+        return fail(ACE_ERR_INVALID, "Unknown activation function");
+    if (c.data_grid != GRID_LEGENDRE_GAUSS && c.data_grid != GRID_EQUIANGULAR)
+        return fail(ACE_ERR_INVALID, "data_grid must be 'legendre-gauss' or 'equiangular'");
+    if (c.encoder_layers < 1) return fail(ACE_ERR_INVALID, "encoder_layers must be >= 1");
+
+    auto n = std::make_unique<ace_sfno>();
+    n->cfg = c;
+    n->H = c.nlat; n->W = c.nlon; n->C = c.embed_dim; n->HW = (long)c.nlat * c.nlon;
+    n->Bmax = c.max_batch > 0 ? c.max_batch : 1;
+    // sfnonet.py:471-472
+    n->L = (int)(c.nlat * c.hard_thresholding_fraction);
+    n->Mm = (int)((c.nlon / 2 + 1) * c.hard_thresholding_fraction);
+    if (n->L < 1 || n->Mm < 1) return fail(ACE_ERR_INVALID, "hard_thresholding_fraction leaves no modes");
+    n->hid = (int)(c.embed_dim * c.mlp_ratio);
+
+    ACE_TRY(plan_build(c.nlat, c.nlon, n->L, n->Mm, GRID_LEGENDRE_GAUSS, n->plan_lg));
+    if (c.data_grid == GRID_LEGENDRE_GAUSS) {
+        n->plan_data = n->plan_lg.get();
+    } else {
+        ACE_TRY(plan_build(c.nlat, c.nlon, n->L, n->Mm, (Grid)c.data_grid, n->plan_data_own));
+        n->plan_data = n->plan_data_own.get();
+    }
+
+    // parameters in the reference's state_dict order
+    const long C = n->C, HW = n->HW;
+    if (c.pos_embed) add_weight(n.get(), "pos_embed", C * HW);
+    long cur = c.in_chans;
+    for (int j = 0; j < c.encoder_layers; ++j) {
+        add_weight(n.get(), "encoder." + std::to_string(2 * j) + ".weight", C * cur);
+        add_weight(n.get(), "encoder." + std::to_string(2 * j) + ".bias", C);
+        cur = C;
+    }
+    add_weight(n.get(), "encoder." + std::to_string(2 * c.encoder_layers) + ".weight", C * cur);
+    for (int i = 0; i < c.num_layers; ++i) {
+        const std::string p = "blocks." + std::to_string(i) + ".";
+        if (c.normalization_layer == 1) { add_weight(n.get(), p + "norm0.weight", C); add_weight(n.get(), p + "norm0.bias", C); }
+        const long fw = c.operator_type == 1 ? C * C * n->L * 2 : C * C * (long)n->L * n->Mm * 2;
+        add_weight(n.get(), p + "filter.filter.weight", fw, i, true);
+        add_weight(n.get(), p + "filter.filter.bias", C);
+        add_weight(n.get(), p + "inner_skip.weight", C * C);
+        add_weight(n.get(), p + "inner_skip.bias", C);
+        if (c.normalization_layer == 1) { add_weight(n.get(), p + "norm1.weight", C); add_weight(n.get(), p + "norm1.bias", C); }
+        if (c.use_mlp) {
+            add_weight(n.get(), p + "mlp.fwd.0.weight", (long)n->hid * C);
+            add_weight(n.get(), p + "mlp.fwd.0.bias", n->hid);
+            add_weight(n.get(), p + "mlp.fwd.2.weight", C * (long)n->hid);
+            add_weight(n.get(), p + "mlp.fwd.2.bias", C);
+        }
+    }
+    cur = C + (c.big_skip ? c.in_chans : 0);
+    for (int j = 0; j < c.encoder_layers; ++j) {
+        add_weight(n.get(), "decoder." + std::to_string(2 * j) + ".weight", C * cur);
+        add_weight(n.get(), "decoder." + std::to_string(2 * j) + ".bias", C);
+        cur = C;
+    }
+    add_weight(n.get(), "decoder." + std::to_string(2 * c.encoder_layers) + ".weight", (long)c.out_chans * cur);
+
+    n->wx.resize(c.num_layers);
+    const size_t act = (size_t)n->Bmax * C * HW;
+    const size_t spec_x = (size_t)n->Mm * n->H * n->Bmax * 2 * C;
+    const size_t spec_d = (size_t)n->L * n->Mm * n->Bmax * 2 * C;
+    HIP_TRY(n->h0.alloc(act));
+    HIP_TRY(n->h1.alloc(act));
+    HIP_TRY(n->Y.alloc(act));
+    HIP_TRY(n->T.alloc(act));
+    if (n->plan_data != n->plan_lg.get()) HIP_TRY(n->R.alloc(act));
+    if (c.use_mlp) HIP_TRY(n->U.alloc((size_t)n->Bmax * n->hid * HW));
+    HIP_TRY(n->X.alloc(spec_x));
+    HIP_TRY(n->D.alloc(spec_d));
+    HIP_TRY(n->E.alloc(spec_d));
+    HIP_TRY(n->stats.alloc((size_t)4 * n->Bmax * C));
+    *out = n.release();
+    return ACE_OK;
+}
+
+extern "C" void ace_sfno_destroy(ace_sfno* n) {
+    if (!n) return;
+    for (auto& kv : n->graphs) (void)hipGraphExecDestroy(kv.second);
+    if (n->capture_stream) (void)hipStreamDestroy(n->capture_stream);
+    delete n;
+}
+
+extern "C" int ace_sfno_num_weights(const ace_sfno* n) { return n ? (int)n->weights.size() : 0; }
+extern "C" const char* ace_sfno_weight_name(const ace_sfno* n, int i) {
+    if (!n || i < 0 || i >= (int)n->weights.size()) return nullptr;
+    return n->weights[i]->name.c_str();
+}
+extern "C" long ace_sfno_weight_numel(const ace_sfno* n, int i) {
+    if (!n || i < 0 || i >= (int)n->weights.size()) return -1;
+    return n->weights[i]->numel;
+}
+
+extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* src, long numel, void* stream) {
+    if (!n || !name || !src) return fail(ACE_ERR_INVALID, "null argument");
+    auto it = n->index.find(name);
+    if (it == n->index.end()) return fail(ACE_ERR_INVALID, std::string("unknown parameter '") + name + "'");
+    Weight& w = *n->weights[it->second];
+    if (numel != w.numel)
+        return fail(ACE_ERR_INVALID, std::string("size mismatch for ") + name + ": expected " +
+                                         std::to_string(w.numel) + " elements, got " + std::to_string(numel));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!w.buf.p) HIP_TRY(w.buf.alloc((size_t)numel, false));
+    HIP_TRY(hipMemcpyAsync(w.buf.p, src, sizeof(float) * numel, hipMemcpyDeviceToDevice, s));
+    if (w.is_filter && n->cfg.operator_type == 1) {
+        DevBuf& wx = n->wx[w.block];
+        const size_t cnt = (size_t)n->L * 2 * n->C * 2 * n->C;
+        if (!wx.p) HIP_TRY(wx.alloc(cnt, false));
+        HIP_TRY(launch_expand_dhconv_weight(w.buf.p, wx.p, n->C, n->C, n->L, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    w.set = true;
+    // parameters changed: captured graphs still point at the same library buffers, so they stay valid
+    return ACE_OK;
+}
+
+static int conv(const ace_sfno* n, const float* Wt, const float* bias, const float* in, long in_bstride, int cin,
+                const float* in2, long in2_bstride, int K1, const float* bsc, const float* bsh, float* out, int cout,
+                const float* R, long r_bstride, const float* rsc, const float* rsh, int act, int batch, hipStream_t s) {
+    GemmArgs g;
+    g.A = Wt; g.lda = cin; g.sA = 0;
+    g.B = in; g.ldb = n->HW; g.sB = in_bstride;
+    g.B2 = in2; g.ldb2 = n->HW; g.sB2 = in2_bstride; g.K1 = in2 ? K1 : -1;
+    g.bsc = bsc; g.bsh = bsh; g.sbs = bsc ? cin : 0;
+    g.C = out; g.ldc = n->HW; g.sC = (long)cout * n->HW;
+    g.bias = bias;
+    g.R = R; g.ldr = n->HW; g.sR = r_bstride;
+    g.rsc = rsc; g.rsh = rsh; g.srs = rsc ? cout : 0;
+    g.M = cout; g.N = (int)n->HW; g.K = cin; g.nbatch = batch; g.act = act;
+    HIP_TRY(launch_gemm(g, s));
+    return ACE_OK;
+}
+
+// hipEvent stage timer: one event after each launch group; the elapsed time between consecutive events
+// is charged to the stage that just ended (the reference's CUDATimer children: fme/core/benchmark/timer.py:105-168,
+// conditional_sfno/sfnonet.py:388-437, s2convolutions.py:372-431).
+enum Stage {
+    ST_ENCODER = 0, ST_NORM0, ST_DFT_FWD, ST_LEGENDRE_FWD, ST_CONTRACT, ST_LEGENDRE_INV, ST_DFT_INV, ST_INNER_SKIP,
+    ST_NORM1, ST_MLP_FC1, ST_MLP_FC2, ST_DECODER, ST_COUNT
+};
+static const char* kStageNames[ST_COUNT] = {
+    "encoder", "norm0_stats", "forward_transform.dft", "forward_transform.legendre", "dhconv",
+    "inverse_transform.legendre", "inverse_transform.dft", "inner_skip+activation", "norm1_stats", "mlp.fc1",
+    "mlp.fc2+outer_skip", "decoder"};
+
+struct StageTimer {
+    hipStream_t s;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> stage;
+    hipError_t err = hipSuccess;
+    explicit StageTimer(hipStream_t st) : s(st) { push(-1); }
+    void push(int st) {
+        hipEvent_t e;
+        hipError_t r = hipEventCreate(&e);
+        if (r == hipSuccess) r = hipEventRecord(e, s);
+        if (r != hipSuccess && err == hipSuccess) err = r;
+        ev.push_back(e);
+        stage.push_back(st);
+    }
+    hipError_t finish(float* ms, int* calls) {
+        hipError_t r = hipStreamSynchronize(s);
+        if (r != hipSuccess) return r;
+        for (int i = 0; i < ST_COUNT; ++i) { ms[i] = 0.f; if (calls) calls[i] = 0; }
+        for (size_t i = 1; i < ev.size(); ++i) {
+            float t = 0.f;
+            r = hipEventElapsedTime(&t, ev[i - 1], ev[i]);
+            if (r != hipSuccess) return r;
+            ms[stage[i]] += t;
+            if (calls) calls[stage[i]] += 1;
+        }
+        return err;
+    }
+    ~StageTimer() { for (auto e : ev) (void)hipEventDestroy(e); }
+};
+#define MARK(st) do { if (tm) tm->push(st); } while (0)
+
+static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStream_t s, StageTimer* tm = nullptr) {
+    const ace_sfno_config& c = n->cfg;
+    const int C = n->C, Cin = c.in_chans, act = c.activation_function;
+    const long HW = n->HW;
+    const long N2 = (long)B * 2 * C;
+    const long actB = (long)C * HW;  // per-sample stride of a C-channel activation
+    auto W = [&](const std::string& name) { return n->w(name); };
+
+    // ---- encoder (sfnonet.py:721-733): [conv+bias, act] x encoder_layers, conv (no bias), + pos_embed
+    const float* cur = in;
+    long cur_bs = (long)Cin * HW;
+    int curC = Cin;
+    float* ping[2] = {n->Y.p, n->T.p};
+    for (int j = 0; j < c.encoder_layers; ++j) {
+        const std::string p = "encoder." + std::to_string(2 * j);
+        ACE_TRY(conv(n, W(p + ".weight"), W(p + ".bias"), cur, cur_bs, curC, nullptr, 0, -1, nullptr, nullptr,
+                     ping[j & 1], C, nullptr, 0, nullptr, nullptr, act, B, s));
+        cur = ping[j & 1]; cur_bs = actB; curC = C;
+    }
+    float* h = n->h0.p;
+    float* hn = n->h1.p;
+    ACE_TRY(conv(n, W("encoder." + std::to_string(2 * c.encoder_layers) + ".weight"), nullptr, cur, cur_bs, curC,
+                 nullptr, 0, -1, nullptr, nullptr, h, C, c.pos_embed ? W("pos_embed") : nullptr, 0, nullptr, nullptr,
+                 ACT_NONE, B, s));
+    MARK(ST_ENCODER);
+    if (n->taps_on) HIP_TRY(hipMemcpyAsync(n->taps[0].p, h, sizeof(float) * B * actB, hipMemcpyDeviceToDevice, s));
+
+    float* sc0 = n->stats.p;
+    float* sh0 = sc0 + (size_t)n->Bmax * C;
+    float* sc1 = sh0 + (size_t)n->Bmax * C;
+    float* sh1 = sc1 + (size_t)n->Bmax * C;
+    const bool norm = c.normalization_layer == 1;
+
+    // ---- blocks (sfnonet.py:217-252)
+    for (int i = 0; i < c.num_layers; ++i) {
+        const std::string p = "blocks." + std::to_string(i) + ".";
+        const ace_sht_plan& fwd = (i == 0) ? *n->plan_data : *n->plan_lg;
+        const ace_sht_plan& inv = (i == c.num_layers - 1) ? *n->plan_data : *n->plan_lg;
+        const bool scale_residual = (&fwd != &inv);  // grids differ (s2convolutions.py:82-86)
+
+        // norm0 as an affine applied on load by every consumer (never materialised)
+        const float *a0 = nullptr, *b0 = nullptr;
+        if (norm) {
+            HIP_TRY(launch_instnorm_stats(h, W(p + "norm0.weight"), W(p + "norm0.bias"), 1e-6f, B, C, HW, sc0, sh0, s));
+            a0 = sc0; b0 = sh0;
+            MARK(ST_NORM0);
+        }
+        // spectral filter (s2convolutions.py:162-197): SHT -> contraction -> inverse SHT + bias
+        ACE_TRY(run_dft_forward(fwd, h, a0, b0, n->X.p, B, C, s));
+        MARK(ST_DFT_FWD);
+        ACE_TRY(run_legendre_forward(fwd, n->X.p, n->D.p, N2, s));
+        MARK(ST_LEGENDRE_FWD);
+        const float* res = h;           // residual = x_norm, applied as (h, a0, b0)
+        const float *ra = a0, *rb = b0;
+        if (scale_residual) {           // residual = inverse(forward(x_norm)) on the output grid
+            ACE_TRY(run_legendre_inverse(inv, n->D.p, n->X.p, N2, s));
+            MARK(ST_LEGENDRE_INV);
+            ACE_TRY(run_dft_inverse(inv, n->X.p, nullptr, n->R.p, B, C, s));
+            MARK(ST_DFT_INV);
+            res = n->R.p; ra = nullptr; rb = nullptr;
+        }
+        if (c.operator_type == 1) {  // dhconv (contractions.py:183-195): per l, (m,b) x 2C times real 2C x 2C
+            GemmArgs g;
+            g.A = n->D.p; g.lda = 2 * C; g.sA = (long)n->Mm * N2;
+            g.B = n->wx[i].p; g.ldb = 2 * C; g.sB = (long)2 * C * 2 * C;
+            g.C = n->E.p; g.ldc = 2 * C; g.sC = (long)n->Mm * N2;
+            g.M = n->Mm * B; g.N = 2 * C; g.K = 2 * C; g.nbatch = n->L;
+            g.tri = TRI_ROWS_LE_BATCH; g.trimul = B;
+            HIP_TRY(launch_gemm(g, s));
+        } else {
+            HIP_TRY(launch_contract_diagonal(n->D.p, W(p + "filter.filter.weight"), n->E.p, B, C, C, n->L, n->Mm, s));
+        }
+        MARK(ST_CONTRACT);
+        ACE_TRY(run_legendre_inverse(inv, n->E.p, n->X.p, N2, s));
+        MARK(ST_LEGENDRE_INV);
+        ACE_TRY(run_dft_inverse(inv, n->X.p, W(p + "filter.filter.bias"), n->Y.p, B, C, s));
+        MARK(ST_DFT_INV);
+
+        // x = act(filter + inner_skip(residual))   (sfnonet.py:229-232)
+        ACE_TRY(conv(n, W(p + "inner_skip.weight"), W(p + "inner_skip.bias"), res, actB, C, nullptr, 0, -1, ra, rb,
+                     n->T.p, C, n->Y.p, actB, nullptr, nullptr, act, B, s));
+        MARK(ST_INNER_SKIP);
+        // norm1 -> MLP -> + residual   (sfnonet.py:234-250)
+        const float *a1 = nullptr, *b1 = nullptr;
+        if (norm) {
+            HIP_TRY(launch_instnorm_stats(n->T.p, W(p + "norm1.weight"), W(p + "norm1.bias"), 1e-6f, B, C, HW, sc1, sh1, s));
+            a1 = sc1; b1 = sh1;
+            MARK(ST_NORM1);
+        }
+        if (c.use_mlp) {
+            ACE_TRY(conv(n, W(p + "mlp.fwd.0.weight"), W(p + "mlp.fwd.0.bias"), n->T.p, actB, C, nullptr, 0, -1, a1, b1,
+                         n->U.p, n->hid, nullptr, 0, nullptr, nullptr, act, B, s));
+            MARK(ST_MLP_FC1);
+            ACE_TRY(conv(n, W(p + "mlp.fwd.2.weight"), W(p + "mlp.fwd.2.bias"), n->U.p, (long)n->hid * HW, n->hid,
+                         nullptr, 0, -1, nullptr, nullptr, hn, C, res, actB, ra, rb, ACT_NONE, B, s));
+        } else {
+            HIP_TRY(launch_rowaffine_add(n->T.p, a1, b1, res, ra, rb, hn, (long)B * C, HW, s));
+        }
+        MARK(ST_MLP_FC2);
+        std::swap(h, hn);
+        if (n->taps_on)
+            HIP_TRY(hipMemcpyAsync(n->taps[i + 1].p, h, sizeof(float) * B * actB, hipMemcpyDeviceToDevice, s));
+    }
+
+    // ---- decoder on cat(x, input) (sfnonet.py:741-747); the concat is two row sources of one GEMM
+    cur = h; cur_bs = actB; curC = C;
+    for (int j = 0; j < c.encoder_layers; ++j) {
+        const std::string p = "decoder." + std::to_string(2 * j);
+        const bool cat = (j == 0 && c.big_skip);
+        ACE_TRY(conv(n, W(p + ".weight"), W(p + ".bias"), cur, cur_bs, cat ? C + Cin : curC, cat ? in : nullptr,
+                     (long)Cin * HW, C, nullptr, nullptr, ping[j & 1], C, nullptr, 0, nullptr, nullptr, act, B, s));
+        cur = ping[j & 1]; cur_bs = actB; curC = C;
+    }
+    ACE_TRY(conv(n, W("decoder." + std::to_string(2 * c.encoder_layers) + ".weight"), nullptr, cur, cur_bs, curC,
+                 nullptr, 0, -1, nullptr, nullptr, out, c.out_chans, nullptr, 0, nullptr, nullptr, ACT_NONE, B, s));
+    MARK(ST_DECODER);
+    return ACE_OK;
+}
+
+static int check_ready(ace_sfno* n, const float* in, float* out, int batch) {
+    if (!n || !in || !out) return fail(ACE_ERR_INVALID, "null argument");
+    if (batch <= 0 || batch > n->Bmax)
+        return fail(ACE_ERR_INVALID, "batch " + std::to_string(batch) + " outside [1, max_batch=" +
+                                         std::to_string(n->Bmax) + "]");
+    for (auto& w : n->weights)
+        if (!w->set) return fail(ACE_ERR_STATE, "parameter '" + w->name + "' has not been set");
+    return ACE_OK;
+}
+
+extern "C" int ace_sfno_forward(ace_sfno* n, const float* in, float* out, int batch, void* stream) {
+    ACE_TRY(check_ready(n, in, out, batch));
+    return forward_impl(n, in, out, batch, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ace_sfno_num_stages(void) { return ST_COUNT; }
+extern "C" const char* ace_sfno_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : nullptr; }
+extern "C" int ace_sfno_forward_timed(ace_sfno* n, const float* in, float* out, int batch, void* stream, float* ms_host,
+                                      int* calls_host) {
+    ACE_TRY(check_ready(n, in, out, batch));
+    if (!ms_host) return fail(ACE_ERR_INVALID, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    StageTimer tm(s);
+    ACE_TRY(forward_impl(n, in, out, batch, s, &tm));
+    HIP_TRY(tm.finish(ms_host, calls_host));
+    return ACE_OK;
+}
+
+extern "C" int ace_sfno_set_taps(ace_sfno* n, int enable) {
+    if (!n) return fail(ACE_ERR_INVALID, "null argument");
+    if (enable && n->taps.empty()) {
+        n->taps = std::vector<DevBuf>(n->cfg.num_layers + 1);
+        for (auto& t : n->taps) HIP_TRY(t.alloc((size_t)n->Bmax * n->C * n->HW));
+    }
+    n->taps_on = enable != 0;
+    return ACE_OK;
+}
+extern "C" int ace_sfno_get_tap(ace_sfno* n, int i, float* dst, int batch, void* stream) {
+    if (!n || !dst) return fail(ACE_ERR_INVALID, "null argument");
+    if (n->taps.empty() || i < -1 || i >= n->cfg.num_layers) return fail(ACE_ERR_STATE, "taps not enabled / bad index");
+    HIP_TRY(hipMemcpyAsync(dst, n->taps[i + 1].p, sizeof(float) * batch * n->C * n->HW, hipMemcpyDeviceToDevice,
+                           static_cast<hipStream_t>(stream)));
+    return ACE_OK;
+}
+
+extern "C" int ace_sfno_forward_graph(ace_sfno* n, const float* in, float* out, int batch, void* stream) {
+    ACE_TRY(check_ready(n, in, out, batch));
+    if (n->taps_on) return fail(ACE_ERR_STATE, "disable taps before using the graph path");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GraphKey key{in, out, batch};
+    auto it = n->graphs.find(key);
+    if (it == n->graphs.end()) {
+        if (!n->capture_stream) HIP_TRY(hipStreamCreateWithFlags(&n->capture_stream, hipStreamNonBlocking));
+        // everything queued on the caller's stream must be visible to the first replay; capture itself runs nothing
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(n->capture_stream, hipStreamCaptureModeThreadLocal));
+        int rc = forward_impl(n, in, out, batch, n->capture_stream);
+        hipError_t e = hipStreamEndCapture(n->capture_stream, &graph);
+        if (rc != ACE_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        HIP_TRY(e);
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HIP_TRY(e);
+        it = n->graphs.emplace(key, exec).first;
+    }
+    HIP_TRY(hipGraphLaunch(it->second, s));
+    return ACE_OK;
+}

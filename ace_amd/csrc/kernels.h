@@ -1,0 +1,82 @@
+// Launch interface of the gfx950 kernels (kernels.hip).  Internal to the library;
+// the public boundary is include/ace_sfno.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ace {
+
+enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SILU = 3 };
+enum Tri {
+    TRI_NONE = 0,
+    TRI_ROWS_GE_BATCH = 1,  // forward Legendre: rows l >= m (tiles wholly below are skipped)
+    TRI_K_GE_BATCH = 2,     // inverse Legendre: k (= l) starts at batch rounded down to the k-tile
+    TRI_ROWS_LE_BATCH = 3   // dhconv: rows (m, b) with m <= l  => M_eff = (batch + 1) * trimul
+};
+
+// C[b] = epilogue( A[b] (M x K, row-major) * B[b] (K x N, row-major) ), batched.
+// All arithmetic is exact fp32 on v_mfma_f32_32x32x2_f32 (k-ordered fma chain).
+struct GemmArgs {
+    const float* A = nullptr; long lda = 0; long sA = 0;
+    const float* B = nullptr; long ldb = 0; long sB = 0;
+    // rows k >= K1 of B come from B2 (row k - K1): the big-skip concat without a copy.  K1 < 0: unused
+    const float* B2 = nullptr; long ldb2 = 0; long sB2 = 0; int K1 = -1;
+    // per-k-row affine applied to B on load: b = b * bsc[k] + bsh[k] (fused instance norm / normalisation)
+    const float* bsc = nullptr; const float* bsh = nullptr; long sbs = 0;
+    float* C = nullptr; long ldc = 0; long sC = 0;
+    const float* bias = nullptr;  // per row
+    // residual added after bias: r = R[row][col] (optionally r * rsc[row] + rsh[row])
+    const float* R = nullptr; long ldr = 0; long sR = 0;
+    const float* rsc = nullptr; const float* rsh = nullptr; long srs = 0;
+    // per-row affine applied last (fused de-normalisation): v = v * osc[row] + osh[row]
+    const float* osc = nullptr; const float* osh = nullptr;
+    int M = 0, N = 0, K = 0, nbatch = 1;
+    int tri = TRI_NONE; int trimul = 1;
+    int act = ACT_NONE;
+};
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// Spectral-space layout used between the kernels ("channel-fastest planar"):
+//   X[m][k][b][ri][c]  (after the longitude DFT)     index ((m*H + k)*Bt + b)*2C + ri*C + c
+//   D[l][m][b][ri][c]  (after the Legendre stage)    index ((l*Mm + m)*Bt + b)*2C + ri*C + c
+struct DftArgs {
+    const float* x = nullptr;  // (Bt, C, H, W) grid-space field
+    float* y = nullptr;        // grid-space output (inverse)
+    const float* spec = nullptr;  // spectral input (inverse)
+    float* spec_out = nullptr;    // spectral output (forward)
+    const float* tc = nullptr; const float* ts = nullptr; int ldt = 0;  // cos / sin tables [Mm][ldt]
+    const float* sc = nullptr; const float* sh = nullptr;  // forward: per-(b,c) affine on x (fused instance norm)
+    const float* bias = nullptr;                           // inverse: per-c bias added to the output
+    int Bt = 1, C = 0, H = 0, W = 0, Mm = 0;
+};
+hipError_t launch_dft_forward(const DftArgs& a, hipStream_t s);
+hipError_t launch_dft_inverse(const DftArgs& a, hipStream_t s);
+
+// per-(b,c) instance-norm statistics over H*W -> affine (scale, shift):
+//   scale = gamma[c] * rsqrt(var + eps),  shift = beta[c] - mean * scale   (biased var, fp64 accumulation)
+hipError_t launch_instnorm_stats(const float* x, const float* gamma, const float* beta, float eps, int Bt, int C,
+                                 long HW, float* scale, float* shift, hipStream_t s);
+
+// layout converters between the internal spectral layout and the reference's (n, L, M) complex64
+hipError_t launch_spec_to_ref(const float* D, float* out, int Bt, int C, int L, int Mm, hipStream_t s);
+hipError_t launch_ref_to_spec(const float* in, float* E, int Bt, int C, int L, int Mm, hipStream_t s);
+
+// "diagonal" operator (contractions.py:169-180): E[l][m][b][:, o] = sum_i D[l][m][b][:, i] * w[i][o][l][m] (complex)
+hipError_t launch_contract_diagonal(const float* D, const float* w, float* E, int Bt, int Cin, int Cout, int L, int Mm,
+                                    hipStream_t s);
+
+// dhconv weight (Cin, Cout, L, 2) -> expanded real matrices Wx[l][2*Cin][2*Cout]
+hipError_t launch_expand_dhconv_weight(const float* w, float* wx, int Cin, int Cout, int L, hipStream_t s);
+
+// y = x * sc[row] + sh[row] + (r ? r * rsc[row] + rsh[row] : 0), rows of length n  (use_mlp=False tail, rare)
+hipError_t launch_rowaffine_add(const float* x, const float* sc, const float* sh, const float* r, const float* rsc,
+                                const float* rsh, float* y, long rows, long n, hipStream_t s);
+
+// stepper glue (packer.py:45-52 + normalizer.py:213-236 fused)
+//   pack:   dst[b][j][:] = (src_j[b][:] - mean[j]) / std[j]   where src_j = srcs[j] + b*strides[j]
+//   unpack: dst_j[b][:] = src[b][j][:] * std[j] + mean[j]
+hipError_t launch_pack_normalize(const float* const* srcs, const long* strides, const float* mean, const float* stdv,
+                                 float* dst, int Bt, int nch, long HW, hipStream_t s);
+hipError_t launch_unpack_denormalize(const float* src, const float* mean, const float* stdv, float* const* dsts,
+                                     const long* strides, int Bt, int nch, long HW, hipStream_t s);
+
+}  // namespace ace

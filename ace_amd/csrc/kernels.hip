@@ -1,0 +1,880 @@
+// gfx950 (MI355X / CDNA4) kernels for the SFNO forward step.
+//
+// One fp32 tile engine - LDS-staged operands, v_mfma_f32_32x32x2_f32 accumulation
+// (exact fp32, k-ordered fma chain, 64-lane wavefronts, 64x64 output per wave) -
+// carries every contraction on the path:
+//   * 1x1 convolutions (encoder, inner skip, MLP, decoder)  sfnonet.py:229, layers.py:117-124
+//   * Legendre quadrature / synthesis, batched over m        sht_fix.py:134-138, 208-219
+//   * dhconv spectral filter, batched over l                 contractions.py:183-195
+//   * folded real DFT along longitude (forward and inverse)  fft.py:61-96
+// Elementwise work (instance-norm affine, bias, exact GELU, residual adds,
+// (de)normalisation) is fused into the operand loaders and epilogues so that
+// no normalised / concatenated / transposed copy of an activation is ever
+// written to HBM.
+//
+// Written for gfx950 only: wavefront = 64, no portability paths.
+#include "kernels.h"
+
+namespace ace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DEVINL __device__ __forceinline__
+
+DEVINL float act_apply(float v, int act) {
+    switch (act) {
+        case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // exact erf GELU (nn.GELU)
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_SILU: return v / (1.0f + expf(-v));
+        default: return v;
+    }
+}
+
+// Workgroup b is observed to run on XCD b % 8.  Give each XCD a contiguous chunk of
+// logical tiles so tiles that share an operand panel also share an L2 (speed only;
+// bijective for any nblk).
+DEVINL int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// row of accumulator register r for lane-half h in a 32x32 MFMA tile
+DEVINL int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+constexpr int BK = 16;  // k-depth of one LDS stage
+
+// ---------------------------------------------------------------------------------------------
+// operand stagers: global -> registers (issued early) -> LDS (written after the MFMAs)
+// ---------------------------------------------------------------------------------------------
+
+// A tile from a row-major [M][K] matrix, stored k-major in LDS: As[k][m] (pitch SA, SA % 8 == 2 so the
+// four transposing ds_write_b32 of a lane group hit 32 distinct banks).
+template <int BM, int NT, bool VEC>
+struct StageA {
+    static constexpr int G = BM * BK / 4 / NT;
+    static constexpr int SA = BM + 2;
+    float4 r[G];
+    DEVINL void load(const float* __restrict__ A, long lda, int m0, int M, int k0, int kend, int tid) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int f = tid + g * NT;
+            const int row = f / (BK / 4), kc = f % (BK / 4);
+            const int m = m0 + row, k = k0 + 4 * kc;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < M && k < kend) {
+                const float* p = A + (long)m * lda + k;
+                if (VEC && k + 3 < kend) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    v.x = p[0];
+                    if (k + 1 < kend) v.y = p[1];
+                    if (k + 2 < kend) v.z = p[2];
+                    if (k + 3 < kend) v.w = p[3];
+                }
+            }
+            r[g] = v;
+        }
+    }
+    DEVINL void store(float* As, int tid) const {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int f = tid + g * NT;
+            const int row = f / (BK / 4), kc = f % (BK / 4);
+            float* d = As + (4 * kc) * SA + row;
+            d[0] = r[g].x;
+            d[SA] = r[g].y;
+            d[2 * SA] = r[g].z;
+            d[3 * SA] = r[g].w;
+        }
+    }
+};
+
+// B tile from a row-major [K][N] matrix: Bs[k][n] (pitch SB = BN + 4, 16-byte rows -> ds_write_b128).
+// Optional second source for rows k >= K1 and optional per-row affine (fused instance norm).
+template <int BN, int NT, bool VEC>
+struct StageB {
+    static constexpr int G = BN * BK / 4 / NT;
+    static constexpr int SB = BN + 4;
+    float4 r[G];
+    DEVINL void load(const float* __restrict__ B, long ldb, const float* __restrict__ B2, long ldb2, int K1,
+                     const float* __restrict__ bsc, const float* __restrict__ bsh, int n0, int N, int k0, int kend,
+                     int tid, int kvalid = 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int f = tid + g * NT;
+            const int kr = f / (BN / 4), nc = f % (BN / 4);
+            const int k = k0 + kr, n = n0 + 4 * nc;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kend && k >= kvalid && n < N) {
+                const float* p = (K1 >= 0 && k >= K1) ? (B2 + (long)(k - K1) * ldb2 + n) : (B + (long)k * ldb + n);
+                if (VEC && n + 3 < N) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    v.x = p[0];
+                    if (n + 1 < N) v.y = p[1];
+                    if (n + 2 < N) v.z = p[2];
+                    if (n + 3 < N) v.w = p[3];
+                }
+                if (bsc != nullptr) {
+                    const float s = bsc[k], t = bsh[k];
+                    v.x = fmaf(v.x, s, t);
+                    v.y = fmaf(v.y, s, t);
+                    v.z = fmaf(v.z, s, t);
+                    v.w = fmaf(v.w, s, t);
+                }
+            }
+            r[g] = v;
+        }
+    }
+    DEVINL void store(float* Bs, int tid) const {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int f = tid + g * NT;
+            const int kr = f / (BN / 4), nc = f % (BN / 4);
+            *reinterpret_cast<float4*>(Bs + kr * SB + 4 * nc) = r[g];
+        }
+    }
+};
+
+// one LDS stage of MFMAs for a 64x64 wave tile: 2x2 tiles of 32x32, K = 2 per instruction;
+// lane half h supplies k = ks + h (A[i][k] / B[k][j] fragments are one VGPR each)
+template <int SA, int SB>
+DEVINL void mma_stage(const float* As, const float* Bs, int arow, int bcol, int h, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 2) {
+        const float a0 = As[(ks + h) * SA + arow];
+        const float a1 = As[(ks + h) * SA + arow + 32];
+        const float b0 = Bs[(ks + h) * SB + bcol];
+        const float b1 = Bs[(ks + h) * SB + bcol + 32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched GEMM with fused epilogue
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN, bool VA, bool VB>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p, int tilesM, int tilesN) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
+    using SA_t = StageA<BM, NT, VA>;
+    using SB_t = StageB<BN, NT, VB>;
+    constexpr int SA = SA_t::SA, SB = SB_t::SB;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * SA + 2 * BK * SB];
+    float* As = smem;
+    float* Bs = smem + 2 * BK * SA;
+
+    const int nblk = tilesM * tilesN * p.nbatch;
+    const int lid = xcd_remap(blockIdx.x, nblk);
+    const int tile_m = lid % tilesM;
+    const int rest = lid / tilesM;
+    const int tile_n = rest % tilesN;
+    const int batch = rest / tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    int M = p.M, kbeg = 0, kvalid = 0;
+    if (p.tri == TRI_ROWS_GE_BATCH) {
+        if (m0 + BM <= batch) return;  // rows l < m: table is zero there, output stays at its memset zeros
+    } else if (p.tri == TRI_K_GE_BATCH) {
+        kbeg = (batch / BK) * BK;
+        kvalid = batch;  // rows l < m of the spectral operand are never written: read them as zero
+    } else if (p.tri == TRI_ROWS_LE_BATCH) {
+        const int me = (batch + 1) * p.trimul;
+        M = me < M ? me : M;
+        if (m0 >= M) return;
+    }
+    const int kend = p.K;
+
+    const float* A = p.A + (long)batch * p.sA;
+    const float* B = p.B + (long)batch * p.sB;
+    const float* B2 = p.B2 ? p.B2 + (long)batch * p.sB2 : nullptr;
+    const float* bsc = p.bsc ? p.bsc + (long)batch * p.sbs : nullptr;
+    const float* bsh = p.bsh ? p.bsh + (long)batch * p.sbs : nullptr;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int arow = wm * 64 + i, bcol = wn * 64 + i;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    SA_t sa;
+    SB_t sb;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        sa.load(A, p.lda, m0, M, kbeg, kend, tid);
+        sb.load(B, p.ldb, B2, p.ldb2, p.K1, bsc, bsh, n0, p.N, kbeg, kend, tid, kvalid);
+        sa.store(As, tid);
+        sb.store(Bs, tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1 < nk);
+        if (more) {  // next stage's global loads fly under this stage's MFMAs
+            const int k0 = kbeg + (kt + 1) * BK;
+            sa.load(A, p.lda, m0, M, k0, kend, tid);
+            sb.load(B, p.ldb, B2, p.ldb2, p.K1, bsc, bsh, n0, p.N, k0, kend, tid, kvalid);
+        }
+        mma_stage<SA, SB>(As + cur * BK * SA, Bs + cur * BK * SB, arow, bcol, h, acc);
+        if (more) {
+            sa.store(As + (cur ^ 1) * BK * SA, tid);
+            sb.store(Bs + (cur ^ 1) * BK * SB, tid);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lanes run along columns (128-byte row segments per store instruction)
+    float* C = p.C + (long)batch * p.sC;
+    const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
+    const float* rsc = p.rsc ? p.rsc + (long)batch * p.srs : nullptr;
+    const float* rsh = p.rsh ? p.rsh + (long)batch * p.srs : nullptr;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 64 + tm * 32 + acc_row(r, h);
+            if (row >= M) continue;
+            const float bv = p.bias ? p.bias[row] : 0.f;
+            float rs = 1.f, rt = 0.f, os = 1.f, ot = 0.f;
+            if (rsc) { rs = rsc[row]; rt = rsh[row]; }
+            if (p.osc) { os = p.osc[row]; ot = p.osh[row]; }
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const int col = n0 + wn * 64 + tn * 32 + i;
+                if (col >= p.N) continue;
+                float v = acc[tm][tn][r] + bv;
+                if (R) {
+                    float rv = R[(long)row * p.ldr + col];
+                    if (rsc) rv = fmaf(rv, rs, rt);
+                    v += rv;
+                }
+                v = act_apply(v, p.act);
+                if (p.osc) v = fmaf(v, os, ot);
+                C[(long)row * p.ldc + col] = v;
+            }
+        }
+    }
+}
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int WM, int WN>
+static hipError_t launch_gemm_cfg(const GemmArgs& a, hipStream_t s) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
+    const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
+    const long nblk = (long)tilesM * tilesN * a.nbatch;
+    if (nblk <= 0) return hipSuccess;
+    const bool va = al16(a.A) && (a.lda % 4 == 0) && (a.sA % 4 == 0);
+    bool vb = al16(a.B) && (a.ldb % 4 == 0) && (a.sB % 4 == 0);
+    if (a.B2) vb = vb && al16(a.B2) && (a.ldb2 % 4 == 0) && (a.sB2 % 4 == 0);
+    dim3 grid((unsigned)nblk), block(NT);
+    if (va && vb)
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, true, true>), grid, block, 0, s, a, tilesM, tilesN);
+    else if (va)
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, true, false>), grid, block, 0, s, a, tilesM, tilesN);
+    else if (vb)
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, false, true>), grid, block, 0, s, a, tilesM, tilesN);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, false, false>), grid, block, 0, s, a, tilesM, tilesN);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
+    // 128x128 when the row count tiles well by 128, else 64x256 (M = 180/181-row spectral problems, M = 50)
+    const int waste128 = ((a.M + 127) / 128) * 128 - a.M;
+    const int waste64 = ((a.M + 63) / 64) * 64 - a.M;
+    if (a.M >= 128 && waste128 <= waste64) return launch_gemm_cfg<2, 2>(a, s);
+    return launch_gemm_cfg<1, 4>(a, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward longitude DFT (2*pi*rfft(norm="forward"), fft.py:61-76 via sht_fix.py:127), folded:
+//   Re X[m] = sum_{w<=W/2} fc[m][w] * (x[w] + x[W-w]),  Im X[m] = sum fs[m][w] * (x[w] - x[W-w])
+// rows = m, columns = (k, b, c), batch = re/im.  The instance-norm affine is applied on load.
+// Output goes straight to the channel-fastest spectral layout X[m][k][b][ri][c].
+// ---------------------------------------------------------------------------------------------
+template <int BN, int NT, bool VEC>
+struct StageFold {
+    static constexpr int G = BN * BK / 4 / NT;
+    static constexpr int SB = BN + 2;  // transposing b32 writes: pitch % 8 == 2
+    float4 r[G];
+    const float* base[G];
+    float sc[G], sh[G];
+    DEVINL void init(const DftArgs& p, int n0, int ncols, int tid) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int f = tid + g * NT;
+            const int n = n0 + f / (BK / 4);
+            base[g] = nullptr;
+            sc[g] = 1.f;
+            sh[g] = 0.f;
+            if (n < ncols) {
+                const int c = n % p.C, kb = n / p.C;
+                const int b = kb % p.Bt, k = kb / p.Bt;
+                base[g] = p.x + ((long)(b * p.C + c) * p.H + k) * p.W;
+                if (p.sc) { sc[g] = p.sc[b * p.C + c]; sh[g] = p.sh[b * p.C + c]; }
+            }
+        }
+    }
+    DEVINL void load(int ri, int W, int Kf, int w0, int tid) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int f = tid + g * NT;
+            const int w = w0 + 4 * (f % (BK / 4));
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            const float* bp = base[g];
+            if (bp != nullptr && w < Kf) {
+                float xv[4];
+                if (VEC && w + 3 < W) {
+                    const float4 t = *reinterpret_cast<const float4*>(bp + w);
+                    xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[e] = (w + e < W) ? bp[w + e] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int we = w + e;
+                    if (we < Kf) {
+                        const float a = fmaf(xv[e], sc[g], sh[g]);
+                        const bool unpaired = (we == 0) || (2 * we == W);
+                        if (unpaired) {
+                            o[e] = ri == 0 ? a : 0.f;
+                        } else {
+                            const float m = fmaf(bp[W - we], sc[g], sh[g]);
+                            o[e] = ri == 0 ? a + m : a - m;
+                        }
+                    }
+                }
+            }
+            r[g] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    DEVINL void store(float* Bs, int tid) const {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int f = tid + g * NT;
+            const int nl = f / (BK / 4), wc = f % (BK / 4);
+            float* d = Bs + (4 * wc) * SB + nl;
+            d[0] = r[g].x;
+            d[SB] = r[g].y;
+            d[2 * SB] = r[g].z;
+            d[3 * SB] = r[g].w;
+        }
+    }
+};
+
+template <int WM, int WN, bool VX>
+__global__ __launch_bounds__(64 * WM * WN) void dft_forward_kernel(DftArgs p, int tilesM, int tilesN) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
+    using SA_t = StageA<BM, NT, true>;  // tables are library-owned, 16B aligned, pitch % 4 == 0
+    using SB_t = StageFold<BN, NT, VX>;
+    constexpr int SA = SA_t::SA, SB = SB_t::SB;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * SA + 2 * BK * SB];
+    float* As = smem;
+    float* Bs = smem + 2 * BK * SA;
+
+    const int nblk = tilesM * tilesN * 2;
+    const int lid = xcd_remap(blockIdx.x, nblk);
+    const int ri = lid & 1;  // re/im tiles of the same columns run back to back (shared x lines in L2)
+    const int tile_m = (lid >> 1) % tilesM;
+    const int tile_n = (lid >> 1) / tilesM;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int ncols = p.H * p.Bt * p.C;
+    const int Kf = p.W / 2 + 1;
+    const float* T = ri == 0 ? p.tc : p.ts;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int arow = wm * 64 + i, bcol = wn * 64 + i;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    SA_t sa;
+    SB_t sb;
+    sb.init(p, n0, ncols, tid);
+    const int nk = (Kf + BK - 1) / BK;
+    sa.load(T, p.ldt, m0, p.Mm, 0, Kf, tid);
+    sb.load(ri, p.W, Kf, 0, tid);
+    sa.store(As, tid);
+    sb.store(Bs, tid);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            sa.load(T, p.ldt, m0, p.Mm, (kt + 1) * BK, Kf, tid);
+            sb.load(ri, p.W, Kf, (kt + 1) * BK, tid);
+        }
+        mma_stage<SA, SB>(As + cur * BK * SA, Bs + cur * BK * SB, arow, bcol, h, acc);
+        if (more) {
+            sa.store(As + (cur ^ 1) * BK * SA, tid);
+            sb.store(Bs + (cur ^ 1) * BK * SB, tid);
+        }
+        __syncthreads();
+    }
+
+    const long N2 = (long)p.Bt * 2 * p.C;
+    long coff[2];
+    bool cok[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int n = n0 + wn * 64 + tn * 32 + i;
+        cok[tn] = n < ncols;
+        const int c = n % p.C, kb = n / p.C;  // kb = k * Bt + b
+        coff[tn] = (long)kb * 2 * p.C + (long)ri * p.C + c;
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + tm * 32 + acc_row(r, h);
+            if (m >= p.Mm) continue;
+            float* orow = p.spec_out + (long)m * p.H * N2;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+                if (cok[tn]) orow[coff[tn]] = acc[tm][tn][r];
+        }
+}
+
+hipError_t launch_dft_forward(const DftArgs& a, hipStream_t s) {
+    constexpr int WM = 1, WN = 4, BM = 64, BN = 256, NT = 256;
+    const int ncols = a.H * a.Bt * a.C;
+    const int tilesM = (a.Mm + BM - 1) / BM, tilesN = (ncols + BN - 1) / BN;
+    const bool vx = al16(a.x) && (a.W % 4 == 0);
+    dim3 grid((unsigned)(tilesM * tilesN * 2)), block(NT);
+    if (vx)
+        hipLaunchKernelGGL((dft_forward_kernel<WM, WN, true>), grid, block, 0, s, a, tilesM, tilesN);
+    else
+        hipLaunchKernelGGL((dft_forward_kernel<WM, WN, false>), grid, block, 0, s, a, tilesM, tilesN);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// inverse longitude DFT (irfft(norm="forward") after zeroing Im of m=0/Nyquist, fft.py:78-96), folded:
+//   P[w] = sum_m Re S[m] gc[m][w],  Q[w] = sum_m Im S[m] gs[m][w];  y[w] = P + Q,  y[W-w] = P - Q
+// rows = (k, b, c) flattened, columns = w <= W/2.  gs[0][:] = gs[W/2][:] = 0 exactly, which is the
+// reference's "zero the imaginary part" step.  The spectral-filter bias is added on the way out.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int NT, bool VEC>
+struct StageSpecK {  // A operand, k-major source: element (row nn, k = m) at spec[m*ms + rb(nn) + ri*C]
+    static constexpr int G = BM * BK / 4 / NT;
+    static constexpr int SA = BM + 4;
+    float4 r[2][G];
+    long rb[G][4];
+    bool ok[G][4];
+    DEVINL void init(int nn0, int nrows, int C, int tid) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int f = tid + g * NT;
+            const int mc = f % (BM / 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int nn = nn0 + 4 * mc + e;
+                ok[g][e] = nn < nrows;
+                rb[g][e] = (long)(nn / C) * 2 * C + (nn % C);
+            }
+        }
+    }
+    DEVINL void load(const float* __restrict__ S, long ms, int C, int Mm, int k0, int tid) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int f = tid + g * NT;
+            const int m = k0 + f / (BM / 4);
+#pragma unroll
+            for (int ri = 0; ri < 2; ++ri) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < Mm) {
+                    const float* p = S + (long)m * ms + (long)ri * C;
+                    if (VEC && ok[g][3]) {
+                        v = *reinterpret_cast<const float4*>(p + rb[g][0]);
+                    } else {
+                        if (ok[g][0]) v.x = p[rb[g][0]];
+                        if (ok[g][1]) v.y = p[rb[g][1]];
+                        if (ok[g][2]) v.z = p[rb[g][2]];
+                        if (ok[g][3]) v.w = p[rb[g][3]];
+                    }
+                }
+                r[ri][g] = v;
+            }
+        }
+    }
+    DEVINL void store(float* As /* [2][BK][SA] */, int tid) const {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int f = tid + g * NT;
+            const int kr = f / (BM / 4), mc = f % (BM / 4);
+            *reinterpret_cast<float4*>(As + kr * SA + 4 * mc) = r[0][g];
+            *reinterpret_cast<float4*>(As + BK * SA + kr * SA + 4 * mc) = r[1][g];
+        }
+    }
+};
+
+template <bool VS>
+__global__ __launch_bounds__(256) void dft_inverse_kernel(DftArgs p, int tilesM, int tilesN) {
+    constexpr int BM = 128, BN = 64, NT = 256;
+    using SA_t = StageSpecK<BM, NT, VS>;
+    using SB_t = StageB<BN, NT, true>;
+    constexpr int SA = SA_t::SA, SB = SB_t::SB;
+    // per buffer: A re/im planes [2][BK][SA], tables cos/sin [2][BK][SB]
+    constexpr int ABUF = 2 * BK * SA, BBUF = 2 * BK * SB;
+    __shared__ __attribute__((aligned(16))) float smem[2 * ABUF + 2 * BBUF];
+    float* As = smem;
+    float* Bs = smem + 2 * ABUF;
+
+    const int nblk = tilesM * tilesN;
+    const int lid = xcd_remap(blockIdx.x, nblk);
+    const int tile_n = lid % tilesN;  // the w-tiles of one row panel run back to back
+    const int tile_m = lid / tilesN;
+    const int nn0 = tile_m * BM, n0 = tile_n * BN;
+    const int nrows = p.H * p.Bt * p.C;
+    const int Kf = p.W / 2 + 1;
+    const long N2 = (long)p.Bt * 2 * p.C;
+    const long ms = (long)p.H * N2;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int arow = wave * 32 + i;
+
+    f32x16 P[2], Q[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { P[t][r] = 0.f; Q[t][r] = 0.f; }
+
+    SA_t sa;
+    SB_t sbc, sbs;
+    sa.init(nn0, nrows, p.C, tid);
+    const int nk = (p.Mm + BK - 1) / BK;
+    sa.load(p.spec, ms, p.C, p.Mm, 0, tid);
+    sbc.load(p.tc, p.ldt, nullptr, 0, -1, nullptr, nullptr, n0, Kf, 0, p.Mm, tid);
+    sbs.load(p.ts, p.ldt, nullptr, 0, -1, nullptr, nullptr, n0, Kf, 0, p.Mm, tid);
+    sa.store(As, tid);
+    sbc.store(Bs, tid);
+    sbs.store(Bs + BK * SB, tid);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            const int k0 = (kt + 1) * BK;
+            sa.load(p.spec, ms, p.C, p.Mm, k0, tid);
+            sbc.load(p.tc, p.ldt, nullptr, 0, -1, nullptr, nullptr, n0, Kf, k0, p.Mm, tid);
+            sbs.load(p.ts, p.ldt, nullptr, 0, -1, nullptr, nullptr, n0, Kf, k0, p.Mm, tid);
+        }
+        {
+            const float* Ar = As + cur * ABUF;
+            const float* Ai = Ar + BK * SA;
+            const float* Bc = Bs + cur * BBUF;
+            const float* Bsn = Bc + BK * SB;
+#pragma unroll
+            for (int ks = 0; ks < BK; ks += 2) {
+                const float ar = Ar[(ks + h) * SA + arow];
+                const float ai = Ai[(ks + h) * SA + arow];
+                const float c0 = Bc[(ks + h) * SB + i];
+                const float c1 = Bc[(ks + h) * SB + i + 32];
+                const float s0 = Bsn[(ks + h) * SB + i];
+                const float s1 = Bsn[(ks + h) * SB + i + 32];
+                P[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, c0, P[0], 0, 0, 0);
+                P[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, c1, P[1], 0, 0, 0);
+                Q[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, s0, Q[0], 0, 0, 0);
+                Q[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, s1, Q[1], 0, 0, 0);
+            }
+        }
+        if (more) {
+            sa.store(As + (cur ^ 1) * ABUF, tid);
+            sbc.store(Bs + (cur ^ 1) * BBUF, tid);
+            sbs.store(Bs + (cur ^ 1) * BBUF + BK * SB, tid);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int nn = nn0 + wave * 32 + acc_row(r, h);
+        if (nn >= nrows) continue;
+        const int c = nn % p.C, kb = nn / p.C;
+        const int b = kb % p.Bt, k = kb / p.Bt;
+        float* yrow = p.y + ((long)(b * p.C + c) * p.H + k) * p.W;
+        const float bv = p.bias ? p.bias[c] : 0.f;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int w = n0 + tn * 32 + i;
+            if (w >= Kf) continue;
+            const float pv = P[tn][r], qv = Q[tn][r];
+            yrow[w] = (pv + qv) + bv;
+            if (w != 0 && 2 * w != p.W) yrow[p.W - w] = (pv - qv) + bv;
+        }
+    }
+}
+
+hipError_t launch_dft_inverse(const DftArgs& a, hipStream_t s) {
+    constexpr int BM = 128, BN = 64;
+    const int nrows = a.H * a.Bt * a.C;
+    const int Kf = a.W / 2 + 1;
+    const int tilesM = (nrows + BM - 1) / BM, tilesN = (Kf + BN - 1) / BN;
+    const bool vs = al16(a.spec) && (a.C % 4 == 0);
+    dim3 grid((unsigned)(tilesM * tilesN)), block(256);
+    if (vs)
+        hipLaunchKernelGGL((dft_inverse_kernel<true>), grid, block, 0, s, a, tilesM, tilesN);
+    else
+        hipLaunchKernelGGL((dft_inverse_kernel<false>), grid, block, 0, s, a, tilesM, tilesN);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// instance-norm statistics (nn.InstanceNorm2d eps=1e-6 affine, sfnonet.py:593-601): one workgroup per
+// (b, c) plane, fp64 accumulation, emits the affine (scale, shift) that consumers apply on load.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void instnorm_stats_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, int C,
+                                                             long HW, float* __restrict__ scale,
+                                                             float* __restrict__ shift) {
+    const int plane = blockIdx.x;
+    const float* xp = x + (long)plane * HW;
+    double s = 0.0, ss = 0.0;
+    const bool vec = ((reinterpret_cast<uintptr_t>(xp) & 15) == 0) && (HW % 4 == 0);
+    if (vec) {
+        const float4* x4 = reinterpret_cast<const float4*>(xp);
+        const long n4 = HW / 4;
+        for (long j = threadIdx.x; j < n4; j += blockDim.x) {
+            const float4 v = x4[j];
+            const float ps = (v.x + v.y) + (v.z + v.w);
+            const float pq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
+            s += (double)ps;
+            ss += (double)pq;
+        }
+    } else {
+        for (long j = threadIdx.x; j < HW; j += blockDim.x) {
+            const double v = (double)xp[j];
+            s += v;
+            ss += v * v;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        ss += __shfl_down(ss, off, 64);
+    }
+    __shared__ double red[2][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0.0, tss = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { ts += red[0][w]; tss += red[1][w]; }
+        const double mean = ts / (double)HW;
+        double var = tss / (double)HW - mean * mean;  // biased variance
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const int c = plane % C;
+        const double g = gamma ? (double)gamma[c] : 1.0;
+        const double bt = beta ? (double)beta[c] : 0.0;
+        const double sc = g * rstd;
+        scale[plane] = (float)sc;
+        shift[plane] = (float)(bt - mean * sc);
+    }
+}
+
+hipError_t launch_instnorm_stats(const float* x, const float* gamma, const float* beta, float eps, int Bt, int C,
+                                 long HW, float* scale, float* shift, hipStream_t s) {
+    hipLaunchKernelGGL(instnorm_stats_kernel, dim3((unsigned)(Bt * C)), dim3(512), 0, s, x, gamma, beta, eps, C, HW,
+                       scale, shift);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout converters (API boundary only; the network path never leaves the internal layout)
+// ---------------------------------------------------------------------------------------------
+__global__ void spec_to_ref_kernel(const float* __restrict__ D, float* __restrict__ out, int Bt, int C, int L, int Mm) {
+    const long total = (long)Bt * C * L * Mm;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int m = t % Mm;
+        long q = t / Mm;
+        const int l = q % L;
+        q /= L;
+        const int c = q % C;
+        const int b = q / C;
+        const long src = (((long)l * Mm + m) * Bt + b) * 2 * C + c;
+        out[2 * t] = D[src];
+        out[2 * t + 1] = D[src + C];
+    }
+}
+__global__ void ref_to_spec_kernel(const float* __restrict__ in, float* __restrict__ E, int Bt, int C, int L, int Mm) {
+    const long total = (long)Bt * C * L * Mm;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int m = t % Mm;
+        long q = t / Mm;
+        const int l = q % L;
+        q /= L;
+        const int c = q % C;
+        const int b = q / C;
+        const long dst = (((long)l * Mm + m) * Bt + b) * 2 * C + c;
+        E[dst] = in[2 * t];
+        E[dst + C] = in[2 * t + 1];
+    }
+}
+static inline unsigned grid_for(long total, int block) {
+    long g = (total + block - 1) / block;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+hipError_t launch_spec_to_ref(const float* D, float* out, int Bt, int C, int L, int Mm, hipStream_t s) {
+    const long total = (long)Bt * C * L * Mm;
+    hipLaunchKernelGGL(spec_to_ref_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, D, out, Bt, C, L, Mm);
+    return hipGetLastError();
+}
+hipError_t launch_ref_to_spec(const float* in, float* E, int Bt, int C, int L, int Mm, hipStream_t s) {
+    const long total = (long)Bt * C * L * Mm;
+    hipLaunchKernelGGL(ref_to_spec_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, E, Bt, C, L, Mm);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// "diagonal" operator: per-(l, m) Cin x Cout complex mat-vec (contractions.py:169-180).  Pure weight
+// bandwidth (the weight is Cin*Cout*L*M complex); only used by small nets and three of the goldens.
+// ---------------------------------------------------------------------------------------------
+__global__ void contract_diagonal_kernel(const float* __restrict__ D, const float* __restrict__ w,
+                                         float* __restrict__ E, int Bt, int Cin, int Cout, int L, int Mm) {
+    const long total = (long)L * Mm * Bt * Cout;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int m = t % Mm;  // m fastest: weight reads coalesce along m
+        long q = t / Mm;
+        const int l = q % L;
+        q /= L;
+        const int o = q % Cout;
+        const int b = q / Cout;
+        const float* xin = D + (((long)l * Mm + m) * Bt + b) * 2 * Cin;
+        float re = 0.f, im = 0.f;
+        for (int i = 0; i < (m <= l ? Cin : 0); ++i) {  // coefficients with m > l are identically zero
+            const float xr = xin[i], xi = xin[Cin + i];
+            const float2 wv = *reinterpret_cast<const float2*>(w + ((((long)i * Cout + o) * L + l) * Mm + m) * 2);
+            re = fmaf(xr, wv.x, re);
+            re = fmaf(-xi, wv.y, re);
+            im = fmaf(xr, wv.y, im);
+            im = fmaf(xi, wv.x, im);
+        }
+        float* eo = E + (((long)l * Mm + m) * Bt + b) * 2 * Cout;
+        eo[o] = re;
+        eo[Cout + o] = im;
+    }
+}
+hipError_t launch_contract_diagonal(const float* D, const float* w, float* E, int Bt, int Cin, int Cout, int L, int Mm,
+                                    hipStream_t s) {
+    const long total = (long)L * Mm * Bt * Cout;
+    hipLaunchKernelGGL(contract_diagonal_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, D, w, E, Bt, Cin, Cout, L,
+                       Mm);
+    return hipGetLastError();
+}
+
+// dhconv weight (Cin, Cout, L, 2) -> per-l real 2Cin x 2Cout matrix acting on planar (re | im) vectors:
+//   [ out_re | out_im ] = [ x_re | x_im ] * [[ w_re, w_im ], [ -w_im, w_re ]]
+__global__ void expand_dhconv_weight_kernel(const float* __restrict__ w, float* __restrict__ wx, int Cin, int Cout,
+                                            int L) {
+    const long total = (long)L * Cin * Cout;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int o = t % Cout;
+        long q = t / Cout;
+        const int i = q % Cin;
+        const int l = q / Cin;
+        const float2 wv = *reinterpret_cast<const float2*>(w + (((long)i * Cout + o) * L + l) * 2);
+        float* base = wx + (long)l * (2 * Cin) * (2 * Cout);
+        base[(long)i * 2 * Cout + o] = wv.x;
+        base[(long)i * 2 * Cout + Cout + o] = wv.y;
+        base[(long)(Cin + i) * 2 * Cout + o] = -wv.y;
+        base[(long)(Cin + i) * 2 * Cout + Cout + o] = wv.x;
+    }
+}
+hipError_t launch_expand_dhconv_weight(const float* w, float* wx, int Cin, int Cout, int L, hipStream_t s) {
+    const long total = (long)L * Cin * Cout;
+    hipLaunchKernelGGL(expand_dhconv_weight_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, w, wx, Cin, Cout, L);
+    return hipGetLastError();
+}
+
+__global__ void rowaffine_add_kernel(const float* __restrict__ x, const float* __restrict__ sc,
+                                     const float* __restrict__ sh, const float* __restrict__ r,
+                                     const float* __restrict__ rsc, const float* __restrict__ rsh,
+                                     float* __restrict__ y, long rows, long n) {
+    const long total = rows * n;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long row = t / n;
+        float v = x[t];
+        if (sc) v = fmaf(v, sc[row], sh[row]);
+        if (r) {
+            float rv = r[t];
+            if (rsc) rv = fmaf(rv, rsc[row], rsh[row]);
+            v += rv;
+        }
+        y[t] = v;
+    }
+}
+hipError_t launch_rowaffine_add(const float* x, const float* sc, const float* sh, const float* r, const float* rsc,
+                                const float* rsh, float* y, long rows, long n, hipStream_t s) {
+    hipLaunchKernelGGL(rowaffine_add_kernel, dim3(grid_for(rows * n, 256)), dim3(256), 0, s, x, sc, sh, r, rsc, rsh, y,
+                       rows, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// stepper glue: gather + normalise into the packed network input, scatter + de-normalise the output
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_normalize_kernel(const float* const* __restrict__ srcs, const long* __restrict__ strides,
+                                      const float* __restrict__ mean, const float* __restrict__ stdv,
+                                      float* __restrict__ dst, int nch, long HW) {
+    const int j = blockIdx.y, b = blockIdx.z;
+    const float* src = srcs[j] + (long)b * strides[j];
+    float* d = dst + ((long)b * nch + j) * HW;
+    const float mu = mean[j], sd = stdv[j];
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < HW; t += (long)gridDim.x * blockDim.x)
+        d[t] = __fdiv_rn(__fsub_rn(src[t], mu), sd);  // normalizer.py:221: (t - means[k]) / stds[k], unfused
+}
+__global__ void unpack_denormalize_kernel(const float* __restrict__ src, const float* __restrict__ mean,
+                                          const float* __restrict__ stdv, float* const* __restrict__ dsts,
+                                          const long* __restrict__ strides, int nch, long HW) {
+    const int j = blockIdx.y, b = blockIdx.z;
+    const float* s = src + ((long)b * nch + j) * HW;
+    float* d = dsts[j] + (long)b * strides[j];
+    const float mu = mean[j], sd = stdv[j];
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < HW; t += (long)gridDim.x * blockDim.x)
+        d[t] = __fadd_rn(__fmul_rn(s[t], sd), mu);  // normalizer.py:236: t * stds[k] + means[k], two roundings
+}
+hipError_t launch_pack_normalize(const float* const* srcs, const long* strides, const float* mean, const float* stdv,
+                                 float* dst, int Bt, int nch, long HW, hipStream_t s) {
+    unsigned gx = (unsigned)((HW + 1023) / 1024);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(pack_normalize_kernel, dim3(gx, nch, Bt), dim3(256), 0, s, srcs, strides, mean, stdv, dst, nch,
+                       HW);
+    return hipGetLastError();
+}
+hipError_t launch_unpack_denormalize(const float* src, const float* mean, const float* stdv, float* const* dsts,
+                                     const long* strides, int Bt, int nch, long HW, hipStream_t s) {
+    unsigned gx = (unsigned)((HW + 1023) / 1024);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(unpack_denormalize_kernel, dim3(gx, nch, Bt), dim3(256), 0, s, src, mean, stdv, dsts, strides,
+                       nch, HW);
+    return hipGetLastError();
+}
+
+}  // namespace ace

@@ -1,0 +1,140 @@
+"""Module registry: the drop-in boundary (fme/core/registry/registry.py:13-59,
+fme/core/registry/module.py:18-210).  Same names, argument meaning and errors:
+`ModuleSelector(type=..., config=...)` looks the builder up by its type string,
+`build(n_in_channels, n_out_channels, dataset_info)` returns a `Module` wrapping an
+`nn.Module` whose parameters carry the reference's names and shapes."""
+
+import abc
+import dataclasses
+from collections.abc import Callable, Mapping
+from typing import Any, ClassVar, Dict, Generic, Optional, Type, TypeVar
+
+import torch
+from torch import nn
+
+T = TypeVar("T")
+
+
+def _strict_from_dict(data_class, data: Mapping[str, Any]):
+    """dacite.from_dict(strict=True) for flat dataclasses (module.py:51-58): unknown keys are an error,
+    missing keys take the dataclass default."""
+    names = {f.name for f in dataclasses.fields(data_class)}
+    extra = set(data) - names
+    if extra:
+        raise ValueError(f'can not match {sorted(extra)} to any data class field of "{data_class.__name__}"')
+    return data_class(**dict(data))
+
+
+class Registry(Generic[T]):
+    """registry.py:13-59."""
+
+    def __init__(self):
+        self._types: Dict[str, Type[T]] = {}
+
+    def register(self, type_name: str) -> Callable[[Type[T]], Type[T]]:
+        def register_func(cls: Type[T]) -> Type[T]:
+            base_type = None
+            if hasattr(self, "__orig_class__"):
+                base_type = self.__orig_class__.__args__[0]
+            if base_type and not issubclass(cls, base_type):
+                raise TypeError(f"{cls} must be a subclass of {base_type}")
+            self._types[type_name] = cls
+            return cls
+
+        return register_func
+
+    def get(self, type_name: str, config: Mapping[str, Any]) -> T:
+        cls = self._types[type_name]  # KeyError for an unknown type, as the reference
+        return cls.from_state(config)
+
+
+@dataclasses.dataclass
+class ModuleConfig(abc.ABC):
+    """module.py:18-58."""
+
+    @abc.abstractmethod
+    def build(self, n_in_channels: int, n_out_channels: int, dataset_info) -> nn.Module: ...
+
+    @classmethod
+    def from_state(cls, state: Mapping[str, Any]) -> "ModuleConfig":
+        return _strict_from_dict(cls, state)
+
+
+CONDITIONAL_BUILDERS = ["NoiseConditionedSFNO", "LocalNet", "SwinTransformer", "NoiseConditionedSwinTransformer"]
+
+
+class Module:
+    """module.py:69-122 (label encodings: only the unconditional case is on this path)."""
+
+    def __init__(self, module: nn.Module, label_encoding=None):
+        self._module = module
+        self._label_encoding = label_encoding
+
+    def __call__(self, input: torch.Tensor, labels=None) -> torch.Tensor:
+        if labels is not None and self._label_encoding is None:
+            raise TypeError("Labels are not allowed for unconditional models")
+        if self._label_encoding is not None:
+            raise NotImplementedError("conditional models are outside the SFNO hot path")
+        return self._module(input)
+
+    @property
+    def torch_module(self) -> nn.Module:
+        return self._module
+
+    def get_state(self) -> Dict[str, Any]:
+        return {**self._module.state_dict(), "label_encoding": None}
+
+    def load_state(self, state: Dict[str, Any]) -> None:
+        state = dict(state)
+        if state.get("label_encoding") is not None:
+            raise NotImplementedError("conditional models are outside the SFNO hot path")
+        state.pop("label_encoding", None)
+        self._module.load_state_dict(state)
+
+    def wrap_module(self, callable: Callable[[nn.Module], nn.Module]) -> "Module":
+        return Module(callable(self._module), self._label_encoding)
+
+    def to(self, device) -> "Module":
+        return Module(self._module.to(device), self._label_encoding)
+
+
+@dataclasses.dataclass
+class ModuleSelector:
+    """module.py:125-210."""
+
+    type: str
+    config: Mapping[str, Any]
+    conditional: bool = False
+    allow_missing_variables: bool = False
+    registry: ClassVar[Registry] = Registry[ModuleConfig]()
+
+    def __post_init__(self):
+        if not isinstance(self.registry, Registry):
+            raise ValueError("ModuleSelector.registry should not be set manually")
+        if self.conditional and self.type not in CONDITIONAL_BUILDERS:
+            raise ValueError(
+                "Conditional predictions require a conditional builder, "
+                f"got {self.type} (available: {CONDITIONAL_BUILDERS})"
+            )
+        self._instance = self.registry.get(self.type, self.config)
+        self.config = dataclasses.asdict(self._instance)  # capture defaults (module.py:158-162)
+
+    @property
+    def module_config(self) -> ModuleConfig:
+        return self._instance
+
+    @classmethod
+    def register(cls, type_name: str):
+        return cls.registry.register(type_name)
+
+    def build(self, n_in_channels: int, n_out_channels: int, dataset_info) -> Module:
+        if self.conditional and len(dataset_info.all_labels) == 0:
+            raise ValueError("Conditional predictions require labels")
+        module = self._instance.build(
+            n_in_channels=n_in_channels, n_out_channels=n_out_channels, dataset_info=dataset_info
+        )
+        return Module(module, None)
+
+    @classmethod
+    def get_available_types(cls):
+        return cls.registry._types.keys()

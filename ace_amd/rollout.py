@@ -1,0 +1,128 @@
+"""RolloutEngine: the stepper loop (fme/ace/stepper/single_module.py:1124-1167) on static HBM
+buffers with the per-step forward replayed from a hipGraph.
+
+Per step s the engine enqueues
+  1. ace_pack_normalize    gather state (previous output or the initial condition) and the forcing
+                           slice (index s, or s+1 for next_step_forcing_names) -> packed, normalised input
+  2. the SFNO forward      (`graph="step"`: the library's captured hipGraph; `graph="window"`: steps 1-3
+                           of the whole window live in one torch-captured hipGraph; `graph=None`: eager launches)
+  3. ace_unpack_denormalize  network output -> out[name][:, s] (denormalised), which is also step s+1's state
+so the numbers are bit-identical to `Stepper.predict` (same kernels, same (x-mean)/std and y*std+mean roundings).
+Nothing is allocated and the host never synchronises inside the window."""
+
+from typing import Dict, Mapping, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .stepper import Stepper
+
+
+class RolloutEngine:
+    def __init__(self, stepper: Stepper, batch: int, n_forward_steps: int, graph: Optional[str] = "step"):
+        if graph not in (None, "step", "window"):
+            raise ValueError("graph must be None, 'step' or 'window'")
+        step = stepper._step_obj
+        cfg = step.config
+        if cfg.residual_prediction or cfg.prescribed_prognostic_names:
+            raise NotImplementedError("residual_prediction / prescribed prognostics are not lowered into the engine")
+        self.stepper = stepper
+        self.net = step.module.torch_module
+        self.B, self.T = batch, n_forward_steps
+        self.H, self.W = step._img_shape
+        self.HW = self.H * self.W
+        self.in_names, self.out_names = list(cfg.in_names), list(cfg.out_names)
+        self.prognostic = [n for n in self.out_names if n in self.in_names]
+        self.forcing_names = [n for n in self.in_names if n not in self.out_names]
+        self.next_step_forcing = set(cfg.next_step_forcing_names)
+        self.graph_mode = graph
+        dev = next(self.net.parameters()).device
+        self.device = dev
+        B, T, H, W = batch, n_forward_steps, self.H, self.W
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.x = torch.zeros(B, len(self.in_names), H, W, **f32)    # packed normalised network input
+        self.y = torch.zeros(B, len(self.out_names), H, W, **f32)   # network output (normalised)
+        self.ic = {n: torch.zeros(B, 1, H, W, **f32) for n in self.prognostic}
+        self.forcing = {n: torch.zeros(B, T + 1, H, W, **f32) for n in self.forcing_names}
+        self.out = {n: torch.zeros(B, T, H, W, **f32) for n in self.out_names}
+        norm = step.normalizer
+        self.in_mean = torch.stack([norm.means[n].to(dev) for n in self.in_names]).contiguous()
+        self.in_std = torch.stack([norm.stds[n].to(dev) for n in self.in_names]).contiguous()
+        self.out_mean = torch.stack([norm.means[n].to(dev) for n in self.out_names]).contiguous()
+        self.out_std = torch.stack([norm.stds[n].to(dev) for n in self.out_names]).contiguous()
+        # per-step pointer tables (device arrays of device pointers) and per-sample strides
+        src_ptrs, src_strides, dst_ptrs = [], [], []
+        for s in range(T):
+            ptrs, strides = [], []
+            for n in self.in_names:
+                if n in self.ic:
+                    if s == 0:
+                        ptrs.append(self.ic[n].data_ptr()); strides.append(self.HW)
+                    else:
+                        ptrs.append(self.out[n].data_ptr() + 4 * (s - 1) * self.HW); strides.append(T * self.HW)
+                else:
+                    t = s + 1 if n in self.next_step_forcing else s
+                    ptrs.append(self.forcing[n].data_ptr() + 4 * t * self.HW); strides.append((T + 1) * self.HW)
+            src_ptrs.append(ptrs); src_strides.append(strides)
+            dst_ptrs.append([self.out[n].data_ptr() + 4 * s * self.HW for n in self.out_names])
+        i64 = dict(dtype=torch.int64, device=dev)
+        self._src_ptrs = torch.tensor(src_ptrs, **i64)
+        self._src_strides = torch.tensor(src_strides, **i64)
+        self._dst_ptrs = torch.tensor(dst_ptrs, **i64)
+        self._dst_strides = torch.full((len(self.out_names),), T * self.HW, **i64)
+        self._window_graph = None
+        self.net._ensure_native(dev, B)
+        self.net.sync_weights()
+
+    # -- one step, enqueued on the current stream
+    def _enqueue_step(self, s: int, use_library_graph: bool):
+        L = _lib.lib()
+        stream = _lib.current_stream()
+        nin, nout = len(self.in_names), len(self.out_names)
+        _lib.check(L.ace_pack_normalize(self._src_ptrs[s].data_ptr(), self._src_strides[s].data_ptr(),
+                                        self.in_mean.data_ptr(), self.in_std.data_ptr(), self.x.data_ptr(),
+                                        self.B, nin, self.HW, stream))
+        fwd = L.ace_sfno_forward_graph if use_library_graph else L.ace_sfno_forward
+        _lib.check(fwd(self.net._native, self.x.data_ptr(), self.y.data_ptr(), self.B, stream))
+        _lib.check(L.ace_unpack_denormalize(self.y.data_ptr(), self.out_mean.data_ptr(), self.out_std.data_ptr(),
+                                            self._dst_ptrs[s].data_ptr(), self._dst_strides.data_ptr(),
+                                            self.B, nout, self.HW, stream))
+
+    def load(self, initial_condition: Mapping[str, torch.Tensor], forcing: Mapping[str, torch.Tensor]):
+        for n in self.prognostic:
+            self.ic[n].copy_(initial_condition[n].reshape(self.B, 1, self.H, self.W))
+        for n in self.forcing_names:
+            self.forcing[n].copy_(forcing[n][:, : self.T + 1])
+
+    def run_window(self):
+        """Enqueue the T steps of the window on the current stream (no host synchronisation)."""
+        if self.graph_mode == "window":
+            if self._window_graph is None:
+                # warm up outside capture (first-touch allocations inside torch), then capture once
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._enqueue_step(0, False)
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for s in range(self.T):
+                        self._enqueue_step(s, False)
+                self._window_graph = g
+            self._window_graph.replay()
+        else:
+            for s in range(self.T):
+                self._enqueue_step(s, self.graph_mode == "step")
+
+    def predict(self, initial_condition, forcing) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
+        """Same contract as Stepper.predict for one window of n_forward_steps."""
+        with torch.no_grad():
+            self.load(initial_condition, forcing)
+            self.run_window()
+        state = {n: self.out[n][:, -1:] for n in self.prognostic}
+        return self.out, state
+
+    def continue_from_last(self):
+        """Carry the final prognostic state into the initial-condition slot (next window of a long rollout)."""
+        for n in self.prognostic:
+            self.ic[n].copy_(self.out[n][:, -1:])

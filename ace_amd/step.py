@@ -1,0 +1,233 @@
+"""Single-module step (fme/core/step/single_module.py:48-511, 595-733; args.py:8-56; output.py:12-28).
+
+normalize -> pack (in_names order) -> network -> unpack (out_names order) -> denormalize
+[-> residual add] [-> prescribed prognostic overwrite].  The corrector and ocean hooks
+of the reference default to identity / None and are not carried;
+configuring them raises instead of being silently ignored."""
+
+import dataclasses
+from collections.abc import Callable, Mapping
+from typing import Any, Dict, List, Optional
+
+import torch
+from torch import nn
+
+from .normalizer import StandardNormalizer
+from .packer import Packer
+from .registry import ModuleSelector
+
+TensorMapping = Mapping[str, torch.Tensor]
+TensorDict = Dict[str, torch.Tensor]
+
+
+@dataclasses.dataclass
+class NormalizationConfig:
+    """means/stds per variable name (fme/core/normalizer.py NormalizationConfig with explicit dicts)."""
+
+    means: Mapping[str, float]
+    stds: Mapping[str, float]
+    fill_nans_on_normalize: bool = False
+    fill_nans_on_denormalize: bool = False
+
+    def build(self, names: List[str]) -> StandardNormalizer:
+        means = {k: torch.tensor(self.means[k], dtype=torch.float) for k in names}
+        stds = {k: torch.tensor(self.stds[k], dtype=torch.float) for k in names}
+        return StandardNormalizer(means, stds, self.fill_nans_on_normalize, self.fill_nans_on_denormalize)
+
+
+class StepArgs:
+    """args.py:8-56."""
+
+    def __init__(self, input: TensorMapping, next_step_input_data: TensorMapping, labels=None,
+                 data_mask: Optional[TensorMapping] = None, stepper_state=None):
+        self.input = input
+        self.next_step_input_data = next_step_input_data
+        self.labels = labels
+        self.data_mask = data_mask
+        self.stepper_state = stepper_state
+
+    def apply_input_process_func(self, func: Callable[[TensorMapping], TensorMapping]) -> "StepArgs":
+        return StepArgs(input=func(self.input), next_step_input_data=func(self.next_step_input_data),
+                        labels=self.labels, data_mask=self.data_mask, stepper_state=self.stepper_state)
+
+
+@dataclasses.dataclass
+class StepOutput:
+    """output.py:12-28 (corrector diagnostics are always empty on this path)."""
+
+    output: TensorDict
+    stepper_state: Any = None
+    corrector_diagnostics: Dict[str, torch.Tensor] = dataclasses.field(default_factory=dict)
+
+
+@dataclasses.dataclass
+class SingleModuleStepConfig:
+    """single_module.py:48-259, restricted to the options on the hot path."""
+
+    builder: ModuleSelector
+    in_names: List[str]
+    out_names: List[str]
+    normalization: NormalizationConfig
+    secondary_decoder: Any = None
+    ocean: Any = None
+    corrector: Any = None
+    next_step_forcing_names: List[str] = dataclasses.field(default_factory=list)
+    prescribed_prognostic_names: List[str] = dataclasses.field(default_factory=list)
+    residual_prediction: bool = False
+    include_channel_mask_inputs: bool = False
+    global_mean_removal: Any = None
+    input_dropout: Any = None
+
+    def __post_init__(self):
+        for field in ("secondary_decoder", "ocean", "corrector", "global_mean_removal", "input_dropout"):
+            if getattr(self, field) is not None:
+                raise NotImplementedError(f"SingleModuleStepConfig.{field} is outside the accelerated hot path")
+        if self.include_channel_mask_inputs:
+            raise NotImplementedError("include_channel_mask_inputs is outside the accelerated hot path")
+        for name in self.prescribed_prognostic_names:
+            if name not in self.out_names:
+                raise ValueError(f"prescribed_prognostic_name '{name}' must be in out_names: {self.out_names}")
+        for name in self.next_step_forcing_names:
+            if name not in self.in_names:
+                raise ValueError(f"next_step_forcing_name '{name}' not in in_names: {self.in_names}")
+            if name in self.out_names:
+                raise ValueError(f"next_step_forcing_name is an output variable: '{name}'")
+
+    @property
+    def n_ic_timesteps(self) -> int:
+        return 1
+
+    @property
+    def _normalize_names(self):
+        return list(set(self.in_names).union(self.out_names))
+
+    @property
+    def input_names(self) -> List[str]:
+        return self.in_names
+
+    @property
+    def output_names(self) -> List[str]:
+        return list(self.out_names)
+
+    @property
+    def prognostic_names(self) -> List[str]:
+        return [n for n in self.out_names if n in self.in_names]
+
+    @property
+    def next_step_input_names(self) -> List[str]:
+        input_only = set(self.input_names).difference(self.output_names)
+        return list(set(input_only).union(self.prescribed_prognostic_names))
+
+    def get_next_step_forcing_names(self) -> List[str]:
+        return self.next_step_forcing_names
+
+    def get_step(self, dataset_info, init_weights: Callable[[List[nn.Module]], None] = lambda _m: None):
+        normalizer = self.normalization.build(self._normalize_names)
+        return SingleModuleStep(config=self, dataset_info=dataset_info, normalizer=normalizer,
+                                init_weights=init_weights)
+
+
+def step_with_adjustments(input: TensorMapping, next_step_input_data: TensorMapping,
+                          network_calls: Callable[[TensorDict], TensorDict], normalizer: StandardNormalizer,
+                          residual_prediction: bool, prognostic_names: List[str],
+                          prescribed_prognostic_names: Optional[List[str]] = None,
+                          stepper_state=None) -> StepOutput:
+    """single_module.py:595-733 with corrector=None, ocean=None, global_mean_removal=None."""
+    if prescribed_prognostic_names is None:
+        prescribed_prognostic_names = []
+    input_norm = normalizer.normalize(input)
+    output_norm = network_calls(input_norm)
+    if residual_prediction:
+        output_norm = {**output_norm, **{k: input_norm[k] + output_norm[k] for k in prognostic_names}}
+    output = normalizer.denormalize(output_norm)
+    for name in prescribed_prognostic_names:
+        if name in next_step_input_data:
+            output = {**output, name: next_step_input_data[name]}
+        else:
+            raise ValueError(f"prescribed_prognostic_name '{name}' not in next_step_input_data")
+    return StepOutput(output=output, stepper_state=stepper_state)
+
+
+class SingleModuleStep:
+    """single_module.py:261-511."""
+
+    TIME_DIM = 1
+    CHANNEL_DIM = -3
+
+    def __init__(self, config: SingleModuleStepConfig, dataset_info, normalizer: StandardNormalizer,
+                 init_weights: Callable[[List[nn.Module]], None] = lambda _m: None, device=None):
+        n_in_channels = len(config.in_names)
+        n_out_channels = len(config.out_names)
+        self.in_packer = Packer(list(config.in_names))
+        self.out_packer = Packer(list(config.out_names))
+        self._normalizer = normalizer
+        module = config.builder.build(n_in_channels=n_in_channels, n_out_channels=n_out_channels,
+                                      dataset_info=dataset_info)
+        dev = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
+        self.module = module.to(dev)
+        init_weights(self.modules)
+        self._img_shape = dataset_info.img_shape
+        self._config = config
+        self._timestep = dataset_info.timestep
+        self.in_names = config.in_names
+        self.out_names = config.out_names
+
+    @property
+    def config(self) -> SingleModuleStepConfig:
+        return self._config
+
+    @property
+    def normalizer(self) -> StandardNormalizer:
+        return self._normalizer
+
+    @property
+    def input_names(self) -> List[str]:
+        return self._config.input_names
+
+    @property
+    def output_names(self) -> List[str]:
+        return self._config.output_names
+
+    @property
+    def prognostic_names(self) -> List[str]:
+        return self._config.prognostic_names
+
+    @property
+    def next_step_forcing_names(self) -> List[str]:
+        return self._config.get_next_step_forcing_names()
+
+    @property
+    def next_step_input_names(self) -> List[str]:
+        return self._config.next_step_input_names
+
+    @property
+    def modules(self) -> nn.ModuleList:
+        return nn.ModuleList([self.module.torch_module])
+
+    def step(self, args: StepArgs, wrapper: Callable[[nn.Module], nn.Module] = lambda x: x) -> StepOutput:
+        def network_call(input_norm: TensorDict) -> TensorDict:
+            if args.data_mask is not None:
+                raise NotImplementedError("data masks are outside the accelerated hot path")
+            input_tensor = self.in_packer.pack(input_norm, axis=self.CHANNEL_DIM)
+            output_tensor = self.module.wrap_module(wrapper)(input_tensor, labels=args.labels)
+            return self.out_packer.unpack(output_tensor, axis=self.CHANNEL_DIM)
+
+        return step_with_adjustments(
+            input=args.input, next_step_input_data=args.next_step_input_data, network_calls=network_call,
+            normalizer=self.normalizer, residual_prediction=self._config.residual_prediction,
+            prognostic_names=self.prognostic_names,
+            prescribed_prognostic_names=self._config.prescribed_prognostic_names,
+            stepper_state=args.stepper_state,
+        )
+
+    def get_state(self):
+        return {"module": self.module.get_state()}
+
+    def load_state(self, state: Dict[str, Any]) -> None:
+        module = dict(state["module"])
+        if "module.device_buffer" in module:
+            del module["module.device_buffer"]
+        # checkpoints written through DummyWrapper/DDP carry a "module." prefix (non_distributed.py:15-28)
+        if module and all(k.startswith("module.") or k == "label_encoding" for k in module):
+            module = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in module.items()}
+        self.module.load_state(module)

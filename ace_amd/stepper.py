@@ -1,0 +1,109 @@
+"""Stepper: the autoregressive loop (fme/ace/stepper/single_module.py:803, 1045-1075, 1124-1259).
+
+`predict_generator` is the reference loop verbatim in behaviour: the state dict feeds
+back prognostic names, input-only (forcing) names are taken at index `step` (or `step+1`
+for `next_step_forcing_names`).  `predict` stacks the per-step outputs over time.
+`ace_amd.rollout.RolloutEngine` is the same loop with static buffers and a captured
+hipGraph per step for long rollouts."""
+
+from collections.abc import Callable, Generator, Mapping
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .step import SingleModuleStep, SingleModuleStepConfig, StepArgs, StepOutput
+
+TensorMapping = Mapping[str, torch.Tensor]
+TensorDict = Dict[str, torch.Tensor]
+
+
+class Stepper:
+    TIME_DIM = 1
+    CHANNEL_DIM = -3
+
+    def __init__(self, step_obj: SingleModuleStep):
+        self._step_obj = step_obj
+        self._input_process_func: Callable[[TensorMapping], TensorMapping] = lambda x: x
+        self._output_masking: Callable[[TensorMapping], TensorDict] = lambda x: dict(x)
+
+    @classmethod
+    def from_config(cls, config: SingleModuleStepConfig, dataset_info, device=None) -> "Stepper":
+        normalizer = config.normalization.build(config._normalize_names)
+        return cls(SingleModuleStep(config, dataset_info, normalizer, device=device))
+
+    # -- properties (single_module.py:960-1043)
+    @property
+    def prognostic_names(self) -> List[str]:
+        return self._step_obj.prognostic_names
+
+    @property
+    def out_names(self) -> List[str]:
+        return self._step_obj.output_names
+
+    @property
+    def n_ic_timesteps(self) -> int:
+        return 1
+
+    @property
+    def modules(self) -> nn.ModuleList:
+        return self._step_obj.modules
+
+    @property
+    def normalizer(self):
+        return self._step_obj.normalizer
+
+    @property
+    def _input_only_names(self) -> set:
+        return set(self._step_obj.input_names).difference(self._step_obj.output_names)
+
+    def set_eval(self):
+        for m in self.modules:
+            m.eval()
+
+    def step(self, args: StepArgs, wrapper: Callable[[nn.Module], nn.Module] = lambda x: x) -> StepOutput:
+        """single_module.py:1045-1075."""
+        args = args.apply_input_process_func(self._input_process_func)
+        result = self._step_obj.step(args=args, wrapper=wrapper)
+        return StepOutput(output=self._output_masking(result.output), stepper_state=result.stepper_state)
+
+    def predict_generator(self, ic_dict: TensorMapping, forcing_dict: TensorMapping, n_forward_steps: int,
+                          labels=None, data_mask=None, stepper_state=None) -> Generator[StepOutput, None, None]:
+        """single_module.py:1124-1167."""
+        state = {k: ic_dict[k].squeeze(self.TIME_DIM) for k in ic_dict}
+        for step in range(n_forward_steps):
+            input_forcing = {
+                k: (forcing_dict[k][:, step] if k not in self._step_obj.next_step_forcing_names
+                    else forcing_dict[k][:, step + 1])
+                for k in self._input_only_names
+            }
+            next_step_input_dict = {k: forcing_dict[k][:, step + 1] for k in self._step_obj.next_step_input_names}
+            input_data = {**state, **input_forcing}
+            result = self.step(StepArgs(input=input_data, next_step_input_data=next_step_input_dict, labels=labels,
+                                        data_mask=data_mask, stepper_state=stepper_state))
+            state = result.output
+            stepper_state = result.stepper_state
+            yield result
+
+    def predict(self, initial_condition: TensorMapping, forcing: TensorMapping,
+                n_forward_steps: Optional[int] = None) -> Tuple[TensorDict, TensorDict]:
+        """single_module.py:1169-1259 on plain dicts: initial_condition name -> (B, 1, H, W) prognostic state,
+        forcing name -> (B, 1 + n_forward_steps, H, W).  Returns (output name -> (B, n_forward_steps, H, W),
+        final prognostic state name -> (B, 1, H, W))."""
+        any_forcing = next(iter(forcing.values()))
+        if n_forward_steps is None:
+            n_forward_steps = any_forcing.shape[self.TIME_DIM] - self.n_ic_timesteps
+        for k, v in initial_condition.items():
+            if v.shape[self.TIME_DIM] != self.n_ic_timesteps:
+                raise ValueError(f"Initial condition must have {self.n_ic_timesteps} timesteps, got {v.shape[1]}.")
+        with torch.no_grad():
+            outs = list(self.predict_generator(initial_condition, forcing, n_forward_steps))
+        data = {k: torch.stack([o.output[k] for o in outs], dim=self.TIME_DIM) for k in outs[0].output}
+        prognostic_state = {k: data[k][:, -1:] for k in self.prognostic_names}
+        return data, prognostic_state
+
+    def get_state(self):
+        return {"step": self._step_obj.get_state()}
+
+    def load_state(self, state):
+        self._step_obj.load_state(state["step"])

@@ -1,0 +1,151 @@
+/*
+ * ace_sfno.h - C ABI of libace_sfno.so: the MI355X-native SFNO forward step.
+ *
+ * This is the drop-in boundary for the hot path of ai2cm/ace (`fme`): the per-step
+ * forward of the Spherical Fourier Neural Operator inside the autoregressive stepper.
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference tree).  The reference is pure Python on torch; its "FFI" for this path is
+ * the nn.Module call boundary, so a maintainer binds these functions with ctypes
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every data pointer is a DEVICE pointer to fp32
+ *     unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls enqueue
+ *     work and return; nothing synchronises unless documented;
+ *   - return value 0 = success; on failure a negative code is returned and
+ *     ace_last_error() holds a message (thread-local).  The library never aborts;
+ *   - tensors are contiguous, row-major, in the reference's own shapes.
+ */
+#ifndef ACE_SFNO_H
+#define ACE_SFNO_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACE_OK 0
+#define ACE_ERR_INVALID (-1)   /* bad argument / unsupported configuration (Python: ValueError) */
+#define ACE_ERR_RUNTIME (-2)   /* HIP runtime failure (Python: RuntimeError) */
+#define ACE_ERR_STATE (-3)     /* call sequence error, e.g. forward before all weights are set */
+
+const char* ace_last_error(void);
+int ace_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Spherical harmonic transform plans.
+ * Replaces RealSHT.__init__ / InverseRealSHT.__init__ (fme/sht_fix.py:69-111, 154-192): quadrature
+ * nodes/weights for `grid` in {"legendre-gauss","lobatto","equiangular"}, the orthonormal
+ * Condon-Shortley Legendre table (fp64 -> fp32) and the folded longitude DFT matrices.
+ * lmax/mmax <= 0 select the reference defaults (lmax = nlat, or nlat-1 for lobatto;
+ * mmax = nlon/2+1).  One plan serves both directions.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ace_sht_plan ace_sht_plan;
+
+int ace_sht_plan_create(int nlat, int nlon, int lmax, int mmax, const char* grid, ace_sht_plan** plan);
+void ace_sht_plan_destroy(ace_sht_plan* plan);
+int ace_sht_plan_dims(const ace_sht_plan* plan, int* nlat, int* nlon, int* lmax, int* mmax);
+
+/* RealSHT.forward (fme/sht_fix.py:119-139): x (n, nlat, nlon) f32 -> coeffs (n, lmax, mmax) complex64
+ * stored interleaved (re, im) as 2*n*lmax*mmax floats.  May grow plan-owned scratch (hipMalloc) on
+ * the first call at a given n; not capture-safe on that first call. */
+int ace_sht_forward(ace_sht_plan* plan, const float* x, float* coeffs, int n, void* stream);
+
+/* InverseRealSHT.forward (fme/sht_fix.py:202-226): coeffs (n, lmax, mmax) complex64 -> x (n, nlat, nlon). */
+int ace_sht_inverse(ace_sht_plan* plan, const float* coeffs, float* x, int n, void* stream);
+
+/* Host-only (no GPU touched): build the fp32 tables into caller buffers for inspection.
+ * which: 0 = forward Legendre*quadrature wt[m][l][k] (dense, mmax*lmax*nlat floats)
+ *        1 = inverse Legendre pct[m][l][k]           (dense, mmax*lmax*nlat floats)
+ *        2 = quadrature nodes cos(theta) ascending (nlat doubles), 3 = quadrature weights (nlat doubles) */
+int ace_sht_tables_host(int nlat, int nlon, int lmax, int mmax, const char* grid, int which, void* out_host);
+
+/* ------------------------------------------------------------------------------------------
+ * Building blocks, exported for parity tests and micro-benchmarks.
+ * ------------------------------------------------------------------------------------------ */
+
+/* nn.Conv2d(Cin, Cout, 1) [+ activation] on (n, Cin, hw) -> (n, Cout, hw)  (sfnonet.py:229, layers.py:117-124).
+ * weight (Cout, Cin) row-major, bias (Cout) or NULL.  act: 0 none, 1 GELU(erf), 2 ReLU, 3 SiLU. */
+int ace_conv1x1(const float* x, const float* weight, const float* bias, float* y, int n, int cin, int cout,
+                long hw, int act, void* stream);
+
+/* nn.InstanceNorm2d(C, eps, affine) (sfnonet.py:593-601) on (n, C, hw); gamma/beta may be NULL. */
+int ace_instance_norm(const float* x, const float* gamma, const float* beta, float eps, float* y, int n, int c,
+                      long hw, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The network.  Replaces SphericalFourierNeuralOperatorNet.__init__/forward
+ * (fme/ace/models/modulus/sfnonet.py:341-685, 713-749) as built by
+ * SphericalFourierNeuralOperatorBuilder.build (fme/ace/registry/sfno.py:44-61).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ace_sfno ace_sfno;
+
+typedef struct ace_sfno_config {
+    int in_chans, out_chans;      /* n_in_channels, n_out_channels of ModuleConfig.build */
+    int nlat, nlon;               /* dataset_info.img_shape */
+    int embed_dim, num_layers;
+    int scale_factor;             /* only 1 is supported */
+    float hard_thresholding_fraction;
+    int operator_type;            /* 0 = "diagonal", 1 = "dhconv" */
+    int normalization_layer;      /* 0 = "none", 1 = "instance_norm" */
+    int activation_function;      /* 1 = "gelu", 2 = "relu", 3 = "silu" */
+    int use_mlp;
+    float mlp_ratio;
+    int encoder_layers;
+    int pos_embed, big_skip;
+    int data_grid;                /* 0 = "legendre-gauss", 2 = "equiangular" */
+    int max_batch;                /* workspace is sized for this many samples (B = samples x ensemble) */
+} ace_sfno_config;
+
+int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** net);
+void ace_sfno_destroy(ace_sfno* net);
+
+/* Upload one parameter by its reference state_dict name: "pos_embed", "encoder.0.weight",
+ * "blocks.3.filter.filter.weight", ...  `src` is a device pointer to `numel` contiguous floats in the
+ * reference's shape; the library keeps its own copy (re-laid-out where a kernel wants it), so the
+ * caller may free or update `src` afterwards and must call this again after an update.
+ * Synchronises `stream` before returning. */
+int ace_sfno_set_weight(ace_sfno* net, const char* name, const float* src, long numel, void* stream);
+
+/* Number of parameters / name of parameter i / its numel, in the reference's state_dict order. */
+int ace_sfno_num_weights(const ace_sfno* net);
+const char* ace_sfno_weight_name(const ace_sfno* net, int i);
+long ace_sfno_weight_numel(const ace_sfno* net, int i);
+
+/* Module.__call__ (fme/core/registry/module.py:74-86): in (batch, in_chans, nlat, nlon) ->
+ * out (batch, out_chans, nlat, nlon).  No allocation, no host synchronisation: capture-safe. */
+int ace_sfno_forward(ace_sfno* net, const float* in, float* out, int batch, void* stream);
+
+/* Measurement: ace_sfno_forward with a hipEvent after every launch group on `stream` (the reference's
+ * CUDATimer children, fme/core/benchmark/timer.py:105-168; block children conditional_sfno/sfnonet.py:388-437,
+ * filter children s2convolutions.py:372-431).  Synchronises `stream`.  ms_host[ace_sfno_num_stages()] receives the
+ * milliseconds per stage summed over blocks, calls_host (optional) the number of launch groups per stage. */
+int ace_sfno_num_stages(void);
+const char* ace_sfno_stage_name(int i);
+int ace_sfno_forward_timed(ace_sfno* net, const float* in, float* out, int batch, void* stream, float* ms_host,
+                           int* calls_host);
+
+/* Debug/test tap: copy the activation after block `i` (batch, embed_dim, nlat, nlon) of the LAST
+ * forward into dst.  i = -1: the encoder output (after pos_embed). Only valid with ace_sfno_set_taps(net, 1). */
+int ace_sfno_set_taps(ace_sfno* net, int enable);
+int ace_sfno_get_tap(ace_sfno* net, int i, float* dst, int batch, void* stream);
+
+/* hipGraph path: captures ace_sfno_forward(in, out, batch) once per distinct (in, out, batch) and
+ * replays it on `stream` afterwards (the autoregressive loop with static buffers). */
+int ace_sfno_forward_graph(ace_sfno* net, const float* in, float* out, int batch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stepper glue (fme/core/packer.py:45-52 + fme/core/normalizer.py:213-236, fused).
+ * srcs/dsts: DEVICE arrays of nch device pointers; strides: DEVICE array of per-sample strides (floats).
+ *   pack:   dst[b][j][:] = (srcs[j][b*strides[j] + :] - mean[j]) / std[j]
+ *   unpack: dsts[j][b*strides[j] + :] = src[b][j][:] * std[j] + mean[j]
+ * ------------------------------------------------------------------------------------------ */
+int ace_pack_normalize(const float* const* srcs, const long* strides, const float* mean, const float* std_,
+                       float* dst, int batch, int nch, long hw, void* stream);
+int ace_unpack_denormalize(const float* src, const float* mean, const float* std_, float* const* dsts,
+                           const long* strides, int batch, int nch, long hw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACE_SFNO_H */

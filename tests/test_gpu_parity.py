@@ -1,0 +1,314 @@
+"""HIP path vs the CPU oracle / golden fixtures, through the C ABI (libace_sfno.so).
+
+Tolerances (fp32 everywhere, stated per test):
+  * single operators        max|err|/max|ref| <= 2e-6   (a handful of fp32 ulps over K<=768 sums)
+  * SHT at 180x360          <= 5e-6
+  * whole-network step      <= 1e-5  (BASELINE.json north_star: "per-step output within 1e-5 rel-err")
+Size-independent properties (round-trip idempotence, linearity, constant field) are
+checked at the full 1-degree size where the oracle would be slow.
+"""
+
+import ctypes
+
+import pytest
+import torch
+
+from _util import build_native_net, load_golden, rel_l2, rel_max
+
+pytestmark = pytest.mark.gpu
+
+OP_TOL = 2e-6
+SHT_TOL = 5e-6
+NET_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda")
+
+
+# ---------------------------------------------------------------------------------- building blocks
+@pytest.mark.parametrize("n,cin,cout,hw,act", [
+    (1, 44, 384, 64800, 1), (2, 16, 16, 162, 1), (1, 2, 3, 162, 0), (3, 18, 16, 288, 2),
+    (1, 428, 50, 4096 + 36, 3), (1, 7, 5, 13, 1), (1, 384, 768, 8000, 1),
+])
+def test_conv1x1(dev, n, cin, cout, hw, act):
+    from ace_amd import _lib
+    g = torch.Generator().manual_seed(n * 1000 + cin)
+    x = torch.randn(n, cin, hw, generator=g)
+    w = torch.randn(cout, cin, generator=g) / cin**0.5
+    b = torch.randn(cout, generator=g)
+    ref = torch.nn.functional.conv1d(x.double(), w.double()[:, :, None], b.double())
+    ref = [ref, torch.nn.functional.gelu(ref), torch.relu(ref), torch.nn.functional.silu(ref)][act]
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    y = torch.empty(n, cout, hw, device=dev)
+    _lib.check(_lib.lib().ace_conv1x1(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), n, cin, cout, hw, act,
+                                      _lib.current_stream()))
+    assert rel_max(y, ref) <= OP_TOL
+
+
+@pytest.mark.parametrize("n,c,hw", [(1, 384, 64800), (2, 16, 162), (3, 5, 77)])
+def test_instance_norm(dev, n, c, hw):
+    from ace_amd import _lib
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(n, c, hw, generator=g) * 3 + 1.5
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    ref = torch.nn.functional.instance_norm(x.double(), weight=gamma.double(), bias=beta.double(), eps=1e-6)
+    xd = x.to(dev)
+    y = torch.empty_like(xd)
+    _lib.check(_lib.lib().ace_instance_norm(_lib.ptr(xd), _lib.ptr(gamma.to(dev)), _lib.ptr(beta.to(dev)), 1e-6,
+                                            _lib.ptr(y), n, c, hw, _lib.current_stream()))
+    assert rel_max(y, ref) <= OP_TOL
+
+
+# ---------------------------------------------------------------------------------- SHT
+def test_sht_golden_regression(dev):
+    """fme/core/benchmark/testdata/{sht,inverse_sht}-regression.pt (lobatto 9x18)."""
+    import ace_amd
+    x = load_golden("gen_sht_input.pt")["x"]
+    g = load_golden("ref_sht-regression.pt")["output"]
+    gi = load_golden("ref_inverse_sht-regression.pt")["output"]
+    sht, isht = ace_amd.RealSHT(9, 18), ace_amd.InverseRealSHT(9, 18)
+    c = sht(x.to(dev))
+    assert c.shape == (1, 8, 10) and c.dtype == torch.complex64
+    torch.testing.assert_close(c.cpu(), g)            # the reference's own bar (rtol 1.3e-6, atol 1e-5)
+    torch.testing.assert_close(isht(c).cpu(), gi)
+    assert rel_max(c, g) <= OP_TOL
+
+
+@pytest.mark.parametrize("nlat,nlon,lmax,mmax,grid,n", [
+    (9, 18, None, None, "lobatto", 1), (9, 18, None, None, "equiangular", 5), (6, 12, None, None, "legendre-gauss", 3),
+    (12, 24, 8, 9, "legendre-gauss", 4), (45, 90, None, None, "legendre-gauss", 16), (13, 27, None, None, "equiangular", 2),
+    (64, 128, 40, 50, "legendre-gauss", 7),
+])
+def test_sht_vs_oracle(dev, nlat, nlon, lmax, mmax, grid, n):
+    import ace_amd
+    import oracle
+    x = torch.randn(n, nlat, nlon, generator=torch.Generator().manual_seed(nlat))
+    o_f = oracle.RealSHT(nlat, nlon, lmax, mmax, grid, dtype=torch.float64)
+    o_i = oracle.InverseRealSHT(nlat, nlon, lmax, mmax, grid, dtype=torch.float64)
+    c_ref = o_f(x)
+    sht = ace_amd.RealSHT(nlat, nlon, lmax, mmax, grid)
+    isht = ace_amd.InverseRealSHT(nlat, nlon, lmax, mmax, grid)
+    c = sht(x.to(dev))
+    assert rel_max(c, c_ref) <= OP_TOL
+    # arbitrary (non band-limited, l<m populated) coefficients through the inverse
+    cz = torch.randn(n, o_i.lmax, o_i.mmax, dtype=torch.complex64, generator=torch.Generator().manual_seed(3))
+    assert rel_max(isht(cz.to(dev)), o_i(cz)) <= OP_TOL
+
+
+def test_sht_leading_dims_and_empty(dev):
+    import ace_amd
+    import oracle
+    sht = ace_amd.RealSHT(12, 24, grid="legendre-gauss")
+    x = torch.randn(2, 3, 12, 24, generator=torch.Generator().manual_seed(0))
+    c = sht(x.to(dev))
+    assert c.shape == (2, 3, 12, 13)
+    assert rel_max(c, oracle.RealSHT(12, 24, grid="legendre-gauss", dtype=torch.float64)(x)) <= OP_TOL
+    assert sht(torch.empty(0, 12, 24, device=dev)).shape == (0, 12, 13)
+    with pytest.raises(AssertionError):
+        sht(torch.zeros(1, 12, 25, device=dev))
+    with pytest.raises(ValueError):
+        ace_amd.RealSHT(12, 24, grid="nonsense")
+    with pytest.raises(NotImplementedError):
+        ace_amd.RealSHT(12, 24, grid="healpix")
+
+
+def test_sht_180x360_vs_reference(dev):
+    """coefficients and round trip emitted by the reference itself (tests/golden/make_golden.py)."""
+    import ace_amd
+    d = load_golden("gen_sht_180x360.pt")
+    x = torch.randn(3, 180, 360, generator=torch.Generator().manual_seed(d["seed"]))
+    sht = ace_amd.RealSHT(180, 360, lmax=180, mmax=181, grid="legendre-gauss")
+    isht = ace_amd.InverseRealSHT(180, 360, lmax=180, mmax=181, grid="legendre-gauss")
+    c = sht(x.to(dev))
+    assert rel_max(c, d["coeffs"]) <= SHT_TOL
+    assert rel_max(isht(c), d["roundtrip"]) <= SHT_TOL
+    assert rel_max(isht(d["coeffs"].to(dev)), d["roundtrip"]) <= SHT_TOL
+
+
+@pytest.mark.parametrize("grid", ["equiangular", "legendre-gauss"])
+@pytest.mark.parametrize("constant", [1.0, 0.42])
+def test_constant_field(dev, grid, constant):
+    """fme/test_harmonics.py:10-25."""
+    import ace_amd
+    coeffs = ace_amd.RealSHT(6, 12, grid=grid).to(dev)(torch.full((6, 12), constant, device=dev)).ravel().cpu()
+    assert abs(coeffs[0]) > 1e-3
+    assert torch.all(coeffs[1:].abs() < 1e-6)
+
+
+def test_full_size_properties(dev):
+    """ACE2 shape (384 fields of 180x360): round-trip idempotence (fme/test_harmonics.py:35-42), linearity and
+    the triangular zero pattern, where the CPU oracle would take minutes."""
+    import ace_amd
+    sht = ace_amd.RealSHT(180, 360, lmax=180, mmax=181, grid="legendre-gauss")
+    isht = ace_amd.InverseRealSHT(180, 360, lmax=180, mmax=181, grid="legendre-gauss")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(384, 180, 360, device=dev, generator=g)
+    y = torch.randn(384, 180, 360, device=dev, generator=g)
+    cx, cy = sht(x), sht(y)
+    p = isht(cx)
+    assert rel_max(isht(sht(p)), p) <= SHT_TOL                       # projection is idempotent
+    assert rel_max(sht(2.5 * x - 0.5 * y), 2.5 * cx - 0.5 * cy) <= SHT_TOL   # linear
+    l = torch.arange(180, device=dev)[:, None]
+    m = torch.arange(181, device=dev)[None, :]
+    assert torch.all(cx[:, (m > l)] == 0)                            # l < m coefficients are exactly zero
+
+
+# ---------------------------------------------------------------------------------- network
+def _oracle_and_native(cfg, state, x, dev):
+    from oracle.sfno import SFNOOracle
+    net = build_native_net(cfg, state, dev)
+    with torch.no_grad():
+        y = net(x.to(dev))
+    ref64 = SFNOOracle(cfg, state, dtype=torch.float64)(x)
+    ref32 = SFNOOracle(cfg, state, dtype=torch.float32)(x)
+    return y, ref32, ref64, net
+
+
+def test_modulus_sfnonet_golden(dev):
+    """fme/ace/models/modulus/testdata/test_sfnonet_output_is_unchanged.pt ('diagonal' operator,
+    equiangular outer grid => residual round-trips through spectral space)."""
+    from oracle.sfno import SFNOConfig
+    d = load_golden("gen_modulus_sfnonet_case.pt")
+    g = load_golden("ref_modulus_sfnonet_output.pt")
+    cfg = SFNOConfig(**d["cfg"])
+    net = build_native_net(cfg, d["state"], dev)
+    with torch.no_grad():
+        y = net(d["x"].to(dev))
+    torch.testing.assert_close(y.cpu(), g)
+    assert rel_max(y, g) <= NET_TOL
+
+
+@pytest.mark.parametrize("name", ["gen_sfno_dhconv_12x24.pt", "gen_sfno_dhconv_equiangular_9x18.pt",
+                                  "gen_sfno_dhconv_180x360_c8.pt"])
+def test_dhconv_nets_vs_reference(dev, name):
+    from oracle.sfno import SFNOConfig, init_state
+    d = load_golden(name)
+    cfg = SFNOConfig(**{**d["cfg"], "img_shape": tuple(d["cfg"]["img_shape"])})
+    state = init_state(cfg, seed=d["seed"])
+    x = torch.randn(d["batch"], cfg.in_chans, *cfg.img_shape, generator=torch.Generator().manual_seed(d["seed"] + 1000))
+    net = build_native_net(cfg, state, dev)
+    with torch.no_grad():
+        y = net(x.to(dev))
+    assert rel_max(y, d["y"]) <= NET_TOL
+
+
+@pytest.mark.parametrize("kw", [
+    dict(normalization_layer="none"), dict(use_mlp=False), dict(big_skip=False, pos_embed=False),
+    dict(activation_function="silu", encoder_layers=2), dict(hard_thresholding_fraction=0.6),
+    dict(operator_type="diagonal", data_grid="equiangular"), dict(num_layers=1, data_grid="equiangular"),
+])
+def test_config_variants_vs_oracle(dev, kw):
+    from oracle.sfno import SFNOConfig, init_state
+    base = dict(in_chans=5, out_chans=4, img_shape=(16, 32), embed_dim=12, num_layers=2, operator_type="dhconv")
+    cfg = SFNOConfig(**{**base, **kw})
+    state = init_state(cfg, seed=3)
+    x = torch.randn(2, 5, 16, 32, generator=torch.Generator().manual_seed(9))
+    y, ref32, ref64, _ = _oracle_and_native(cfg, state, x, dev)
+    assert rel_max(y, ref64) <= NET_TOL
+
+
+def test_block_taps_vs_oracle(dev):
+    """teacher-forced per-block error at a mid size (C=64, 45x90), against the fp64 oracle."""
+    from oracle.sfno import SFNOConfig, SFNOOracle, init_state
+    cfg = SFNOConfig(in_chans=6, out_chans=5, img_shape=(45, 90), embed_dim=64, num_layers=3, operator_type="dhconv")
+    state = init_state(cfg, seed=4)
+    x = torch.randn(2, 6, 45, 90, generator=torch.Generator().manual_seed(10))
+    net = build_native_net(cfg, state, dev)
+    with torch.no_grad():
+        y, taps = net.forward_with_taps(x.to(dev))
+    ref, rtaps = SFNOOracle(cfg, state, dtype=torch.float64).forward(x, return_blocks=True)
+    for i, rt in enumerate(rtaps):
+        assert rel_max(taps[i + 1], rt) <= NET_TOL, f"block {i}"
+    assert rel_max(y, ref) <= NET_TOL
+
+
+def test_graph_replay_matches_eager(dev):
+    from oracle.sfno import SFNOConfig, init_state
+    cfg = SFNOConfig(in_chans=4, out_chans=4, img_shape=(24, 48), embed_dim=16, num_layers=2, operator_type="dhconv")
+    net = build_native_net(cfg, init_state(cfg, seed=6), dev)
+    x = torch.randn(1, 4, 24, 48, device=dev)
+    out = torch.empty(1, 4, 24, 48, device=dev)
+    with torch.no_grad():
+        ref = net(x).clone()
+        for _ in range(3):
+            net.forward_graph(x, out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        x.normal_()                      # same storage, new contents: replay must see them
+        ref2 = net(x).clone()
+        net.forward_graph(x, out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref2)
+
+
+def test_errors(dev):
+    """Module / builder error behaviour (module.py:77-82, sfno.py:50-53, registry.py:58)."""
+    import ace_amd
+    sel = ace_amd.ModuleSelector(type="SphericalFourierNeuralOperatorNet", config={"embed_dim": 8, "num_layers": 1})
+    mod = sel.build(2, 2, ace_amd.DatasetInfo((8, 16))).to(dev)
+    with pytest.raises(TypeError):
+        mod(torch.zeros(1, 2, 8, 16, device=dev), labels=object())
+    with pytest.raises(AssertionError):
+        mod(torch.zeros(1, 2, 8, 17, device=dev))
+    with pytest.raises(ValueError):
+        sel.build(2, 2, ace_amd.DatasetInfo((8, 16), all_labels={"a"}))
+    with pytest.raises(KeyError):
+        ace_amd.ModuleSelector(type="NoSuchNet", config={})
+    with pytest.raises(ValueError):
+        ace_amd.ModuleSelector(type="SphericalFourierNeuralOperatorNet", config={"no_such_field": 1})
+
+
+# ---------------------------------------------------------------------------------- stepper
+def test_stepper_predict_golden(dev):
+    """fme/ace/stepper/testdata/stepper_predict_regression.pt through the registry + Stepper mirror."""
+    import ace_amd
+    from ace_amd.step import NormalizationConfig
+    d = load_golden("gen_stepper_case.pt")
+    g = load_golden("ref_stepper_predict_regression.pt")
+    names = ["a", "b", "c"]
+    config = ace_amd.SingleModuleStepConfig(
+        builder=ace_amd.ModuleSelector(type="SphericalFourierNeuralOperatorNet",
+                                       config={"embed_dim": 16, "num_layers": 2}),
+        in_names=d["in_names"], out_names=d["out_names"],
+        normalization=NormalizationConfig(means={k: d["mean"] for k in names}, stds={k: d["std"] for k in names}),
+    )
+    stepper = ace_amd.Stepper.from_config(config, ace_amd.DatasetInfo((9, 18)), device=dev)
+    stepper.load_state({"step": {"module": {**d["state"], "label_encoding": None}}})
+    stepper.set_eval()
+    out, nxt = stepper.predict({"b": d["b"][:, :1].to(dev)}, {"a": d["a"].to(dev)})
+    torch.testing.assert_close(out["b"].cpu(), g["output.b"])
+    torch.testing.assert_close(out["c"].cpu(), g["output.c"])
+    torch.testing.assert_close(nxt["b"].cpu(), g["next_state.b"])
+
+
+def test_rollout_engine_matches_stepper(dev):
+    """hipGraph rollout with static buffers == the dict-of-tensors Stepper loop, bit for bit."""
+    import ace_amd
+    from ace_amd.rollout import RolloutEngine
+    from ace_amd.step import NormalizationConfig
+    in_names = ["f0", "p0", "p1", "f1"]
+    out_names = ["p1", "d0", "p0"]
+    names = sorted(set(in_names + out_names))
+    config = ace_amd.SingleModuleStepConfig(
+        builder=ace_amd.ModuleSelector(type="SphericalFourierNeuralOperatorNet",
+                                       config={"embed_dim": 16, "num_layers": 2, "operator_type": "dhconv"}),
+        in_names=in_names, out_names=out_names, next_step_forcing_names=["f1"],
+        normalization=NormalizationConfig(means={k: 0.1 * (i + 1) for i, k in enumerate(names)},
+                                          stds={k: 1.0 + 0.1 * i for i, k in enumerate(names)}),
+    )
+    torch.manual_seed(0)
+    stepper = ace_amd.Stepper.from_config(config, ace_amd.DatasetInfo((12, 24)), device=dev)
+    stepper.set_eval()
+    B, T = 2, 5
+    ic = {k: torch.randn(B, 1, 12, 24, device=dev) for k in ["p0", "p1"]}
+    forcing = {k: torch.randn(B, T + 1, 12, 24, device=dev) for k in ["f0", "f1"]}
+    ref, ref_state = stepper.predict(ic, forcing)
+    eng = RolloutEngine(stepper, batch=B, n_forward_steps=T)
+    out, state = eng.predict(ic, forcing)
+    for k in out_names:
+        assert torch.equal(out[k], ref[k]), k
+    for k in ["p0", "p1"]:
+        assert torch.equal(state[k], ref_state[k])
