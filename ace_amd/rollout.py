@@ -70,6 +70,11 @@ class RolloutEngine:
         self._src_strides = torch.tensor(src_strides, **i64)
         self._dst_ptrs = torch.tensor(dst_ptrs, **i64)
         self._dst_strides = torch.full((len(self.out_names),), T * self.HW, **i64)
+        # plain ints for the per-step launches (no tensor indexing on the hot host path)
+        nin, nout = len(self.in_names), len(self.out_names)
+        self._src_ptr_addr = [self._src_ptrs.data_ptr() + 8 * s * nin for s in range(T)]
+        self._src_stride_addr = [self._src_strides.data_ptr() + 8 * s * nin for s in range(T)]
+        self._dst_ptr_addr = [self._dst_ptrs.data_ptr() + 8 * s * nout for s in range(T)]
         self._window_graph = None
         self.net._ensure_native(dev, B)
         self.net.sync_weights()
@@ -79,13 +84,13 @@ class RolloutEngine:
         L = _lib.lib()
         stream = _lib.current_stream()
         nin, nout = len(self.in_names), len(self.out_names)
-        _lib.check(L.ace_pack_normalize(self._src_ptrs[s].data_ptr(), self._src_strides[s].data_ptr(),
+        _lib.check(L.ace_pack_normalize(self._src_ptr_addr[s], self._src_stride_addr[s],
                                         self.in_mean.data_ptr(), self.in_std.data_ptr(), self.x.data_ptr(),
                                         self.B, nin, self.HW, stream))
         fwd = L.ace_sfno_forward_graph if use_library_graph else L.ace_sfno_forward
         _lib.check(fwd(self.net._native, self.x.data_ptr(), self.y.data_ptr(), self.B, stream))
         _lib.check(L.ace_unpack_denormalize(self.y.data_ptr(), self.out_mean.data_ptr(), self.out_std.data_ptr(),
-                                            self._dst_ptrs[s].data_ptr(), self._dst_strides.data_ptr(),
+                                            self._dst_ptr_addr[s], self._dst_strides.data_ptr(),
                                             self.B, nout, self.HW, stream))
 
     def load(self, initial_condition: Mapping[str, torch.Tensor], forcing: Mapping[str, torch.Tensor]):

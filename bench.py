@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""bench.py - rollout steps/s of the ACE2-shape 1-degree SFNO on N MI355X (one ensemble member per GPU).
+
+    python bench.py --gpus 1 --steps 40 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole hot path over one synthetic state: gather+normalise the 44 input fields,
+the SFNO forward (8 blocks, embed 384, 180x360, fp32), scatter+denormalise the 50 output fields, feed the 36
+prognostic fields back.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# ---- workload: BASELINE.json configs[1] ("ACE2-ERA5-shape 1-degree SFNO ... one MI355X, hipGraph-captured step")
+ACE2 = dict(embed_dim=384, num_layers=8, operator_type="dhconv", scale_factor=1, data_grid="legendre-gauss")
+IMG = (180, 360)
+N_FORCING, N_PROGNOSTIC, N_DIAGNOSTIC = 8, 36, 14       # 44 in / 50 out, 58 distinct names
+PEAK_MFMA_F32 = 157.3      # TFLOP/s dense, v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md)
+PEAK_HBM = 8000.0          # GB/s spec (6290 achievable)
+
+
+def names():
+    forcing = [f"forcing_{i}" for i in range(N_FORCING)]
+    prog = [f"prog_{i}" for i in range(N_PROGNOSTIC)]
+    diag = [f"diag_{i}" for i in range(N_DIAGNOSTIC)]
+    return forcing, prog, diag
+
+
+def stage_model(C=384, H=180, W=360, L=180, M=181, hid=768, cin=44, cout=50):
+    """Algorithmic flops / bytes per launch of each stage (DESIGN.md section 'Kernels'), B = 1."""
+    act = C * H * W * 4
+    coef = C * L * M * 8
+    tab = M * L * H * 4
+    dftm = 2 * M * (W // 2 + 1) * 4
+    return {
+        # name: (flops, hbm_bytes)  - dense counts; the triangular (l >= m) work actually done is ~half for legendre
+        "forward_transform.dft": (2 * 2 * M * (W // 2 + 1) * C * H, act + coef + dftm),
+        "forward_transform.legendre": (2 * 2 * C * M * L * H, 2 * coef + tab),
+        "dhconv": (8 * C * C * L * M, 2 * coef + 4 * C * C * L * 4),
+        "inverse_transform.legendre": (2 * 2 * C * M * L * H, 2 * coef + tab),
+        "inverse_transform.dft": (2 * 2 * M * (W // 2 + 1) * C * H, act + coef + dftm),
+        "inner_skip+activation": (2 * C * C * H * W, 3 * act),
+        "mlp.fc1": (2 * hid * C * H * W, act + hid * H * W * 4),
+        "mlp.fc2+outer_skip": (2 * hid * C * H * W, 2 * act + hid * H * W * 4),
+        "norm0_stats": (3 * C * H * W, act),
+        "norm1_stats": (3 * C * H * W, act),
+        "encoder": (2 * (cin * C + C * C) * H * W, cin * H * W * 4 + 4 * act),
+        "decoder": (2 * ((C + cin) * C + C * cout) * H * W, 3 * act + (cin + cout) * H * W * 4),
+    }
+
+
+def build_stepper(dev, seed):
+    import ace_amd
+    from ace_amd.step import NormalizationConfig
+
+    forcing, prog, diag = names()
+    in_names = forcing + prog
+    out_names = prog + diag
+    allnames = forcing + prog + diag
+    cfg = ace_amd.SingleModuleStepConfig(
+        builder=ace_amd.ModuleSelector(type="SphericalFourierNeuralOperatorNet", config=ACE2),
+        in_names=in_names, out_names=out_names,
+        normalization=NormalizationConfig(means={k: 0.1 for k in allnames}, stds={k: 1.1 for k in allnames}),
+    )
+    torch.manual_seed(seed)  # weights generated on CPU exactly as the reference initialises them, then uploaded
+    stepper = ace_amd.Stepper.from_config(cfg, ace_amd.DatasetInfo(IMG), device=dev)
+    stepper.set_eval()
+    return stepper, forcing, prog, diag
+
+
+def cpu_baseline(stepper, x_cpu):
+    """The reference CPU path, restated (oracle 'port'), timed on this box's host cores: one forward step."""
+    from oracle.sfno import SFNOConfig, SFNOOracle
+
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    cfg = SFNOConfig(in_chans=N_FORCING + N_PROGNOSTIC, out_chans=N_PROGNOSTIC + N_DIAGNOSTIC, img_shape=IMG,
+                     embed_dim=384, num_layers=8, operator_type="dhconv")
+    state = {k: v.detach().cpu() for k, v in stepper.modules[0].state_dict().items()}
+    net = SFNOOracle(cfg, state)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        y = net(x_cpu)
+    dt = time.perf_counter() - t0
+    return dict(value=1.0 / dt, unit="steps/s", cores=threads, kind="port",
+                sample=f"1 forward step of the same ACE2-shape network (B=1, fp32, torch-CPU ops, {threads} threads), "
+                       f"{dt:.1f} s"), y
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--graph", default="step", choices=["none", "step", "window"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from ace_amd import _lib
+    from ace_amd.distributed import Distributed
+    from ace_amd.rollout import RolloutEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if args.gpus != world:
+        assert world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        assert args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = Distributed.get_instance()
+
+    K, Wm = args.steps, args.warmup
+    stepper, forcing, prog, diag = build_stepper(dev, seed=0)   # same weights on every rank (one model, N members)
+    T = K
+    eng = RolloutEngine(stepper, batch=1, n_forward_steps=T, graph=None if args.graph == "none" else args.graph)
+    g = torch.Generator().manual_seed(1 + rank)                   # member `rank`: its own initial state
+    ic = {n: torch.randn(1, 1, *IMG, generator=g).to(dev) for n in prog}
+    fc = {n: torch.randn(1, T + 1, *IMG, generator=g).to(dev) for n in forcing}
+    eng.load(ic, fc)
+    ens_mean = torch.zeros(len(eng.out_names), *IMG, device=dev)
+
+    def window(n_steps):
+        for s in range(n_steps):
+            eng._enqueue_step(s % T, eng.graph_mode == "step")
+
+    with torch.no_grad():
+        if eng.graph_mode == "window":
+            eng.run_window()                                      # untimed: captures the K-step window and replays it
+        else:
+            window(max(Wm, 1))                                    # untimed warm-up (graph capture happens here)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if eng.graph_mode == "window":
+            eng.run_window()
+        else:
+            window(K)
+        if world > 1:  # ensemble-mean diagnostic of the final state, once per window (reference cadence)
+            ens_mean.copy_(torch.stack([eng.out[n][0, K - 1] for n in eng.out_names]))
+            dist.reduce_mean(ens_mean)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.reduce_max(tmax)
+    dt = float(tmax.item())
+
+    result = None
+    if rank == 0:
+        # ---- per-stage HIP-event timing of the forward (same stream the kernels are launched on)
+        L = _lib.lib()
+        ns = L.ace_sfno_num_stages()
+        ms = (ctypes.c_float * ns)()
+        calls = (ctypes.c_int * ns)()
+        acc = [0.0] * ns
+        reps = 5
+        net = eng.net
+        for _ in range(reps):
+            _lib.check(L.ace_sfno_forward_timed(net._native, eng.x.data_ptr(), eng.y.data_ptr(), 1,
+                                                _lib.current_stream(), ms, calls))
+            for i in range(ns):
+                acc[i] += ms[i] / reps
+        model = stage_model()
+        stages = {}
+        for i in range(ns):
+            nm = L.ace_sfno_stage_name(i).decode()
+            per_launch_ms = acc[i] / max(calls[i], 1)
+            fl, by = model[nm]
+            stages[nm] = dict(ms_per_step=round(acc[i], 4), launches=calls[i], us_per_launch=round(per_launch_ms * 1e3, 2),
+                              tflops=round(fl / per_launch_ms / 1e9, 2), gbps=round(by / per_launch_ms / 1e6, 1))
+        dom = max(stages, key=lambda k: stages[k]["ms_per_step"])
+        fl, by = model[dom]
+        t_launch = stages[dom]["us_per_launch"] * 1e-6
+        roofline = dict(kernel=f"gemm_f32_kernel ({dom})", bound="mfma", achieved=round(fl / t_launch / 1e12, 2),
+                        peak=PEAK_MFMA_F32, unit="TFLOP/s", frac=round(fl / t_launch / 1e12 / PEAK_MFMA_F32, 4),
+                        traffic=None)
+        sht_ms = (stages["forward_transform.dft"]["us_per_launch"] + stages["forward_transform.legendre"]["us_per_launch"])
+        sht_bytes = 384 * 180 * 360 * 4 + 181 * 180 * 180 * 4 + 384 * 180 * 181 * 8     # 223.1 MB
+        roofline_sht = dict(kernel="forward SHT (dft_forward_kernel + gemm_f32_kernel legendre)", bound="hbm",
+                            achieved=round(sht_bytes / (sht_ms * 1e-6) / 1e9, 1), peak=PEAK_HBM, unit="GB/s",
+                            frac=round(sht_bytes / (sht_ms * 1e-6) / 1e9 / PEAK_HBM, 4), traffic=None)
+        cpu = None
+        if not args.no_cpu_baseline:
+            with torch.no_grad():
+                x_cpu = eng.x.detach().cpu()
+                y_gpu = eng.y.detach().cpu()
+            cpu, y_cpu = cpu_baseline(stepper, x_cpu)
+            cpu["parity_rel_err_vs_gpu"] = float((y_gpu - y_cpu).abs().max() / y_cpu.abs().max())
+        steps_per_s = world * K / dt
+        result = {
+            "metric": "rollout steps/sec (6-hourly forward steps of the 1-degree SFNO, whole job)",
+            "value": round(steps_per_s, 3), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "simulated_years_per_day": round(steps_per_s * 86400 / 1460, 1),
+            "config": {"workload": "ACE2-ERA5-shape 1deg SFNO rollout (BASELINE.json configs[1]): embed 384, 8 layers, "
+                                   "dhconv, 44 in / 50 out channels, 180x360 legendre-gauss, lmax 180, mmax 181, "
+                                   "B=1 member per GPU, random-init weights",
+                       "members": world, "members_per_gpu": 1, "graph": args.graph,
+                       "collective": "RCCL all-reduce mean of the (50,180,360) output state once per window" if world > 1 else "none"},
+            "roofline": roofline, "roofline_sht": roofline_sht, "stages": stages, "cpu_baseline": cpu,
+        }
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps(result))
+    dist.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -41,7 +41,8 @@ def conv_cases():
         ref = torch.nn.functional.conv1d(x.double(), w.double()[:, :, None], b.double())
         ref = [ref, torch.nn.functional.gelu(ref), torch.relu(ref), torch.nn.functional.silu(ref)][act]
         y = torch.full((n, cout, hw), float("nan"), device=dev)
-        _lib.check(_lib.lib().ace_conv1x1(_lib.ptr(x.to(dev)), _lib.ptr(w.to(dev)), _lib.ptr(b.to(dev)), _lib.ptr(y),
+        xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)  # keep alive until the kernel has run
+        _lib.check(_lib.lib().ace_conv1x1(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y),
                                           n, cin, cout, hw, act, _lib.current_stream()))
         torch.cuda.synchronize()
         print(f"conv1x1 n={n} cin={cin} cout={cout} hw={hw} act={act}: relmax {rel_max(y, ref):.3e} nan={int(torch.isnan(y).sum())}")
@@ -55,7 +56,8 @@ def norm_cases():
         gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
         ref = torch.nn.functional.instance_norm(x.double(), weight=gamma.double(), bias=beta.double(), eps=1e-6)
         y = torch.empty(n, c, hw, device=dev)
-        _lib.check(_lib.lib().ace_instance_norm(_lib.ptr(x.to(dev)), _lib.ptr(gamma.to(dev)), _lib.ptr(beta.to(dev)),
+        xd, gd, bd = x.to(dev), gamma.to(dev), beta.to(dev)
+        _lib.check(_lib.lib().ace_instance_norm(_lib.ptr(xd), _lib.ptr(gd), _lib.ptr(bd),
                                                 1e-6, _lib.ptr(y), n, c, hw, _lib.current_stream()))
         print(f"instance_norm n={n} c={c} hw={hw}: relmax {rel_max(y, ref):.3e}")
 
