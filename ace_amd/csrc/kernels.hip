@@ -45,58 +45,63 @@ DEVINL int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 constexpr int BK = 16;  // k-depth of one LDS stage
 
 // ---------------------------------------------------------------------------------------------
-// operand stagers: global -> registers (issued early) -> LDS (written after the MFMAs)
+// operand stagers: global -> registers (issued early, never touched before the MFMAs) -> LDS (after them).
+// Loads are branch-free: out-of-range lanes read a clamped in-range address and the value is zeroed by a
+// select, so the compiler emits straight-line global_load_dwordx4 with no wait between them.
 // ---------------------------------------------------------------------------------------------
 
 // A tile from a row-major [M][K] matrix, stored k-major in LDS: As[k][m] (pitch SA, SA % 8 == 2 so the
 // four transposing ds_write_b32 of a lane group hit 32 distinct banks).
+// VEC requires: base 16B aligned, lda % 4 == 0, kend % 4 == 0.
 template <int BM, int NT, bool VEC>
 struct StageA {
     static constexpr int G = BM * BK / 4 / NT;
     static constexpr int SA = BM + 2;
     float4 r[G];
+    // raw loads only (clamped addresses): nothing here may consume a loaded value, or the compiler has to
+    // wait for the whole stage before the MFMAs.  Out-of-range elements are zeroed in store().
     DEVINL void load(const float* __restrict__ A, long lda, int m0, int M, int k0, int kend, int tid) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int f = tid + g * NT;
             const int row = f / (BK / 4), kc = f % (BK / 4);
             const int m = m0 + row, k = k0 + 4 * kc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < M && k < kend) {
-                const float* p = A + (long)m * lda + k;
-                if (VEC && k + 3 < kend) {
-                    v = *reinterpret_cast<const float4*>(p);
-                } else {
-                    v.x = p[0];
-                    if (k + 1 < kend) v.y = p[1];
-                    if (k + 2 < kend) v.z = p[2];
-                    if (k + 3 < kend) v.w = p[3];
-                }
+            const float* prow = A + (long)(m < M ? m : 0) * lda;
+            if (VEC) {
+                r[g] = *reinterpret_cast<const float4*>(prow + (k < kend ? k : 0));
+            } else {
+                r[g] = make_float4(prow[k < kend ? k : 0], prow[k + 1 < kend ? k + 1 : 0], prow[k + 2 < kend ? k + 2 : 0],
+                                   prow[k + 3 < kend ? k + 3 : 0]);
             }
-            r[g] = v;
         }
     }
-    DEVINL void store(float* As, int tid) const {
+    DEVINL void store(float* As, int m0, int M, int k0, int kend, int tid) const {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int f = tid + g * NT;
             const int row = f / (BK / 4), kc = f % (BK / 4);
+            const int k = k0 + 4 * kc;
+            const bool rok = m0 + row < M;
             float* d = As + (4 * kc) * SA + row;
-            d[0] = r[g].x;
-            d[SA] = r[g].y;
-            d[2 * SA] = r[g].z;
-            d[3 * SA] = r[g].w;
+            d[0] = (rok && k < kend) ? r[g].x : 0.f;
+            d[SA] = (rok && k + 1 < kend) ? r[g].y : 0.f;
+            d[2 * SA] = (rok && k + 2 < kend) ? r[g].z : 0.f;
+            d[3 * SA] = (rok && k + 3 < kend) ? r[g].w : 0.f;
         }
     }
 };
 
 // B tile from a row-major [K][N] matrix: Bs[k][n] (pitch SB = BN + 4, 16-byte rows -> ds_write_b128).
-// Optional second source for rows k >= K1 and optional per-row affine (fused instance norm).
-template <int BN, int NT, bool VEC>
+// Optional second source for rows k >= K1 (the big-skip concat) and optional per-row affine (fused instance
+// norm): the scale/shift are fetched with the tile and applied when the tile is written to LDS.
+// VEC requires: bases 16B aligned, ldb % 4 == 0, N % 4 == 0.
+template <int BN, int NT, bool VEC, bool AFF>
 struct StageB {
     static constexpr int G = BN * BK / 4 / NT;
     static constexpr int SB = BN + 4;
     float4 r[G];
+    float sc[AFF ? G : 1], sh[AFF ? G : 1];
+    // raw loads only (see StageA::load)
     DEVINL void load(const float* __restrict__ B, long ldb, const float* __restrict__ B2, long ldb2, int K1,
                      const float* __restrict__ bsc, const float* __restrict__ bsh, int n0, int N, int k0, int kend,
                      int tid, int kvalid = 0) {
@@ -105,63 +110,79 @@ struct StageB {
             const int f = tid + g * NT;
             const int kr = f / (BN / 4), nc = f % (BN / 4);
             const int k = k0 + kr, n = n0 + 4 * nc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < kend && k >= kvalid && n < N) {
-                const float* p = (K1 >= 0 && k >= K1) ? (B2 + (long)(k - K1) * ldb2 + n) : (B + (long)k * ldb + n);
-                if (VEC && n + 3 < N) {
-                    v = *reinterpret_cast<const float4*>(p);
-                } else {
-                    v.x = p[0];
-                    if (n + 1 < N) v.y = p[1];
-                    if (n + 2 < N) v.z = p[2];
-                    if (n + 3 < N) v.w = p[3];
-                }
-                if (bsc != nullptr) {
-                    const float s = bsc[k], t = bsh[k];
-                    v.x = fmaf(v.x, s, t);
-                    v.y = fmaf(v.y, s, t);
-                    v.z = fmaf(v.z, s, t);
-                    v.w = fmaf(v.w, s, t);
-                }
+            const int kk = ((k < kend) && (k >= kvalid)) ? k : kvalid;  // kvalid < kend whenever the tile is reached
+            const float* prow = (K1 >= 0 && kk >= K1) ? (B2 + (long)(kk - K1) * ldb2) : (B + (long)kk * ldb);
+            if (VEC) {
+                r[g] = *reinterpret_cast<const float4*>(prow + (n < N ? n : 0));
+            } else {
+                r[g] = make_float4(prow[n < N ? n : 0], prow[n + 1 < N ? n + 1 : 0], prow[n + 2 < N ? n + 2 : 0],
+                                   prow[n + 3 < N ? n + 3 : 0]);
             }
-            r[g] = v;
+            if (AFF) { sc[g] = bsc[kk]; sh[g] = bsh[kk]; }
         }
     }
-    DEVINL void store(float* Bs, int tid) const {
+    DEVINL void store(float* Bs, int n0, int N, int k0, int kend, int tid, int kvalid = 0) const {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int f = tid + g * NT;
             const int kr = f / (BN / 4), nc = f % (BN / 4);
-            *reinterpret_cast<float4*>(Bs + kr * SB + 4 * nc) = r[g];
+            const int k = k0 + kr, n = n0 + 4 * nc;
+            const bool kok = (k < kend) && (k >= kvalid);
+            float4 v = r[g];
+            if (AFF) {
+                v.x = fmaf(v.x, sc[g], sh[g]);
+                v.y = fmaf(v.y, sc[g], sh[g]);
+                v.z = fmaf(v.z, sc[g], sh[g]);
+                v.w = fmaf(v.w, sc[g], sh[g]);
+            }
+            v.x = (kok && n < N) ? v.x : 0.f;
+            v.y = (kok && n + 1 < N) ? v.y : 0.f;
+            v.z = (kok && n + 2 < N) ? v.z : 0.f;
+            v.w = (kok && n + 3 < N) ? v.w : 0.f;
+            *reinterpret_cast<float4*>(Bs + kr * SB + 4 * nc) = v;
         }
     }
 };
 
-// one LDS stage of MFMAs for a 64x64 wave tile: 2x2 tiles of 32x32, K = 2 per instruction;
-// lane half h supplies k = ks + h (A[i][k] / B[k][j] fragments are one VGPR each)
+// one LDS stage of MFMAs for a 64x64 wave tile: 2x2 tiles of 32x32, K = 2 per instruction; lane half h supplies
+// k = ks + h (A[i][k] / B[k][j] fragments are one VGPR each).  Fragments are fetched PF k-steps ahead of the
+// MFMAs that consume them so the LDS round trip hides under the previous MFMAs.
 template <int SA, int SB>
 DEVINL void mma_stage(const float* As, const float* Bs, int arow, int bcol, int h, f32x16 (&acc)[2][2]) {
+    constexpr int NS = BK / 2;  // k-steps per stage
+    constexpr int PF = 2;       // prefetch distance in k-steps
+    float fa[NS][2], fb[NS][2];
 #pragma unroll
-    for (int ks = 0; ks < BK; ks += 2) {
-        const float a0 = As[(ks + h) * SA + arow];
-        const float a1 = As[(ks + h) * SA + arow + 32];
-        const float b0 = Bs[(ks + h) * SB + bcol];
-        const float b1 = Bs[(ks + h) * SB + bcol + 32];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    for (int s = 0; s < NS; ++s) {
+        fa[s][0] = As[(2 * s + h) * SA + arow];
+        fa[s][1] = As[(2 * s + h) * SA + arow + 32];
+        fb[s][0] = Bs[(2 * s + h) * SB + bcol];
+        fb[s][1] = Bs[(2 * s + h) * SB + bcol + 32];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][0], fb[s][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][0], fb[s][1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][1], fb[s][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][1], fb[s][1], acc[1][1], 0, 0, 0);
+    }
+    // pin the interleave: fragments for k-step s+PF are read (2 ds_read2_b32) while the MFMAs of step s run
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * PF, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        if (s + PF < NS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // batched GEMM with fused epilogue
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, bool VA, bool VB>
+template <int WM, int WN, bool VEC, bool AFF, bool RES>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p, int tilesM, int tilesN) {
     constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
-    using SA_t = StageA<BM, NT, VA>;
-    using SB_t = StageB<BN, NT, VB>;
+    using SA_t = StageA<BM, NT, VEC>;
+    using SB_t = StageB<BN, NT, VEC, AFF>;
     constexpr int SA = SA_t::SA, SB = SB_t::SB;
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * SA + 2 * BK * SB];
     float* As = smem;
@@ -177,7 +198,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p, int 
 
     int M = p.M, kbeg = 0, kvalid = 0;
     if (p.tri == TRI_ROWS_GE_BATCH) {
-        if (m0 + BM <= batch) return;  // rows l < m: table is zero there, output stays at its memset zeros
+        if (m0 + BM <= batch) return;  // rows l < m: table is zero there, nothing downstream reads them
     } else if (p.tri == TRI_K_GE_BATCH) {
         kbeg = (batch / BK) * BK;
         kvalid = batch;  // rows l < m of the spectral operand are never written: read them as zero
@@ -191,8 +212,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p, int 
     const float* A = p.A + (long)batch * p.sA;
     const float* B = p.B + (long)batch * p.sB;
     const float* B2 = p.B2 ? p.B2 + (long)batch * p.sB2 : nullptr;
-    const float* bsc = p.bsc ? p.bsc + (long)batch * p.sbs : nullptr;
-    const float* bsh = p.bsh ? p.bsh + (long)batch * p.sbs : nullptr;
+    const float* bsc = AFF ? p.bsc + (long)batch * p.sbs : nullptr;
+    const float* bsh = AFF ? p.bsh + (long)batch * p.sbs : nullptr;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -214,54 +235,74 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p, int 
     if (nk > 0) {
         sa.load(A, p.lda, m0, M, kbeg, kend, tid);
         sb.load(B, p.ldb, B2, p.ldb2, p.K1, bsc, bsh, n0, p.N, kbeg, kend, tid, kvalid);
-        sa.store(As, tid);
-        sb.store(Bs, tid);
+        sa.store(As, m0, M, kbeg, kend, tid);
+        sb.store(Bs, n0, p.N, kbeg, kend, tid, kvalid);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1 < nk);
+        const int k0 = kbeg + (kt + 1) * BK;
         if (more) {  // next stage's global loads fly under this stage's MFMAs
-            const int k0 = kbeg + (kt + 1) * BK;
             sa.load(A, p.lda, m0, M, k0, kend, tid);
             sb.load(B, p.ldb, B2, p.ldb2, p.K1, bsc, bsh, n0, p.N, k0, kend, tid, kvalid);
         }
+        __builtin_amdgcn_sched_barrier(0);  // nothing that consumes the loads may move above the MFMAs
         mma_stage<SA, SB>(As + cur * BK * SA, Bs + cur * BK * SB, arow, bcol, h, acc);
+        __builtin_amdgcn_sched_barrier(0);
         if (more) {
-            sa.store(As + (cur ^ 1) * BK * SA, tid);
-            sb.store(Bs + (cur ^ 1) * BK * SB, tid);
+            sa.store(As + (cur ^ 1) * BK * SA, m0, M, k0, kend, tid);
+            sb.store(Bs + (cur ^ 1) * BK * SB, n0, p.N, k0, kend, tid, kvalid);
         }
         __syncthreads();
     }
 
-    // epilogue: lanes run along columns (128-byte row segments per store instruction)
+    // epilogue: lanes run along columns (128-byte row segments per store instruction).  Per 4-row register quad:
+    // all row parameters and all residual values are fetched first (clamped addresses, no branches), then the
+    // 8 outputs are finished and stored.
     float* C = p.C + (long)batch * p.sC;
-    const float* R = p.R ? p.R + (long)batch * p.sR : nullptr;
+    const float* R = RES ? p.R + (long)batch * p.sR : nullptr;
     const float* rsc = p.rsc ? p.rsc + (long)batch * p.srs : nullptr;
-    const float* rsh = p.rsh ? p.rsh + (long)batch * p.srs : nullptr;
+    const float* rsh = p.rsc ? p.rsh + (long)batch * p.srs : nullptr;
+    const int col0 = n0 + wn * 64 + i, col1 = col0 + 32;
+    const bool c0ok = col0 < p.N, c1ok = col1 < p.N;
+    const int cc0 = c0ok ? col0 : 0, cc1 = c1ok ? col1 : 0;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 64 + tm * 32 + acc_row(r, h);
-            if (row >= M) continue;
-            const float bv = p.bias ? p.bias[row] : 0.f;
-            float rs = 1.f, rt = 0.f, os = 1.f, ot = 0.f;
-            if (rsc) { rs = rsc[row]; rt = rsh[row]; }
-            if (p.osc) { os = p.osc[row]; ot = p.osh[row]; }
+        for (int q = 0; q < 4; ++q) {
+            const int rbase = m0 + wm * 64 + tm * 32 + 8 * q + 4 * h;
+            float bv[4], rs[4], rt[4], os[4], ot[4], rv0[4], rv1[4];
+            int rr[4];
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
-                const int col = n0 + wn * 64 + tn * 32 + i;
-                if (col >= p.N) continue;
-                float v = acc[tm][tn][r] + bv;
-                if (R) {
-                    float rv = R[(long)row * p.ldr + col];
-                    if (rsc) rv = fmaf(rv, rs, rt);
-                    v += rv;
+            for (int e = 0; e < 4; ++e) {
+                rr[e] = (rbase + e < M) ? rbase + e : 0;
+                bv[e] = p.bias ? p.bias[rr[e]] : 0.f;
+                rs[e] = rsc ? rsc[rr[e]] : 1.f;
+                rt[e] = rsc ? rsh[rr[e]] : 0.f;
+                os[e] = p.osc ? p.osc[rr[e]] : 1.f;
+                ot[e] = p.osc ? p.osh[rr[e]] : 0.f;
+                if (RES) {
+                    rv0[e] = R[(long)rr[e] * p.ldr + cc0];
+                    rv1[e] = R[(long)rr[e] * p.ldr + cc1];
                 }
-                v = act_apply(v, p.act);
-                if (p.osc) v = fmaf(v, os, ot);
-                C[(long)row * p.ldc + col] = v;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool rok = rbase + e < M;
+                float v0 = acc[tm][0][4 * q + e] + bv[e];
+                float v1 = acc[tm][1][4 * q + e] + bv[e];
+                if (RES) {
+                    v0 += fmaf(rv0[e], rs[e], rt[e]);
+                    v1 += fmaf(rv1[e], rs[e], rt[e]);
+                }
+                v0 = act_apply(v0, p.act);
+                v1 = act_apply(v1, p.act);
+                v0 = fmaf(v0, os[e], ot[e]);
+                v1 = fmaf(v1, os[e], ot[e]);
+                float* crow = C + (long)rr[e] * p.ldc;
+                if (rok && c0ok) crow[col0] = v0;
+                if (rok && c1ok) crow[col1] = v1;
             }
         }
     }
@@ -269,25 +310,32 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p, int 
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+template <int WM, int WN, bool VEC>
+static hipError_t launch_gemm_vec(const GemmArgs& a, hipStream_t s, int tilesM, int tilesN, dim3 grid, dim3 block) {
+    const bool aff = a.bsc != nullptr, res = a.R != nullptr;
+    if (aff && res)
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, VEC, true, true>), grid, block, 0, s, a, tilesM, tilesN);
+    else if (aff)
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, VEC, true, false>), grid, block, 0, s, a, tilesM, tilesN);
+    else if (res)
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, VEC, false, true>), grid, block, 0, s, a, tilesM, tilesN);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, VEC, false, false>), grid, block, 0, s, a, tilesM, tilesN);
+    return hipGetLastError();
+}
+
 template <int WM, int WN>
 static hipError_t launch_gemm_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
     const long nblk = (long)tilesM * tilesN * a.nbatch;
     if (nblk <= 0) return hipSuccess;
-    const bool va = al16(a.A) && (a.lda % 4 == 0) && (a.sA % 4 == 0);
-    bool vb = al16(a.B) && (a.ldb % 4 == 0) && (a.sB % 4 == 0);
-    if (a.B2) vb = vb && al16(a.B2) && (a.ldb2 % 4 == 0) && (a.sB2 % 4 == 0);
+    bool vec = al16(a.A) && (a.lda % 4 == 0) && (a.sA % 4 == 0) && (a.K % 4 == 0) && al16(a.B) && (a.ldb % 4 == 0) &&
+               (a.sB % 4 == 0) && (a.N % 4 == 0);
+    if (a.B2) vec = vec && al16(a.B2) && (a.ldb2 % 4 == 0) && (a.sB2 % 4 == 0);
     dim3 grid((unsigned)nblk), block(NT);
-    if (va && vb)
-        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, true, true>), grid, block, 0, s, a, tilesM, tilesN);
-    else if (va)
-        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, true, false>), grid, block, 0, s, a, tilesM, tilesN);
-    else if (vb)
-        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, false, true>), grid, block, 0, s, a, tilesM, tilesN);
-    else
-        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, false, false>), grid, block, 0, s, a, tilesM, tilesN);
-    return hipGetLastError();
+    if (vec) return launch_gemm_vec<WM, WN, true>(a, s, tilesM, tilesN, grid, block);
+    return launch_gemm_vec<WM, WN, false>(a, s, tilesM, tilesN, grid, block);
 }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
@@ -301,14 +349,18 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // forward longitude DFT (2*pi*rfft(norm="forward"), fft.py:61-76 via sht_fix.py:127), folded:
 //   Re X[m] = sum_{w<=W/2} fc[m][w] * (x[w] + x[W-w]),  Im X[m] = sum fs[m][w] * (x[w] - x[W-w])
-// rows = m, columns = (k, b, c), batch = re/im.  The instance-norm affine is applied on load.
-// Output goes straight to the channel-fastest spectral layout X[m][k][b][ri][c].
+// rows = m, columns = (k, b, c).  One workgroup produces BOTH the real and the imaginary rows of its columns
+// (two accumulator sets fed by the even / odd folds of the same loaded x values), so x is read once per
+// m-tile.  The instance-norm affine and the fold happen when the tile is written to LDS, after the MFMAs
+// of the previous stage.  Output goes straight to the channel-fastest spectral layout X[m][k][b][ri][c].
 // ---------------------------------------------------------------------------------------------
 template <int BN, int NT, bool VEC>
 struct StageFold {
     static constexpr int G = BN * BK / 4 / NT;
     static constexpr int SB = BN + 2;  // transposing b32 writes: pitch % 8 == 2
-    float4 r[G];
+    float4 fw[G];   // x[w .. w+3]
+    float4 mr[G];   // x[W-w-4 .. W-w-1] (reversed neighbours of the mirror), VEC path
+    float m0v[G];   // x[W-w] (mirror of element 0)
     const float* base[G];
     float sc[G], sh[G];
     DEVINL void init(const DftArgs& p, int n0, int ncols, int tid) {
@@ -316,156 +368,178 @@ struct StageFold {
         for (int g = 0; g < G; ++g) {
             const int f = tid + g * NT;
             const int n = n0 + f / (BK / 4);
-            base[g] = nullptr;
+            const int nn = n < ncols ? n : 0;
+            const int c = nn % p.C, kb = nn / p.C;
+            const int b = kb % p.Bt, k = kb / p.Bt;
+            base[g] = p.x + ((long)(b * p.C + c) * p.H + k) * p.W;
             sc[g] = 1.f;
             sh[g] = 0.f;
-            if (n < ncols) {
-                const int c = n % p.C, kb = n / p.C;
-                const int b = kb % p.Bt, k = kb / p.Bt;
-                base[g] = p.x + ((long)(b * p.C + c) * p.H + k) * p.W;
-                if (p.sc) { sc[g] = p.sc[b * p.C + c]; sh[g] = p.sh[b * p.C + c]; }
-            }
+            if (p.sc) { sc[g] = p.sc[b * p.C + c]; sh[g] = p.sh[b * p.C + c]; }
+            if (n >= ncols) { sc[g] = 0.f; sh[g] = 0.f; }  // columns past the end contribute exact zeros
         }
     }
-    DEVINL void load(int ri, int W, int Kf, int w0, int tid) {
+    // element e of this group is longitude w+e; its mirror is W-w-e
+    DEVINL void load(int W, int w0, int tid) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int f = tid + g * NT;
             const int w = w0 + 4 * (f % (BK / 4));
-            float o[4] = {0.f, 0.f, 0.f, 0.f};
             const float* bp = base[g];
-            if (bp != nullptr && w < Kf) {
-                float xv[4];
-                if (VEC && w + 3 < W) {
-                    const float4 t = *reinterpret_cast<const float4*>(bp + w);
-                    xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) xv[e] = (w + e < W) ? bp[w + e] : 0.f;
-                }
+            if (VEC) {  // W % 4 == 0: w+3 < W always holds for w <= W/2 rounded to 4 when W >= 8
+                const int wc = (w + 3 < W) ? w : 0;
+                fw[g] = *reinterpret_cast<const float4*>(bp + wc);
+                const int mo = W - w - 4;  // >= 0 iff w + 4 <= W
+                mr[g] = *reinterpret_cast<const float4*>(bp + (mo >= 0 ? mo : 0));
+                m0v[g] = bp[(w > 0 && w < W) ? W - w : 0];
+            } else {
+                float t[4], u[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int we = w + e;
-                    if (we < Kf) {
-                        const float a = fmaf(xv[e], sc[g], sh[g]);
-                        const bool unpaired = (we == 0) || (2 * we == W);
-                        if (unpaired) {
-                            o[e] = ri == 0 ? a : 0.f;
-                        } else {
-                            const float m = fmaf(bp[W - we], sc[g], sh[g]);
-                            o[e] = ri == 0 ? a + m : a - m;
-                        }
-                    }
+                    t[e] = bp[we < W ? we : 0];
+                    u[e] = bp[(we > 0 && we < W) ? W - we : 0];
                 }
+                fw[g] = make_float4(t[0], t[1], t[2], t[3]);
+                m0v[g] = u[0];
+                mr[g] = make_float4(0.f, u[3], u[2], u[1]);  // same packing as the VEC path: (.w,.z,.y) = mirrors of e=1,2,3
             }
-            r[g] = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
-    DEVINL void store(float* Bs, int tid) const {
+    // writes the even fold into Be and the odd fold into Bo
+    DEVINL void store(float* Be, float* Bo, int W, int Kf, int w0, int tid) const {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int f = tid + g * NT;
             const int nl = f / (BK / 4), wc = f % (BK / 4);
-            float* d = Bs + (4 * wc) * SB + nl;
-            d[0] = r[g].x;
-            d[SB] = r[g].y;
-            d[2 * SB] = r[g].z;
-            d[3 * SB] = r[g].w;
+            const int w = w0 + 4 * wc;
+            const float xs[4] = {fw[g].x, fw[g].y, fw[g].z, fw[g].w};
+            const float ms[4] = {m0v[g], mr[g].w, mr[g].z, mr[g].y};
+            float* de = Be + (4 * wc) * SB + nl;
+            float* dd = Bo + (4 * wc) * SB + nl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int we = w + e;
+                const float a = fmaf(xs[e], sc[g], sh[g]);
+                const float m = fmaf(ms[e], sc[g], sh[g]);
+                const bool in = we < Kf;
+                const bool unpaired = (we == 0) || (2 * we == W);
+                de[e * SB] = in ? (unpaired ? a : a + m) : 0.f;
+                dd[e * SB] = (in && !unpaired) ? a - m : 0.f;
+            }
         }
     }
 };
 
-template <int WM, int WN, bool VX>
-__global__ __launch_bounds__(64 * WM * WN) void dft_forward_kernel(DftArgs p, int tilesM, int tilesN) {
-    constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
-    using SA_t = StageA<BM, NT, true>;  // tables are library-owned, 16B aligned, pitch % 4 == 0
+template <bool VX>
+__global__ __launch_bounds__(256) void dft_forward_kernel(DftArgs p, int tilesM, int tilesN) {
+    constexpr int BM = 64, BN = 128, NT = 256;     // 4 waves along n; each wave: 64 (m) x 32 (n) x {re, im}
+    using SA_t = StageA<BM, NT, true>;  // tables are library-owned: 16B aligned, pitch % 4 == 0, zero padded
     using SB_t = StageFold<BN, NT, VX>;
     constexpr int SA = SA_t::SA, SB = SB_t::SB;
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * SA + 2 * BK * SB];
+    constexpr int ABUF = 2 * BK * SA, BBUF = 2 * BK * SB;  // per buffer: {cos, sin} tables, {even, odd} folds
+    __shared__ __attribute__((aligned(16))) float smem[2 * ABUF + 2 * BBUF];
     float* As = smem;
-    float* Bs = smem + 2 * BK * SA;
+    float* Bs = smem + 2 * ABUF;
 
-    const int nblk = tilesM * tilesN * 2;
+    const int nblk = tilesM * tilesN;
     const int lid = xcd_remap(blockIdx.x, nblk);
-    const int ri = lid & 1;  // re/im tiles of the same columns run back to back (shared x lines in L2)
-    const int tile_m = (lid >> 1) % tilesM;
-    const int tile_n = (lid >> 1) / tilesM;
+    const int tile_m = lid % tilesM;  // the m-tiles of one column panel run back to back (shared x lines in L2)
+    const int tile_n = lid / tilesM;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int ncols = p.H * p.Bt * p.C;
     const int Kf = p.W / 2 + 1;
-    const float* T = ri == 0 ? p.tc : p.ts;
+    const int Kp = p.ldt;  // table pitch = Kf rounded up to 4, zero padded
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-    const int arow = wm * 64 + i, bcol = wn * 64 + i;
+    const int bcol = wave * 32 + i;
 
-    f32x16 acc[2][2];
+    f32x16 Re[2], Im[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int r = 0; r < 16; ++r) { Re[t][r] = 0.f; Im[t][r] = 0.f; }
 
-    SA_t sa;
+    SA_t sac, sas;
     SB_t sb;
     sb.init(p, n0, ncols, tid);
     const int nk = (Kf + BK - 1) / BK;
-    sa.load(T, p.ldt, m0, p.Mm, 0, Kf, tid);
-    sb.load(ri, p.W, Kf, 0, tid);
-    sa.store(As, tid);
-    sb.store(Bs, tid);
+    sac.load(p.tc, p.ldt, m0, p.Mm, 0, Kp, tid);
+    sas.load(p.ts, p.ldt, m0, p.Mm, 0, Kp, tid);
+    sb.load(p.W, 0, tid);
+    sac.store(As, m0, p.Mm, 0, Kp, tid);
+    sas.store(As + BK * SA, m0, p.Mm, 0, Kp, tid);
+    sb.store(Bs, Bs + BK * SB, p.W, Kf, 0, tid);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1 < nk);
         if (more) {
-            sa.load(T, p.ldt, m0, p.Mm, (kt + 1) * BK, Kf, tid);
-            sb.load(ri, p.W, Kf, (kt + 1) * BK, tid);
+            const int k0 = (kt + 1) * BK;
+            sac.load(p.tc, p.ldt, m0, p.Mm, k0, Kp, tid);
+            sas.load(p.ts, p.ldt, m0, p.Mm, k0, Kp, tid);
+            sb.load(p.W, k0, tid);
         }
-        mma_stage<SA, SB>(As + cur * BK * SA, Bs + cur * BK * SB, arow, bcol, h, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float* Ac = As + cur * ABUF;
+            const float* Asn = Ac + BK * SA;
+            const float* Be = Bs + cur * BBUF;
+            const float* Bo = Be + BK * SB;
+#pragma unroll
+            for (int ks = 0; ks < BK; ks += 2) {
+                const float c0 = Ac[(ks + h) * SA + i];
+                const float c1 = Ac[(ks + h) * SA + i + 32];
+                const float s0 = Asn[(ks + h) * SA + i];
+                const float s1 = Asn[(ks + h) * SA + i + 32];
+                const float ev = Be[(ks + h) * SB + bcol];
+                const float od = Bo[(ks + h) * SB + bcol];
+                Re[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, ev, Re[0], 0, 0, 0);
+                Re[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, ev, Re[1], 0, 0, 0);
+                Im[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(s0, od, Im[0], 0, 0, 0);
+                Im[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, od, Im[1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (more) {
-            sa.store(As + (cur ^ 1) * BK * SA, tid);
-            sb.store(Bs + (cur ^ 1) * BK * SB, tid);
+            const int k0 = (kt + 1) * BK;
+            sac.store(As + (cur ^ 1) * ABUF, m0, p.Mm, k0, Kp, tid);
+            sas.store(As + (cur ^ 1) * ABUF + BK * SA, m0, p.Mm, k0, Kp, tid);
+            sb.store(Bs + (cur ^ 1) * BBUF, Bs + (cur ^ 1) * BBUF + BK * SB, p.W, Kf, k0, tid);
         }
         __syncthreads();
     }
 
     const long N2 = (long)p.Bt * 2 * p.C;
-    long coff[2];
-    bool cok[2];
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const int n = n0 + wn * 64 + tn * 32 + i;
-        cok[tn] = n < ncols;
+    const int n = n0 + bcol;
+    if (n < ncols) {
         const int c = n % p.C, kb = n / p.C;  // kb = k * Bt + b
-        coff[tn] = (long)kb * 2 * p.C + (long)ri * p.C + c;
+        float* obase = p.spec_out + (long)kb * 2 * p.C + c;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + tm * 32 + acc_row(r, h);
+                if (m < p.Mm) {
+                    float* o = obase + (long)m * p.H * N2;
+                    o[0] = Re[tm][r];
+                    o[p.C] = Im[tm][r];
+                }
+            }
     }
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 64 + tm * 32 + acc_row(r, h);
-            if (m >= p.Mm) continue;
-            float* orow = p.spec_out + (long)m * p.H * N2;
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-                if (cok[tn]) orow[coff[tn]] = acc[tm][tn][r];
-        }
 }
 
 hipError_t launch_dft_forward(const DftArgs& a, hipStream_t s) {
-    constexpr int WM = 1, WN = 4, BM = 64, BN = 256, NT = 256;
+    constexpr int BM = 64, BN = 128;
     const int ncols = a.H * a.Bt * a.C;
     const int tilesM = (a.Mm + BM - 1) / BM, tilesN = (ncols + BN - 1) / BN;
-    const bool vx = al16(a.x) && (a.W % 4 == 0);
-    dim3 grid((unsigned)(tilesM * tilesN * 2)), block(NT);
+    const bool vx = al16(a.x) && (a.W % 4 == 0) && (a.W >= 8);
+    dim3 grid((unsigned)(tilesM * tilesN)), block(256);
     if (vx)
-        hipLaunchKernelGGL((dft_forward_kernel<WM, WN, true>), grid, block, 0, s, a, tilesM, tilesN);
+        hipLaunchKernelGGL((dft_forward_kernel<true>), grid, block, 0, s, a, tilesM, tilesN);
     else
-        hipLaunchKernelGGL((dft_forward_kernel<WM, WN, false>), grid, block, 0, s, a, tilesM, tilesN);
+        hipLaunchKernelGGL((dft_forward_kernel<false>), grid, block, 0, s, a, tilesM, tilesN);
     return hipGetLastError();
 }
 
@@ -480,18 +554,19 @@ struct StageSpecK {  // A operand, k-major source: element (row nn, k = m) at sp
     static constexpr int G = BM * BK / 4 / NT;
     static constexpr int SA = BM + 4;
     float4 r[2][G];
-    long rb[G][4];
-    bool ok[G][4];
+    long rb[G][VEC ? 1 : 4];
+    bool ok[G][VEC ? 1 : 4];
     DEVINL void init(int nn0, int nrows, int C, int tid) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int f = tid + g * NT;
             const int mc = f % (BM / 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < (VEC ? 1 : 4); ++e) {
                 const int nn = nn0 + 4 * mc + e;
-                ok[g][e] = nn < nrows;
-                rb[g][e] = (long)(nn / C) * 2 * C + (nn % C);
+                ok[g][e] = nn < nrows;  // VEC: C % 4 == 0 so the four rows are valid together
+                const int nc = ok[g][e] ? nn : 0;
+                rb[g][e] = (long)(nc / C) * 2 * C + (nc % C);
             }
         }
     }
@@ -500,31 +575,30 @@ struct StageSpecK {  // A operand, k-major source: element (row nn, k = m) at sp
         for (int g = 0; g < G; ++g) {
             const int f = tid + g * NT;
             const int m = k0 + f / (BM / 4);
+            const float* p0 = S + (long)(m < Mm ? m : 0) * ms;
 #pragma unroll
             for (int ri = 0; ri < 2; ++ri) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < Mm) {
-                    const float* p = S + (long)m * ms + (long)ri * C;
-                    if (VEC && ok[g][3]) {
-                        v = *reinterpret_cast<const float4*>(p + rb[g][0]);
-                    } else {
-                        if (ok[g][0]) v.x = p[rb[g][0]];
-                        if (ok[g][1]) v.y = p[rb[g][1]];
-                        if (ok[g][2]) v.z = p[rb[g][2]];
-                        if (ok[g][3]) v.w = p[rb[g][3]];
-                    }
-                }
-                r[ri][g] = v;
+                const float* p = p0 + (long)ri * C;
+                if (VEC) r[ri][g] = *reinterpret_cast<const float4*>(p + rb[g][0]);
+                else r[ri][g] = make_float4(p[rb[g][0]], p[rb[g][1]], p[rb[g][2]], p[rb[g][3]]);
             }
         }
     }
-    DEVINL void store(float* As /* [2][BK][SA] */, int tid) const {
+    DEVINL void store(float* As /* [2][BK][SA] */, int Mm, int k0, int tid) const {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int f = tid + g * NT;
             const int kr = f / (BM / 4), mc = f % (BM / 4);
-            *reinterpret_cast<float4*>(As + kr * SA + 4 * mc) = r[0][g];
-            *reinterpret_cast<float4*>(As + BK * SA + kr * SA + 4 * mc) = r[1][g];
+            const bool mok = k0 + kr < Mm;
+#pragma unroll
+            for (int ri = 0; ri < 2; ++ri) {
+                float4 v = r[ri][g];
+                v.x = (mok && ok[g][0]) ? v.x : 0.f;
+                v.y = (mok && ok[g][VEC ? 0 : 1]) ? v.y : 0.f;
+                v.z = (mok && ok[g][VEC ? 0 : 2]) ? v.z : 0.f;
+                v.w = (mok && ok[g][VEC ? 0 : 3]) ? v.w : 0.f;
+                *reinterpret_cast<float4*>(As + ri * BK * SA + kr * SA + 4 * mc) = v;
+            }
         }
     }
 };
@@ -533,7 +607,7 @@ template <bool VS>
 __global__ __launch_bounds__(256) void dft_inverse_kernel(DftArgs p, int tilesM, int tilesN) {
     constexpr int BM = 128, BN = 64, NT = 256;
     using SA_t = StageSpecK<BM, NT, VS>;
-    using SB_t = StageB<BN, NT, true>;
+    using SB_t = StageB<BN, NT, true, false>;
     constexpr int SA = SA_t::SA, SB = SB_t::SB;
     // per buffer: A re/im planes [2][BK][SA], tables cos/sin [2][BK][SB]
     constexpr int ABUF = 2 * BK * SA, BBUF = 2 * BK * SB;
@@ -548,6 +622,7 @@ __global__ __launch_bounds__(256) void dft_inverse_kernel(DftArgs p, int tilesM,
     const int nn0 = tile_m * BM, n0 = tile_n * BN;
     const int nrows = p.H * p.Bt * p.C;
     const int Kf = p.W / 2 + 1;
+    const int Np = p.ldt;  // table pitch (Kf rounded up to 4, zero padded): vector loads never straddle the end
     const long N2 = (long)p.Bt * 2 * p.C;
     const long ms = (long)p.H * N2;
 
@@ -567,11 +642,11 @@ __global__ __launch_bounds__(256) void dft_inverse_kernel(DftArgs p, int tilesM,
     sa.init(nn0, nrows, p.C, tid);
     const int nk = (p.Mm + BK - 1) / BK;
     sa.load(p.spec, ms, p.C, p.Mm, 0, tid);
-    sbc.load(p.tc, p.ldt, nullptr, 0, -1, nullptr, nullptr, n0, Kf, 0, p.Mm, tid);
-    sbs.load(p.ts, p.ldt, nullptr, 0, -1, nullptr, nullptr, n0, Kf, 0, p.Mm, tid);
-    sa.store(As, tid);
-    sbc.store(Bs, tid);
-    sbs.store(Bs + BK * SB, tid);
+    sbc.load(p.tc, p.ldt, nullptr, 0, -1, nullptr, nullptr, n0, Np, 0, p.Mm, tid);
+    sbs.load(p.ts, p.ldt, nullptr, 0, -1, nullptr, nullptr, n0, Np, 0, p.Mm, tid);
+    sa.store(As, p.Mm, 0, tid);
+    sbc.store(Bs, n0, Np, 0, p.Mm, tid);
+    sbs.store(Bs + BK * SB, n0, Np, 0, p.Mm, tid);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
@@ -579,9 +654,10 @@ __global__ __launch_bounds__(256) void dft_inverse_kernel(DftArgs p, int tilesM,
         if (more) {
             const int k0 = (kt + 1) * BK;
             sa.load(p.spec, ms, p.C, p.Mm, k0, tid);
-            sbc.load(p.tc, p.ldt, nullptr, 0, -1, nullptr, nullptr, n0, Kf, k0, p.Mm, tid);
-            sbs.load(p.ts, p.ldt, nullptr, 0, -1, nullptr, nullptr, n0, Kf, k0, p.Mm, tid);
+            sbc.load(p.tc, p.ldt, nullptr, 0, -1, nullptr, nullptr, n0, Np, k0, p.Mm, tid);
+            sbs.load(p.ts, p.ldt, nullptr, 0, -1, nullptr, nullptr, n0, Np, k0, p.Mm, tid);
         }
+        __builtin_amdgcn_sched_barrier(0);
         {
             const float* Ar = As + cur * ABUF;
             const float* Ai = Ar + BK * SA;
@@ -601,14 +677,17 @@ __global__ __launch_bounds__(256) void dft_inverse_kernel(DftArgs p, int tilesM,
                 Q[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, s1, Q[1], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (more) {
-            sa.store(As + (cur ^ 1) * ABUF, tid);
-            sbc.store(Bs + (cur ^ 1) * BBUF, tid);
-            sbs.store(Bs + (cur ^ 1) * BBUF + BK * SB, tid);
+            const int k0 = (kt + 1) * BK;
+            sa.store(As + (cur ^ 1) * ABUF, p.Mm, k0, tid);
+            sbc.store(Bs + (cur ^ 1) * BBUF, n0, Np, k0, p.Mm, tid);
+            sbs.store(Bs + (cur ^ 1) * BBUF + BK * SB, n0, Np, k0, p.Mm, tid);
         }
         __syncthreads();
     }
 
+    const int w0c = n0 + i, w1c = n0 + 32 + i;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int nn = nn0 + wave * 32 + acc_row(r, h);
@@ -619,7 +698,7 @@ __global__ __launch_bounds__(256) void dft_inverse_kernel(DftArgs p, int tilesM,
         const float bv = p.bias ? p.bias[c] : 0.f;
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
-            const int w = n0 + tn * 32 + i;
+            const int w = tn == 0 ? w0c : w1c;
             if (w >= Kf) continue;
             const float pv = P[tn][r], qv = Q[tn][r];
             yrow[w] = (pv + qv) + bv;
