@@ -150,7 +150,10 @@ struct StageB {
 template <int SA, int SB>
 DEVINL void mma_stage(const float* As, const float* Bs, int arow, int bcol, int h, f32x16 (&acc)[2][2]) {
     constexpr int NS = BK / 2;  // k-steps per stage
-    constexpr int PF = 2;       // prefetch distance in k-steps
+#ifndef ACE_PF
+#define ACE_PF 2
+#endif
+    constexpr int PF = ACE_PF;  // prefetch distance in k-steps
     float fa[NS][2], fb[NS][2];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -178,8 +181,11 @@ DEVINL void mma_stage(const float* As, const float* Bs, int arow, int bcol, int 
 // ---------------------------------------------------------------------------------------------
 // batched GEMM with fused epilogue
 // ---------------------------------------------------------------------------------------------
+#ifndef ACE_LB
+#define ACE_LB 1
+#endif
 template <int WM, int WN, bool VEC, bool AFF, bool RES>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p, int tilesM, int tilesN) {
+__global__ __launch_bounds__(64 * WM * WN, ACE_LB) void gemm_f32_kernel(GemmArgs p, int tilesM, int tilesN) {
     constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
     using SA_t = StageA<BM, NT, VEC>;
     using SB_t = StageB<BN, NT, VEC, AFF>;
@@ -243,18 +249,37 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p, int 
         const int cur = kt & 1;
         const bool more = (kt + 1 < nk);
         const int k0 = kbeg + (kt + 1) * BK;
+#ifndef ACE_EXP_NOGLOBAL
         if (more) {  // next stage's global loads fly under this stage's MFMAs
             sa.load(A, p.lda, m0, M, k0, kend, tid);
             sb.load(B, p.ldb, B2, p.ldb2, p.K1, bsc, bsh, n0, p.N, k0, kend, tid, kvalid);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);  // nothing that consumes the loads may move above the MFMAs
+#ifdef ACE_EXP_NOLDSREAD
+        {   // timing probe: operands from registers (no LDS traffic in the loop)
+            const float xa = (float)(tid & 7) * 0.25f, xb = (float)(tid & 3) * 0.5f;
+#pragma unroll
+            for (int s = 0; s < BK / 2; ++s) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, xb, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, xb, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, xb, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, xb, acc[1][1], 0, 0, 0);
+            }
+        }
+#else
         mma_stage<SA, SB>(As + cur * BK * SA, Bs + cur * BK * SB, arow, bcol, h, acc);
+#endif
         __builtin_amdgcn_sched_barrier(0);
+#ifndef ACE_EXP_NOLDSWRITE
         if (more) {
             sa.store(As + (cur ^ 1) * BK * SA, m0, M, k0, kend, tid);
             sb.store(Bs + (cur ^ 1) * BK * SB, n0, p.N, k0, kend, tid, kvalid);
         }
+#endif
+#ifndef ACE_EXP_NOBARRIER
         __syncthreads();
+#endif
     }
 
     // epilogue: lanes run along columns (128-byte row segments per store instruction).  Per 4-row register quad:
