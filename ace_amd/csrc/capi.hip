@@ -125,7 +125,7 @@ static int run_legendre_forward(const ace_sht_plan& pl, const float* X, float* D
     g.A = pl.wt.p; g.lda = pl.Hp; g.sA = (long)pl.lmax * pl.Hp;
     g.B = X; g.ldb = N2; g.sB = (long)pl.nlat * N2;
     g.C = D; g.ldc = (long)pl.mmax * N2; g.sC = N2;
-    g.M = pl.lmax; g.N = (int)N2; g.K = pl.nlat; g.nbatch = pl.mmax;
+    g.M = pl.lmax; g.N = (int)N2; g.K = pl.nlat; g.nbatch = pl.mmax; g.a_kpad = pl.Hp;
     g.tri = TRI_ROWS_GE_BATCH;
     HIP_TRY(launch_gemm(g, s));
     return ACE_OK;
@@ -136,7 +136,7 @@ static int run_legendre_inverse(const ace_sht_plan& pl, const float* E, float* X
     g.A = pl.pt.p; g.lda = pl.Lp; g.sA = (long)pl.nlat * pl.Lp;
     g.B = E; g.ldb = (long)pl.mmax * N2; g.sB = N2;
     g.C = X; g.ldc = N2; g.sC = (long)pl.nlat * N2;
-    g.M = pl.nlat; g.N = (int)N2; g.K = pl.lmax; g.nbatch = pl.mmax;
+    g.M = pl.nlat; g.N = (int)N2; g.K = pl.lmax; g.nbatch = pl.mmax; g.a_kpad = pl.Lp;
     g.tri = TRI_K_GE_BATCH;
     HIP_TRY(launch_gemm(g, s));
     return ACE_OK;
@@ -225,6 +225,7 @@ extern "C" int ace_conv1x1(const float* x, const float* weight, const float* bia
     g.B = x; g.ldb = hw; g.sB = (long)cin * hw;
     g.C = y; g.ldc = hw; g.sC = (long)cout * hw;
     g.bias = bias; g.M = cout; g.N = (int)hw; g.K = cin; g.nbatch = n; g.act = act;
+    g.a_kpad = cin;  // caller's weight is unpadded: only K % stage-depth == 0 qualifies for the direct-to-LDS engine
     HIP_TRY(launch_gemm(g, static_cast<hipStream_t>(stream)));
     return ACE_OK;
 }
@@ -263,10 +264,11 @@ extern "C" int ace_unpack_denormalize(const float* src, const float* mean, const
 struct Weight {
     std::string name;
     long numel = 0;
-    DevBuf buf;    // library copy in the reference's layout
+    DevBuf buf;    // library copy (reference layout; conv weights: rows zero-padded to `pitch`)
     bool set = false;
     int block = -1;
     bool is_filter = false;
+    int rows = 0, cols = 0, pitch = 0;  // conv weights (rows x cols), pitch = cols rounded up to 32
 };
 
 struct GraphKey {
@@ -285,6 +287,7 @@ struct ace_sfno {
     std::vector<DevBuf> wx;  // per block: dhconv weight expanded to real [L][2C][2C]
     // workspace
     DevBuf h0, h1, Y, T, R, U, X, D, E, stats;
+    DevBuf Wf0, bf0, Wf1, bf1;  // instance-norm affine folded into inner_skip / mlp.fc1 weights, per sample
     bool taps_on = false;
     std::vector<DevBuf> taps;
     std::map<GraphKey, hipGraphExec_t> graphs;
@@ -301,6 +304,13 @@ static void add_weight(ace_sfno* n, const std::string& name, long numel, int blo
     w->name = name; w->numel = numel; w->block = block; w->is_filter = is_filter;
     n->index[name] = (int)n->weights.size();
     n->weights.push_back(std::move(w));
+}
+// 1x1-conv weight (rows x cols): kept zero-padded to a multiple of 32 columns so the direct-to-LDS GEMM can
+// read whole k-stages
+static void add_conv_weight(ace_sfno* n, const std::string& name, int rows, int cols) {
+    add_weight(n, name, (long)rows * cols);
+    Weight& w = *n->weights.back();
+    w.rows = rows; w.cols = cols; w.pitch = (cols + 31) & ~31;
 }
 
 extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
@@ -341,34 +351,34 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     if (c.pos_embed) add_weight(n.get(), "pos_embed", C * HW);
     long cur = c.in_chans;
     for (int j = 0; j < c.encoder_layers; ++j) {
-        add_weight(n.get(), "encoder." + std::to_string(2 * j) + ".weight", C * cur);
+        add_conv_weight(n.get(), "encoder." + std::to_string(2 * j) + ".weight", (int)C, (int)cur);
         add_weight(n.get(), "encoder." + std::to_string(2 * j) + ".bias", C);
         cur = C;
     }
-    add_weight(n.get(), "encoder." + std::to_string(2 * c.encoder_layers) + ".weight", C * cur);
+    add_conv_weight(n.get(), "encoder." + std::to_string(2 * c.encoder_layers) + ".weight", (int)C, (int)cur);
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string p = "blocks." + std::to_string(i) + ".";
         if (c.normalization_layer == 1) { add_weight(n.get(), p + "norm0.weight", C); add_weight(n.get(), p + "norm0.bias", C); }
         const long fw = c.operator_type == 1 ? C * C * n->L * 2 : C * C * (long)n->L * n->Mm * 2;
         add_weight(n.get(), p + "filter.filter.weight", fw, i, true);
         add_weight(n.get(), p + "filter.filter.bias", C);
-        add_weight(n.get(), p + "inner_skip.weight", C * C);
+        add_conv_weight(n.get(), p + "inner_skip.weight", (int)C, (int)C);
         add_weight(n.get(), p + "inner_skip.bias", C);
         if (c.normalization_layer == 1) { add_weight(n.get(), p + "norm1.weight", C); add_weight(n.get(), p + "norm1.bias", C); }
         if (c.use_mlp) {
-            add_weight(n.get(), p + "mlp.fwd.0.weight", (long)n->hid * C);
+            add_conv_weight(n.get(), p + "mlp.fwd.0.weight", n->hid, (int)C);
             add_weight(n.get(), p + "mlp.fwd.0.bias", n->hid);
-            add_weight(n.get(), p + "mlp.fwd.2.weight", C * (long)n->hid);
+            add_conv_weight(n.get(), p + "mlp.fwd.2.weight", (int)C, n->hid);
             add_weight(n.get(), p + "mlp.fwd.2.bias", C);
         }
     }
     cur = C + (c.big_skip ? c.in_chans : 0);
     for (int j = 0; j < c.encoder_layers; ++j) {
-        add_weight(n.get(), "decoder." + std::to_string(2 * j) + ".weight", C * cur);
+        add_conv_weight(n.get(), "decoder." + std::to_string(2 * j) + ".weight", (int)C, (int)cur);
         add_weight(n.get(), "decoder." + std::to_string(2 * j) + ".bias", C);
         cur = C;
     }
-    add_weight(n.get(), "decoder." + std::to_string(2 * c.encoder_layers) + ".weight", (long)c.out_chans * cur);
+    add_conv_weight(n.get(), "decoder." + std::to_string(2 * c.encoder_layers) + ".weight", c.out_chans, (int)cur);
 
     n->wx.resize(c.num_layers);
     const size_t act = (size_t)n->Bmax * C * HW;
@@ -384,6 +394,15 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     HIP_TRY(n->D.alloc(spec_d));
     HIP_TRY(n->E.alloc(spec_d));
     HIP_TRY(n->stats.alloc((size_t)4 * n->Bmax * C));
+    if (c.normalization_layer == 1) {
+        const size_t cp = (size_t)((C + 31) & ~31);
+        HIP_TRY(n->Wf0.alloc((size_t)n->Bmax * C * cp));
+        HIP_TRY(n->bf0.alloc((size_t)n->Bmax * C));
+        if (c.use_mlp) {
+            HIP_TRY(n->Wf1.alloc((size_t)n->Bmax * n->hid * cp));
+            HIP_TRY(n->bf1.alloc((size_t)n->Bmax * n->hid));
+        }
+    }
     *out = n.release();
     return ACE_OK;
 }
@@ -414,8 +433,14 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
         return fail(ACE_ERR_INVALID, std::string("size mismatch for ") + name + ": expected " +
                                          std::to_string(w.numel) + " elements, got " + std::to_string(numel));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!w.buf.p) HIP_TRY(w.buf.alloc((size_t)numel, false));
-    HIP_TRY(hipMemcpyAsync(w.buf.p, src, sizeof(float) * numel, hipMemcpyDeviceToDevice, s));
+    if (w.pitch > 0) {
+        if (!w.buf.p) HIP_TRY(w.buf.alloc((size_t)w.rows * w.pitch, true));  // zero padding columns
+        HIP_TRY(hipMemcpy2DAsync(w.buf.p, sizeof(float) * w.pitch, src, sizeof(float) * w.cols, sizeof(float) * w.cols,
+                                 w.rows, hipMemcpyDeviceToDevice, s));
+    } else {
+        if (!w.buf.p) HIP_TRY(w.buf.alloc((size_t)numel, false));
+        HIP_TRY(hipMemcpyAsync(w.buf.p, src, sizeof(float) * numel, hipMemcpyDeviceToDevice, s));
+    }
     if (w.is_filter && n->cfg.operator_type == 1) {
         DevBuf& wx = n->wx[w.block];
         const size_t cnt = (size_t)n->L * 2 * n->C * 2 * n->C;
@@ -428,20 +453,32 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
     return ACE_OK;
 }
 
-static int conv(const ace_sfno* n, const float* Wt, const float* bias, const float* in, long in_bstride, int cin,
-                const float* in2, long in2_bstride, int K1, const float* bsc, const float* bsh, float* out, int cout,
-                const float* R, long r_bstride, const float* rsc, const float* rsh, int act, int batch, hipStream_t s) {
+// one 1x1 convolution = one batched GEMM launch.  A operand: (ptr, pitch, per-sample stride); bias: (ptr, per-sample stride)
+struct ConvW { const float* w; int pitch; long sw; const float* bias; long sbias; };
+static ConvW conv_weight(const ace_sfno* n, const std::string& wname, const std::string& bname) {
+    const Weight& w = *n->weights[n->index.at(wname)];
+    return ConvW{w.buf.p, w.pitch, 0, bname.empty() ? nullptr : n->w(bname), 0};
+}
+static int conv(const ace_sfno* n, const ConvW& cw, const float* in, long in_bstride, int cin, const float* in2,
+                long in2_bstride, int K1, float* out, int cout, const float* R, long r_bstride, const float* rsc,
+                const float* rsh, int act, int batch, hipStream_t s) {
     GemmArgs g;
-    g.A = Wt; g.lda = cin; g.sA = 0;
+    g.A = cw.w; g.lda = cw.pitch; g.sA = cw.sw; g.a_kpad = cw.pitch;
     g.B = in; g.ldb = n->HW; g.sB = in_bstride;
     g.B2 = in2; g.ldb2 = n->HW; g.sB2 = in2_bstride; g.K1 = in2 ? K1 : -1;
-    g.bsc = bsc; g.bsh = bsh; g.sbs = bsc ? cin : 0;
     g.C = out; g.ldc = n->HW; g.sC = (long)cout * n->HW;
-    g.bias = bias;
+    g.bias = cw.bias; g.sbias = cw.sbias;
     g.R = R; g.ldr = n->HW; g.sR = r_bstride;
     g.rsc = rsc; g.rsh = rsh; g.srs = rsc ? cout : 0;
     g.M = cout; g.N = (int)n->HW; g.K = cin; g.nbatch = batch; g.act = act;
     HIP_TRY(launch_gemm(g, s));
+    return ACE_OK;
+}
+// the instance-norm affine (a, b) of the conv input folded into its weight: returns the per-sample operand
+static int fold(const ace_sfno* n, const ConvW& cw, int O, int I, const float* a, const float* b, float* Wf, float* bf,
+                int batch, hipStream_t s, ConvW* out) {
+    HIP_TRY(launch_fold_affine(cw.w, cw.pitch, a, b, cw.bias, Wf, bf, batch, O, I, s));
+    *out = ConvW{Wf, cw.pitch, (long)O * cw.pitch, bf, O};
     return ACE_OK;
 }
 
@@ -503,15 +540,14 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     float* ping[2] = {n->Y.p, n->T.p};
     for (int j = 0; j < c.encoder_layers; ++j) {
         const std::string p = "encoder." + std::to_string(2 * j);
-        ACE_TRY(conv(n, W(p + ".weight"), W(p + ".bias"), cur, cur_bs, curC, nullptr, 0, -1, nullptr, nullptr,
-                     ping[j & 1], C, nullptr, 0, nullptr, nullptr, act, B, s));
+        ACE_TRY(conv(n, conv_weight(n, p + ".weight", p + ".bias"), cur, cur_bs, curC, nullptr, 0, -1, ping[j & 1], C,
+                     nullptr, 0, nullptr, nullptr, act, B, s));
         cur = ping[j & 1]; cur_bs = actB; curC = C;
     }
     float* h = n->h0.p;
     float* hn = n->h1.p;
-    ACE_TRY(conv(n, W("encoder." + std::to_string(2 * c.encoder_layers) + ".weight"), nullptr, cur, cur_bs, curC,
-                 nullptr, 0, -1, nullptr, nullptr, h, C, c.pos_embed ? W("pos_embed") : nullptr, 0, nullptr, nullptr,
-                 ACT_NONE, B, s));
+    ACE_TRY(conv(n, conv_weight(n, "encoder." + std::to_string(2 * c.encoder_layers) + ".weight", ""), cur, cur_bs, curC,
+                 nullptr, 0, -1, h, C, c.pos_embed ? W("pos_embed") : nullptr, 0, nullptr, nullptr, ACT_NONE, B, s));
     MARK(ST_ENCODER);
     if (n->taps_on) HIP_TRY(hipMemcpyAsync(n->taps[0].p, h, sizeof(float) * B * actB, hipMemcpyDeviceToDevice, s));
 
@@ -554,7 +590,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             g.A = n->D.p; g.lda = 2 * C; g.sA = (long)n->Mm * N2;
             g.B = n->wx[i].p; g.ldb = 2 * C; g.sB = (long)2 * C * 2 * C;
             g.C = n->E.p; g.ldc = 2 * C; g.sC = (long)n->Mm * N2;
-            g.M = n->Mm * B; g.N = 2 * C; g.K = 2 * C; g.nbatch = n->L;
+            g.M = n->Mm * B; g.N = 2 * C; g.K = 2 * C; g.nbatch = n->L; g.a_kpad = 2 * C;
             g.tri = TRI_ROWS_LE_BATCH; g.trimul = B;
             HIP_TRY(launch_gemm(g, s));
         } else {
@@ -567,8 +603,9 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         MARK(ST_DFT_INV);
 
         // x = act(filter + inner_skip(residual))   (sfnonet.py:229-232)
-        ACE_TRY(conv(n, W(p + "inner_skip.weight"), W(p + "inner_skip.bias"), res, actB, C, nullptr, 0, -1, ra, rb,
-                     n->T.p, C, n->Y.p, actB, nullptr, nullptr, act, B, s));
+        ConvW wskip = conv_weight(n, p + "inner_skip.weight", p + "inner_skip.bias");
+        if (ra) ACE_TRY(fold(n, wskip, C, C, ra, rb, n->Wf0.p, n->bf0.p, B, s, &wskip));
+        ACE_TRY(conv(n, wskip, res, actB, C, nullptr, 0, -1, n->T.p, C, n->Y.p, actB, nullptr, nullptr, act, B, s));
         MARK(ST_INNER_SKIP);
         // norm1 -> MLP -> + residual   (sfnonet.py:234-250)
         const float *a1 = nullptr, *b1 = nullptr;
@@ -578,11 +615,12 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             MARK(ST_NORM1);
         }
         if (c.use_mlp) {
-            ACE_TRY(conv(n, W(p + "mlp.fwd.0.weight"), W(p + "mlp.fwd.0.bias"), n->T.p, actB, C, nullptr, 0, -1, a1, b1,
-                         n->U.p, n->hid, nullptr, 0, nullptr, nullptr, act, B, s));
+            ConvW wfc1 = conv_weight(n, p + "mlp.fwd.0.weight", p + "mlp.fwd.0.bias");
+            if (a1) ACE_TRY(fold(n, wfc1, n->hid, C, a1, b1, n->Wf1.p, n->bf1.p, B, s, &wfc1));
+            ACE_TRY(conv(n, wfc1, n->T.p, actB, C, nullptr, 0, -1, n->U.p, n->hid, nullptr, 0, nullptr, nullptr, act, B, s));
             MARK(ST_MLP_FC1);
-            ACE_TRY(conv(n, W(p + "mlp.fwd.2.weight"), W(p + "mlp.fwd.2.bias"), n->U.p, (long)n->hid * HW, n->hid,
-                         nullptr, 0, -1, nullptr, nullptr, hn, C, res, actB, ra, rb, ACT_NONE, B, s));
+            ACE_TRY(conv(n, conv_weight(n, p + "mlp.fwd.2.weight", p + "mlp.fwd.2.bias"), n->U.p, (long)n->hid * HW,
+                         n->hid, nullptr, 0, -1, hn, C, res, actB, ra, rb, ACT_NONE, B, s));
         } else {
             HIP_TRY(launch_rowaffine_add(n->T.p, a1, b1, res, ra, rb, hn, (long)B * C, HW, s));
         }
@@ -597,12 +635,12 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     for (int j = 0; j < c.encoder_layers; ++j) {
         const std::string p = "decoder." + std::to_string(2 * j);
         const bool cat = (j == 0 && c.big_skip);
-        ACE_TRY(conv(n, W(p + ".weight"), W(p + ".bias"), cur, cur_bs, cat ? C + Cin : curC, cat ? in : nullptr,
-                     (long)Cin * HW, C, nullptr, nullptr, ping[j & 1], C, nullptr, 0, nullptr, nullptr, act, B, s));
+        ACE_TRY(conv(n, conv_weight(n, p + ".weight", p + ".bias"), cur, cur_bs, cat ? C + Cin : curC,
+                     cat ? in : nullptr, (long)Cin * HW, C, ping[j & 1], C, nullptr, 0, nullptr, nullptr, act, B, s));
         cur = ping[j & 1]; cur_bs = actB; curC = C;
     }
-    ACE_TRY(conv(n, W("decoder." + std::to_string(2 * c.encoder_layers) + ".weight"), nullptr, cur, cur_bs, curC,
-                 nullptr, 0, -1, nullptr, nullptr, out, c.out_chans, nullptr, 0, nullptr, nullptr, ACT_NONE, B, s));
+    ACE_TRY(conv(n, conv_weight(n, "decoder." + std::to_string(2 * c.encoder_layers) + ".weight", ""), cur, cur_bs, curC,
+                 nullptr, 0, -1, out, c.out_chans, nullptr, 0, nullptr, nullptr, ACT_NONE, B, s));
     MARK(ST_DECODER);
     return ACE_OK;
 }

@@ -23,7 +23,10 @@ struct GemmArgs {
     // per-k-row affine applied to B on load: b = b * bsc[k] + bsh[k] (fused instance norm / normalisation)
     const float* bsc = nullptr; const float* bsh = nullptr; long sbs = 0;
     float* C = nullptr; long ldc = 0; long sC = 0;
-    const float* bias = nullptr;  // per row
+    const float* bias = nullptr; long sbias = 0;  // per row (optionally per batch)
+    // number of readable columns per A row that are either data (k < K) or zero padding; the direct-to-LDS
+    // engine needs a_kpad >= roundup(K, stage depth).  0 = unknown (register-staged engine is used)
+    int a_kpad = 0;
     // residual added after bias: r = R[row][col] (optionally r * rsc[row] + rsh[row])
     const float* R = nullptr; long ldr = 0; long sR = 0;
     const float* rsc = nullptr; const float* rsh = nullptr; long srs = 0;
@@ -34,6 +37,7 @@ struct GemmArgs {
     int act = ACT_NONE;
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+void set_force_v1(bool v);  // tests / A-B: route everything through the register-staged engine
 
 // Spectral-space layout used between the kernels ("channel-fastest planar"):
 //   X[m][k][b][ri][c]  (after the longitude DFT)     index ((m*H + k)*Bt + b)*2C + ri*C + c
@@ -70,6 +74,11 @@ hipError_t launch_expand_dhconv_weight(const float* w, float* wx, int Cin, int C
 // y = x * sc[row] + sh[row] + (r ? r * rsc[row] + rsh[row] : 0), rows of length n  (use_mlp=False tail, rare)
 hipError_t launch_rowaffine_add(const float* x, const float* sc, const float* sh, const float* r, const float* rsc,
                                 const float* rsh, float* y, long rows, long n, hipStream_t s);
+
+// fold a per-(sample, input-channel) affine (a, b) into a conv weight: Wf = W diag(a) (pitch ldw, zero padded),
+// bf = bias + W b.  W is (O, I) with pitch ldw.
+hipError_t launch_fold_affine(const float* W, long ldw, const float* a, const float* b, const float* bias, float* Wf,
+                              float* bf, int nsamples, int O, int I, hipStream_t s);
 
 // stepper glue (packer.py:45-52 + normalizer.py:213-236 fused)
 //   pack:   dst[b][j][:] = (src_j[b][:] - mean[j]) / std[j]   where src_j = srcs[j] + b*strides[j]

@@ -15,6 +15,8 @@
 // Written for gfx950 only: wavefront = 64, no portability paths.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace ace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -289,6 +291,11 @@ __global__ __launch_bounds__(64 * WM * WN, ACE_LB) void gemm_f32_kernel(GemmArgs
     const float* R = RES ? p.R + (long)batch * p.sR : nullptr;
     const float* rsc = p.rsc ? p.rsc + (long)batch * p.srs : nullptr;
     const float* rsh = p.rsc ? p.rsh + (long)batch * p.srs : nullptr;
+    const float* bias1 = p.bias ? p.bias + (long)batch * p.sbias : nullptr;
+    const float* osc = p.osc;
+    const float* osh = p.osh;
+    const long ldc = p.ldc, ldr = p.ldr;
+    const int actk = p.act;
     const int col0 = n0 + wn * 64 + i, col1 = col0 + 32;
     const bool c0ok = col0 < p.N, c1ok = col1 < p.N;
     const int cc0 = c0ok ? col0 : 0, cc1 = c1ok ? col1 : 0;
@@ -302,14 +309,21 @@ __global__ __launch_bounds__(64 * WM * WN, ACE_LB) void gemm_f32_kernel(GemmArgs
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 rr[e] = (rbase + e < M) ? rbase + e : 0;
-                bv[e] = p.bias ? p.bias[rr[e]] : 0.f;
-                rs[e] = rsc ? rsc[rr[e]] : 1.f;
-                rt[e] = rsc ? rsh[rr[e]] : 0.f;
-                os[e] = p.osc ? p.osc[rr[e]] : 1.f;
-                ot[e] = p.osc ? p.osh[rr[e]] : 0.f;
+                // optional row parameters without branches: absent ones read a valid dummy address (A) and are
+                // replaced by the neutral value with a select, so all loads of the quad issue back to back
+                const float t0 = (bias1 ? bias1 : A)[bias1 ? rr[e] : 0];
+                const float t1 = (rsc ? rsc : A)[rsc ? rr[e] : 0];
+                const float t2 = (rsc ? rsh : A)[rsc ? rr[e] : 0];
+                const float t3 = (osc ? osc : A)[osc ? rr[e] : 0];
+                const float t4 = (osc ? osh : A)[osc ? rr[e] : 0];
+                bv[e] = bias1 ? t0 : 0.f;
+                rs[e] = rsc ? t1 : 1.f;
+                rt[e] = rsc ? t2 : 0.f;
+                os[e] = osc ? t3 : 1.f;
+                ot[e] = osc ? t4 : 0.f;
                 if (RES) {
-                    rv0[e] = R[(long)rr[e] * p.ldr + cc0];
-                    rv1[e] = R[(long)rr[e] * p.ldr + cc1];
+                    rv0[e] = R[(long)rr[e] * ldr + cc0];
+                    rv1[e] = R[(long)rr[e] * ldr + cc1];
                 }
             }
 #pragma unroll
@@ -321,11 +335,251 @@ __global__ __launch_bounds__(64 * WM * WN, ACE_LB) void gemm_f32_kernel(GemmArgs
                     v0 += fmaf(rv0[e], rs[e], rt[e]);
                     v1 += fmaf(rv1[e], rs[e], rt[e]);
                 }
-                v0 = act_apply(v0, p.act);
-                v1 = act_apply(v1, p.act);
+                v0 = act_apply(v0, actk);
+                v1 = act_apply(v1, actk);
                 v0 = fmaf(v0, os[e], ot[e]);
                 v1 = fmaf(v1, os[e], ot[e]);
-                float* crow = C + (long)rr[e] * p.ldc;
+                float* crow = C + (long)rr[e] * ldc;
+                if (rok && c0ok) crow[col0] = v0;
+                if (rok && c1ok) crow[col1] = v1;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched GEMM, direct-to-LDS variant ("v2"): both operand tiles are brought in with
+// global_load_lds_dwordx4 (1 KiB per wave instruction, no VGPR staging, no LDS write pass).
+//   * B tile  Bs[k][n]  (n contiguous): lane-linear image of BK rows of the row-major source.
+//   * A tile  As[m][k]  (k contiguous, pitch BK): lane-linear too; the 16-byte slot a lane FETCHES is
+//     XOR-swizzled on the source side (slot ^ (row / rows-per-256B) mod slots) so that the per-lane
+//     ds_read_b128 fragment reads of 16 different rows spread over all 64 banks.
+//   * k permutation: lane half h owns k in [h*BK/2, (h+1)*BK/2) of the stage, so an A fragment is BK/8
+//     consecutive float4 of one row; MFMA sums are order-insensitive up to fp32 rounding of the chain.
+// Requirements (checked by the launcher): 16B-aligned bases, lda/ldb % 4 == 0, N % 4 == 0, every A row
+// readable AND zero for k in [K, roundup(K, BK)) (library-owned padded weights/tables, or K % BK == 0).
+// Out-of-range rows/columns are CLAMPED to valid addresses: the zero A columns annihilate the extra B rows,
+// extra A rows / B columns only feed outputs that are never stored.  No per-k affine (the caller folds
+// the instance-norm affine into the weights).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) char* lds_cp;
+
+// One 1-KiB LDS-DMA piece: lane L's 16 bytes at gsrc land at lds_base + 16*L.  Issued as inline asm so that
+// hipcc does not order later ds_reads of the OTHER buffer behind it (it would insert vmcnt(0) before every
+// fragment read); completion is waited for by hand (vmcnt(0) + barrier) at the end of the stage.
+DEVINL void glds16(const float* gsrc, float* lds_base_uniform) {
+    unsigned keep;
+    const unsigned addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cp)lds_base_uniform);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(addr)
+                 : "memory");
+}
+
+template <int WM, int WN, int BKT, bool RES>
+__global__ __launch_bounds__(64 * WM * WN) void gemm2_f32_kernel(GemmArgs p, int tilesM, int tilesN) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
+    constexpr int SL = BKT / 4;             // 16-byte slots per A row
+    constexpr int RW = 64 / BKT;            // A rows per 256-byte bank window
+    constexpr int ACH = BM * BKT / 256;     // 1 KiB chunks of the A tile
+    constexpr int BCH = BKT * BN / 256;     // 1 KiB chunks of the B tile
+    constexpr int AROWS = 256 / BKT;        // A rows per chunk
+    constexpr int ABUF = BM * BKT, BBUF = BKT * BN;  // floats per buffer
+    extern __shared__ __attribute__((aligned(16))) float smem2[];
+    float* As = smem2;              // [2][BM][BKT]
+    float* Bs = smem2 + 2 * ABUF;   // [2][BKT][BN]
+
+    const int nblk = tilesM * tilesN * p.nbatch;
+    const int lid = xcd_remap(blockIdx.x, nblk);
+    const int tile_m = lid % tilesM;
+    const int rest = lid / tilesM;
+    const int tile_n = rest % tilesN;
+    const int batch = rest / tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    int M = p.M, kbeg = 0;
+    if (p.tri == TRI_ROWS_GE_BATCH) {
+        if (m0 + BM <= batch) return;
+    } else if (p.tri == TRI_K_GE_BATCH) {
+        kbeg = (batch / BKT) * BKT;
+    } else if (p.tri == TRI_ROWS_LE_BATCH) {
+        const int me = (batch + 1) * p.trimul;
+        M = me < M ? me : M;
+        if (m0 >= M) return;
+    }
+    const int K = p.K;
+    const float* A = p.A + (long)batch * p.sA;
+    const float* B = p.B + (long)batch * p.sB;
+    const float* B2 = p.B2 ? p.B2 + (long)batch * p.sB2 : nullptr;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- per-lane source descriptors of the chunks this wave fetches (fixed over the k loop)
+    constexpr int ACW = (ACH + NW - 1) / NW, BCW = (BCH + NW - 1) / NW;
+    const float* asrc[ACW];
+    int bn[BCW];   // clamped column of the 16-byte piece this lane fetches
+    int bkr[BCW];  // its k row inside the stage
+#pragma unroll
+    for (int c = 0; c < ACW; ++c) {
+        const int ca = wave + c * NW;
+        const int row = ca * AROWS + lane / SL;
+        const int ps = lane % SL;
+        const int ls = ps ^ ((row / RW) % SL);
+        int m = m0 + row;
+        m = m < M ? m : M - 1;
+        asrc[c] = A + (long)m * p.lda + 4 * ls;
+    }
+#pragma unroll
+    for (int c = 0; c < BCW; ++c) {
+        const int cb = wave + c * NW;
+        bkr[c] = (cb * 256 + lane * 4) / BN;
+        const int n = n0 + (cb * 256 + lane * 4) % BN;
+        bn[c] = n < p.N ? n : p.N - 4;
+    }
+
+    // kernel-argument fields used inside the loop, as SSA values: the asm "memory" clobber of glds16 would
+    // otherwise force a reload (global_load + vmcnt(0)) of each of them after every DMA piece
+    const long ldb = p.ldb, ldb2 = p.ldb2;
+    const int K1 = p.K1;
+
+    auto issue = [&](int k0, int buf) {
+        float* Ab = As + buf * ABUF;
+        float* Bb = Bs + buf * BBUF;
+#pragma unroll
+        for (int c = 0; c < ACW; ++c) {
+            const int ca = wave + c * NW;
+            if (ACH % NW == 0 || ca < ACH)
+                glds16(asrc[c] + k0, Ab + ca * 256);
+        }
+#pragma unroll
+        for (int c = 0; c < BCW; ++c) {
+            const int cb = wave + c * NW;
+            if (BCH % NW == 0 || cb < BCH) {
+                int k = k0 + bkr[c];
+                k = k < K ? k : K - 1;
+                const long n = bn[c];
+                const float* src = (K1 >= 0 && k >= K1) ? (B2 + (long)(k - K1) * ldb2 + n) : (B + (long)k * ldb + n);
+                glds16(src, Bb + cb * 256);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // fragment addressing
+    const int arow0 = wm * 64 + i, arow1 = arow0 + 32;
+    const int key0 = (arow0 / RW) % SL, key1 = (arow1 / RW) % SL;
+    const int bcol = wn * 64 + i;
+    constexpr int NS = BKT / 2;   // k-steps per stage
+    constexpr int NV = BKT / 8;   // float4 fragments per row per stage
+
+    const int nk = (K - kbeg + BKT - 1) / BKT;
+    if (nk > 0) issue(kbeg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue(kbeg + (kt + 1) * BKT, cur ^ 1);
+        const float* Ab = As + cur * ABUF;
+        const float* Bb = Bs + cur * BBUF + (h * NS) * BN + bcol;
+        float4 a0[NV], a1[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            a0[j] = *reinterpret_cast<const float4*>(Ab + arow0 * BKT + 4 * ((h * NV + j) ^ key0));
+            a1[j] = *reinterpret_cast<const float4*>(Ab + arow1 * BKT + 4 * ((h * NV + j) ^ key1));
+        }
+        float b0[NS], b1[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            b0[s] = Bb[s * BN];
+            b1[s] = Bb[s * BN + 32];
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float4 va = a0[s / 4], vb = a1[s / 4];
+            const float x0 = (s % 4 == 0) ? va.x : (s % 4 == 1) ? va.y : (s % 4 == 2) ? va.z : va.w;
+            const float x1 = (s % 4 == 0) ? vb.x : (s % 4 == 1) ? vb.y : (s % 4 == 2) ? vb.z : vb.w;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, b0[s], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, b1[s], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, b0[s], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, b1[s], acc[1][1], 0, 0, 0);
+        }
+        // pin the interleave: all A fragments + the first PF B pairs up front, then one B pair per MFMA quad
+        constexpr int PF2 = 3;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NV + PF2, 0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (s + PF2 < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's next-stage DMA has landed ...
+        __syncthreads();                                  // ... and so has everyone's; cur may be overwritten
+    }
+
+    // epilogue (same as v1)
+    float* C = p.C + (long)batch * p.sC;
+    const float* R = RES ? p.R + (long)batch * p.sR : nullptr;
+    const float* rsc = p.rsc ? p.rsc + (long)batch * p.srs : nullptr;
+    const float* rsh = p.rsc ? p.rsh + (long)batch * p.srs : nullptr;
+    const float* bias = p.bias ? p.bias + (long)batch * p.sbias : nullptr;
+    const float* osc = p.osc;
+    const float* osh = p.osh;
+    const long ldc = p.ldc, ldr = p.ldr;
+    const int actk = p.act;
+    const int col0 = n0 + wn * 64 + i, col1 = col0 + 32;
+    const bool c0ok = col0 < p.N, c1ok = col1 < p.N;
+    const int cc0 = c0ok ? col0 : 0, cc1 = c1ok ? col1 : 0;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rbase = m0 + wm * 64 + tm * 32 + 8 * q + 4 * h;
+            float bv[4], rs[4], rt[4], os[4], ot[4], rv0[4], rv1[4];
+            int rr[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                rr[e] = (rbase + e < M) ? rbase + e : 0;
+                // optional row parameters without branches: absent ones read a valid dummy address (A) and are
+                // replaced by the neutral value with a select, so all loads of the quad issue back to back
+                const float t0 = (bias ? bias : A)[bias ? rr[e] : 0];
+                const float t1 = (rsc ? rsc : A)[rsc ? rr[e] : 0];
+                const float t2 = (rsc ? rsh : A)[rsc ? rr[e] : 0];
+                const float t3 = (osc ? osc : A)[osc ? rr[e] : 0];
+                const float t4 = (osc ? osh : A)[osc ? rr[e] : 0];
+                bv[e] = bias ? t0 : 0.f;
+                rs[e] = rsc ? t1 : 1.f;
+                rt[e] = rsc ? t2 : 0.f;
+                os[e] = osc ? t3 : 1.f;
+                ot[e] = osc ? t4 : 0.f;
+                if (RES) {
+                    rv0[e] = R[(long)rr[e] * ldr + cc0];
+                    rv1[e] = R[(long)rr[e] * ldr + cc1];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool rok = rbase + e < M;
+                float v0 = acc[tm][0][4 * q + e] + bv[e];
+                float v1 = acc[tm][1][4 * q + e] + bv[e];
+                if (RES) {
+                    v0 += fmaf(rv0[e], rs[e], rt[e]);
+                    v1 += fmaf(rv1[e], rs[e], rt[e]);
+                }
+                v0 = act_apply(v0, actk);
+                v1 = act_apply(v1, actk);
+                v0 = fmaf(v0, os[e], ot[e]);
+                v1 = fmaf(v1, os[e], ot[e]);
+                float* crow = C + (long)rr[e] * ldc;
                 if (rok && c0ok) crow[col0] = v0;
                 if (rok && c1ok) crow[col1] = v1;
             }
@@ -334,6 +588,8 @@ __global__ __launch_bounds__(64 * WM * WN, ACE_LB) void gemm_f32_kernel(GemmArgs
 }
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static bool g_force_v1 = (getenv("ACE_FORCE_V1") != nullptr);  // A/B switch for measurements
+void set_force_v1(bool v) { g_force_v1 = v; }
 
 template <int WM, int WN, bool VEC>
 static hipError_t launch_gemm_vec(const GemmArgs& a, hipStream_t s, int tilesM, int tilesN, dim3 grid, dim3 block) {
@@ -349,9 +605,35 @@ static hipError_t launch_gemm_vec(const GemmArgs& a, hipStream_t s, int tilesM, 
     return hipGetLastError();
 }
 
+template <int WM, int WN, int BKT>
+static hipError_t launch_gemm2_cfg(const GemmArgs& a, hipStream_t s, int tilesM, int tilesN, dim3 grid, dim3 block) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr size_t lds = (size_t)2 * (BM * BKT + BKT * BN) * sizeof(float);
+    static bool configured[2] = {false, false};
+    const bool res = a.R != nullptr;
+    if (!configured[res]) {
+        hipError_t e = res ? hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_f32_kernel<WM, WN, BKT, true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                           : hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_f32_kernel<WM, WN, BKT, false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured[res] = true;
+    }
+    if (res)
+        hipLaunchKernelGGL((gemm2_f32_kernel<WM, WN, BKT, true>), grid, block, lds, s, a, tilesM, tilesN);
+    else
+        hipLaunchKernelGGL((gemm2_f32_kernel<WM, WN, BKT, false>), grid, block, lds, s, a, tilesM, tilesN);
+    return hipGetLastError();
+}
+
+#ifndef ACE_GEMM2_BK
+#define ACE_GEMM2_BK 32
+#endif
+
 template <int WM, int WN>
 static hipError_t launch_gemm_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
+    constexpr int BK2 = ACE_GEMM2_BK;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
     const long nblk = (long)tilesM * tilesN * a.nbatch;
     if (nblk <= 0) return hipSuccess;
@@ -359,6 +641,12 @@ static hipError_t launch_gemm_cfg(const GemmArgs& a, hipStream_t s) {
                (a.sB % 4 == 0) && (a.N % 4 == 0);
     if (a.B2) vec = vec && al16(a.B2) && (a.ldb2 % 4 == 0) && (a.sB2 % 4 == 0);
     dim3 grid((unsigned)nblk), block(NT);
+    // direct-to-LDS engine: needs zero-padded (or exact) A rows up to the stage depth and no per-k affine
+    const int kround = ((a.K + BK2 - 1) / BK2) * BK2;
+    const bool v2 = !g_force_v1 && al16(a.A) && (a.lda % 4 == 0) && (a.sA % 4 == 0) && al16(a.B) && (a.ldb % 4 == 0) &&
+                    (a.sB % 4 == 0) && (a.N % 4 == 0) && (a.N >= 4) && (a.bsc == nullptr) && (a.a_kpad >= kround) &&
+                    (!a.B2 || (al16(a.B2) && (a.ldb2 % 4 == 0) && (a.sB2 % 4 == 0))) && a.M >= 1 && a.K >= 1;
+    if (v2) return launch_gemm2_cfg<WM, WN, BK2>(a, s, tilesM, tilesN, grid, block);
     if (vec) return launch_gemm_vec<WM, WN, true>(a, s, tilesM, tilesN, grid, block);
     return launch_gemm_vec<WM, WN, false>(a, s, tilesM, tilesN, grid, block);
 }
@@ -978,6 +1266,44 @@ hipError_t launch_unpack_denormalize(const float* src, const float* mean, const 
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(unpack_denormalize_kernel, dim3(gx, nch, Bt), dim3(256), 0, s, src, mean, stdv, dsts, strides,
                        nch, HW);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// fold a per-(sample, input-channel) affine into a 1x1-conv weight:  W (a x + b) + bias = (W diag(a)) x + (W b + bias)
+//   Wf[s][o][i] = W[o][i] * a[s][i]  (columns i in [I, ldw) are zero),   bf[s][o] = bias[o] + sum_i W[o][i] * b[s][i]
+// This is how the instance norm (sfnonet.py:218-221, 234-238) reaches the direct-to-LDS GEMM, which cannot touch its
+// B operand: ~0.6-1.2 MB of work per conv instead of a 100 MB normalised activation.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void fold_affine_kernel(const float* __restrict__ W, long ldw,
+                                                          const float* __restrict__ a, const float* __restrict__ b,
+                                                          const float* __restrict__ bias, float* __restrict__ Wf,
+                                                          float* __restrict__ bf, int O, int I) {
+    const int o = blockIdx.x, smp = blockIdx.y;
+    const float* wr = W + (long)o * ldw;
+    float* wo = Wf + ((long)smp * O + o) * ldw;
+    const float* as = a + (long)smp * I;
+    const float* bs = b + (long)smp * I;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < (int)ldw; i += blockDim.x) {
+        float v = 0.f;
+        if (i < I) {
+            const float w = wr[i];
+            v = w * as[i];
+            acc += (double)w * (double)bs[i];
+        }
+        wo[i] = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ double red[2];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) bf[(long)smp * O + o] = (float)((bias ? (double)bias[o] : 0.0) + red[0] + red[1]);
+}
+hipError_t launch_fold_affine(const float* W, long ldw, const float* a, const float* b, const float* bias, float* Wf,
+                              float* bf, int nsamples, int O, int I, hipStream_t s) {
+    hipLaunchKernelGGL(fold_affine_kernel, dim3(O, nsamples), dim3(128), 0, s, W, ldw, a, b, bias, Wf, bf, O, I);
     return hipGetLastError();
 }
 

@@ -112,8 +112,8 @@ std::string build_sht_tables(int nlat, int nlon, int lmax, int mmax, Grid grid, 
     if (mmax <= 0) mmax = nlon / 2 + 1;                               // fme/sht_fix.py:104
     if (mmax > nlon / 2 + 1) return "mmax > nlon/2+1 is not supported";
     t.nlat = nlat; t.nlon = nlon; t.lmax = lmax; t.mmax = mmax;
-    t.Hp = round4(nlat);
-    t.Lp = round4(lmax);
+    t.Hp = (nlat + 31) & ~31;   // zero-padded to the deepest GEMM stage (direct-to-LDS engine reads whole stages)
+    t.Lp = (lmax + 31) & ~31;
     t.Kf = nlon / 2 + 1;
     t.Kfp = round4(t.Kf);
 

@@ -21,8 +21,8 @@ void quadrature(Grid g, int n, std::vector<double>& x, std::vector<double>& w);
 
 struct ShtTables {
     int nlat = 0, nlon = 0, lmax = 0, mmax = 0;
-    int Hp = 0;   // nlat rounded up to 4 (row pitch of wt)
-    int Lp = 0;   // lmax rounded up to 4 (row pitch of pt)
+    int Hp = 0;   // nlat rounded up to 32 (row pitch of wt, zero padded)
+    int Lp = 0;   // lmax rounded up to 32 (row pitch of pt, zero padded)
     int Kf = 0;   // nlon/2 + 1: number of folded longitudes
     int Kfp = 0;  // Kf rounded up to 4 (row pitch of fc/fs/gc/gs)
     // forward Legendre x quadrature weights: wt[m][l][k] (pitch Hp), zero for l < m
