@@ -22,7 +22,7 @@ class AceSfnoConfig(ctypes.Structure):
         ("hard_thresholding_fraction", c_float), ("operator_type", c_int),
         ("normalization_layer", c_int), ("activation_function", c_int), ("use_mlp", c_int),
         ("mlp_ratio", c_float), ("encoder_layers", c_int), ("pos_embed", c_int), ("big_skip", c_int),
-        ("data_grid", c_int), ("max_batch", c_int),
+        ("data_grid", c_int), ("max_batch", c_int), ("precision", c_int),
     ]
 
 
@@ -37,6 +37,7 @@ SIGNATURES = {
     "ace_sht_inverse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ace_sht_tables_host": (c_int, [c_int, c_int, c_int, c_int, c_char_p, c_int, c_void_p]),
     "ace_conv1x1": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p]),
+    "ace_conv1x1_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p]),
     "ace_instance_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_long, c_void_p]),
     "ace_sfno_create": (c_int, [POINTER(AceSfnoConfig), POINTER(c_void_p)]),
     "ace_sfno_destroy": (None, [c_void_p]),

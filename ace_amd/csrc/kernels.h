@@ -37,7 +37,17 @@ struct GemmArgs {
     int act = ACT_NONE;
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
-void set_force_v1(bool v);  // tests / A-B: route everything through the register-staged engine
+void set_force_v1(bool v);
+
+// Compensated-fp16 engine (f16x3): same contract as launch_gemm, but the A operand is given pre-split into two
+// fp16 planes (hi, lo; pitch g.lda HALVES, rows zero-padded to a multiple of 32 columns: g.a_kpad), scaled by the
+// power of two `ascale`; B is scaled by the power of two `bscale` on the fly.  g.A is ignored.
+bool gemm_f16x3_eligible(const GemmArgs& g);
+hipError_t launch_gemm_f16x3(const GemmArgs& g, const void* Ahi, const void* Alo, float ascale, float bscale,
+                             hipStream_t s);
+// fp32 matrix (rows x cols, pitch lds) -> fp16 hi/lo planes (pitch ldd halves, zero padded), values scaled by `scale`
+hipError_t launch_split_f16(const float* src, long lds, void* hi, void* lo, long ldd, long rows, int cols, float scale,
+                            hipStream_t s);  // tests / A-B: route everything through the register-staged engine
 
 // Spectral-space layout used between the kernels ("channel-fastest planar"):
 //   X[m][k][b][ri][c]  (after the longitude DFT)     index ((m*H + k)*Bt + b)*2C + ri*C + c

@@ -587,6 +587,276 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f32_kernel(GemmArgs p, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// batched GEMM, compensated-fp16 variant ("v3", f16x3): fp32-class accuracy on the 16x faster fp16 MFMA.
+// Every fp32 operand is split x = hi + lo with hi = fp16(x), lo = fp16(x - hi) (22 significant bits after a
+// power-of-two pre-scale that keeps hi/lo in fp16's normal range); fp16 x fp16 products are exact in fp32, so
+//     A.B  ~=  Ahi.Bhi + Ahi.Blo + Alo.Bhi          (dropped lo.lo term ~ 2^-22 relative)
+// on v_mfma_f32_32x32x16_f16 with fp32 accumulation: 3 MFMAs of 32 cycles do the work of 8 fp32 MFMAs of 64.
+//   * A (weights / tables) is pre-split once by split_f16_kernel into two fp16 planes [M][lda] (zero padded to the
+//     stage depth) and DMA'd to LDS with global_load_lds, source-swizzled for conflict-free ds_read_b128.
+//   * B (activations, fp32 in HBM) is split on the fly: each thread loads 8 consecutive k rows of 2/4 columns,
+//     applies the optional per-row affine (fused instance norm) and the power-of-two scale, converts, and writes
+//     16-byte k-packed entries Bs[k/8][n][8 halves] - exactly the MFMA B fragment of one lane.
+//   * epilogue as v1/v2 with the product of the two scales undone (exact, powers of two).
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+struct Gemm3Args {
+    GemmArgs g;                 // B, C, epilogue, shapes (g.A unused)
+    const _Float16* Ahi = nullptr; const _Float16* Alo = nullptr;  // [M][lda] fp16 planes, lda in halves (= g.lda)
+    float bscale = 1.f;         // power of two applied to B before the split
+    float oscale = 1.f;         // 1 / (ascale * bscale), applied to the accumulator
+};
+
+template <int WM, int WN, bool AFF, bool RES>
+__global__ __launch_bounds__(64 * WM * WN) void gemm3_f16x3_kernel(Gemm3Args q, int tilesM, int tilesN) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN, NT = 64 * NW;
+    constexpr int BKT = 32;                   // k per stage
+    constexpr int NPT = BN / 64;              // columns per thread in the B stager (2 or 4)
+    constexpr int APL = BM * BKT;             // halves per A plane per buffer
+    constexpr int BPL = BKT * BN;             // halves per B plane per buffer
+    constexpr int ACH = BM * BKT * 2 / 1024;  // 1 KiB DMA pieces per A plane
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem3[];
+    _Float16* As = smem3;                     // [2 buf][2 plane][BM][32]
+    _Float16* Bs = smem3 + 2 * 2 * APL;       // [2 buf][2 plane][4 kg][BN][8]
+    const GemmArgs& p = q.g;
+
+    const int nblk = tilesM * tilesN * p.nbatch;
+    const int lid = xcd_remap(blockIdx.x, nblk);
+    const int tile_m = lid % tilesM;
+    const int rest = lid / tilesM;
+    const int tile_n = rest % tilesN;
+    const int batch = rest / tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    int M = p.M, kbeg = 0;
+    if (p.tri == TRI_ROWS_GE_BATCH) {
+        if (m0 + BM <= batch) return;
+    } else if (p.tri == TRI_K_GE_BATCH) {
+        kbeg = (batch / BKT) * BKT;
+    } else if (p.tri == TRI_ROWS_LE_BATCH) {
+        const int me = (batch + 1) * p.trimul;
+        M = me < M ? me : M;
+        if (m0 >= M) return;
+    }
+    const int K = p.K, N = p.N;
+    const long lda = p.lda, ldb = p.ldb, ldb2 = p.ldb2;
+    const int K1 = p.K1;
+    const _Float16* Ahi = q.Ahi + (long)batch * p.sA;
+    const _Float16* Alo = q.Alo + (long)batch * p.sA;
+    const float* B = p.B + (long)batch * p.sB;
+    const float* B2 = p.B2 ? p.B2 + (long)batch * p.sB2 : nullptr;
+    const float* bsc = AFF ? p.bsc + (long)batch * p.sbs : nullptr;
+    const float* bsh = AFF ? p.bsh + (long)batch * p.sbs : nullptr;
+    const float bscale = q.bscale;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, g = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- A DMA descriptors: piece = 16 rows x 64 B; lane -> (row, physical slot); fetches the swizzled logical slot
+    constexpr int ACW = (ACH + NW - 1) / NW;
+    long aoff[ACW];
+#pragma unroll
+    for (int c = 0; c < ACW; ++c) {
+        const int ca = wave + c * NW;
+        const int row = ca * 16 + lane / 4;
+        const int ls = (lane % 4) ^ ((row >> 2) & 3);
+        int m = m0 + row;
+        m = m < M ? m : M - 1;
+        aoff[c] = (long)m * lda + 8 * ls;
+    }
+    // ---- B stager: thread -> (k group of 8, NPT consecutive columns)
+    const int bkg = tid / 64;                 // 0..3 (NT == 256)
+    const int bnl = (tid % 64) * NPT;         // column inside the tile
+    int bn = n0 + bnl;
+    bn = bn + NPT <= N ? bn : N - NPT;        // clamp (N % NPT == 0): extra columns feed outputs never stored
+    float breg[8][NPT];
+    float bs_[AFF ? 8 : 1], bt_[AFF ? 8 : 1];
+
+    auto issue = [&](int k0, int buf) {
+        _Float16* Ab = As + buf * 2 * APL;
+#pragma unroll
+        for (int c = 0; c < ACW; ++c) {
+            const int ca = wave + c * NW;
+            if (ACH % NW == 0 || ca < ACH) {
+                glds16(reinterpret_cast<const float*>(Ahi + aoff[c] + k0), reinterpret_cast<float*>(Ab + ca * 512));
+                glds16(reinterpret_cast<const float*>(Alo + aoff[c] + k0), reinterpret_cast<float*>(Ab + APL + ca * 512));
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int k = k0 + 8 * bkg + e;
+            k = k < K ? k : K - 1;  // rows past K meet zero A columns
+            const float* src = (K1 >= 0 && k >= K1) ? (B2 + (long)(k - K1) * ldb2 + bn) : (B + (long)k * ldb + bn);
+            if (NPT == 4) {
+                const float4 v = *reinterpret_cast<const float4*>(src);
+                breg[e][0] = v.x; breg[e][1] = v.y; breg[e][NPT - 2] = v.z; breg[e][NPT - 1] = v.w;
+            } else {
+                const float2 v = *reinterpret_cast<const float2*>(src);
+                breg[e][0] = v.x; breg[e][1] = v.y;
+            }
+            if (AFF) { bs_[e] = bsc[k]; bt_[e] = bsh[k]; }
+        }
+    };
+    auto stash = [&](int buf) {  // split + write the staged B registers (after the MFMAs of the current stage)
+        _Float16* Bb = Bs + buf * 2 * BPL;
+#pragma unroll
+        for (int c = 0; c < NPT; ++c) {
+            half8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = breg[e][c];
+                if (AFF) x = fmaf(x, bs_[e], bt_[e]);
+                x = __builtin_amdgcn_fmed3f(x * bscale, -65504.f, 65504.f);
+                const _Float16 hh = (_Float16)x;
+                hi[e] = hh;
+                lo[e] = (_Float16)(x - (float)hh);
+            }
+            *reinterpret_cast<half8*>(Bb + ((long)bkg * BN + bnl + c) * 8) = hi;
+            *reinterpret_cast<half8*>(Bb + BPL + ((long)bkg * BN + bnl + c) * 8) = lo;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int arow0 = wm * 64 + i, arow1 = arow0 + 32;
+    const int key0 = (arow0 >> 2) & 3, key1 = (arow1 >> 2) & 3;
+    const int bcol0 = wn * 64 + i, bcol1 = bcol0 + 32;
+
+    const int nk = (K - kbeg + BKT - 1) / BKT;
+    if (nk > 0) {
+        issue(kbeg, 0);
+        stash(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) issue(kbeg + (kt + 1) * BKT, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const _Float16* Ah = As + cur * 2 * APL;
+        const _Float16* Al = Ah + APL;
+        const _Float16* Bh = Bs + cur * 2 * BPL;
+        const _Float16* Bl = Bh + BPL;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {  // two 16-deep chunks per stage; lane group g owns k = 16c + 8g .. +7
+            const int ls = 2 * c + g;
+            const half8 ah0 = *reinterpret_cast<const half8*>(Ah + arow0 * 32 + 8 * (ls ^ key0));
+            const half8 ah1 = *reinterpret_cast<const half8*>(Ah + arow1 * 32 + 8 * (ls ^ key1));
+            const half8 al0 = *reinterpret_cast<const half8*>(Al + arow0 * 32 + 8 * (ls ^ key0));
+            const half8 al1 = *reinterpret_cast<const half8*>(Al + arow1 * 32 + 8 * (ls ^ key1));
+            const half8 bh0 = *reinterpret_cast<const half8*>(Bh + ((long)ls * BN + bcol0) * 8);
+            const half8 bh1 = *reinterpret_cast<const half8*>(Bh + ((long)ls * BN + bcol1) * 8);
+            const half8 bl0 = *reinterpret_cast<const half8*>(Bl + ((long)ls * BN + bcol0) * 8);
+            const half8 bl1 = *reinterpret_cast<const half8*>(Bl + ((long)ls * BN + bcol1) * 8);
+            // small cross terms first, the hi.hi term last
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stash(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // epilogue
+    const float osc_acc = q.oscale;
+    float* C = p.C + (long)batch * p.sC;
+    const float* R = RES ? p.R + (long)batch * p.sR : nullptr;
+    const float* rsc = p.rsc ? p.rsc + (long)batch * p.srs : nullptr;
+    const float* rsh = p.rsc ? p.rsh + (long)batch * p.srs : nullptr;
+    const float* bias = p.bias ? p.bias + (long)batch * p.sbias : nullptr;
+    const float* osc = p.osc;
+    const float* osh = p.osh;
+    const float* dummy = B;
+    const long ldc = p.ldc, ldr = p.ldr;
+    const int actk = p.act;
+    const int col0 = n0 + wn * 64 + i, col1 = col0 + 32;
+    const bool c0ok = col0 < N, c1ok = col1 < N;
+    const int cc0 = c0ok ? col0 : 0, cc1 = c1ok ? col1 : 0;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int rbase = m0 + wm * 64 + tm * 32 + 8 * qd + 4 * g;
+            float bv[4], rs[4], rt[4], os[4], ot[4], rv0[4], rv1[4];
+            int rr[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                rr[e] = (rbase + e < M) ? rbase + e : 0;
+                const float t0 = (bias ? bias : dummy)[bias ? rr[e] : 0];
+                const float t1 = (rsc ? rsc : dummy)[rsc ? rr[e] : 0];
+                const float t2 = (rsc ? rsh : dummy)[rsc ? rr[e] : 0];
+                const float t3 = (osc ? osc : dummy)[osc ? rr[e] : 0];
+                const float t4 = (osc ? osh : dummy)[osc ? rr[e] : 0];
+                bv[e] = bias ? t0 : 0.f;
+                rs[e] = rsc ? t1 : 1.f;
+                rt[e] = rsc ? t2 : 0.f;
+                os[e] = osc ? t3 : 1.f;
+                ot[e] = osc ? t4 : 0.f;
+                if (RES) {
+                    rv0[e] = R[(long)rr[e] * ldr + cc0];
+                    rv1[e] = R[(long)rr[e] * ldr + cc1];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool rok = rbase + e < M;
+                float v0 = fmaf(acc[tm][0][4 * qd + e], osc_acc, bv[e]);
+                float v1 = fmaf(acc[tm][1][4 * qd + e], osc_acc, bv[e]);
+                if (RES) {
+                    v0 += fmaf(rv0[e], rs[e], rt[e]);
+                    v1 += fmaf(rv1[e], rs[e], rt[e]);
+                }
+                v0 = act_apply(v0, actk);
+                v1 = act_apply(v1, actk);
+                v0 = fmaf(v0, os[e], ot[e]);
+                v1 = fmaf(v1, os[e], ot[e]);
+                float* crow = C + (long)rr[e] * ldc;
+                if (rok && c0ok) crow[col0] = v0;
+                if (rok && c1ok) crow[col1] = v1;
+            }
+        }
+    }
+}
+
+// fp32 (rows x cols, pitch lds) -> two fp16 planes hi/lo (pitch ldd halves, columns >= cols zero), x scaled by `scale`
+__global__ void split_f16_kernel(const float* __restrict__ src, long lds_, _Float16* __restrict__ hi,
+                                 _Float16* __restrict__ lo, long ldd, long rows, int cols, float scale) {
+    const long total = rows * ldd;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long r = t / ldd;
+        const int c = (int)(t % ldd);
+        float x = 0.f;
+        if (c < cols) x = __builtin_amdgcn_fmed3f(src[r * lds_ + c] * scale, -65504.f, 65504.f);
+        const _Float16 h = (_Float16)x;
+        hi[t] = h;
+        lo[t] = (_Float16)(x - (float)h);
+    }
+}
+
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static bool g_force_v1 = (getenv("ACE_FORCE_V1") != nullptr);  // A/B switch for measurements
 void set_force_v1(bool v) { g_force_v1 = v; }
@@ -657,6 +927,65 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     const int waste64 = ((a.M + 63) / 64) * 64 - a.M;
     if (a.M >= 128 && waste128 <= waste64) return launch_gemm_cfg<2, 2>(a, s);
     return launch_gemm_cfg<1, 4>(a, s);
+}
+
+
+template <int WM, int WN>
+static hipError_t launch_gemm3_cfg(const Gemm3Args& a, hipStream_t s) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
+    const int tilesM = (a.g.M + BM - 1) / BM, tilesN = (a.g.N + BN - 1) / BN;
+    const long nblk = (long)tilesM * tilesN * a.g.nbatch;
+    if (nblk <= 0) return hipSuccess;
+    constexpr size_t lds = (size_t)2 * 2 * (BM * 32 + 32 * BN) * sizeof(_Float16);
+    const bool aff = a.g.bsc != nullptr, res = a.g.R != nullptr;
+    const void* fn = aff ? (res ? (const void*)gemm3_f16x3_kernel<WM, WN, true, true> : (const void*)gemm3_f16x3_kernel<WM, WN, true, false>)
+                         : (res ? (const void*)gemm3_f16x3_kernel<WM, WN, false, true> : (const void*)gemm3_f16x3_kernel<WM, WN, false, false>);
+    static bool configured[4] = {false, false, false, false};
+    const int ci = (aff ? 2 : 0) + (res ? 1 : 0);
+    if (!configured[ci]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured[ci] = true;
+    }
+    dim3 grid((unsigned)nblk), block(NT);
+    if (aff && res) hipLaunchKernelGGL((gemm3_f16x3_kernel<WM, WN, true, true>), grid, block, lds, s, a, tilesM, tilesN);
+    else if (aff) hipLaunchKernelGGL((gemm3_f16x3_kernel<WM, WN, true, false>), grid, block, lds, s, a, tilesM, tilesN);
+    else if (res) hipLaunchKernelGGL((gemm3_f16x3_kernel<WM, WN, false, true>), grid, block, lds, s, a, tilesM, tilesN);
+    else hipLaunchKernelGGL((gemm3_f16x3_kernel<WM, WN, false, false>), grid, block, lds, s, a, tilesM, tilesN);
+    return hipGetLastError();
+}
+
+bool gemm_f16x3_eligible(const GemmArgs& a) {
+    const int npt = 4;  // strictest alignment of the two tile shapes
+    bool ok = al16(a.B) && (a.ldb % 4 == 0) && (a.sB % 4 == 0) && (a.N % npt == 0) && (a.N >= npt) && (a.lda % 8 == 0) &&
+              (a.sA % 8 == 0) && (a.a_kpad >= ((a.K + 31) / 32) * 32) && a.M >= 1 && a.K >= 1;
+    if (a.B2) ok = ok && al16(a.B2) && (a.ldb2 % 4 == 0) && (a.sB2 % 4 == 0);
+    return ok;
+}
+
+hipError_t launch_gemm_f16x3(const GemmArgs& g, const void* Ahi, const void* Alo, float ascale, float bscale,
+                             hipStream_t s) {
+    Gemm3Args a;
+    a.g = g;
+    a.Ahi = static_cast<const _Float16*>(Ahi);
+    a.Alo = static_cast<const _Float16*>(Alo);
+    a.bscale = bscale;
+    a.oscale = 1.0f / (ascale * bscale);
+    const int waste128 = ((g.M + 127) / 128) * 128 - g.M;
+    const int waste64 = ((g.M + 63) / 64) * 64 - g.M;
+    if (g.M >= 128 && waste128 <= waste64) return launch_gemm3_cfg<2, 2>(a, s);
+    return launch_gemm3_cfg<1, 4>(a, s);
+}
+
+hipError_t launch_split_f16(const float* src, long lds_, void* hi, void* lo, long ldd, long rows, int cols, float scale,
+                            hipStream_t s) {
+    const long total = rows * ldd;
+    long gsz = (total + 255) / 256;
+    if (gsz > 16384) gsz = 16384;
+    if (gsz < 1) gsz = 1;
+    hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)gsz), dim3(256), 0, s, src, lds_, static_cast<_Float16*>(hi),
+                       static_cast<_Float16*>(lo), ldd, rows, cols, scale);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------

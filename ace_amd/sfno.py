@@ -18,6 +18,7 @@ reference's order at construction); `forward` is one call into the HIP library.
 import ctypes
 import dataclasses
 import math
+import os
 from typing import Any, Literal, Optional, Tuple
 
 import torch
@@ -31,6 +32,7 @@ _NORM = {"none": 0, "instance_norm": 1}
 _ACT = {"gelu": 1, "relu": 2, "silu": 3}
 _ACT_LAYER = {"gelu": nn.GELU, "relu": nn.ReLU, "silu": nn.SiLU}
 _GRID = {"legendre-gauss": 0, "equiangular": 2}
+_PRECISION = {"fp32": 0, "f16x3": 1}
 
 
 def trunc_normal_(tensor, mean=0.0, std=1.0, a=-2.0, b=2.0):
@@ -236,6 +238,11 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
 
         self.apply(self._init_weights)
 
+        # arithmetic of the 1x1 convolutions: "fp32" (exact fp32 MFMA, the reference's arithmetic) or "f16x3"
+        # (compensated fp16 MFMA, fp32-class accuracy, ~5x the MFMA rate); not part of the reference API
+        self.precision = os.environ.get("ACE_SFNO_PRECISION", "fp32")
+        if self.precision not in _PRECISION:
+            raise ValueError(f"ACE_SFNO_PRECISION must be one of {list(_PRECISION)}")
         self._native = None          # ace_sfno* handle
         self._native_key = None      # (device index, max_batch)
         self._uploaded = {}          # name -> (data_ptr, version) at last upload
@@ -260,8 +267,17 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             activation_function=_ACT[self.activation_function], use_mlp=int(self.use_mlp),
             mlp_ratio=float(self.mlp_ratio), encoder_layers=self.encoder_layers,
             pos_embed=int(hasattr(self, "pos_embed")), big_skip=int(self.big_skip),
-            data_grid=_GRID[self.data_grid], max_batch=max_batch,
+            data_grid=_GRID[self.data_grid], max_batch=max_batch, precision=_PRECISION[self.precision],
         )
+
+    def set_precision(self, precision: str):
+        """Switch the conv arithmetic ("fp32" | "f16x3"); rebuilds the native handle on next use."""
+        if precision not in _PRECISION:
+            raise ValueError(f"precision must be one of {list(_PRECISION)}")
+        if precision != self.precision:
+            self.precision = precision
+            self._release_native()
+        return self
 
     def _release_native(self):
         if self._native is not None:

@@ -69,6 +69,11 @@ int ace_sht_tables_host(int nlat, int nlon, int lmax, int mmax, const char* grid
 int ace_conv1x1(const float* x, const float* weight, const float* bias, float* y, int n, int cin, int cout,
                 long hw, int act, void* stream);
 
+/* Same contraction on the compensated-fp16 engine ("f16x3": both operands split hi+lo fp16, three exact-product
+ * MFMAs, fp32 accumulation).  Test / micro-benchmark entry: prepares the weight planes on every call and synchronises. */
+int ace_conv1x1_f16x3(const float* x, const float* weight, const float* bias, float* y, int n, int cin, int cout,
+                      long hw, int act, void* stream);
+
 /* nn.InstanceNorm2d(C, eps, affine) (sfnonet.py:593-601) on (n, C, hw); gamma/beta may be NULL. */
 int ace_instance_norm(const float* x, const float* gamma, const float* beta, float eps, float* y, int n, int c,
                       long hw, void* stream);
@@ -95,6 +100,9 @@ typedef struct ace_sfno_config {
     int pos_embed, big_skip;
     int data_grid;                /* 0 = "legendre-gauss", 2 = "equiangular" */
     int max_batch;                /* workspace is sized for this many samples (B = samples x ensemble) */
+    int precision;                /* 0 = exact fp32 MFMA everywhere (the reference's arithmetic);
+                                     1 = "f16x3": 1x1 convolutions on compensated fp16 MFMA (hi/lo split of both
+                                     operands, 3 exact-product MFMAs, fp32 accumulate): fp32-class accuracy */
 } ace_sfno_config;
 
 int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** net);

@@ -48,6 +48,31 @@ def conv_cases():
         print(f"conv1x1 n={n} cin={cin} cout={cout} hw={hw} act={act}: relmax {rel_max(y, ref):.3e} nan={int(torch.isnan(y).sum())}")
 
 
+def f16x3_cases():
+    """compensated-fp16 conv vs fp64, next to the exact-fp32 engine on the same data."""
+    from ace_amd import _lib
+    L = _lib.lib()
+    for (n, cin, cout, hw, act, xs) in [(1, 384, 768, 64800, 1, 1.0), (1, 768, 384, 64800, 0, 1.0), (2, 16, 16, 164, 1, 1.0),
+                                        (1, 44, 384, 4096, 1, 1.0), (1, 428, 50, 4132, 0, 1.0), (1, 384, 384, 8000, 0, 30.0),
+                                        (1, 384, 384, 8000, 0, 1e-3)]:
+        g = torch.Generator().manual_seed(cin)
+        x = (torch.randn(n, cin, hw, generator=g) * xs)
+        w = torch.nn.init.trunc_normal_(torch.empty(cout, cin), std=0.02, generator=g)
+        b = torch.randn(cout, generator=g) * 0.01
+        ref = torch.nn.functional.conv1d(x.double(), w.double()[:, :, None], b.double())
+        if act == 1:
+            ref = torch.nn.functional.gelu(ref)
+        xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+        y16 = torch.full((n, cout, hw), float("nan"), device=dev)
+        y32 = torch.full((n, cout, hw), float("nan"), device=dev)
+        st = _lib.current_stream()
+        _lib.check(L.ace_conv1x1_f16x3(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y16), n, cin, cout, hw, act, st))
+        _lib.check(L.ace_conv1x1(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y32), n, cin, cout, hw, act, st))
+        torch.cuda.synchronize()
+        print(f"conv n={n} cin={cin} cout={cout} hw={hw} act={act} xscale={xs}: f16x3 relmax {rel_max(y16, ref):.3e} "
+              f"l2 {rel_l2(y16, ref):.3e} | fp32 relmax {rel_max(y32, ref):.3e} l2 {rel_l2(y32, ref):.3e} nan={int(torch.isnan(y16).sum())}")
+
+
 def norm_cases():
     from ace_amd import _lib
     for (n, c, hw) in [(2, 16, 162), (3, 5, 77), (1, 384, 64800)]:
@@ -149,7 +174,7 @@ def ace2_shape():
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), torch.__version__)
     which = sys.argv[1:] or ["conv", "norm", "sht", "net", "ace2"]
-    table = {"conv": conv_cases, "norm": norm_cases, "sht": sht_cases, "net": net_cases, "ace2": ace2_shape}
+    table = {"f16x3": f16x3_cases, "conv": conv_cases, "norm": norm_cases, "sht": sht_cases, "net": net_cases, "ace2": ace2_shape}
     for w in which:
         section(w)
         guarded(table[w])
