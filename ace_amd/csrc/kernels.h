@@ -5,7 +5,7 @@
 
 namespace ace {
 
-enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SILU = 3 };
+enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SILU = 3, ACT_GELU_FAST = 4 /* erf to 1.1e-7 abs */ };
 enum Tri {
     TRI_NONE = 0,
     TRI_ROWS_GE_BATCH = 1,  // forward Legendre: rows l >= m (tiles wholly below are skipped)

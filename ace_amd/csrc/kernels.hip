@@ -23,8 +23,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define DEVINL __device__ __forceinline__
 
+// erf(x) = sign(x) (1 - 2^-q(|x|)), q a degree-9 fit of -log2(erfc(t)) on [0, 4] (erf(4) = 1 - 1.5e-8 rounds to 1).
+// Max abs error 1.1e-7 (tools/fit_fast_erf.py), i.e. ~2 fp32 ulps of the result, for ~14 instructions instead of
+// the ~60 of libm's erff.  Used by the compensated-fp16 engine, whose MFMA time no longer hides the epilogue.
+DEVINL float fast_erf(float x) {
+    const float t = fminf(fabsf(x), 4.0f);
+    float q = -1.150086973e-05f;
+    q = fmaf(q, t, 1.518900972e-04f);
+    q = fmaf(q, t, -8.436889620e-04f);
+    q = fmaf(q, t, 2.264559502e-03f);
+    q = fmaf(q, t, -7.151089812e-05f);
+    q = fmaf(q, t, -2.773463540e-02f);
+    q = fmaf(q, t, 1.483123451e-01f);
+    q = fmaf(q, t, 9.184418917e-01f);
+    q = fmaf(q, t, 1.627907395e+00f);
+    q = q * t;
+    return copysignf(1.0f - __builtin_amdgcn_exp2f(-q), x);
+}
+
 DEVINL float act_apply(float v, int act) {
     switch (act) {
+        case ACT_GELU_FAST: return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
         case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // exact erf GELU (nn.GELU)
         case ACT_RELU: return v > 0.f ? v : 0.f;
         case ACT_SILU: return v / (1.0f + expf(-v));
@@ -610,17 +629,26 @@ struct Gemm3Args {
     float oscale = 1.f;         // 1 / (ascale * bscale), applied to the accumulator
 };
 
+constexpr int G3_KAFF = 1024;  // largest K whose per-row affine is kept in LDS by the f16x3 engine
+
 template <int WM, int WN, bool AFF, bool RES>
-__global__ __launch_bounds__(64 * WM * WN) void gemm3_f16x3_kernel(Gemm3Args q, int tilesM, int tilesN) {
-    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN, NT = 64 * NW;
+__global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args q, int tilesM, int tilesN) {
+    // Wave-specialised: waves [0, NW) are MMA waves (LDS fragments -> MFMA -> epilogue), waves [NW, 2 NW) are loader
+    // waves (A DMA issue, B row loads, hi/lo split, LDS writes).  The split's VALU work and the MFMAs run on the
+    // same SIMDs at the same time (separate pipes); one workgroup barrier per stage hands buffers over.
+    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN, NT = 128 * NW, NL = 64 * NW;
+    static_assert(NL == 256, "B stager mapping assumes 256 loader threads");
     constexpr int BKT = 32;                   // k per stage
-    constexpr int NPT = BN / 64;              // columns per thread in the B stager (2 or 4)
+    constexpr int NPT = BN / 64;              // columns per loader thread (2 or 4)
     constexpr int APL = BM * BKT;             // halves per A plane per buffer
     constexpr int BPL = BKT * BN;             // halves per B plane per buffer
     constexpr int ACH = BM * BKT * 2 / 1024;  // 1 KiB DMA pieces per A plane
+    constexpr int ACW = (ACH + NW - 1) / NW;  // pieces per loader wave per plane
+    static_assert(ACH % NW == 0, "A pieces must divide evenly over the loader waves (counted vmcnt)");
     extern __shared__ __attribute__((aligned(16))) _Float16 smem3[];
-    _Float16* As = smem3;                     // [2 buf][2 plane][BM][32]
-    _Float16* Bs = smem3 + 2 * 2 * APL;       // [2 buf][2 plane][4 kg][BN][8]
+    _Float16* As = smem3;                     // [2 buf][2 plane][BM][32]        DMA target, one stage ahead
+    _Float16* Bs = smem3 + 2 * 2 * APL;       // [2 buf][2 plane][4 kg][BN][8]   written from registers
+    float* Aff = reinterpret_cast<float*>(smem3 + 2 * 2 * APL + 2 * 2 * BPL);  // [2][G3_KAFF] scale | shift (AFF only)
     const GemmArgs& p = q.g;
 
     const int nblk = tilesM * tilesN * p.nbatch;
@@ -642,86 +670,140 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm3_f16x3_kernel(Gemm3Args q, 
         if (m0 >= M) return;
     }
     const int K = p.K, N = p.N;
-    const long lda = p.lda, ldb = p.ldb, ldb2 = p.ldb2;
-    const int K1 = p.K1;
-    const _Float16* Ahi = q.Ahi + (long)batch * p.sA;
-    const _Float16* Alo = q.Alo + (long)batch * p.sA;
-    const float* B = p.B + (long)batch * p.sB;
-    const float* B2 = p.B2 ? p.B2 + (long)batch * p.sB2 : nullptr;
-    const float* bsc = AFF ? p.bsc + (long)batch * p.sbs : nullptr;
-    const float* bsh = AFF ? p.bsh + (long)batch * p.sbs : nullptr;
-    const float bscale = q.bscale;
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 31, g = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
+    const int nk = (K - kbeg + BKT - 1) / BKT;
 
-    // ---- A DMA descriptors: piece = 16 rows x 64 B; lane -> (row, physical slot); fetches the swizzled logical slot
-    constexpr int ACW = (ACH + NW - 1) / NW;
-    long aoff[ACW];
-#pragma unroll
-    for (int c = 0; c < ACW; ++c) {
-        const int ca = wave + c * NW;
-        const int row = ca * 16 + lane / 4;
-        const int ls = (lane % 4) ^ ((row >> 2) & 3);
-        int m = m0 + row;
-        m = m < M ? m : M - 1;
-        aoff[c] = (long)m * lda + 8 * ls;
+    if (AFF) {  // per-row affine of B (fused instance norm), pre-multiplied by the power-of-two scale
+        const float* bsc = p.bsc + (long)batch * p.sbs;
+        const float* bsh = p.bsh + (long)batch * p.sbs;
+        for (int k = tid; k < K; k += NT) {
+            Aff[k] = bsc[k] * q.bscale;
+            Aff[G3_KAFF + k] = bsh[k] * q.bscale;
+        }
+        __syncthreads();
     }
-    // ---- B stager: thread -> (k group of 8, NPT consecutive columns)
-    const int bkg = tid / 64;                 // 0..3 (NT == 256)
-    const int bnl = (tid % 64) * NPT;         // column inside the tile
-    int bn = n0 + bnl;
-    bn = bn + NPT <= N ? bn : N - NPT;        // clamp (N % NPT == 0): extra columns feed outputs never stored
-    float breg[8][NPT];
-    float bs_[AFF ? 8 : 1], bt_[AFF ? 8 : 1];
 
-    auto issue = [&](int k0, int buf) {
-        _Float16* Ab = As + buf * 2 * APL;
+    if (wave >= NW) {
+        // =========================== loader waves ===========================
+        const int lw = wave - NW;            // loader wave index
+        const int ltid = tid - NL;           // 0..255
+        const long lda = p.lda, ldb = p.ldb, ldb2 = p.ldb2;
+        const int K1 = p.K1;
+        const _Float16* Ahi = q.Ahi + (long)batch * p.sA;
+        const _Float16* Alo = q.Alo + (long)batch * p.sA;
+        const float* B = p.B + (long)batch * p.sB;
+        const float* B2 = p.B2 ? p.B2 + (long)batch * p.sB2 : nullptr;
+        const float bscale = q.bscale;
+        // A DMA: piece = 16 rows x 64 B; lane -> (row, physical slot), fetches the XOR-swizzled logical slot
+        long aoff[ACW];
 #pragma unroll
         for (int c = 0; c < ACW; ++c) {
-            const int ca = wave + c * NW;
-            if (ACH % NW == 0 || ca < ACH) {
+            const int ca = lw + c * NW;
+            const int row = ca * 16 + lane / 4;
+            const int ls = (lane % 4) ^ ((row >> 2) & 3);
+            int m = m0 + row;
+            m = m < M ? m : M - 1;
+            aoff[c] = (long)m * lda + 8 * ls;
+        }
+        // B stager: thread -> (k group of 8, NPT consecutive columns)
+        const int bkg = ltid / 64;           // 0..3
+        const int bnl = (ltid % 64) * NPT;
+        int bn = n0 + bnl;
+        bn = bn + NPT <= N ? bn : N - NPT;   // clamp (N % NPT == 0): extra columns feed outputs never stored
+
+        struct BRegs { float v[8][NPT]; };
+        auto issue_a = [&](int k0, int abuf) {
+            _Float16* Ab = As + abuf * 2 * APL;
+#pragma unroll
+            for (int c = 0; c < ACW; ++c) {
+                const int ca = lw + c * NW;
                 glds16(reinterpret_cast<const float*>(Ahi + aoff[c] + k0), reinterpret_cast<float*>(Ab + ca * 512));
                 glds16(reinterpret_cast<const float*>(Alo + aoff[c] + k0), reinterpret_cast<float*>(Ab + APL + ca * 512));
             }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int k = k0 + 8 * bkg + e;
-            k = k < K ? k : K - 1;  // rows past K meet zero A columns
-            const float* src = (K1 >= 0 && k >= K1) ? (B2 + (long)(k - K1) * ldb2 + bn) : (B + (long)k * ldb + bn);
-            if (NPT == 4) {
-                const float4 v = *reinterpret_cast<const float4*>(src);
-                breg[e][0] = v.x; breg[e][1] = v.y; breg[e][NPT - 2] = v.z; breg[e][NPT - 1] = v.w;
-            } else {
-                const float2 v = *reinterpret_cast<const float2*>(src);
-                breg[e][0] = v.x; breg[e][1] = v.y;
-            }
-            if (AFF) { bs_[e] = bsc[k]; bt_[e] = bsh[k]; }
-        }
-    };
-    auto stash = [&](int buf) {  // split + write the staged B registers (after the MFMAs of the current stage)
-        _Float16* Bb = Bs + buf * 2 * BPL;
-#pragma unroll
-        for (int c = 0; c < NPT; ++c) {
-            half8 hi, lo;
+        };
+        auto issue_b = [&](int k0, BRegs& r) {  // exactly 8 row loads
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float x = breg[e][c];
-                if (AFF) x = fmaf(x, bs_[e], bt_[e]);
-                x = __builtin_amdgcn_fmed3f(x * bscale, -65504.f, 65504.f);
-                const _Float16 hh = (_Float16)x;
-                hi[e] = hh;
-                lo[e] = (_Float16)(x - (float)hh);
+                int k = k0 + 8 * bkg + e;
+                k = k < K ? k : K - 1;  // rows past K meet zero A columns
+                const float* src = (K1 >= 0 && k >= K1) ? (B2 + (long)(k - K1) * ldb2 + bn) : (B + (long)k * ldb + bn);
+                if (NPT == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(src);
+                    r.v[e][0] = v.x; r.v[e][1] = v.y; r.v[e][NPT - 2] = v.z; r.v[e][NPT - 1] = v.w;
+                } else {
+                    const float2 v = *reinterpret_cast<const float2*>(src);
+                    r.v[e][0] = v.x; r.v[e][1] = v.y;
+                }
             }
-            *reinterpret_cast<half8*>(Bb + ((long)bkg * BN + bnl + c) * 8) = hi;
-            *reinterpret_cast<half8*>(Bb + BPL + ((long)bkg * BN + bnl + c) * 8) = lo;
+        };
+        auto stash = [&](int k0, int bbuf, const BRegs& r) {
+            _Float16* Bb = Bs + bbuf * 2 * BPL;
+            float sc[8], sh[8];
+            if (AFF) {
+                int kk = k0 + 8 * bkg;
+                kk = kk + 8 <= G3_KAFF ? kk : G3_KAFF - 8;
+                const float4 s0 = *reinterpret_cast<const float4*>(Aff + kk), s1 = *reinterpret_cast<const float4*>(Aff + kk + 4);
+                const float4 t0 = *reinterpret_cast<const float4*>(Aff + G3_KAFF + kk),
+                             t1 = *reinterpret_cast<const float4*>(Aff + G3_KAFF + kk + 4);
+                sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+                sh[0] = t0.x; sh[1] = t0.y; sh[2] = t0.z; sh[3] = t0.w; sh[4] = t1.x; sh[5] = t1.y; sh[6] = t1.z; sh[7] = t1.w;
+            }
+#pragma unroll
+            for (int c = 0; c < NPT; ++c) {
+                half8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = r.v[e][c];
+                    x = AFF ? fmaf(x, sc[e], sh[e]) : x * bscale;
+                    x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+                    const _Float16 hh = (_Float16)x;
+                    hi[e] = hh;
+                    lo[e] = (_Float16)(x - (float)hh);
+                }
+                *reinterpret_cast<half8*>(Bb + ((long)bkg * BN + bnl + c) * 8) = hi;
+                *reinterpret_cast<half8*>(Bb + BPL + ((long)bkg * BN + bnl + c) * 8) = lo;
+            }
+        };
+        // Stage t is computed from As[t & 1] / Bs[t & 1].  A (weights, L2 resident): DMA one stage ahead.  B
+        // (activations): row loads two stages ahead into register set t & 1, split into Bs[(t+1) & 1] during stage t.
+        // VMEM retires in order and each stage issues [A DMA of t+1][8 B loads of t+2]: "A of t+1 landed, B of t+2 may
+        // still fly" is exactly vmcnt(8).
+        BRegs r0, r1;
+        if (nk > 0) { issue_a(kbeg, 0); issue_b(kbeg, r0); }
+        if (nk > 1) issue_b(kbeg + BKT, r1);
+        if (nk > 0) stash(kbeg, 0, r0);
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            {
+                const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+                if (more1) issue_a(kbeg + (kt + 1) * BKT, 1);
+                if (more2) issue_b(kbeg + (kt + 2) * BKT, r0);
+                if (more1) stash(kbeg + (kt + 1) * BKT, 1, r1);
+                if (more2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            if (kt + 1 >= nk) break;
+            {
+                const bool more1 = kt + 2 < nk, more2 = kt + 3 < nk;
+                if (more1) issue_a(kbeg + (kt + 2) * BKT, 0);
+                if (more2) issue_b(kbeg + (kt + 3) * BKT, r1);
+                if (more1) stash(kbeg + (kt + 2) * BKT, 0, r0);
+                if (more2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
         }
-    };
+        return;
+    }
 
+    // =========================== MMA waves ===========================
+    const int i = lane & 31, g = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -734,55 +816,47 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm3_f16x3_kernel(Gemm3Args q, 
     const int key0 = (arow0 >> 2) & 3, key1 = (arow1 >> 2) & 3;
     const int bcol0 = wn * 64 + i, bcol1 = bcol0 + 32;
 
-    const int nk = (K - kbeg + BKT - 1) / BKT;
-    if (nk > 0) {
-        issue(kbeg, 0);
-        stash(0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();  // stage 0 is in LDS
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) issue(kbeg + (kt + 1) * BKT, cur ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-        const _Float16* Ah = As + cur * 2 * APL;
+        const int buf = kt & 1;
+        const _Float16* Ah = As + buf * 2 * APL;
         const _Float16* Al = Ah + APL;
-        const _Float16* Bh = Bs + cur * 2 * BPL;
+        const _Float16* Bh = Bs + buf * 2 * BPL;
         const _Float16* Bl = Bh + BPL;
+        half8 ah0[2], ah1[2], al0[2], al1[2], bh0[2], bh1[2], bl0[2], bl1[2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {  // two 16-deep chunks per stage; lane group g owns k = 16c + 8g .. +7
-            const int ls = 2 * c + g;
-            const half8 ah0 = *reinterpret_cast<const half8*>(Ah + arow0 * 32 + 8 * (ls ^ key0));
-            const half8 ah1 = *reinterpret_cast<const half8*>(Ah + arow1 * 32 + 8 * (ls ^ key1));
-            const half8 al0 = *reinterpret_cast<const half8*>(Al + arow0 * 32 + 8 * (ls ^ key0));
-            const half8 al1 = *reinterpret_cast<const half8*>(Al + arow1 * 32 + 8 * (ls ^ key1));
-            const half8 bh0 = *reinterpret_cast<const half8*>(Bh + ((long)ls * BN + bcol0) * 8);
-            const half8 bh1 = *reinterpret_cast<const half8*>(Bh + ((long)ls * BN + bcol1) * 8);
-            const half8 bl0 = *reinterpret_cast<const half8*>(Bl + ((long)ls * BN + bcol0) * 8);
-            const half8 bl1 = *reinterpret_cast<const half8*>(Bl + ((long)ls * BN + bcol1) * 8);
-            // small cross terms first, the hi.hi term last
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc[1][1], 0, 0, 0);
+        for (int c = 0; c < 2; ++c) {  // all fragments of the stage up front: 16 ds_read_b128
+            const int ls = 2 * c + g;  // lane group g owns k = 16c + 8g .. +7
+            ah0[c] = *reinterpret_cast<const half8*>(Ah + arow0 * 32 + 8 * (ls ^ key0));
+            ah1[c] = *reinterpret_cast<const half8*>(Ah + arow1 * 32 + 8 * (ls ^ key1));
+            al0[c] = *reinterpret_cast<const half8*>(Al + arow0 * 32 + 8 * (ls ^ key0));
+            al1[c] = *reinterpret_cast<const half8*>(Al + arow1 * 32 + 8 * (ls ^ key1));
+            bh0[c] = *reinterpret_cast<const half8*>(Bh + ((long)ls * BN + bcol0) * 8);
+            bh1[c] = *reinterpret_cast<const half8*>(Bh + ((long)ls * BN + bcol1) * 8);
+            bl0[c] = *reinterpret_cast<const half8*>(Bl + ((long)ls * BN + bcol0) * 8);
+            bl1[c] = *reinterpret_cast<const half8*>(Bl + ((long)ls * BN + bcol1) * 8);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) stash(cur ^ 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {  // small cross terms first, the hi.hi term last
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0[c], bh0[c], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0[c], bh1[c], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1[c], bh0[c], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1[c], bh1[c], acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[c], bl0[c], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[c], bl1[c], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[c], bl0[c], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[c], bl1[c], acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[c], bh0[c], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[c], bh1[c], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[c], bh0[c], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[c], bh1[c], acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();  // fragments are in registers (lgkmcnt(0) precedes the barrier): the buffer may be refilled
     }
 
     // epilogue
     const float osc_acc = q.oscale;
+    const float* B = p.B + (long)batch * p.sB;
     float* C = p.C + (long)batch * p.sC;
     const float* R = RES ? p.R + (long)batch * p.sR : nullptr;
     const float* rsc = p.rsc ? p.rsc + (long)batch * p.srs : nullptr;
@@ -932,11 +1006,11 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
 
 template <int WM, int WN>
 static hipError_t launch_gemm3_cfg(const Gemm3Args& a, hipStream_t s) {
-    constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
+    constexpr int BM = 64 * WM, BN = 64 * WN, NT = 128 * WM * WN;  // MMA waves + loader waves
     const int tilesM = (a.g.M + BM - 1) / BM, tilesN = (a.g.N + BN - 1) / BN;
     const long nblk = (long)tilesM * tilesN * a.g.nbatch;
     if (nblk <= 0) return hipSuccess;
-    constexpr size_t lds = (size_t)2 * 2 * (BM * 32 + 32 * BN) * sizeof(_Float16);
+    const size_t lds = (size_t)2 * 2 * (BM * 32 + 32 * BN) * sizeof(_Float16) + (a.g.bsc ? 2 * G3_KAFF * sizeof(float) : 0);
     const bool aff = a.g.bsc != nullptr, res = a.g.R != nullptr;
     const void* fn = aff ? (res ? (const void*)gemm3_f16x3_kernel<WM, WN, true, true> : (const void*)gemm3_f16x3_kernel<WM, WN, true, false>)
                          : (res ? (const void*)gemm3_f16x3_kernel<WM, WN, false, true> : (const void*)gemm3_f16x3_kernel<WM, WN, false, false>);
@@ -960,6 +1034,7 @@ bool gemm_f16x3_eligible(const GemmArgs& a) {
     bool ok = al16(a.B) && (a.ldb % 4 == 0) && (a.sB % 4 == 0) && (a.N % npt == 0) && (a.N >= npt) && (a.lda % 8 == 0) &&
               (a.sA % 8 == 0) && (a.a_kpad >= ((a.K + 31) / 32) * 32) && a.M >= 1 && a.K >= 1;
     if (a.B2) ok = ok && al16(a.B2) && (a.ldb2 % 4 == 0) && (a.sB2 % 4 == 0);
+    if (a.bsc) ok = ok && (((a.K + 31) / 32) * 32 <= G3_KAFF);
     return ok;
 }
 

@@ -70,3 +70,24 @@ if __name__ == "__main__":
         conv(4096, 4096, 4096, 0, max(iters // 4, 2), "sq   4096^3      ")
     if which in ("sht", "all"):
         sht(iters)
+
+
+def conv16(cout, cin, hw, act, iters, name):
+    L = _lib.lib()
+    x = torch.randn(1, cin, hw, device=dev)
+    w = torch.randn(cout, cin, device=dev) * 0.02
+    b = torch.randn(cout, device=dev)
+    y = torch.empty(1, cout, hw, device=dev)
+    st = _lib.current_stream()
+    for _ in range(iters):
+        _lib.check(L.ace_conv1x1_f16x3(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), 1, cin, cout, hw, act, st))
+    torch.cuda.synchronize()
+    print(name, "done (time it from the kernel trace)")
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1].startswith("h")):
+    which = sys.argv[1]
+    if which in ("hfc1", "hall"):
+        conv16(768, 384, 64800, 1, 3, "f16x3 fc1")
+    if which in ("hfc2", "hall"):
+        conv16(384, 768, 64800, 0, 3, "f16x3 fc2")
