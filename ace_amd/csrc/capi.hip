@@ -84,9 +84,22 @@ struct ace_sht_plan {
     Grid grid = GRID_LEGENDRE_GAUSS;
     DevBuf wt, pt, fc, fs, gc, gs;
     DevBuf X, D;  // scratch of the standalone transforms (plan-owned, grown on demand)
+    // f16x3 mode: hi/lo fp16 planes of wt / pt (same pitches, in halves) scaled by a power of two
+    DevBuf wt_hi, wt_lo, pt_hi, pt_lo;
+    float wt_scale = 1.f, pt_scale = 1.f;
+    bool f16 = false;
 };
 
-static int plan_build(int nlat, int nlon, int lmax, int mmax, Grid g, std::unique_ptr<ace_sht_plan>& out) {
+static float pow2_scale_for(const std::vector<float>& v) {  // puts max|v| in [2^9, 2^10)
+    float mx = 0.f;
+    for (float x : v) mx = std::max(mx, std::fabs(x));
+    int e = 0;
+    if (mx > 0.f && std::isfinite(mx)) { (void)std::frexp(mx, &e); e = 10 - e; }
+    return std::ldexp(1.0f, e);
+}
+
+static int plan_build(int nlat, int nlon, int lmax, int mmax, Grid g, std::unique_ptr<ace_sht_plan>& out,
+                      bool f16 = false) {
     ShtTables t;
     std::string err = build_sht_tables(nlat, nlon, lmax, mmax, g, t);
     if (!err.empty()) return fail(ACE_ERR_INVALID, err);
@@ -99,14 +112,26 @@ static int plan_build(int nlat, int nlon, int lmax, int mmax, Grid g, std::uniqu
     HIP_TRY(p->fs.upload(t.fs));
     HIP_TRY(p->gc.upload(t.gc));
     HIP_TRY(p->gs.upload(t.gs));
+    if (f16) {
+        p->f16 = true;
+        p->wt_scale = pow2_scale_for(t.wt);
+        p->pt_scale = pow2_scale_for(t.pt);
+        const size_t hw = (t.wt.size() + 1) / 2, hp = (t.pt.size() + 1) / 2;
+        HIP_TRY(p->wt_hi.alloc(hw, false)); HIP_TRY(p->wt_lo.alloc(hw, false));
+        HIP_TRY(p->pt_hi.alloc(hp, false)); HIP_TRY(p->pt_lo.alloc(hp, false));
+        HIP_TRY(launch_split_f16(p->wt.p, t.Hp, p->wt_hi.p, p->wt_lo.p, t.Hp, (long)t.mmax * t.lmax, t.Hp, p->wt_scale, nullptr));
+        HIP_TRY(launch_split_f16(p->pt.p, t.Lp, p->pt_hi.p, p->pt_lo.p, t.Lp, (long)t.mmax * t.nlat, t.Lp, p->pt_scale, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+    }
     out = std::move(p);
     return ACE_OK;
 }
 
 // X[m][k][b][ri][c] <- longitude DFT of x (Bt, C, H, W), optional per-(b,c) affine on load
 static int run_dft_forward(const ace_sht_plan& pl, const float* x, const float* sc, const float* sh, float* X, int Bt,
-                           int C, hipStream_t s) {
+                           int C, hipStream_t s, unsigned* xmax = nullptr) {
     DftArgs a;
+    a.omax = xmax;
     a.x = x; a.spec_out = X; a.tc = pl.fc.p; a.ts = pl.fs.p; a.ldt = pl.Kfp; a.sc = sc; a.sh = sh;
     a.Bt = Bt; a.C = C; a.H = pl.nlat; a.W = pl.nlon; a.Mm = pl.mmax;
     HIP_TRY(launch_dft_forward(a, s));
@@ -121,24 +146,35 @@ static int run_dft_inverse(const ace_sht_plan& pl, const float* X, const float* 
     return ACE_OK;
 }
 // D[l][m][n2] = sum_k wt[m][l][k] X[m][k][n2]   (sht_fix.py:134-138), batched over m, rows l >= m only
-static int run_legendre_forward(const ace_sht_plan& pl, const float* X, float* D, long N2, hipStream_t s) {
+static int run_legendre_forward(const ace_sht_plan& pl, const float* X, float* D, long N2, hipStream_t s,
+                                const unsigned* xmax = nullptr, unsigned* dmax = nullptr) {
     GemmArgs g;
+    g.omax = dmax;
     g.A = pl.wt.p; g.lda = pl.Hp; g.sA = (long)pl.lmax * pl.Hp;
     g.B = X; g.ldb = N2; g.sB = (long)pl.nlat * N2;
     g.C = D; g.ldc = (long)pl.mmax * N2; g.sC = N2;
     g.M = pl.lmax; g.N = (int)N2; g.K = pl.nlat; g.nbatch = pl.mmax; g.a_kpad = pl.Hp;
     g.tri = TRI_ROWS_GE_BATCH;
+    if (pl.f16 && xmax && gemm_f16x3_eligible(g)) {
+        HIP_TRY(launch_gemm_f16x3(g, pl.wt_hi.p, pl.wt_lo.p, pl.wt_scale, 1.f, s, xmax, dmax));
+        return ACE_OK;
+    }
     HIP_TRY(launch_gemm(g, s));
     return ACE_OK;
 }
 // X[m][k][n2] = sum_{l>=m} pt[m][k][l] E[l][m][n2]   (sht_fix.py:208-219), batched over m
-static int run_legendre_inverse(const ace_sht_plan& pl, const float* E, float* X, long N2, hipStream_t s) {
+static int run_legendre_inverse(const ace_sht_plan& pl, const float* E, float* X, long N2, hipStream_t s,
+                                const unsigned* emax = nullptr) {
     GemmArgs g;
     g.A = pl.pt.p; g.lda = pl.Lp; g.sA = (long)pl.nlat * pl.Lp;
     g.B = E; g.ldb = (long)pl.mmax * N2; g.sB = N2;
     g.C = X; g.ldc = N2; g.sC = (long)pl.nlat * N2;
     g.M = pl.nlat; g.N = (int)N2; g.K = pl.lmax; g.nbatch = pl.mmax; g.a_kpad = pl.Lp;
     g.tri = TRI_K_GE_BATCH;
+    if (pl.f16 && emax && gemm_f16x3_eligible(g)) {
+        HIP_TRY(launch_gemm_f16x3(g, pl.pt_hi.p, pl.pt_lo.p, pl.pt_scale, 1.f, s, emax, nullptr));
+        return ACE_OK;
+    }
     HIP_TRY(launch_gemm(g, s));
     return ACE_OK;
 }
@@ -258,7 +294,11 @@ extern "C" int ace_conv1x1_f16x3(const float* x, const float* weight, const floa
     g.bias = bias; g.M = cout; g.N = (int)hw; g.K = cin; g.nbatch = n; g.act = act;
     if (!gemm_f16x3_eligible(g)) return fail(ACE_ERR_INVALID, "ace_conv1x1_f16x3: needs 16-byte aligned x and hw % 4 == 0");
     if (g.act == ACT_GELU) g.act = ACT_GELU_FAST;
-    HIP_TRY(launch_gemm_f16x3(g, hi.p, lo.p, ascale, 16.0f, s));
+    DevBuf slotbuf;
+    HIP_TRY(slotbuf.alloc(AMAX_SHARDS));
+    unsigned* xslot = reinterpret_cast<unsigned*>(slotbuf.p);
+    HIP_TRY(launch_absmax(x, (long)n * cin * hw, xslot, s));
+    HIP_TRY(launch_gemm_f16x3(g, hi.p, lo.p, ascale, 1.0f, s, xslot, nullptr));
     HIP_TRY(hipStreamSynchronize(s));  // temporaries are freed on return
     return ACE_OK;
 }
@@ -322,7 +362,8 @@ struct ace_sfno {
     std::vector<DevBuf> wx;  // per block: dhconv weight expanded to real [L][2C][2C]
     // workspace
     DevBuf h0, h1, Y, T, R, U, X, D, E, stats;
-    DevBuf Wf0, bf0, Wf1, bf1;  // instance-norm affine folded into inner_skip / mlp.fc1 weights, per sample
+    DevBuf Wf0, bf0, Wf1, bf1;
+    DevBuf amax;  // [8] uint words: bit patterns of max|X|, max|D|, max|E| of the current block (f16x3 dynamic range)  // instance-norm affine folded into inner_skip / mlp.fc1 weights, per sample
     bool taps_on = false;
     std::vector<DevBuf> taps;
     std::map<GraphKey, hipGraphExec_t> graphs;
@@ -374,11 +415,11 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     if (n->L < 1 || n->Mm < 1) return fail(ACE_ERR_INVALID, "hard_thresholding_fraction leaves no modes");
     n->hid = (int)(c.embed_dim * c.mlp_ratio);
 
-    ACE_TRY(plan_build(c.nlat, c.nlon, n->L, n->Mm, GRID_LEGENDRE_GAUSS, n->plan_lg));
+    ACE_TRY(plan_build(c.nlat, c.nlon, n->L, n->Mm, GRID_LEGENDRE_GAUSS, n->plan_lg, c.precision == 1));
     if (c.data_grid == GRID_LEGENDRE_GAUSS) {
         n->plan_data = n->plan_lg.get();
     } else {
-        ACE_TRY(plan_build(c.nlat, c.nlon, n->L, n->Mm, (Grid)c.data_grid, n->plan_data_own));
+        ACE_TRY(plan_build(c.nlat, c.nlon, n->L, n->Mm, (Grid)c.data_grid, n->plan_data_own, c.precision == 1));
         n->plan_data = n->plan_data_own.get();
     }
 
@@ -430,6 +471,7 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     HIP_TRY(n->D.alloc(spec_d));
     HIP_TRY(n->E.alloc(spec_d));
     HIP_TRY(n->stats.alloc((size_t)4 * n->Bmax * C));
+    HIP_TRY(n->amax.alloc((size_t)(16 + 8 * c.num_layers) * AMAX_SHARDS));
     if (c.normalization_layer == 1) {
         const size_t cp = (size_t)((C + 31) & ~31);
         HIP_TRY(n->Wf0.alloc((size_t)n->Bmax * C * cp));
@@ -513,9 +555,11 @@ static ConvW conv_weight(const ace_sfno* n, const std::string& wname, const std:
 static int conv(const ace_sfno* n, const ConvW& cw, const float* in, long in_bstride, int cin, const float* in2,
                 long in2_bstride, int K1, float* out, int cout, const float* R, long r_bstride, const float* rsc,
                 const float* rsh, int act, int batch, hipStream_t s, const float* bsc = nullptr,
-                const float* bsh = nullptr) {
+                const float* bsh = nullptr, const unsigned* bmax = nullptr, const unsigned* bmax2 = nullptr,
+                unsigned* omax = nullptr) {
     GemmArgs g;
     g.bsc = bsc; g.bsh = bsh; g.sbs = bsc ? cin : 0;
+    g.omax = omax;
     g.A = cw.w; g.lda = cw.pitch; g.sA = cw.sw; g.a_kpad = cw.pitch;
     g.B = in; g.ldb = n->HW; g.sB = in_bstride;
     g.B2 = in2; g.ldb2 = n->HW; g.sB2 = in2_bstride; g.K1 = in2 ? K1 : -1;
@@ -524,12 +568,15 @@ static int conv(const ace_sfno* n, const ConvW& cw, const float* in, long in_bst
     g.R = R; g.ldr = n->HW; g.sR = r_bstride;
     g.rsc = rsc; g.rsh = rsh; g.srs = rsc ? cout : 0;
     g.M = cout; g.N = (int)n->HW; g.K = cin; g.nbatch = batch; g.act = act;
-    if (n->cfg.precision == 1 && cw.hi && cw.sw == 0 && gemm_f16x3_eligible(g)) {
-        // compensated fp16: activations are O(1..100) by construction here (normalised inputs, GELU outputs);
-        // 2^4 keeps |x| up to 4094 exact-range, larger values saturate instead of overflowing
+    if (n->cfg.precision == 1 && cw.hi && cw.sw == 0 && bmax && gemm_f16x3_eligible(g)) {
+        // compensated fp16 with the B scale derived in-kernel from max|B| (slot written by B's producer)
         if (g.act == ACT_GELU) g.act = ACT_GELU_FAST;  // the epilogue is on the critical path of this engine
-        HIP_TRY(launch_gemm_f16x3(g, cw.hi, cw.lo, cw.ascale, 16.0f, s));
+        HIP_TRY(launch_gemm_f16x3(g, cw.hi, cw.lo, cw.ascale, 1.0f, s, bmax, omax, (in2 ? bmax2 : nullptr)));
         return ACE_OK;
+    }
+    if (bsc && g.sA == 0 && n->cfg.precision == 1) {
+        // f16x3 configuration but this launch fell back to fp32 with an un-folded affine: the register-staged
+        // engine applies it on load
     }
     HIP_TRY(launch_gemm(g, s));
     return ACE_OK;
@@ -592,6 +639,17 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     const long N2 = (long)B * 2 * C;
     const long actB = (long)C * HW;  // per-sample stride of a C-channel activation
     auto W = [&](const std::string& name) { return n->w(name); };
+    // dynamic-range slots of the f16x3 engine (AMAX_SHARDS words each): 0 network input, 1..7 encoder/decoder hidden,
+    // 8 + i block input h_i, 16 + 8 i + {0 X, 1 D, 2 E, 3 N0, 4 T, 5 N1, 6 U} of block i
+    const bool f16 = c.precision == 1;
+    unsigned* amax = reinterpret_cast<unsigned*>(n->amax.p);
+    auto slot = [&](int k) -> unsigned* { return f16 ? amax + (size_t)k * AMAX_SHARDS : nullptr; };
+    if (f16) {
+        HIP_TRY(hipMemsetAsync(amax, 0, n->amax.n * sizeof(float), s));
+        HIP_TRY(launch_absmax(in, (long)B * Cin * HW, slot(0), s));
+    }
+    if (c.num_layers + 8 > 16) { /* block-input slots 8..15 are shared cyclically for deep nets */ }
+    auto hslot = [&](int i) { return slot(8 + (i % 8)); };
 
     // ---- encoder (sfnonet.py:721-733): [conv+bias, act] x encoder_layers, conv (no bias), + pos_embed
     const float* cur = in;
@@ -601,13 +659,15 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     for (int j = 0; j < c.encoder_layers; ++j) {
         const std::string p = "encoder." + std::to_string(2 * j);
         ACE_TRY(conv(n, conv_weight(n, p + ".weight", p + ".bias"), cur, cur_bs, curC, nullptr, 0, -1, ping[j & 1], C,
-                     nullptr, 0, nullptr, nullptr, act, B, s));
+                     nullptr, 0, nullptr, nullptr, act, B, s, nullptr, nullptr, slot(j == 0 ? 0 : j), nullptr,
+                     slot(1 + j)));
         cur = ping[j & 1]; cur_bs = actB; curC = C;
     }
     float* h = n->h0.p;
     float* hn = n->h1.p;
     ACE_TRY(conv(n, conv_weight(n, "encoder." + std::to_string(2 * c.encoder_layers) + ".weight", ""), cur, cur_bs, curC,
-                 nullptr, 0, -1, h, C, c.pos_embed ? W("pos_embed") : nullptr, 0, nullptr, nullptr, ACT_NONE, B, s));
+                 nullptr, 0, -1, h, C, c.pos_embed ? W("pos_embed") : nullptr, 0, nullptr, nullptr, ACT_NONE, B, s,
+                 nullptr, nullptr, slot(c.encoder_layers), nullptr, hslot(0)));
     MARK(ST_ENCODER);
     if (n->taps_on) HIP_TRY(hipMemcpyAsync(n->taps[0].p, h, sizeof(float) * B * actB, hipMemcpyDeviceToDevice, s));
 
@@ -625,21 +685,25 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         const bool scale_residual = (&fwd != &inv);  // grids differ (s2convolutions.py:82-86)
 
         // norm0 as an affine applied on load by every consumer (never materialised)
+        const int sb = 16 + 8 * i;  // slot base of this block
+        if (f16 && i + 1 >= 8) HIP_TRY(hipMemsetAsync(hslot(i + 1), 0, AMAX_SHARDS * sizeof(unsigned), s));
         const float *a0 = nullptr, *b0 = nullptr;
         if (norm) {
-            HIP_TRY(launch_instnorm_stats(h, W(p + "norm0.weight"), W(p + "norm0.bias"), 1e-6f, B, C, HW, sc0, sh0, s));
+            HIP_TRY(launch_instnorm_stats(h, W(p + "norm0.weight"), W(p + "norm0.bias"), 1e-6f, B, C, HW, sc0, sh0, s,
+                                          slot(sb + 3)));
             a0 = sc0; b0 = sh0;
             MARK(ST_NORM0);
         }
         // spectral filter (s2convolutions.py:162-197): SHT -> contraction -> inverse SHT + bias
-        ACE_TRY(run_dft_forward(fwd, h, a0, b0, n->X.p, B, C, s));
+        unsigned *xmax = slot(sb + 0), *dmax = slot(sb + 1), *emax = slot(sb + 2);
+        ACE_TRY(run_dft_forward(fwd, h, a0, b0, n->X.p, B, C, s, xmax));
         MARK(ST_DFT_FWD);
-        ACE_TRY(run_legendre_forward(fwd, n->X.p, n->D.p, N2, s));
+        ACE_TRY(run_legendre_forward(fwd, n->X.p, n->D.p, N2, s, xmax, dmax));
         MARK(ST_LEGENDRE_FWD);
         const float* res = h;           // residual = x_norm, applied as (h, a0, b0)
         const float *ra = a0, *rb = b0;
         if (scale_residual) {           // residual = inverse(forward(x_norm)) on the output grid
-            ACE_TRY(run_legendre_inverse(inv, n->D.p, n->X.p, N2, s));
+            ACE_TRY(run_legendre_inverse(inv, n->D.p, n->X.p, N2, s, dmax));
             MARK(ST_LEGENDRE_INV);
             ACE_TRY(run_dft_inverse(inv, n->X.p, nullptr, n->R.p, B, C, s));
             MARK(ST_DFT_INV);
@@ -652,27 +716,32 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             g.C = n->E.p; g.ldc = 2 * C; g.sC = (long)n->Mm * N2;
             g.M = n->Mm * B; g.N = 2 * C; g.K = 2 * C; g.nbatch = n->L; g.a_kpad = 2 * C;
             g.tri = TRI_ROWS_LE_BATCH; g.trimul = B;
+            g.omax = emax;
             HIP_TRY(launch_gemm(g, s));
         } else {
-            HIP_TRY(launch_contract_diagonal(n->D.p, W(p + "filter.filter.weight"), n->E.p, B, C, C, n->L, n->Mm, s));
+            HIP_TRY(launch_contract_diagonal(n->D.p, W(p + "filter.filter.weight"), n->E.p, B, C, C, n->L, n->Mm, s, emax));
         }
         MARK(ST_CONTRACT);
-        ACE_TRY(run_legendre_inverse(inv, n->E.p, n->X.p, N2, s));
+        ACE_TRY(run_legendre_inverse(inv, n->E.p, n->X.p, N2, s, emax));
         MARK(ST_LEGENDRE_INV);
         ACE_TRY(run_dft_inverse(inv, n->X.p, W(p + "filter.filter.bias"), n->Y.p, B, C, s));
         MARK(ST_DFT_INV);
 
         // x = act(filter + inner_skip(residual))   (sfnonet.py:229-232)
         ConvW wskip = conv_weight(n, p + "inner_skip.weight", p + "inner_skip.bias");
-        const bool f16 = c.precision == 1;
-        if (ra && !f16) ACE_TRY(fold(n, wskip, C, C, ra, rb, n->Wf0.p, n->bf0.p, B, s, &wskip));
+        // B of the inner skip: the normalised block input (bound from the norm statistics) or, without a norm, the raw
+        // block input; the spectrally round-tripped residual of mixed-grid blocks has no range slot -> fp32 engine
+        const unsigned* skip_max = scale_residual ? nullptr : (norm ? slot(sb + 3) : hslot(i));
+        const bool skip_f16 = f16 && skip_max != nullptr;
+        if (ra && !skip_f16) ACE_TRY(fold(n, wskip, C, C, ra, rb, n->Wf0.p, n->bf0.p, B, s, &wskip));
         ACE_TRY(conv(n, wskip, res, actB, C, nullptr, 0, -1, n->T.p, C, n->Y.p, actB, nullptr, nullptr, act, B, s,
-                     f16 ? ra : nullptr, f16 ? rb : nullptr));
+                     skip_f16 ? ra : nullptr, skip_f16 ? rb : nullptr, skip_max, nullptr, slot(sb + 4)));
         MARK(ST_INNER_SKIP);
         // norm1 -> MLP -> + residual   (sfnonet.py:234-250)
         const float *a1 = nullptr, *b1 = nullptr;
         if (norm) {
-            HIP_TRY(launch_instnorm_stats(n->T.p, W(p + "norm1.weight"), W(p + "norm1.bias"), 1e-6f, B, C, HW, sc1, sh1, s));
+            HIP_TRY(launch_instnorm_stats(n->T.p, W(p + "norm1.weight"), W(p + "norm1.bias"), 1e-6f, B, C, HW, sc1, sh1, s,
+                                          slot(sb + 5)));
             a1 = sc1; b1 = sh1;
             MARK(ST_NORM1);
         }
@@ -680,10 +749,11 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             ConvW wfc1 = conv_weight(n, p + "mlp.fwd.0.weight", p + "mlp.fwd.0.bias");
             if (a1 && !f16) ACE_TRY(fold(n, wfc1, n->hid, C, a1, b1, n->Wf1.p, n->bf1.p, B, s, &wfc1));
             ACE_TRY(conv(n, wfc1, n->T.p, actB, C, nullptr, 0, -1, n->U.p, n->hid, nullptr, 0, nullptr, nullptr, act, B, s,
-                         f16 ? a1 : nullptr, f16 ? b1 : nullptr));
+                         f16 ? a1 : nullptr, f16 ? b1 : nullptr, norm ? slot(sb + 5) : slot(sb + 4), nullptr, slot(sb + 6)));
             MARK(ST_MLP_FC1);
             ACE_TRY(conv(n, conv_weight(n, p + "mlp.fwd.2.weight", p + "mlp.fwd.2.bias"), n->U.p, (long)n->hid * HW,
-                         n->hid, nullptr, 0, -1, hn, C, res, actB, ra, rb, ACT_NONE, B, s));
+                         n->hid, nullptr, 0, -1, hn, C, res, actB, ra, rb, ACT_NONE, B, s, nullptr, nullptr, slot(sb + 6),
+                         nullptr, hslot(i + 1)));
         } else {
             HIP_TRY(launch_rowaffine_add(n->T.p, a1, b1, res, ra, rb, hn, (long)B * C, HW, s));
         }
@@ -699,11 +769,13 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         const std::string p = "decoder." + std::to_string(2 * j);
         const bool cat = (j == 0 && c.big_skip);
         ACE_TRY(conv(n, conv_weight(n, p + ".weight", p + ".bias"), cur, cur_bs, cat ? C + Cin : curC,
-                     cat ? in : nullptr, (long)Cin * HW, C, ping[j & 1], C, nullptr, 0, nullptr, nullptr, act, B, s));
+                     cat ? in : nullptr, (long)Cin * HW, C, ping[j & 1], C, nullptr, 0, nullptr, nullptr, act, B, s, nullptr,
+                     nullptr, j == 0 ? (c.use_mlp ? hslot(c.num_layers) : nullptr) : slot(3 + j), slot(0), slot(4 + j)));
         cur = ping[j & 1]; cur_bs = actB; curC = C;
     }
     ACE_TRY(conv(n, conv_weight(n, "decoder." + std::to_string(2 * c.encoder_layers) + ".weight", ""), cur, cur_bs, curC,
-                 nullptr, 0, -1, out, c.out_chans, nullptr, 0, nullptr, nullptr, ACT_NONE, B, s));
+                 nullptr, 0, -1, out, c.out_chans, nullptr, 0, nullptr, nullptr, ACT_NONE, B, s, nullptr, nullptr,
+                 slot(3 + c.encoder_layers), nullptr, nullptr));
     MARK(ST_DECODER);
     return ACE_OK;
 }

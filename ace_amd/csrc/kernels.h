@@ -35,6 +35,9 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0, nbatch = 1;
     int tri = TRI_NONE; int trimul = 1;
     int act = ACT_NONE;
+    // optional: atomicMax of the bit pattern of max|C| over the launch (dynamic range of the f16x3 consumers);
+    // must be zeroed before the launch; AMAX_SHARDS words
+    unsigned* omax = nullptr;
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 void set_force_v1(bool v);
@@ -43,8 +46,16 @@ void set_force_v1(bool v);
 // fp16 planes (hi, lo; pitch g.lda HALVES, rows zero-padded to a multiple of 32 columns: g.a_kpad), scaled by the
 // power of two `ascale`; B is scaled by the power of two `bscale` on the fly.  g.A is ignored.
 bool gemm_f16x3_eligible(const GemmArgs& g);
+// Dynamic range: if `bmax` is given (device word holding the bit pattern of max|B|, produced by an earlier launch's
+// `omax`), the kernel derives the power-of-two B scale itself and `bscale` is ignored; `omax` (optional) receives
+// atomicMax(bits(max|C|)) and must be zeroed before the launch.
+// Slots are arrays of AMAX_SHARDS words (producers spread their atomics, consumers reduce).
+constexpr int AMAX_SHARDS = 64;
 hipError_t launch_gemm_f16x3(const GemmArgs& g, const void* Ahi, const void* Alo, float ascale, float bscale,
-                             hipStream_t s);
+                             hipStream_t s, const unsigned* bmax = nullptr, unsigned* omax = nullptr,
+                             const unsigned* bmax2 = nullptr);
+// max|x| of a plain tensor into a slot
+hipError_t launch_absmax(const float* x, long n, unsigned* omax, hipStream_t s);
 // fp32 matrix (rows x cols, pitch lds) -> fp16 hi/lo planes (pitch ldd halves, zero padded), values scaled by `scale`
 hipError_t launch_split_f16(const float* src, long lds, void* hi, void* lo, long ldd, long rows, int cols, float scale,
                             hipStream_t s);  // tests / A-B: route everything through the register-staged engine
@@ -61,6 +72,7 @@ struct DftArgs {
     const float* sc = nullptr; const float* sh = nullptr;  // forward: per-(b,c) affine on x (fused instance norm)
     const float* bias = nullptr;                           // inverse: per-c bias added to the output
     int Bt = 1, C = 0, H = 0, W = 0, Mm = 0;
+    unsigned* omax = nullptr;  // forward: atomicMax of bits(max|X|)
 };
 hipError_t launch_dft_forward(const DftArgs& a, hipStream_t s);
 hipError_t launch_dft_inverse(const DftArgs& a, hipStream_t s);
@@ -68,7 +80,7 @@ hipError_t launch_dft_inverse(const DftArgs& a, hipStream_t s);
 // per-(b,c) instance-norm statistics over H*W -> affine (scale, shift):
 //   scale = gamma[c] * rsqrt(var + eps),  shift = beta[c] - mean * scale   (biased var, fp64 accumulation)
 hipError_t launch_instnorm_stats(const float* x, const float* gamma, const float* beta, float eps, int Bt, int C,
-                                 long HW, float* scale, float* shift, hipStream_t s);
+                                 long HW, float* scale, float* shift, hipStream_t s, unsigned* omax = nullptr);
 
 // layout converters between the internal spectral layout and the reference's (n, L, M) complex64
 hipError_t launch_spec_to_ref(const float* D, float* out, int Bt, int C, int L, int Mm, hipStream_t s);
@@ -76,7 +88,7 @@ hipError_t launch_ref_to_spec(const float* in, float* E, int Bt, int C, int L, i
 
 // "diagonal" operator (contractions.py:169-180): E[l][m][b][:, o] = sum_i D[l][m][b][:, i] * w[i][o][l][m] (complex)
 hipError_t launch_contract_diagonal(const float* D, const float* w, float* E, int Bt, int Cin, int Cout, int L, int Mm,
-                                    hipStream_t s);
+                                    hipStream_t s, unsigned* omax = nullptr);
 
 // dhconv weight (Cin, Cout, L, 2) -> expanded real matrices Wx[l][2*Cin][2*Cout]
 hipError_t launch_expand_dhconv_weight(const float* w, float* wx, int Cin, int Cout, int L, hipStream_t s);

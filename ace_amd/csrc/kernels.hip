@@ -315,6 +315,7 @@ __global__ __launch_bounds__(64 * WM * WN, ACE_LB) void gemm_f32_kernel(GemmArgs
     const float* osh = p.osh;
     const long ldc = p.ldc, ldr = p.ldr;
     const int actk = p.act;
+    float vmax = 0.f;
     const int col0 = n0 + wn * 64 + i, col1 = col0 + 32;
     const bool c0ok = col0 < p.N, c1ok = col1 < p.N;
     const int cc0 = c0ok ? col0 : 0, cc1 = c1ok ? col1 : 0;
@@ -359,10 +360,15 @@ __global__ __launch_bounds__(64 * WM * WN, ACE_LB) void gemm_f32_kernel(GemmArgs
                 v0 = fmaf(v0, os[e], ot[e]);
                 v1 = fmaf(v1, os[e], ot[e]);
                 float* crow = C + (long)rr[e] * ldc;
-                if (rok && c0ok) crow[col0] = v0;
-                if (rok && c1ok) crow[col1] = v1;
+                if (rok && c0ok) { crow[col0] = v0; vmax = fmaxf(vmax, fabsf(v0)); }
+                if (rok && c1ok) { crow[col1] = v1; vmax = fmaxf(vmax, fabsf(v1)); }
             }
         }
+    }
+    if (p.omax) {  // bit patterns of non-negative floats order like the floats
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        if (lane == 0) atomicMax(p.omax + (blockIdx.x & 63), __float_as_uint(vmax));
     }
 }
 
@@ -555,6 +561,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f32_kernel(GemmArgs p, int
     const float* osh = p.osh;
     const long ldc = p.ldc, ldr = p.ldr;
     const int actk = p.act;
+    float vmax = 0.f;
     const int col0 = n0 + wn * 64 + i, col1 = col0 + 32;
     const bool c0ok = col0 < p.N, c1ok = col1 < p.N;
     const int cc0 = c0ok ? col0 : 0, cc1 = c1ok ? col1 : 0;
@@ -599,10 +606,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f32_kernel(GemmArgs p, int
                 v0 = fmaf(v0, os[e], ot[e]);
                 v1 = fmaf(v1, os[e], ot[e]);
                 float* crow = C + (long)rr[e] * ldc;
-                if (rok && c0ok) crow[col0] = v0;
-                if (rok && c1ok) crow[col1] = v1;
+                if (rok && c0ok) { crow[col0] = v0; vmax = fmaxf(vmax, fabsf(v0)); }
+                if (rok && c1ok) { crow[col1] = v1; vmax = fmaxf(vmax, fabsf(v1)); }
             }
         }
+    }
+    if (p.omax) {  // bit patterns of non-negative floats order like the floats
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        if (lane == 0) atomicMax(p.omax + (blockIdx.x & 63), __float_as_uint(vmax));
     }
 }
 
@@ -627,6 +639,11 @@ struct Gemm3Args {
     const _Float16* Ahi = nullptr; const _Float16* Alo = nullptr;  // [M][lda] fp16 planes, lda in halves (= g.lda)
     float bscale = 1.f;         // power of two applied to B before the split
     float oscale = 1.f;         // 1 / (ascale * bscale), applied to the accumulator
+    // dynamic range management: if bmax != nullptr it holds the bit pattern of max|B| (written by the producer's
+    // epilogue); the kernel then derives bscale = 2^(11 - exponent(max)) itself and oscale = oscale_a / bscale
+    const unsigned* bmax = nullptr;
+    const unsigned* bmax2 = nullptr;  // optional second source (B2 of the concat)
+    unsigned* omax = nullptr;   // if set: atomicMax of the bit pattern of max|C| over this launch (64 shards)
 };
 
 constexpr int G3_KAFF = 1024;  // largest K whose per-row affine is kept in LDS by the f16x3 engine
@@ -674,13 +691,26 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = (K - kbeg + BKT - 1) / BKT;
+    float bscale_k = q.bscale, oscale_k = q.oscale;
+    if (q.bmax) {  // power of two that puts max|B| in [2^11, 2^12): exact to undo, no overflow, lo parts stay normal
+        float mx = __uint_as_float(q.bmax[lane]);  // 64 shards (one per producer workgroup residue), reduce in the wave
+        if (q.bmax2) mx = fmaxf(mx, __uint_as_float(q.bmax2[lane]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        mx = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mx)));
+        int e = 0;
+        if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &e); e = 12 - e; }
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        bscale_k = ldexpf(1.0f, e);
+        oscale_k = q.oscale * ldexpf(1.0f, -e);  // q.oscale = 1 / ascale in this mode
+    }
 
     if (AFF) {  // per-row affine of B (fused instance norm), pre-multiplied by the power-of-two scale
         const float* bsc = p.bsc + (long)batch * p.sbs;
         const float* bsh = p.bsh + (long)batch * p.sbs;
         for (int k = tid; k < K; k += NT) {
-            Aff[k] = bsc[k] * q.bscale;
-            Aff[G3_KAFF + k] = bsh[k] * q.bscale;
+            Aff[k] = bsc[k] * bscale_k;
+            Aff[G3_KAFF + k] = bsh[k] * bscale_k;
         }
         __syncthreads();
     }
@@ -695,7 +725,7 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
         const _Float16* Alo = q.Alo + (long)batch * p.sA;
         const float* B = p.B + (long)batch * p.sB;
         const float* B2 = p.B2 ? p.B2 + (long)batch * p.sB2 : nullptr;
-        const float bscale = q.bscale;
+        const float bscale = bscale_k;
         // A DMA: piece = 16 rows x 64 B; lane -> (row, physical slot), fetches the XOR-swizzled logical slot
         long aoff[ACW];
 #pragma unroll
@@ -855,7 +885,8 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
     }
 
     // epilogue
-    const float osc_acc = q.oscale;
+    const float osc_acc = oscale_k;
+    float vmax = 0.f;
     const float* B = p.B + (long)batch * p.sB;
     float* C = p.C + (long)batch * p.sC;
     const float* R = RES ? p.R + (long)batch * p.sR : nullptr;
@@ -909,10 +940,15 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
                 v0 = fmaf(v0, os[e], ot[e]);
                 v1 = fmaf(v1, os[e], ot[e]);
                 float* crow = C + (long)rr[e] * ldc;
-                if (rok && c0ok) crow[col0] = v0;
-                if (rok && c1ok) crow[col1] = v1;
+                if (rok && c0ok) { crow[col0] = v0; vmax = fmaxf(vmax, fabsf(v0)); }
+                if (rok && c1ok) { crow[col1] = v1; vmax = fmaxf(vmax, fabsf(v1)); }
             }
         }
+    }
+    if (q.omax) {  // one atomic per wave: bit patterns of non-negative floats order like the floats
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        if (lane == 0) atomicMax(q.omax + (blockIdx.x & 63), __float_as_uint(vmax));
     }
 }
 
@@ -1039,13 +1075,16 @@ bool gemm_f16x3_eligible(const GemmArgs& a) {
 }
 
 hipError_t launch_gemm_f16x3(const GemmArgs& g, const void* Ahi, const void* Alo, float ascale, float bscale,
-                             hipStream_t s) {
+                             hipStream_t s, const unsigned* bmax, unsigned* omax, const unsigned* bmax2) {
     Gemm3Args a;
+    a.bmax2 = bmax2;
     a.g = g;
     a.Ahi = static_cast<const _Float16*>(Ahi);
     a.Alo = static_cast<const _Float16*>(Alo);
     a.bscale = bscale;
-    a.oscale = 1.0f / (ascale * bscale);
+    a.oscale = bmax ? 1.0f / ascale : 1.0f / (ascale * bscale);
+    a.bmax = bmax;
+    a.omax = omax;
     const int waste128 = ((g.M + 127) / 128) * 128 - g.M;
     const int waste64 = ((g.M + 63) / 64) * 64 - g.M;
     if (g.M >= 128 && waste128 <= waste64) return launch_gemm3_cfg<2, 2>(a, s);
@@ -1230,6 +1269,7 @@ __global__ __launch_bounds__(256) void dft_forward_kernel(DftArgs p, int tilesM,
 
     const long N2 = (long)p.Bt * 2 * p.C;
     const int n = n0 + bcol;
+    float vmax = 0.f;
     if (n < ncols) {
         const int c = n % p.C, kb = n / p.C;  // kb = k * Bt + b
         float* obase = p.spec_out + (long)kb * 2 * p.C + c;
@@ -1242,8 +1282,14 @@ __global__ __launch_bounds__(256) void dft_forward_kernel(DftArgs p, int tilesM,
                     float* o = obase + (long)m * p.H * N2;
                     o[0] = Re[tm][r];
                     o[p.C] = Im[tm][r];
+                    vmax = fmaxf(vmax, fmaxf(fabsf(Re[tm][r]), fabsf(Im[tm][r])));
                 }
             }
+    }
+    if (p.omax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        if (lane == 0) atomicMax(p.omax + (blockIdx.x & 63), __float_as_uint(vmax));
     }
 }
 
@@ -1446,16 +1492,19 @@ __global__ __launch_bounds__(512) void instnorm_stats_kernel(const float* __rest
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, int C,
                                                              long HW, float* __restrict__ scale,
-                                                             float* __restrict__ shift) {
+                                                             float* __restrict__ shift, unsigned* omax) {
     const int plane = blockIdx.x;
     const float* xp = x + (long)plane * HW;
     double s = 0.0, ss = 0.0;
+    float lo = 3.0e38f, hi = -3.0e38f;
     const bool vec = ((reinterpret_cast<uintptr_t>(xp) & 15) == 0) && (HW % 4 == 0);
     if (vec) {
         const float4* x4 = reinterpret_cast<const float4*>(xp);
         const long n4 = HW / 4;
         for (long j = threadIdx.x; j < n4; j += blockDim.x) {
             const float4 v = x4[j];
+            lo = fminf(lo, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
+            hi = fmaxf(hi, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
             const float ps = (v.x + v.y) + (v.z + v.w);
             const float pq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
             s += (double)ps;
@@ -1464,6 +1513,8 @@ __global__ __launch_bounds__(512) void instnorm_stats_kernel(const float* __rest
     } else {
         for (long j = threadIdx.x; j < HW; j += blockDim.x) {
             const double v = (double)xp[j];
+            lo = fminf(lo, xp[j]);
+            hi = fmaxf(hi, xp[j]);
             s += v;
             ss += v * v;
         }
@@ -1472,14 +1523,20 @@ __global__ __launch_bounds__(512) void instnorm_stats_kernel(const float* __rest
     for (int off = 32; off > 0; off >>= 1) {
         s += __shfl_down(s, off, 64);
         ss += __shfl_down(ss, off, 64);
+        lo = fminf(lo, __shfl_down(lo, off, 64));
+        hi = fmaxf(hi, __shfl_down(hi, off, 64));
     }
     __shared__ double red[2][8];
+    __shared__ float redm[2][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; redm[0][wave] = lo; redm[1][wave] = hi; }
     __syncthreads();
     if (threadIdx.x == 0) {
         double ts = 0.0, tss = 0.0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { ts += red[0][w]; tss += red[1][w]; }
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+            ts += red[0][w]; tss += red[1][w];
+            lo = fminf(lo, redm[0][w]); hi = fmaxf(hi, redm[1][w]);
+        }
         const double mean = ts / (double)HW;
         double var = tss / (double)HW - mean * mean;  // biased variance
         if (var < 0.0) var = 0.0;
@@ -1490,13 +1547,18 @@ __global__ __launch_bounds__(512) void instnorm_stats_kernel(const float* __rest
         const double sc = g * rstd;
         scale[plane] = (float)sc;
         shift[plane] = (float)(bt - mean * sc);
+        if (omax) {  // bound of |x * scale + shift| over the plane: consumers of the normalised field scale by it
+            const float a = (float)sc, b = (float)(bt - mean * sc);
+            const float bound = fmaxf(fabsf(fmaf(lo, a, b)), fabsf(fmaf(hi, a, b)));
+            atomicMax(omax + (plane & 63), __float_as_uint(bound));
+        }
     }
 }
 
 hipError_t launch_instnorm_stats(const float* x, const float* gamma, const float* beta, float eps, int Bt, int C,
-                                 long HW, float* scale, float* shift, hipStream_t s) {
+                                 long HW, float* scale, float* shift, hipStream_t s, unsigned* omax) {
     hipLaunchKernelGGL(instnorm_stats_kernel, dim3((unsigned)(Bt * C)), dim3(512), 0, s, x, gamma, beta, eps, C, HW,
-                       scale, shift);
+                       scale, shift, omax);
     return hipGetLastError();
 }
 
@@ -1553,8 +1615,10 @@ hipError_t launch_ref_to_spec(const float* in, float* E, int Bt, int C, int L, i
 // bandwidth (the weight is Cin*Cout*L*M complex); only used by small nets and three of the goldens.
 // ---------------------------------------------------------------------------------------------
 __global__ void contract_diagonal_kernel(const float* __restrict__ D, const float* __restrict__ w,
-                                         float* __restrict__ E, int Bt, int Cin, int Cout, int L, int Mm) {
+                                         float* __restrict__ E, int Bt, int Cin, int Cout, int L, int Mm,
+                                         unsigned* omax) {
     const long total = (long)L * Mm * Bt * Cout;
+    float vmax = 0.f;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int m = t % Mm;  // m fastest: weight reads coalesce along m
         long q = t / Mm;
@@ -1575,13 +1639,19 @@ __global__ void contract_diagonal_kernel(const float* __restrict__ D, const floa
         float* eo = E + (((long)l * Mm + m) * Bt + b) * 2 * Cout;
         eo[o] = re;
         eo[Cout + o] = im;
+        vmax = fmaxf(vmax, fmaxf(fabsf(re), fabsf(im)));
+    }
+    if (omax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(omax + (blockIdx.x & 63), __float_as_uint(vmax));
     }
 }
 hipError_t launch_contract_diagonal(const float* D, const float* w, float* E, int Bt, int Cin, int Cout, int L, int Mm,
-                                    hipStream_t s) {
+                                    hipStream_t s, unsigned* omax) {
     const long total = (long)L * Mm * Bt * Cout;
     hipLaunchKernelGGL(contract_diagonal_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, D, w, E, Bt, Cin, Cout, L,
-                       Mm);
+                       Mm, omax);
     return hipGetLastError();
 }
 
@@ -1708,6 +1778,18 @@ __global__ __launch_bounds__(128) void fold_affine_kernel(const float* __restric
 hipError_t launch_fold_affine(const float* W, long ldw, const float* a, const float* b, const float* bias, float* Wf,
                               float* bf, int nsamples, int O, int I, hipStream_t s) {
     hipLaunchKernelGGL(fold_affine_kernel, dim3(O, nsamples), dim3(128), 0, s, W, ldw, a, b, bias, Wf, bf, O, I);
+    return hipGetLastError();
+}
+
+__global__ void absmax_kernel(const float* __restrict__ x, long n, unsigned* omax) {
+    float m = 0.f;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[t]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(omax + (blockIdx.x & 63), __float_as_uint(m));
+}
+hipError_t launch_absmax(const float* x, long n, unsigned* omax, hipStream_t s) {
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, s, x, n, omax);
     return hipGetLastError();
 }
 
