@@ -359,7 +359,9 @@ struct ace_sfno {
     ace_sht_plan* plan_data = nullptr;  // == plan_lg.get() when data_grid is legendre-gauss
     std::vector<std::unique_ptr<Weight>> weights;
     std::map<std::string, int> index;
-    std::vector<DevBuf> wx;  // per block: dhconv weight expanded to real [L][2C][2C]
+    std::vector<DevBuf> wx;  // per block: dhconv weight expanded to real [L][2C][2C] (fp32 engines)
+    std::vector<DevBuf> wx_hi, wx_lo;  // per block: the same operand k-packed as fp16 hi/lo planes (f16x3 engine)
+    std::vector<float> wx_scale;
     // workspace
     DevBuf h0, h1, Y, T, R, U, X, D, E, stats;
     DevBuf Wf0, bf0, Wf1, bf1;
@@ -458,6 +460,9 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     add_conv_weight(n.get(), "decoder." + std::to_string(2 * c.encoder_layers) + ".weight", c.out_chans, (int)cur);
 
     n->wx.resize(c.num_layers);
+    n->wx_hi.resize(c.num_layers);
+    n->wx_lo.resize(c.num_layers);
+    n->wx_scale.assign(c.num_layers, 1.f);
     const size_t act = (size_t)n->Bmax * C * HW;
     const size_t spec_x = (size_t)n->Mm * n->H * n->Bmax * 2 * C;
     const size_t spec_d = (size_t)n->L * n->Mm * n->Bmax * 2 * C;
@@ -520,10 +525,29 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
         HIP_TRY(hipMemcpyAsync(w.buf.p, src, sizeof(float) * numel, hipMemcpyDeviceToDevice, s));
     }
     if (w.is_filter && n->cfg.operator_type == 1) {
-        DevBuf& wx = n->wx[w.block];
         const size_t cnt = (size_t)n->L * 2 * n->C * 2 * n->C;
-        if (!wx.p) HIP_TRY(wx.alloc(cnt, false));
-        HIP_TRY(launch_expand_dhconv_weight(w.buf.p, wx.p, n->C, n->C, n->L, s));
+        const bool packed = n->cfg.precision == 1 && (2 * n->C) % 32 == 0;
+        if (packed) {  // f16x3: k-packed fp16 hi/lo planes scaled so that max|w| lands in [2^9, 2^10)
+            DevBuf slotbuf;
+            HIP_TRY(slotbuf.alloc(AMAX_SHARDS));
+            HIP_TRY(launch_absmax(w.buf.p, numel, reinterpret_cast<unsigned*>(slotbuf.p), s));
+            unsigned bits[AMAX_SHARDS];
+            HIP_TRY(hipMemcpyAsync(bits, slotbuf.p, sizeof(bits), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            float mx = 0.f;
+            for (unsigned b : bits) { float f; std::memcpy(&f, &b, 4); mx = std::max(mx, f); }
+            int e = 0;
+            if (mx > 0.f && std::isfinite(mx)) { (void)std::frexp(mx, &e); e = 10 - e; }
+            n->wx_scale[w.block] = std::ldexp(1.0f, e);
+            if (!n->wx_hi[w.block].p) HIP_TRY(n->wx_hi[w.block].alloc((cnt + 1) / 2, false));
+            if (!n->wx_lo[w.block].p) HIP_TRY(n->wx_lo[w.block].alloc((cnt + 1) / 2, false));
+            HIP_TRY(launch_pack_dhconv_f16(w.buf.p, n->wx_hi[w.block].p, n->wx_lo[w.block].p, n->C, n->C, n->L,
+                                           n->wx_scale[w.block], s));
+        } else {
+            DevBuf& wx = n->wx[w.block];
+            if (!wx.p) HIP_TRY(wx.alloc(cnt, false));
+            HIP_TRY(launch_expand_dhconv_weight(w.buf.p, wx.p, n->C, n->C, n->L, s));
+        }
     }
     HIP_TRY(hipStreamSynchronize(s));
     if (w.pitch > 0 && n->cfg.precision == 1) {
@@ -717,7 +741,12 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             g.M = n->Mm * B; g.N = 2 * C; g.K = 2 * C; g.nbatch = n->L; g.a_kpad = 2 * C;
             g.tri = TRI_ROWS_LE_BATCH; g.trimul = B;
             g.omax = emax;
-            HIP_TRY(launch_gemm(g, s));
+            if (f16 && n->wx_hi[i].p) {
+                HIP_TRY(launch_gemm_f16x3_adyn(g, n->wx_hi[i].p, n->wx_lo[i].p, 2 * C, (long)2 * C * 2 * C, n->wx_scale[i],
+                                               dmax, emax, s));
+            } else {
+                HIP_TRY(launch_gemm(g, s));
+            }
         } else {
             HIP_TRY(launch_contract_diagonal(n->D.p, W(p + "filter.filter.weight"), n->E.p, B, C, C, n->L, n->Mm, s, emax));
         }

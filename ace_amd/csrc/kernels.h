@@ -54,6 +54,11 @@ constexpr int AMAX_SHARDS = 64;
 hipError_t launch_gemm_f16x3(const GemmArgs& g, const void* Ahi, const void* Alo, float ascale, float bscale,
                              hipStream_t s, const unsigned* bmax = nullptr, unsigned* omax = nullptr,
                              const unsigned* bmax2 = nullptr);
+// Mirrored roles: A = fp32 activations (row-major, split on the fly, scale from the `amax` slot), B = static operand
+// pre-packed as fp16 hi/lo planes [batch][K/8][ldn][8] scaled by the power of two `bscale_static`.
+hipError_t launch_gemm_f16x3_adyn(const GemmArgs& g, const void* Bhi, const void* Blo, long ldn, long sB_halves,
+                                  float bscale_static, const unsigned* amax, unsigned* omax, hipStream_t s);
+hipError_t launch_pack_dhconv_f16(const float* w, void* hi, void* lo, int Cin, int Cout, int L, float scale, hipStream_t s);
 // max|x| of a plain tensor into a slot
 hipError_t launch_absmax(const float* x, long n, unsigned* omax, hipStream_t s);
 // fp32 matrix (rows x cols, pitch lds) -> fp16 hi/lo planes (pitch ldd halves, zero padded), values scaled by `scale`

@@ -648,7 +648,7 @@ struct Gemm3Args {
 
 constexpr int G3_KAFF = 1024;  // largest K whose per-row affine is kept in LDS by the f16x3 engine
 
-template <int WM, int WN, bool AFF, bool RES>
+template <int WM, int WN, bool AFF, bool RES, bool ADYN = false>
 __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args q, int tilesM, int tilesN) {
     // Wave-specialised: waves [0, NW) are MMA waves (LDS fragments -> MFMA -> epilogue), waves [NW, 2 NW) are loader
     // waves (A DMA issue, B row loads, hi/lo split, LDS writes).  The split's VALU work and the MFMAs run on the
@@ -715,7 +715,110 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
         __syncthreads();
     }
 
-    if (wave >= NW) {
+    if (ADYN && wave >= NW) {
+        // ============ loader waves, mirrored roles: A is the fp32 activation (row-major, k contiguous), split on
+        // the fly; B is a static operand pre-packed on the host side as fp16 hi/lo planes [K/8][ldn][8] and DMA'd ====
+        const int lw = wave - NW;
+        const int ltid = tid - NL;
+        const long lda = p.lda;
+        const float* A = p.A + (long)batch * p.sA;
+        const _Float16* Bhi = q.Ahi + (long)batch * p.sB;   // planes of the packed B operand (sB in halves)
+        const _Float16* Blo = q.Alo + (long)batch * p.sB;
+        const long ldn = p.ldb;                             // columns per k-group row of the packed operand
+        constexpr int AE = BM * 4 / NL;                     // (row, 8-k chunk) entries per loader thread (1 or 2)
+        constexpr int BCH = 4 * BN / 64;                    // 1 KiB pieces per B plane per stage
+        constexpr int BCW = BCH / NW;
+        static_assert(BCH % NW == 0, "B pieces must divide evenly over the loader waves");
+        const float* arow[AE];
+        int aslot[AE];
+#pragma unroll
+        for (int e = 0; e < AE; ++e) {
+            const int idx = ltid + e * NL;
+            const int row = idx / 4, kc = idx % 4;
+            int m = m0 + row;
+            m = m < M ? m : M - 1;
+            arow[e] = A + (long)m * lda + 8 * kc;
+            aslot[e] = row * 32 + 8 * (kc ^ ((row >> 2) & 3));   // halves; same XOR swizzle the MMA waves read with
+        }
+        long boff[BCW];
+#pragma unroll
+        for (int c = 0; c < BCW; ++c) {
+            const int cb = lw + c * NW;                     // piece -> (k group, 64 columns)
+            const int kgi = cb / (BN / 64), nb = cb % (BN / 64);
+            int nn = n0 + nb * 64 + lane;
+            nn = nn < N ? nn : N - 1;
+            boff[c] = ((long)kgi * ldn + nn) * 8;
+        }
+        struct ARegs { float4 v[AE][2]; };
+        auto issue_b = [&](int k0, int bbuf) {              // 2*BCW DMA pieces
+            _Float16* Bb = Bs + bbuf * 2 * BPL;
+            const long kgoff = (long)(k0 / 8) * ldn * 8;
+#pragma unroll
+            for (int c = 0; c < BCW; ++c) {
+                const int cb = lw + c * NW;
+                glds16(reinterpret_cast<const float*>(Bhi + kgoff + boff[c]), reinterpret_cast<float*>(Bb + cb * 512));
+                glds16(reinterpret_cast<const float*>(Blo + kgoff + boff[c]), reinterpret_cast<float*>(Bb + BPL + cb * 512));
+            }
+        };
+        auto issue_a = [&](int k0, ARegs& r) {              // exactly 2*AE loads
+#pragma unroll
+            for (int e = 0; e < AE; ++e) {
+                r.v[e][0] = *reinterpret_cast<const float4*>(arow[e] + k0);
+                r.v[e][1] = *reinterpret_cast<const float4*>(arow[e] + k0 + 4);
+            }
+        };
+        const float ascale_dyn = bscale_k;                  // the dynamic operand's power-of-two scale
+        auto stash = [&](int abuf, const ARegs& r) {
+            _Float16* Ab = As + abuf * 2 * APL;
+#pragma unroll
+            for (int e = 0; e < AE; ++e) {
+                const float xs[8] = {r.v[e][0].x, r.v[e][0].y, r.v[e][0].z, r.v[e][0].w,
+                                     r.v[e][1].x, r.v[e][1].y, r.v[e][1].z, r.v[e][1].w};
+                half8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = __builtin_amdgcn_fmed3f(xs[j] * ascale_dyn, -65504.f, 65504.f);
+                    const _Float16 hh = (_Float16)x;
+                    hi[j] = hh;
+                    lo[j] = (_Float16)(x - (float)hh);
+                }
+                *reinterpret_cast<half8*>(Ab + aslot[e]) = hi;
+                *reinterpret_cast<half8*>(Ab + APL + aslot[e]) = lo;
+            }
+        };
+        // same pipeline as below with the roles swapped: B DMA one stage ahead, A registers two stages ahead;
+        // each stage issues [B DMA of t+1][2*AE A loads of t+2] -> vmcnt(2*AE)
+        ARegs r0, r1;
+        if (nk > 0) { issue_b(kbeg, 0); issue_a(kbeg, r0); }
+        if (nk > 1) issue_a(kbeg + BKT, r1);
+        if (nk > 0) stash(0, r0);
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * AE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            {
+                const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+                if (more1) issue_b(kbeg + (kt + 1) * BKT, 1);
+                if (more2) issue_a(kbeg + (kt + 2) * BKT, r0);
+                if (more1) stash(1, r1);
+                if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * AE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            if (kt + 1 >= nk) break;
+            {
+                const bool more1 = kt + 2 < nk, more2 = kt + 3 < nk;
+                if (more1) issue_b(kbeg + (kt + 2) * BKT, 0);
+                if (more2) issue_a(kbeg + (kt + 3) * BKT, r1);
+                if (more1) stash(0, r0);
+                if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * AE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+        return;
+    }
+    if (!ADYN && wave >= NW) {
         // =========================== loader waves ===========================
         const int lw = wave - NW;            // loader wave index
         const int ltid = tid - NL;           // 0..255
@@ -887,7 +990,7 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
     // epilogue
     const float osc_acc = oscale_k;
     float vmax = 0.f;
-    const float* B = p.B + (long)batch * p.sB;
+    const float* B = ADYN ? p.A : p.B + (long)batch * p.sB;
     float* C = p.C + (long)batch * p.sC;
     const float* R = RES ? p.R + (long)batch * p.sR : nullptr;
     const float* rsc = p.rsc ? p.rsc + (long)batch * p.srs : nullptr;
@@ -1100,6 +1203,80 @@ hipError_t launch_split_f16(const float* src, long lds_, void* hi, void* lo, lon
     hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)gsz), dim3(256), 0, s, src, lds_, static_cast<_Float16*>(hi),
                        static_cast<_Float16*>(lo), ldd, rows, cols, scale);
     return hipGetLastError();
+}
+
+// dhconv weight (Cin, Cout, L, 2) -> per-l real 2Cin x 2Cout operand in the f16x3 engine's k-packed form:
+//   planes hi/lo [l][K/8][ldn][8] halves, K = 2 Cin (rows (ri, i)), ldn = 2 Cout (columns (r', o)), values scaled by `scale`
+//   [ out_re | out_im ] = [ x_re | x_im ] * [[ w_re, w_im ], [ -w_im, w_re ]]
+__global__ void pack_dhconv_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                       int Cin, int Cout, int L, float scale) {
+    const int K = 2 * Cin, N = 2 * Cout;
+    const long total = (long)L * K * N;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int e = t % 8;          // k within the group (fastest in memory)
+        long q = t / 8;
+        const int n = q % N;
+        q /= N;
+        const int kg = q % (K / 8);
+        const int l = q / (K / 8);
+        const int k = kg * 8 + e;
+        const int ri = k / Cin, i = k % Cin, rp = n / Cout, o = n % Cout;
+        const float2 wv = *reinterpret_cast<const float2*>(w + (((long)i * Cout + o) * L + l) * 2);
+        float v = (ri == rp) ? wv.x : (ri == 0 ? wv.y : -wv.y);
+        v = __builtin_amdgcn_fmed3f(v * scale, -65504.f, 65504.f);
+        const _Float16 h = (_Float16)v;
+        hi[t] = h;
+        lo[t] = (_Float16)(v - (float)h);
+    }
+}
+hipError_t launch_pack_dhconv_f16(const float* w, void* hi, void* lo, int Cin, int Cout, int L, float scale, hipStream_t s) {
+    const long total = (long)L * 2 * Cin * 2 * Cout;
+    long gsz = (total + 255) / 256;
+    if (gsz > 32768) gsz = 32768;
+    hipLaunchKernelGGL(pack_dhconv_f16_kernel, dim3((unsigned)gsz), dim3(256), 0, s, w, static_cast<_Float16*>(hi),
+                       static_cast<_Float16*>(lo), Cin, Cout, L, scale);
+    return hipGetLastError();
+}
+
+// f16x3 with the roles mirrored: A = fp32 activations (split on the fly, dynamic scale from amax), B = packed static
+// operand (planes Bhi/Blo, [K/8][ldn][8] per batch with batch stride sB_halves).  Requirements: K % 32 == 0, lda % 4 == 0,
+// A 16B aligned.  g.B / g.ldb are ignored (ldn and the plane pointers describe B).
+template <int WM, int WN>
+static hipError_t launch_gemm3_adyn_cfg(const Gemm3Args& a, hipStream_t s) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, NT = 128 * WM * WN;
+    const int tilesM = (a.g.M + BM - 1) / BM, tilesN = (a.g.N + BN - 1) / BN;
+    const long nblk = (long)tilesM * tilesN * a.g.nbatch;
+    if (nblk <= 0) return hipSuccess;
+    const size_t lds = (size_t)2 * 2 * (BM * 32 + 32 * BN) * sizeof(_Float16);
+    const bool res = a.g.R != nullptr;
+    static bool configured[2] = {false, false};
+    if (!configured[res]) {
+        const void* fn = res ? (const void*)gemm3_f16x3_kernel<WM, WN, false, true, true>
+                             : (const void*)gemm3_f16x3_kernel<WM, WN, false, false, true>;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured[res] = true;
+    }
+    dim3 grid((unsigned)nblk), block(NT);
+    if (res) hipLaunchKernelGGL((gemm3_f16x3_kernel<WM, WN, false, true, true>), grid, block, lds, s, a, tilesM, tilesN);
+    else hipLaunchKernelGGL((gemm3_f16x3_kernel<WM, WN, false, false, true>), grid, block, lds, s, a, tilesM, tilesN);
+    return hipGetLastError();
+}
+hipError_t launch_gemm_f16x3_adyn(const GemmArgs& g, const void* Bhi, const void* Blo, long ldn, long sB_halves,
+                                  float bscale_static, const unsigned* amax, unsigned* omax, hipStream_t s) {
+    Gemm3Args a;
+    a.g = g;
+    a.g.ldb = ldn;
+    a.g.sB = sB_halves;
+    a.Ahi = static_cast<const _Float16*>(Bhi);
+    a.Alo = static_cast<const _Float16*>(Blo);
+    a.oscale = 1.0f / bscale_static;   // dynamic part is derived in-kernel from amax
+    a.bmax = amax;
+    a.omax = omax;
+    const int waste128 = ((g.M + 127) / 128) * 128 - g.M;
+    const int waste64 = ((g.M + 63) / 64) * 64 - g.M;
+    if (g.M >= 128 && waste128 <= waste64) return launch_gemm3_adyn_cfg<2, 2>(a, s);
+    return launch_gemm3_adyn_cfg<1, 4>(a, s);
 }
 
 // ---------------------------------------------------------------------------------------------
