@@ -98,37 +98,18 @@ def cpu_baseline(stepper, x_cpu):
                        f"{dt:.1f} s"), y
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--graph", default="step", choices=["none", "step", "window"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
+def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, world, rank):
+    """One precision mode: K timed steps (barrier + sync on both sides, max over ranks) + per-stage HIP-event times."""
     from ace_amd import _lib
-    from ace_amd.distributed import Distributed
     from ace_amd.rollout import RolloutEngine
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    if args.gpus != world:
-        assert world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-        assert args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = Distributed.get_instance()
-
-    K, Wm = args.steps, args.warmup
-    stepper, forcing, prog, diag = build_stepper(dev, seed=0)   # same weights on every rank (one model, N members)
+    net = stepper.modules[0]
+    net.set_precision(precision)
     T = K
-    eng = RolloutEngine(stepper, batch=1, n_forward_steps=T, graph=None if args.graph == "none" else args.graph)
+    eng = RolloutEngine(stepper, batch=1, n_forward_steps=T, graph=None if graph == "none" else graph)
     g = torch.Generator().manual_seed(1 + rank)                   # member `rank`: its own initial state
     ic = {n: torch.randn(1, 1, *IMG, generator=g).to(dev) for n in prog}
-    fc = {n: torch.randn(1, T + 1, *IMG, generator=g).to(dev) for n in forcing}
+    fc = {n: torch.randn(1, T + 1, *IMG, generator=g).to(dev) for n in forcing_names}
     eng.load(ic, fc)
     ens_mean = torch.zeros(len(eng.out_names), *IMG, device=dev)
 
@@ -160,16 +141,14 @@ def main():
     dist.reduce_max(tmax)
     dt = float(tmax.item())
 
-    result = None
-    if rank == 0:
-        # ---- per-stage HIP-event timing of the forward (same stream the kernels are launched on)
+    stages = None
+    if rank == 0:  # per-stage HIP-event timing of the forward, on the stream the kernels are launched on
         L = _lib.lib()
         ns = L.ace_sfno_num_stages()
         ms = (ctypes.c_float * ns)()
         calls = (ctypes.c_int * ns)()
         acc = [0.0] * ns
         reps = 5
-        net = eng.net
         for _ in range(reps):
             _lib.check(L.ace_sfno_forward_timed(net._native, eng.x.data_ptr(), eng.y.data_ptr(), 1,
                                                 _lib.current_stream(), ms, calls))
@@ -183,38 +162,95 @@ def main():
             fl, by = model[nm]
             stages[nm] = dict(ms_per_step=round(acc[i], 4), launches=calls[i], us_per_launch=round(per_launch_ms * 1e3, 2),
                               tflops=round(fl / per_launch_ms / 1e9, 2), gbps=round(by / per_launch_ms / 1e6, 1))
+    x_cpu = eng.x.detach().cpu() if rank == 0 else None
+    y_gpu = eng.y.detach().cpu() if rank == 0 else None
+    del eng
+    torch.cuda.empty_cache()
+    return dict(dt=dt, stages=stages, x_cpu=x_cpu, y_gpu=y_gpu)
+
+
+# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/r01_pmc_*
+MEASURED_TRAFFIC = {("f16x3", "mlp.fc1"): 353.0e6, ("f16x3", "mlp.fc2+outer_skip"): 326.0e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--graph", default="step", choices=["none", "step", "window"])
+    ap.add_argument("--precision", default="both", choices=["both", "f16x3", "fp32"],
+                    help="'both': time the default (f16x3) and the exact-fp32 arithmetic in the same run")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from ace_amd.distributed import Distributed
+    from ace_amd.sfno import DEFAULT_PRECISION
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if args.gpus != world:
+        assert world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        assert args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = Distributed.get_instance()
+
+    K, Wm = args.steps, args.warmup
+    stepper, forcing, prog, diag = build_stepper(dev, seed=0)   # same weights on every rank (one model, N members)
+    modes = [DEFAULT_PRECISION] + (["fp32" if DEFAULT_PRECISION != "fp32" else "f16x3"] if args.precision == "both" else [])
+    if args.precision in ("f16x3", "fp32"):
+        modes = [args.precision]
+    runs = {m: time_mode(stepper, m, forcing, prog, dist, dev, K, Wm, args.graph, world, rank) for m in modes}
+
+    result = None
+    if rank == 0:
+        main_mode = modes[0]
+        r = runs[main_mode]
+        stages = r["stages"]
+        model = stage_model()
         dom = max(stages, key=lambda k: stages[k]["ms_per_step"])
         fl, by = model[dom]
         t_launch = stages[dom]["us_per_launch"] * 1e-6
-        roofline = dict(kernel=f"gemm_f32_kernel ({dom})", bound="mfma", achieved=round(fl / t_launch / 1e12, 2),
-                        peak=PEAK_MFMA_F32, unit="TFLOP/s", frac=round(fl / t_launch / 1e12 / PEAK_MFMA_F32, 4),
-                        traffic=None)
-        sht_ms = (stages["forward_transform.dft"]["us_per_launch"] + stages["forward_transform.legendre"]["us_per_launch"])
+        if main_mode == "fp32":   # exact-fp32 MFMA: the contraction kernels are bound by the fp32 matrix pipe
+            roofline = dict(kernel=f"gemm_f32 engine ({dom})", bound="mfma", achieved=round(fl / t_launch / 1e12, 2),
+                            peak=PEAK_MFMA_F32, unit="TFLOP/s", frac=round(fl / t_launch / 1e12 / PEAK_MFMA_F32, 4),
+                            traffic=MEASURED_TRAFFIC.get((main_mode, dom)))
+        else:                     # compensated-fp16 MFMA (3 x 1/16 of the fp32 cost): HBM is the bounding roofline
+            roofline = dict(kernel=f"gemm3_f16x3_kernel ({dom})", bound="hbm", achieved=round(by / t_launch / 1e9, 1),
+                            peak=PEAK_HBM, unit="GB/s", frac=round(by / t_launch / 1e9 / PEAK_HBM, 4),
+                            traffic=MEASURED_TRAFFIC.get((main_mode, dom)),
+                            mfma_f16_tflops=round(3 * fl / t_launch / 1e12, 1), mfma_f16_peak=2500.0)
+        sht_us = stages["forward_transform.dft"]["us_per_launch"] + stages["forward_transform.legendre"]["us_per_launch"]
         sht_bytes = 384 * 180 * 360 * 4 + 181 * 180 * 180 * 4 + 384 * 180 * 181 * 8     # 223.1 MB
-        roofline_sht = dict(kernel="forward SHT (dft_forward_kernel + gemm_f32_kernel legendre)", bound="hbm",
-                            achieved=round(sht_bytes / (sht_ms * 1e-6) / 1e9, 1), peak=PEAK_HBM, unit="GB/s",
-                            frac=round(sht_bytes / (sht_ms * 1e-6) / 1e9 / PEAK_HBM, 4), traffic=None)
+        roofline_sht = dict(kernel="forward SHT (dft_forward_kernel + Legendre GEMM)", bound="hbm",
+                            achieved=round(sht_bytes / (sht_us * 1e-6) / 1e9, 1), peak=PEAK_HBM, unit="GB/s",
+                            frac=round(sht_bytes / (sht_us * 1e-6) / 1e9 / PEAK_HBM, 4), traffic=None)
         cpu = None
         if not args.no_cpu_baseline:
-            with torch.no_grad():
-                x_cpu = eng.x.detach().cpu()
-                y_gpu = eng.y.detach().cpu()
-            cpu, y_cpu = cpu_baseline(stepper, x_cpu)
-            cpu["parity_rel_err_vs_gpu"] = float((y_gpu - y_cpu).abs().max() / y_cpu.abs().max())
-        steps_per_s = world * K / dt
+            cpu, y_cpu = cpu_baseline(stepper, r["x_cpu"])
+            cpu["parity_rel_err_vs_gpu"] = {m: float((runs[m]["y_gpu"] - y_cpu).abs().max() / y_cpu.abs().max()) for m in modes}
+        steps_per_s = world * K / r["dt"]
+        dtype = {"fp32": "f32", "f16x3": "f32 (contractions with K>=32 on error-compensated fp16x3 MFMA, fp32 accumulate; "
+                                         "DFT, norms, epilogues fp32; measured error vs fp64 below the fp32 CPU reference's)"}
         result = {
             "metric": "rollout steps/sec (6-hourly forward steps of the 1-degree SFNO, whole job)",
             "value": round(steps_per_s, 3), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step": round(r["dt"] / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dtype[main_mode], "data": "synthetic",
             "simulated_years_per_day": round(steps_per_s * 86400 / 1460, 1),
             "config": {"workload": "ACE2-ERA5-shape 1deg SFNO rollout (BASELINE.json configs[1]): embed 384, 8 layers, "
                                    "dhconv, 44 in / 50 out channels, 180x360 legendre-gauss, lmax 180, mmax 181, "
                                    "B=1 member per GPU, random-init weights",
-                       "members": world, "members_per_gpu": 1, "graph": args.graph,
+                       "members": world, "members_per_gpu": 1, "graph": args.graph, "precision": main_mode,
                        "collective": "RCCL all-reduce mean of the (50,180,360) output state once per window" if world > 1 else "none"},
             "roofline": roofline, "roofline_sht": roofline_sht, "stages": stages, "cpu_baseline": cpu,
         }
+        for m in modes[1:]:
+            result[f"mode_{m}"] = {"value": round(world * K / runs[m]["dt"], 3), "unit": "steps/s",
+                                   "ms_per_step": round(runs[m]["dt"] / K * 1e3, 4), "stages": runs[m]["stages"]}
     dist.barrier()
     if rank == 0:
         print(json.dumps(result))

@@ -31,8 +31,9 @@ def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
 
 
-def build_native_net(cfg, state, device="cuda"):
-    """ace_amd network for an oracle SFNOConfig, loaded with `state` (strict)."""
+def build_native_net(cfg, state, device="cuda", precision=None):
+    """ace_amd network for an oracle SFNOConfig, loaded with `state` (strict).  precision: None (library default),
+    "fp32" or "f16x3"."""
     import types
 
     from ace_amd.sfno import SphericalFourierNeuralOperatorNet
@@ -48,4 +49,6 @@ def build_native_net(cfg, state, device="cuda"):
     net = SphericalFourierNeuralOperatorNet(params=params, in_chans=cfg.in_chans, out_chans=cfg.out_chans,
                                             img_shape=tuple(cfg.img_shape), mlp_ratio=cfg.mlp_ratio)
     net.load_state_dict({k: v for k, v in state.items()}, strict=True)
+    if precision is not None:
+        net.set_precision(precision)
     return net.to(device).eval()

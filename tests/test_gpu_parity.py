@@ -28,6 +28,13 @@ def dev():
     return torch.device("cuda")
 
 
+# every network-level parity test runs in both arithmetic modes of the contractions:
+#   "fp32"  exact-fp32 MFMA everywhere; "f16x3" error-compensated fp16 MFMA (the default)
+@pytest.fixture(params=["f16x3", "fp32"])
+def precision(request):
+    return request.param
+
+
 # ---------------------------------------------------------------------------------- building blocks
 @pytest.mark.parametrize("n,cin,cout,hw,act", [
     (1, 44, 384, 64800, 1), (2, 16, 16, 162, 1), (1, 2, 3, 162, 0), (3, 18, 16, 288, 2),
@@ -157,9 +164,9 @@ def test_full_size_properties(dev):
 
 
 # ---------------------------------------------------------------------------------- network
-def _oracle_and_native(cfg, state, x, dev):
+def _oracle_and_native(cfg, state, x, dev, precision):
     from oracle.sfno import SFNOOracle
-    net = build_native_net(cfg, state, dev)
+    net = build_native_net(cfg, state, dev, precision)
     with torch.no_grad():
         y = net(x.to(dev))
     ref64 = SFNOOracle(cfg, state, dtype=torch.float64)(x)
@@ -167,14 +174,14 @@ def _oracle_and_native(cfg, state, x, dev):
     return y, ref32, ref64, net
 
 
-def test_modulus_sfnonet_golden(dev):
+def test_modulus_sfnonet_golden(dev, precision):
     """fme/ace/models/modulus/testdata/test_sfnonet_output_is_unchanged.pt ('diagonal' operator,
     equiangular outer grid => residual round-trips through spectral space)."""
     from oracle.sfno import SFNOConfig
     d = load_golden("gen_modulus_sfnonet_case.pt")
     g = load_golden("ref_modulus_sfnonet_output.pt")
     cfg = SFNOConfig(**d["cfg"])
-    net = build_native_net(cfg, d["state"], dev)
+    net = build_native_net(cfg, d["state"], dev, precision)
     with torch.no_grad():
         y = net(d["x"].to(dev))
     torch.testing.assert_close(y.cpu(), g)
@@ -183,13 +190,13 @@ def test_modulus_sfnonet_golden(dev):
 
 @pytest.mark.parametrize("name", ["gen_sfno_dhconv_12x24.pt", "gen_sfno_dhconv_equiangular_9x18.pt",
                                   "gen_sfno_dhconv_180x360_c8.pt"])
-def test_dhconv_nets_vs_reference(dev, name):
+def test_dhconv_nets_vs_reference(dev, name, precision):
     from oracle.sfno import SFNOConfig, init_state
     d = load_golden(name)
     cfg = SFNOConfig(**{**d["cfg"], "img_shape": tuple(d["cfg"]["img_shape"])})
     state = init_state(cfg, seed=d["seed"])
     x = torch.randn(d["batch"], cfg.in_chans, *cfg.img_shape, generator=torch.Generator().manual_seed(d["seed"] + 1000))
-    net = build_native_net(cfg, state, dev)
+    net = build_native_net(cfg, state, dev, precision)
     with torch.no_grad():
         y = net(x.to(dev))
     assert rel_max(y, d["y"]) <= NET_TOL
@@ -200,23 +207,23 @@ def test_dhconv_nets_vs_reference(dev, name):
     dict(activation_function="silu", encoder_layers=2), dict(hard_thresholding_fraction=0.6),
     dict(operator_type="diagonal", data_grid="equiangular"), dict(num_layers=1, data_grid="equiangular"),
 ])
-def test_config_variants_vs_oracle(dev, kw):
+def test_config_variants_vs_oracle(dev, kw, precision):
     from oracle.sfno import SFNOConfig, init_state
     base = dict(in_chans=5, out_chans=4, img_shape=(16, 32), embed_dim=12, num_layers=2, operator_type="dhconv")
     cfg = SFNOConfig(**{**base, **kw})
     state = init_state(cfg, seed=3)
     x = torch.randn(2, 5, 16, 32, generator=torch.Generator().manual_seed(9))
-    y, ref32, ref64, _ = _oracle_and_native(cfg, state, x, dev)
+    y, ref32, ref64, _ = _oracle_and_native(cfg, state, x, dev, precision)
     assert rel_max(y, ref64) <= NET_TOL
 
 
-def test_block_taps_vs_oracle(dev):
+def test_block_taps_vs_oracle(dev, precision):
     """teacher-forced per-block error at a mid size (C=64, 45x90), against the fp64 oracle."""
     from oracle.sfno import SFNOConfig, SFNOOracle, init_state
     cfg = SFNOConfig(in_chans=6, out_chans=5, img_shape=(45, 90), embed_dim=64, num_layers=3, operator_type="dhconv")
     state = init_state(cfg, seed=4)
     x = torch.randn(2, 6, 45, 90, generator=torch.Generator().manual_seed(10))
-    net = build_native_net(cfg, state, dev)
+    net = build_native_net(cfg, state, dev, precision)
     with torch.no_grad():
         y, taps = net.forward_with_taps(x.to(dev))
     ref, rtaps = SFNOOracle(cfg, state, dtype=torch.float64).forward(x, return_blocks=True)
@@ -225,10 +232,10 @@ def test_block_taps_vs_oracle(dev):
     assert rel_max(y, ref) <= NET_TOL
 
 
-def test_graph_replay_matches_eager(dev):
+def test_graph_replay_matches_eager(dev, precision):
     from oracle.sfno import SFNOConfig, init_state
     cfg = SFNOConfig(in_chans=4, out_chans=4, img_shape=(24, 48), embed_dim=16, num_layers=2, operator_type="dhconv")
-    net = build_native_net(cfg, init_state(cfg, seed=6), dev)
+    net = build_native_net(cfg, init_state(cfg, seed=6), dev, precision)
     x = torch.randn(1, 4, 24, 48, device=dev)
     out = torch.empty(1, 4, 24, 48, device=dev)
     with torch.no_grad():
@@ -242,6 +249,61 @@ def test_graph_replay_matches_eager(dev):
         net.forward_graph(x, out)
         torch.cuda.synchronize()
         assert torch.equal(out, ref2)
+
+
+@pytest.mark.parametrize("scale", [1e-4, 1.0, 3e3])
+def test_f16x3_dynamic_range(dev, scale):
+    """the compensated engine derives its power-of-two operand scales from the data: inputs and weights far from
+    O(1) (trained nets, unnormalised fields) must not cost accuracy."""
+    from oracle.sfno import SFNOConfig, SFNOOracle, init_state
+    cfg = SFNOConfig(in_chans=4, out_chans=3, img_shape=(24, 48), embed_dim=32, num_layers=2, operator_type="dhconv")
+    state = init_state(cfg, seed=8)
+    for k in state:  # rescale weights so intermediate activations drift far from O(1)
+        if k.endswith("filter.filter.weight") or k.startswith("encoder.0.weight"):
+            state[k] = state[k] * scale
+    x = torch.randn(2, 4, 24, 48, generator=torch.Generator().manual_seed(2)) * scale
+    net = build_native_net(cfg, state, dev, "f16x3")
+    with torch.no_grad():
+        y = net(x.to(dev))
+    ref = SFNOOracle(cfg, state, dtype=torch.float64)(x)
+    assert torch.isfinite(y).all()
+    assert rel_max(y, ref) <= NET_TOL
+
+
+def test_f16x3_conv_vs_fp64(dev):
+    """the f16x3 building block against fp64 (and against the exact-fp32 engine's own error)."""
+    from ace_amd import _lib
+    L = _lib.lib()
+    for (n, cin, cout, hw, act, xs) in [(1, 384, 768, 8192, 1, 1.0), (2, 48, 40, 164, 1, 50.0), (1, 428, 50, 4132, 0, 1e-3)]:
+        g = torch.Generator().manual_seed(cin)
+        x = torch.randn(n, cin, hw, generator=g) * xs
+        w = torch.nn.init.trunc_normal_(torch.empty(cout, cin), std=0.02, generator=g)
+        b = torch.randn(cout, generator=g) * 0.01 * xs
+        ref = torch.nn.functional.conv1d(x.double(), w.double()[:, :, None], b.double())
+        if act:
+            ref = torch.nn.functional.gelu(ref)
+        xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+        y = torch.empty(n, cout, hw, device=dev)
+        _lib.check(L.ace_conv1x1_f16x3(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), n, cin, cout, hw, act,
+                                       _lib.current_stream()))
+        assert rel_max(y, ref) <= OP_TOL
+
+
+def test_race_screen(dev, precision):
+    """repeated eager / graph-replayed forwards are bitwise identical (LDS-DMA pipelines, counted vmcnt, wave roles)."""
+    from oracle.sfno import SFNOConfig, init_state
+    for (C, hw, L, B) in [(32, (45, 90), 2, 2), (64, (24, 48), 2, 1)]:
+        cfg = SFNOConfig(in_chans=4, out_chans=4, img_shape=hw, embed_dim=C, num_layers=L, operator_type="dhconv")
+        net = build_native_net(cfg, init_state(cfg, seed=6), dev, precision)
+        x = torch.randn(B, 4, *hw, device=dev)
+        out = torch.empty(B, 4, *hw, device=dev)
+        with torch.no_grad():
+            ref = net(x).clone()
+            for _ in range(15):
+                y = net(x)
+                net.forward_graph(x, out)
+                torch.cuda.synchronize()
+                assert torch.equal(y, ref) and torch.equal(out, ref)
 
 
 def test_errors(dev):
