@@ -38,6 +38,7 @@ SIGNATURES = {
     "ace_sht_tables_host": (c_int, [c_int, c_int, c_int, c_int, c_char_p, c_int, c_void_p]),
     "ace_conv1x1": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p]),
     "ace_conv1x1_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p]),
+    "ace_mlp_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_long, c_int, c_void_p]),
     "ace_instance_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_long, c_void_p]),
     "ace_sfno_create": (c_int, [POINTER(AceSfnoConfig), POINTER(c_void_p)]),
     "ace_sfno_destroy": (None, [c_void_p]),

@@ -303,6 +303,81 @@ extern "C" int ace_conv1x1_f16x3(const float* x, const float* weight, const floa
     return ACE_OK;
 }
 
+// one-off preparation of a 1x1-conv weight for the f16x3 engines (what ace_sfno_set_weight does once per parameter)
+struct PreparedWeight { DevBuf hi, lo; int pitch = 0; float ascale = 1.f, winf = 0.f; };
+static int prepare_weight(const float* weight, int rows, int cols, hipStream_t s, PreparedWeight& out, bool tiled) {
+    std::vector<float> host((size_t)rows * cols);
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(host.data(), weight, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+    float mx = 0.f;
+    for (int r = 0; r < rows; ++r) {
+        double rs = 0.0;
+        for (int c = 0; c < cols; ++c) { const float v = std::fabs(host[(size_t)r * cols + c]); mx = std::max(mx, v); rs += v; }
+        out.winf = std::max(out.winf, (float)(rs * (1.0 + 1e-6)));
+    }
+    int e = 0;
+    if (mx > 0.f && std::isfinite(mx)) { (void)std::frexp(mx, &e); e = 10 - e; }
+    out.ascale = std::ldexp(1.0f, e);
+    out.pitch = (cols + 31) & ~31;
+    const size_t halves = (size_t)((rows + 15) / 16 * 16) * out.pitch;
+    HIP_TRY(out.hi.alloc((halves + 1) / 2, false));
+    HIP_TRY(out.lo.alloc((halves + 1) / 2, false));
+    if (tiled) HIP_TRY(launch_split_f16_tiled(weight, cols, out.hi.p, out.lo.p, out.pitch, rows, cols, out.ascale, s));
+    else HIP_TRY(launch_split_f16(weight, cols, out.hi.p, out.lo.p, out.pitch, rows, cols, out.ascale, s));
+    return ACE_OK;
+}
+
+// The reference's MLP (fme/ace/models/modulus/layers.py:97-137: 1x1 conv -> activation -> 1x1 conv, drop_rate 0) on
+// the packed-operand f16x3 engine: x is split once into P format, fc1 writes the hidden activation straight in
+// P format (bound-scaled), fc2 consumes it by DMA.  Operator-level entry for tests / benchmarks.
+extern "C" int ace_mlp_f16x3(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y,
+                             int n, int cin, int hid, int cout, long hw, int act, void* stream) {
+    if (!x || !w1 || !w2 || !y || n <= 0 || cin <= 0 || hid <= 0 || cout <= 0 || hw <= 0)
+        return fail(ACE_ERR_INVALID, "ace_mlp_f16x3: bad argument");
+    if (cin % 8 != 0 || hid % 8 != 0 || hw % 4 != 0)
+        return fail(ACE_ERR_INVALID, "ace_mlp_f16x3: needs cin % 8 == 0, hid % 8 == 0, hw % 4 == 0");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PreparedWeight p1, p2;
+    ACE_TRY(prepare_weight(w1, hid, cin, s, p1, true));
+    ACE_TRY(prepare_weight(w2, cout, hid, s, p2, true));
+    float b1max = 0.f;
+    if (b1) {
+        std::vector<float> hb((size_t)hid);
+        HIP_TRY(hipMemcpy(hb.data(), b1, hb.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (float v : hb) b1max = std::max(b1max, std::fabs(v));
+    }
+    DevBuf slots, xp, up;
+    HIP_TRY(slots.alloc(2 * AMAX_SHARDS, true));
+    HIP_TRY(xp.alloc((size_t)n * cin * hw, true));   // two fp16 planes = one fp32 tensor's bytes
+    HIP_TRY(up.alloc((size_t)n * hid * hw, true));
+    unsigned* xslot = reinterpret_cast<unsigned*>(slots.p);
+    unsigned* uslot = xslot + AMAX_SHARDS;
+    _Float16* xh = reinterpret_cast<_Float16*>(xp.p);
+    _Float16* xl = xh + (size_t)n * cin * hw;
+    _Float16* uh = reinterpret_cast<_Float16*>(up.p);
+    _Float16* ul = uh + (size_t)n * hid * hw;
+    HIP_TRY(launch_absmax(x, (long)n * cin * hw, xslot, s));
+    HIP_TRY(launch_pack_pformat(x, hw, (long)cin * hw, cin, (int)hw, n, nullptr, nullptr, 0, xslot, xh, xl, hw,
+                                (long)cin * hw, s));
+    Gemm4Args a;
+    a.Ahi = reinterpret_cast<const _Float16*>(p1.hi.p); a.Alo = reinterpret_cast<const _Float16*>(p1.lo.p);
+    a.lda = p1.pitch; a.ascale = p1.ascale; a.a_tiled = 1;
+    a.Bhi = xh; a.Blo = xl; a.ldn = hw; a.sB = (long)cin * hw; a.bmax = xslot;
+    a.Chi = uh; a.Clo = ul; a.ldnc = hw; a.sCp = (long)hid * hw; a.cw = p1.winf; a.cb = b1max; a.cslot = uslot;
+    a.bias = b1; a.M = hid; a.N = (int)hw; a.K = cin; a.nbatch = n;
+    a.act = act == ACT_GELU ? ACT_GELU_FAST : act;
+    HIP_TRY(launch_gemm_f16x3_packed(a, s));
+    Gemm4Args b;
+    b.Ahi = reinterpret_cast<const _Float16*>(p2.hi.p); b.Alo = reinterpret_cast<const _Float16*>(p2.lo.p);
+    b.lda = p2.pitch; b.ascale = p2.ascale; b.a_tiled = 1;
+    b.Bhi = uh; b.Blo = ul; b.ldn = hw; b.sB = (long)hid * hw; b.bmax = uslot;
+    b.C = y; b.ldc = hw; b.sC = (long)cout * hw;
+    b.bias = b2; b.M = cout; b.N = (int)hw; b.K = hid; b.nbatch = n; b.act = ACT_NONE;
+    HIP_TRY(launch_gemm_f16x3_packed(b, s));
+    HIP_TRY(hipStreamSynchronize(s));  // temporaries are freed on return
+    return ACE_OK;
+}
+
 extern "C" int ace_instance_norm(const float* x, const float* gamma, const float* beta, float eps, float* y, int n,
                                  int c, long hw, void* stream) {
     if (!x || !y || n <= 0 || c <= 0 || hw <= 0) return fail(ACE_ERR_INVALID, "ace_instance_norm: bad argument");
@@ -344,6 +419,9 @@ struct Weight {
     int rows = 0, cols = 0, pitch = 0;  // conv weights (rows x cols), pitch = cols rounded up to 32
     DevBuf hi, lo;      // f16x3 mode: fp16 planes of the conv weight scaled by `ascale` (pitch halves)
     float ascale = 1.f;
+    DevBuf thi, tlo;    // the same planes in the v4 engine's A-tile order (rows padded to 16)
+    float winf = 0.f;   // conv weights: max row sum of |w| (bounds |W x| by winf * max|x|)
+    float absmax = 0.f; // small parameters (biases): max |value|
 };
 
 struct GraphKey {
@@ -364,6 +442,7 @@ struct ace_sfno {
     std::vector<float> wx_scale;
     // workspace
     DevBuf h0, h1, Y, T, R, U, X, D, E, stats;
+    DevBuf P;  // f16x3: a C-channel activation as P-format fp16 hi/lo planes (input of the packed-operand GEMM)
     DevBuf Wf0, bf0, Wf1, bf1;
     DevBuf amax;  // [8] uint words: bit patterns of max|X|, max|D|, max|E| of the current block (f16x3 dynamic range)  // instance-norm affine folded into inner_skip / mlp.fc1 weights, per sample
     bool taps_on = false;
@@ -471,7 +550,8 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     HIP_TRY(n->Y.alloc(act));
     HIP_TRY(n->T.alloc(act));
     if (n->plan_data != n->plan_lg.get()) HIP_TRY(n->R.alloc(act));
-    if (c.use_mlp) HIP_TRY(n->U.alloc((size_t)n->Bmax * n->hid * HW));
+    if (c.use_mlp) HIP_TRY(n->U.alloc((size_t)n->Bmax * n->hid * HW, true));
+    if (c.precision == 1) HIP_TRY(n->P.alloc(act, true));
     HIP_TRY(n->X.alloc(spec_x));
     HIP_TRY(n->D.alloc(spec_d));
     HIP_TRY(n->E.alloc(spec_d));
@@ -556,6 +636,12 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
         HIP_TRY(hipMemcpy(host.data(), w.buf.p, host.size() * sizeof(float), hipMemcpyDeviceToHost));
         float mx = 0.f;
         for (float v : host) mx = std::max(mx, std::fabs(v));
+        w.winf = 0.f;
+        for (int r = 0; r < w.rows; ++r) {
+            double rs = 0.0;
+            for (int cidx = 0; cidx < w.cols; ++cidx) rs += std::fabs((double)host[(size_t)r * w.pitch + cidx]);
+            w.winf = std::max(w.winf, (float)(rs * (1.0 + 1e-6)));
+        }
         int e = 0;
         if (mx > 0.f && std::isfinite(mx)) { (void)std::frexp(mx, &e); e = 10 - e; }
         w.ascale = std::ldexp(1.0f, e);
@@ -563,7 +649,17 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
         if (!w.hi.p) HIP_TRY(w.hi.alloc((halves + 1) / 2, false));
         if (!w.lo.p) HIP_TRY(w.lo.alloc((halves + 1) / 2, false));
         HIP_TRY(launch_split_f16(w.buf.p, w.pitch, w.hi.p, w.lo.p, w.pitch, w.rows, w.pitch, w.ascale, s));
+        const size_t thalves = (size_t)((w.rows + 15) / 16 * 16) * w.pitch;
+        if (!w.thi.p) HIP_TRY(w.thi.alloc((thalves + 1) / 2, false));
+        if (!w.tlo.p) HIP_TRY(w.tlo.alloc((thalves + 1) / 2, false));
+        HIP_TRY(launch_split_f16_tiled(w.buf.p, w.pitch, w.thi.p, w.tlo.p, w.pitch, w.rows, w.cols, w.ascale, s));
         HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (w.pitch == 0 && !w.is_filter && numel <= (1 << 16)) {  // biases: bound used by the P-format producers
+        std::vector<float> host((size_t)numel);
+        HIP_TRY(hipMemcpy(host.data(), w.buf.p, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+        w.absmax = 0.f;
+        for (float v : host) w.absmax = std::max(w.absmax, std::fabs(v));
     }
     w.set = true;
     // parameters changed: captured graphs still point at the same library buffers, so they stay valid
@@ -610,6 +706,38 @@ static int fold(const ace_sfno* n, const ConvW& cw, int O, int I, const float* a
                 int batch, hipStream_t s, ConvW* out) {
     HIP_TRY(launch_fold_affine(cw.w, cw.pitch, a, b, cw.bias, Wf, bf, batch, O, I, s));
     *out = ConvW{Wf, cw.pitch, (long)O * cw.pitch, bf, O};
+    return ACE_OK;
+}
+
+// f16x3 "v4": 1x1 convolution whose input already is in P format (fp16 hi/lo planes [cin/8][HW][8] per sample, scaled
+// from the bound in `in_slot`).  Output: fp32 (+ omax) and/or P-format planes for the next convolution.
+static bool packed_ok(const ace_sfno* n, int cin) {
+    static const bool off = getenv("ACE_NO_PK") != nullptr;   // A/B switch for measurements
+    return !off && n->cfg.precision == 1 && n->P.p && cin % 8 == 0 && n->HW % 4 == 0;
+}
+static int pack_act(const ace_sfno* n, const float* x, long x_bs, int cin, const float* sc, const float* sh,
+                    const unsigned* slot, void* hi, void* lo, int batch, hipStream_t s) {
+    HIP_TRY(launch_pack_pformat(x, n->HW, x_bs, cin, (int)n->HW, batch, sc, sh, sc ? cin : 0, slot, hi, lo, n->HW,
+                                (long)cin * n->HW, s));
+    return ACE_OK;
+}
+static int conv_pk(const ace_sfno* n, const Weight& w, const float* bias, const void* bhi, const void* blo, int cin,
+                   const unsigned* in_slot, float* out, int cout, const float* R, long r_bs, const float* rsc,
+                   const float* rsh, int act, int batch, hipStream_t s, unsigned* omax, void* ohi = nullptr,
+                   void* olo = nullptr, float cb = 0.f, unsigned* cslot = nullptr) {
+    Gemm4Args a;
+    a.Ahi = static_cast<const _Float16*>((const void*)w.thi.p); a.Alo = static_cast<const _Float16*>((const void*)w.tlo.p);
+    a.lda = w.pitch; a.sA = 0; a.ascale = w.ascale; a.a_tiled = 1;
+    a.Bhi = static_cast<const _Float16*>(bhi); a.Blo = static_cast<const _Float16*>(blo);
+    a.ldn = n->HW; a.sB = (long)cin * n->HW; a.bmax = in_slot;
+    a.C = out; a.ldc = n->HW; a.sC = (long)cout * n->HW; a.omax = omax;
+    a.Chi = static_cast<_Float16*>(ohi); a.Clo = static_cast<_Float16*>(olo); a.ldnc = n->HW; a.sCp = (long)cout * n->HW;
+    a.cw = w.winf; a.cb = cb; a.cslot = cslot;
+    a.bias = bias; a.sbias = 0;
+    a.R = R; a.ldr = n->HW; a.sR = r_bs; a.rsc = rsc; a.rsh = rsh; a.srs = rsc ? cout : 0;
+    a.M = cout; a.N = (int)n->HW; a.K = cin; a.nbatch = batch;
+    a.act = act == ACT_GELU ? ACT_GELU_FAST : act;
+    HIP_TRY(launch_gemm_f16x3_packed(a, s));
     return ACE_OK;
 }
 
@@ -669,7 +797,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     unsigned* amax = reinterpret_cast<unsigned*>(n->amax.p);
     auto slot = [&](int k) -> unsigned* { return f16 ? amax + (size_t)k * AMAX_SHARDS : nullptr; };
     if (f16) {
-        HIP_TRY(hipMemsetAsync(amax, 0, n->amax.n * sizeof(float), s));
+        HIP_TRY(launch_zero_u32(amax, (long)n->amax.n, s));
         HIP_TRY(launch_absmax(in, (long)B * Cin * HW, slot(0), s));
     }
     if (c.num_layers + 8 > 16) { /* block-input slots 8..15 are shared cyclically for deep nets */ }
@@ -710,7 +838,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
 
         // norm0 as an affine applied on load by every consumer (never materialised)
         const int sb = 16 + 8 * i;  // slot base of this block
-        if (f16 && i + 1 >= 8) HIP_TRY(hipMemsetAsync(hslot(i + 1), 0, AMAX_SHARDS * sizeof(unsigned), s));
+        if (f16 && i + 1 >= 8) HIP_TRY(launch_zero_u32(hslot(i + 1), AMAX_SHARDS, s));
         const float *a0 = nullptr, *b0 = nullptr;
         if (norm) {
             HIP_TRY(launch_instnorm_stats(h, W(p + "norm0.weight"), W(p + "norm0.bias"), 1e-6f, B, C, HW, sc0, sh0, s,
@@ -762,9 +890,19 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         // block input; the spectrally round-tripped residual of mixed-grid blocks has no range slot -> fp32 engine
         const unsigned* skip_max = scale_residual ? nullptr : (norm ? slot(sb + 3) : hslot(i));
         const bool skip_f16 = f16 && skip_max != nullptr;
-        if (ra && !skip_f16) ACE_TRY(fold(n, wskip, C, C, ra, rb, n->Wf0.p, n->bf0.p, B, s, &wskip));
-        ACE_TRY(conv(n, wskip, res, actB, C, nullptr, 0, -1, n->T.p, C, n->Y.p, actB, nullptr, nullptr, act, B, s,
-                     skip_f16 ? ra : nullptr, skip_f16 ? rb : nullptr, skip_max, nullptr, slot(sb + 4)));
+        const bool pk = skip_f16 && packed_ok(n, C) && (!c.use_mlp || n->hid % 8 == 0);
+        _Float16* Ph = reinterpret_cast<_Float16*>(n->P.p);
+        _Float16* Pl = Ph + (size_t)n->Bmax * C * HW;
+        if (pk) {
+            const Weight& ws = *n->weights[n->index.at(p + "inner_skip.weight")];
+            ACE_TRY(pack_act(n, res, actB, C, ra, rb, skip_max, Ph, Pl, B, s));
+            ACE_TRY(conv_pk(n, ws, W(p + "inner_skip.bias"), Ph, Pl, C, skip_max, n->T.p, C, n->Y.p, actB, nullptr, nullptr,
+                            act, B, s, slot(sb + 4)));
+        } else {
+            if (ra && !skip_f16) ACE_TRY(fold(n, wskip, C, C, ra, rb, n->Wf0.p, n->bf0.p, B, s, &wskip));
+            ACE_TRY(conv(n, wskip, res, actB, C, nullptr, 0, -1, n->T.p, C, n->Y.p, actB, nullptr, nullptr, act, B, s,
+                         skip_f16 ? ra : nullptr, skip_f16 ? rb : nullptr, skip_max, nullptr, slot(sb + 4)));
+        }
         MARK(ST_INNER_SKIP);
         // norm1 -> MLP -> + residual   (sfnonet.py:234-250)
         const float *a1 = nullptr, *b1 = nullptr;
@@ -774,7 +912,22 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             a1 = sc1; b1 = sh1;
             MARK(ST_NORM1);
         }
-        if (c.use_mlp) {
+        if (c.use_mlp && pk) {
+            // fc1 reads norm1(T) packed; its epilogue writes U = act(.) straight in P format (bound-scaled), which fc2
+            // consumes by DMA: the hidden activation never exists in fp32
+            const Weight& w1 = *n->weights[n->index.at(p + "mlp.fwd.0.weight")];
+            const Weight& b1w = *n->weights[n->index.at(p + "mlp.fwd.0.bias")];
+            const Weight& w2 = *n->weights[n->index.at(p + "mlp.fwd.2.weight")];
+            const unsigned* tmax = norm ? slot(sb + 5) : slot(sb + 4);
+            _Float16* Uh = reinterpret_cast<_Float16*>(n->U.p);
+            _Float16* Ul = Uh + (size_t)n->Bmax * n->hid * HW;
+            ACE_TRY(pack_act(n, n->T.p, actB, C, a1, b1, tmax, Ph, Pl, B, s));
+            ACE_TRY(conv_pk(n, w1, b1w.buf.p, Ph, Pl, C, tmax, nullptr, n->hid, nullptr, 0, nullptr, nullptr, act, B, s,
+                            nullptr, Uh, Ul, b1w.absmax, slot(sb + 6)));
+            MARK(ST_MLP_FC1);
+            ACE_TRY(conv_pk(n, w2, W(p + "mlp.fwd.2.bias"), Uh, Ul, n->hid, slot(sb + 6), hn, C, res, actB, ra, rb, ACT_NONE,
+                            B, s, hslot(i + 1)));
+        } else if (c.use_mlp) {
             ConvW wfc1 = conv_weight(n, p + "mlp.fwd.0.weight", p + "mlp.fwd.0.bias");
             if (a1 && !f16) ACE_TRY(fold(n, wfc1, n->hid, C, a1, b1, n->Wf1.p, n->bf1.p, B, s, &wfc1));
             ACE_TRY(conv(n, wfc1, n->T.p, actB, C, nullptr, 0, -1, n->U.p, n->hid, nullptr, 0, nullptr, nullptr, act, B, s,

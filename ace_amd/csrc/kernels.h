@@ -59,11 +59,41 @@ hipError_t launch_gemm_f16x3(const GemmArgs& g, const void* Ahi, const void* Alo
 hipError_t launch_gemm_f16x3_adyn(const GemmArgs& g, const void* Bhi, const void* Blo, long ldn, long sB_halves,
                                   float bscale_static, const unsigned* amax, unsigned* omax, hipStream_t s);
 hipError_t launch_pack_dhconv_f16(const float* w, void* hi, void* lo, int Cin, int Cout, int L, float scale, hipStream_t s);
+hipError_t launch_zero_u32(unsigned* p, long n, hipStream_t s);
 // max|x| of a plain tensor into a slot
 hipError_t launch_absmax(const float* x, long n, unsigned* omax, hipStream_t s);
 // fp32 matrix (rows x cols, pitch lds) -> fp16 hi/lo planes (pitch ldd halves, zero padded), values scaled by `scale`
 hipError_t launch_split_f16(const float* src, long lds, void* hi, void* lo, long ldd, long rows, int cols, float scale,
                             hipStream_t s);  // tests / A-B: route everything through the register-staged engine
+
+// Compensated-fp16 engine with BOTH operands pre-split ("v4", see kernels.hip): A = row-major fp16 hi/lo planes,
+// B = k-packed "P format" planes [K/8][ldn][8 halves]; optional P-format output over the rows of C.
+struct Gemm4Args {
+    const _Float16* Ahi = nullptr; const _Float16* Alo = nullptr; long lda = 0; long sA = 0;   // halves
+    const _Float16* Bhi = nullptr; const _Float16* Blo = nullptr; long ldn = 0; long sB = 0;   // ldn entries per k group; sB halves
+    int a_tiled = 0;                            // A planes are in split_f16_tiled order (lda = padded K)
+    float ascale = 1.f, bscale = 1.f;           // static power-of-two scales (used when the slot pointer is null)
+    const unsigned* amax = nullptr;             // dynamic operands: slot holding the bound the producer scaled with
+    const unsigned* bmax = nullptr;
+    float* C = nullptr; long ldc = 0; long sC = 0;                 // fp32 output (optional when PK)
+    _Float16* Chi = nullptr; _Float16* Clo = nullptr; long ldnc = 0; long sCp = 0;  // P-format output over rows of C
+    float cw = 0.f, cb = 0.f;                   // PK: |C| <= cw * bound(B) + cb; published to cslot, scale derived from it
+    unsigned* cslot = nullptr;
+    unsigned* omax = nullptr;                   // fp32 output: atomicMax of bits(max|C|)
+    const float* bias = nullptr; long sbias = 0;
+    const float* R = nullptr; long ldr = 0; long sR = 0;
+    const float* rsc = nullptr; const float* rsh = nullptr; long srs = 0;
+    int M = 0, N = 0, K = 0, nbatch = 1;
+    int tri = TRI_NONE; int trimul = 1;
+    int act = ACT_NONE;
+};
+hipError_t launch_gemm_f16x3_packed(const Gemm4Args& a, hipStream_t s);
+hipError_t launch_split_f16_tiled(const float* src, long lds_, void* hi, void* lo, long ldd, long rows, int cols,
+                                  float scale, hipStream_t s);
+// fp32 [K][N] -> P-format planes with optional per-row affine; scale = 2^(12 - exponent(slot))
+hipError_t launch_pack_pformat(const float* src, long ldb, long sSrc, int K, int N, int nbatch, const float* sc,
+                               const float* sh, long sbs, const unsigned* slot, void* hi, void* lo, long ldn, long sPl,
+                               hipStream_t s);
 
 // Spectral-space layout used between the kernels ("channel-fastest planar"):
 //   X[m][k][b][ri][c]  (after the longitude DFT)     index ((m*H + k)*Bt + b)*2C + ri*C + c

@@ -41,6 +41,12 @@ DEVINL float fast_erf(float x) {
     return copysignf(1.0f - __builtin_amdgcn_exp2f(-q), x);
 }
 
+// Dynamic-range slots are written with device-scope atomics (performed at the memory side on this multi-XCD part);
+// read them the same way so that a copy of the line left in this XCD's L2 by an earlier forward is never used.
+DEVINL unsigned slot_load(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 DEVINL float act_apply(float v, int act) {
     switch (act) {
         case ACT_GELU_FAST: return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
@@ -401,6 +407,17 @@ DEVINL void glds16(const float* gsrc, float* lds_base_uniform) {
                  : "memory");
 }
 
+// 4 bytes per lane variant: used as an L2 prefetch ("touch": one lane per 128-byte line, data discarded into a
+// scratch corner of LDS - no VGPR destination that a late return could clobber)
+DEVINL void glds4(const void* gsrc, void* lds_base_uniform) {
+    unsigned keep;
+    const unsigned addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cp)lds_base_uniform);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(addr)
+                 : "memory");
+}
+
 template <int WM, int WN, int BKT, bool RES>
 __global__ __launch_bounds__(64 * WM * WN) void gemm2_f32_kernel(GemmArgs p, int tilesM, int tilesN) {
     constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
@@ -693,8 +710,8 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
     const int nk = (K - kbeg + BKT - 1) / BKT;
     float bscale_k = q.bscale, oscale_k = q.oscale;
     if (q.bmax) {  // power of two that puts max|B| in [2^11, 2^12): exact to undo, no overflow, lo parts stay normal
-        float mx = __uint_as_float(q.bmax[lane]);  // 64 shards (one per producer workgroup residue), reduce in the wave
-        if (q.bmax2) mx = fmaxf(mx, __uint_as_float(q.bmax2[lane]));
+        float mx = __uint_as_float(slot_load(q.bmax + lane));  // 64 shards (one per producer workgroup residue), reduce in the wave
+        if (q.bmax2) mx = fmaxf(mx, __uint_as_float(slot_load(q.bmax2 + lane)));
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
         mx = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mx)));
@@ -1070,6 +1087,36 @@ __global__ void split_f16_kernel(const float* __restrict__ src, long lds_, _Floa
     }
 }
 
+// fp32 (rows x cols, pitch lds) -> fp16 hi/lo planes in the v4 engine's A-tile order: [rows/16][ldd/32][16][4 slots][8],
+// slot s of row r holds the logical 8-k chunk s ^ ((r >> 2) & 3) (the LDS image the fragment reads expect); ldd =
+// cols rounded up to 32, rows rounded up to 16, padding zero
+__global__ void split_f16_tiled_kernel(const float* __restrict__ src, long lds_, _Float16* __restrict__ hi,
+                                       _Float16* __restrict__ lo, long ldd, long rows, int cols, float scale) {
+    const long rows16 = (rows + 15) / 16 * 16;
+    const long total = rows16 * ldd;
+    const long nst = ldd / 32;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long e = t % 8, ps = (t / 8) % 4, r = (t / 32) % 16, st = (t / 512) % nst, rb = t / (512 * nst);
+        const long row = rb * 16 + r;
+        const long ls = ps ^ ((row >> 2) & 3);
+        const long c = st * 32 + ls * 8 + e;
+        float x = 0.f;
+        if (row < rows && c < cols) x = __builtin_amdgcn_fmed3f(src[row * lds_ + c] * scale, -65504.f, 65504.f);
+        const _Float16 h = (_Float16)x;
+        hi[t] = h;
+        lo[t] = (_Float16)(x - (float)h);
+    }
+}
+hipError_t launch_split_f16_tiled(const float* src, long lds_, void* hi, void* lo, long ldd, long rows, int cols,
+                                  float scale, hipStream_t s) {
+    const long total = (rows + 15) / 16 * 16 * ldd;
+    if (total <= 0 || ldd % 32 != 0) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65535 * 16 ? (total + 255) / 256 : 65535 * 16);
+    hipLaunchKernelGGL(split_f16_tiled_kernel, dim3(grid), dim3(256), 0, s, src, lds_, static_cast<_Float16*>(hi),
+                       static_cast<_Float16*>(lo), ldd, rows, cols, scale);
+    return hipGetLastError();
+}
+
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static bool g_force_v1 = (getenv("ACE_FORCE_V1") != nullptr);  // A/B switch for measurements
 void set_force_v1(bool v) { g_force_v1 = v; }
@@ -1277,6 +1324,482 @@ hipError_t launch_gemm_f16x3_adyn(const GemmArgs& g, const void* Bhi, const void
     const int waste64 = ((g.M + 63) / 64) * 64 - g.M;
     if (g.M >= 128 && waste128 <= waste64) return launch_gemm3_adyn_cfg<2, 2>(a, s);
     return launch_gemm3_adyn_cfg<1, 4>(a, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched GEMM, compensated-fp16, both operands pre-split ("v4").  Same arithmetic as v3 (three fp16 MFMA products
+// per tile, fp32 accumulate), but neither operand is converted here:
+//   * A: fp16 hi/lo planes, row-major [M][lda] (k contiguous, rows zero-padded to the stage depth) - weights/tables
+//     split once at upload, or activations written this way by their producer;
+//   * B: fp16 hi/lo planes in the k-packed "P format" [K/8][ldn][8 halves]: entry (kg, n) holds k = 8kg..8kg+7 of
+//     column n, i.e. exactly the MFMA B fragment of one lane.  Activations are written in this format by their
+//     producer's epilogue (PK output below) or by pack_pformat_kernel; 4 bytes per element, like fp32.
+// Both tiles come in by LDS-DMA.  4 waves (no loader waves), up to 256 VGPRs: the fragments of stage t+1 are read
+// from LDS into a second register set while the MFMAs of stage t run; one barrier per stage; the DMA of stage t+2
+// is issued right after that barrier.  Epilogue as v3, plus the optional P-format output over the rows of C.
+// ---------------------------------------------------------------------------------------------
+
+// power of two that maps a bound to [2^11, 2^12) (fp16 keeps 11 more bits below; lo parts stay normal for every
+// element within 2^-13 of the bound and lose absolute, not relative, accuracy below that)
+DEVINL int pow2_exponent_for(float mx) {
+    int e = 0;
+    if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &e); e = 12 - e; }
+    return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+DEVINL float slot_reduce(const unsigned* slot, int lane) {
+    float mx = __uint_as_float(slot_load(slot + lane));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mx)));
+}
+
+#ifdef ACE_X_TRACE
+__device__ unsigned long long g4_trace[64];
+extern "C" int ace_debug_g4_trace(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g4_trace), sizeof(g4_trace)); }
+#define G4T(ev) do { if (blockIdx.x == 700 && threadIdx.x == 0) g4_trace[ev] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define G4T(ev) do { } while (0)
+#endif
+#ifndef ACE_G4_PFD
+#define ACE_G4_PFD 0   // L2 prefetch distance of the v4 engine (0 = off: measured neutral-to-negative, r01 profiles)
+#endif
+#ifndef ACE_G4_RTOUCH
+#define ACE_G4_RTOUCH 0
+#endif
+struct Frags4 { half8 ah[2], al[2], bh[2], bl[2]; };  // one 16-deep k half: [tile]
+
+template <int WM, int WN, bool RES, bool PK>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args q, int tilesM, int tilesN) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
+    static_assert(NW == 4, "piece distribution assumes 4 waves");
+    constexpr int BKT = 32;
+    constexpr int APL = BM * BKT;             // halves per A plane per buffer
+    constexpr int BPL = BKT * BN;             // halves per B plane per buffer
+    constexpr int ACW = BM * BKT * 2 / 1024 / NW;   // 1 KiB pieces per wave per A plane (2 or 1)
+    constexpr int BCW = 4 * BN / 64 / NW;           // 1 KiB pieces per wave per B plane (2 or 4)
+    constexpr int PCS = 2 * (ACW + BCW);            // DMA pieces per wave per stage
+    constexpr int PFD = ACE_G4_PFD;                 // prefetch distance (stages beyond the DMA'd one)
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem4[];
+    _Float16* As = smem4;                     // [2 buf][2 plane][BM][32]
+    _Float16* Bs = smem4 + 2 * 2 * APL;       // [2 buf][2 plane][4 kg][BN][8]
+    _Float16* Scratch = Bs + 2 * 2 * BPL;     // [NW][128]: landing zone of the prefetch touches (never read)
+
+    const int nblk = tilesM * tilesN * q.nbatch;
+    const int lid = xcd_remap(blockIdx.x, nblk);
+    const int tile_m = lid % tilesM;
+    const int rest = lid / tilesM;
+    const int tile_n = rest % tilesN;
+    const int batch = rest / tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    int M = q.M, kbeg = 0;
+    if (q.tri == TRI_ROWS_GE_BATCH) {
+        if (m0 + BM <= batch) return;
+    } else if (q.tri == TRI_K_GE_BATCH) {
+        kbeg = (batch / BKT) * BKT;
+    } else if (q.tri == TRI_ROWS_LE_BATCH) {
+        const int me = (batch + 1) * q.trimul;
+        M = me < M ? me : M;
+        if (m0 >= M) return;
+    }
+    G4T(0);
+    const int K = q.K, N = q.N;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = (K - kbeg + BKT - 1) / BKT;
+    const int nkg = (K + 7) / 8;              // valid k groups of the packed operand
+
+    // dynamic-range slots: loaded now, reduced after the first DMAs are in flight
+    const unsigned raw_a = q.amax ? slot_load(q.amax + lane) : 0u;
+    const unsigned raw_b = q.bmax ? slot_load(q.bmax + lane) : 0u;
+
+    // ---- DMA descriptors of this wave's pieces (fixed over the k loop)
+    const _Float16* Ahi = q.Ahi + (long)batch * q.sA;
+    const _Float16* Alo = q.Alo + (long)batch * q.sA;
+    const _Float16* Bhi = q.Bhi + (long)batch * q.sB;
+    const _Float16* Blo = q.Blo + (long)batch * q.sB;
+    const long lda = q.lda, ldn = q.ldn;
+    long aoff[ACW];
+    const int a_tiled = q.a_tiled;
+    const long astage = a_tiled ? 512 : BKT;   // halves between consecutive k stages of one piece
+#pragma unroll
+    for (int c = 0; c < ACW; ++c) {   // piece = 16 rows x 64 B
+        const int ca = wave + c * NW;
+        if (a_tiled) {   // pre-tiled static operand: the piece is 1 KiB contiguous, already in its (swizzled) LDS image
+            int rb = m0 / 16 + ca;
+            const int nrb = (q.M + 15) / 16;
+            rb = rb < nrb ? rb : nrb - 1;
+            aoff[c] = (long)rb * lda * 16 + lane * 8;     // lda = padded K (multiple of 32)
+        } else {         // row-major planes: the lane fetches the XOR-swizzled logical slot of its row
+            const int row = ca * 16 + lane / 4;
+            const int ls = (lane % 4) ^ ((row >> 2) & 3);
+            int m = m0 + row;
+            m = m < M ? m : M - 1;
+            aoff[c] = (long)m * lda + 8 * ls;
+        }
+    }
+    int bkg[BCW];
+    long bcol[BCW];
+#pragma unroll
+    for (int c = 0; c < BCW; ++c) {   // piece = one k group x 64 columns
+        const int cb = wave + c * NW;
+        bkg[c] = cb / (BN / 64);
+        int nn = n0 + (cb % (BN / 64)) * 64 + lane;
+        nn = nn < N ? nn : N - 1;
+        bcol[c] = (long)nn * 8;
+    }
+    auto issue = [&](int k0, int buf) {
+        _Float16* Ab = As + buf * 2 * APL;
+        _Float16* Bb = Bs + buf * 2 * BPL;
+#pragma unroll
+        for (int c = 0; c < ACW; ++c) {
+            const int ca = wave + c * NW;
+            const long ak = (long)(k0 / BKT) * astage;
+            glds16(reinterpret_cast<const float*>(Ahi + aoff[c] + ak), reinterpret_cast<float*>(Ab + ca * 512));
+            glds16(reinterpret_cast<const float*>(Alo + aoff[c] + ak), reinterpret_cast<float*>(Ab + APL + ca * 512));
+        }
+#pragma unroll
+        for (int c = 0; c < BCW; ++c) {
+            const int cb = wave + c * NW;
+            int kg = k0 / 8 + bkg[c];
+            kg = kg < nkg ? kg : nkg - 1;   // groups past K meet zero A columns (values there are finite)
+            const long off = (long)kg * ldn * 8 + bcol[c];
+            glds16(reinterpret_cast<const float*>(Bhi + off), reinterpret_cast<float*>(Bb + cb * 512));
+            glds16(reinterpret_cast<const float*>(Blo + off), reinterpret_cast<float*>(Bb + BPL + cb * 512));
+        }
+        // L2 prefetch of the B lines of stage (k0 / BKT + PFD): the DMA above has one stage of lookahead, enough for an
+        // L2 hit but not for an HBM miss.  One lane per 128-byte line (BN lines per stage: 4 k groups x 2 planes x BN/8),
+        // BN/4 lanes per wave; always exactly one instruction per call so that the counted waits stay uniform.
+        if (PFD > 0) {
+            const int li = wave * (BN / 4) + (lane % (BN / 4));
+            const int plane = li / (BN / 2), rem = li % (BN / 2);
+            int kg = (k0 + PFD * BKT) / 8 + rem / (BN / 8);
+            kg = kg < nkg ? kg : nkg - 1;
+            int nn = n0 + (rem % (BN / 8)) * 8;
+            nn = nn < N ? nn : N - 1;
+            const _Float16* src = (plane ? Blo : Bhi) + ((long)kg * ldn + nn) * 8;
+            glds4(src, Scratch + wave * 128);
+        }
+    };
+
+    const int i = lane & 31, g = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int arow0 = wm * 64 + i, arow1 = arow0 + 32;
+    const int key0 = (arow0 >> 2) & 3, key1 = (arow1 >> 2) & 3;
+    const int bcol0 = wn * 64 + i, bcol1 = bcol0 + 32;
+    auto load_frags = [&](Frags4& f, int buf, int c) {
+        const _Float16* Ah = As + buf * 2 * APL;
+        const _Float16* Al = Ah + APL;
+        const _Float16* Bh = Bs + buf * 2 * BPL;
+        const _Float16* Bl = Bh + BPL;
+        const int ls = 2 * c + g;  // lane group g owns k = 16c + 8g .. +7
+        f.al[0] = *reinterpret_cast<const half8*>(Al + arow0 * 32 + 8 * (ls ^ key0));
+        f.al[1] = *reinterpret_cast<const half8*>(Al + arow1 * 32 + 8 * (ls ^ key1));
+        f.bh[0] = *reinterpret_cast<const half8*>(Bh + ((long)ls * BN + bcol0) * 8);
+        f.bh[1] = *reinterpret_cast<const half8*>(Bh + ((long)ls * BN + bcol1) * 8);
+        f.ah[0] = *reinterpret_cast<const half8*>(Ah + arow0 * 32 + 8 * (ls ^ key0));
+        f.ah[1] = *reinterpret_cast<const half8*>(Ah + arow1 * 32 + 8 * (ls ^ key1));
+        f.bl[0] = *reinterpret_cast<const half8*>(Bl + ((long)ls * BN + bcol0) * 8);
+        f.bl[1] = *reinterpret_cast<const half8*>(Bl + ((long)ls * BN + bcol1) * 8);
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    auto mma = [&](const Frags4& f) {  // 12 MFMAs: small cross terms first, the hi.hi term last
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[a], f.bh[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bl[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bh[b], acc[a][b], 0, 0, 0);
+    };
+    auto interleave = [&]() {  // 8 fragment reads spread under 12 MFMAs
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+    };
+
+    // Software pipeline at half-stage granularity: while the 12 MFMAs of one 16-deep half run, the fragments of the
+    // next half are read from LDS into the other register set.  One barrier per stage, between the two halves: by
+    // then every wave has read all of buffer t & 1, so the DMA of stage t + 2 may overwrite it, and the DMA of
+    // stage t + 1 (issued one stage earlier) has landed.
+    Frags4 f0, f1;
+    G4T(1);
+    if (RES && ACE_G4_RTOUCH) {  // touch the residual tile now: BM rows x (BN * 4 / 128) lines, it is needed only in the epilogue
+        const float* Rt = q.R + (long)batch * q.sR;
+        constexpr int LPR = BN / 32;                       // 128-byte lines per tile row
+#pragma unroll
+        for (int t = 0; t < BM * LPR / (64 * NW); ++t) {
+            const int li = (t * NW + wave) * 64 + lane;
+            int row = m0 + li / LPR;
+            row = row < M ? row : M - 1;
+            int col = n0 + (li % LPR) * 32;
+            col = col < N ? col : N - 1;
+            glds4(Rt + (long)row * q.ldr + col, Scratch + wave * 128);
+        }
+    }
+    if (nk > 0) issue(kbeg, 0);
+    if (nk > 1) issue(kbeg + BKT, 1);
+    // scales: the producer of a dynamic operand scaled it by 2^(12 - exponent(bound)); undo both here (exact)
+    auto wave_max = [&](unsigned raw) {
+        float mx = __uint_as_float(raw);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mx)));
+    };
+    float bbound = 0.f;
+    float inv_a = 1.0f / q.ascale, inv_b = 1.0f / q.bscale;
+    if (q.amax) inv_a = ldexpf(1.0f, -pow2_exponent_for(wave_max(raw_a)));
+    if (q.bmax) { bbound = wave_max(raw_b); inv_b = ldexpf(1.0f, -pow2_exponent_for(bbound)); }
+    float cscale = 1.f;
+    if (PK) {  // bound of this launch's output, identical in every workgroup; consumers read it from cslot
+        const float cbound = fmaf(q.cw, bbound, q.cb);
+        cscale = ldexpf(1.0f, pow2_exponent_for(cbound));
+        if (tid == 0) atomicMax(q.cslot + (blockIdx.x & 63), __float_as_uint(cbound));
+    }
+    constexpr int NTOUCH = PFD > 0 ? 1 : 0;   // prefetch touches per issue() that may stay outstanding
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PCS + NTOUCH) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    G4T(2);
+    if (nk > 0) load_frags(f0, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        load_frags(f1, cur, 1);
+        mma(f0);
+        interleave();
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NTOUCH) : "memory");   // all but the newest prefetch touch
+        __syncthreads();
+        if (kt + 2 < nk) issue(kbeg + (kt + 2) * BKT, cur);
+        if (kt + 1 < nk) load_frags(f0, cur ^ 1, 0);
+        mma(f1);
+        interleave();
+        G4T(3 + (kt < 40 ? kt : 40));
+    }
+    G4T(50);
+
+    // ---- epilogue
+    float vmax = 0.f;
+    float* C = q.C ? q.C + (long)batch * q.sC : nullptr;
+    const float* R = RES ? q.R + (long)batch * q.sR : nullptr;
+    const float* rsc = q.rsc ? q.rsc + (long)batch * q.srs : nullptr;
+    const float* rsh = q.rsc ? q.rsh + (long)batch * q.srs : nullptr;
+    const float* bias = q.bias ? q.bias + (long)batch * q.sbias : nullptr;
+    const float* dummy = reinterpret_cast<const float*>(q.Ahi);
+    const long ldc = q.ldc, ldr = q.ldr;
+    const int actk = q.act;
+    if (!PK) {
+        // fp32 output through LDS: each wave parks its 64x64 tile (accumulator layout) in its own 16 KiB of the now idle
+        // operand buffers and reads it back row-contiguous, so that residual loads and stores are 16 B per lane
+        // (4 rows x 256 B per wave instruction instead of 2 rows x 128 B) - 4x fewer vector-memory instructions.
+        // No barrier: all LDS reads of the main loop completed before its last barrier, and waves use disjoint regions.
+        float* Ts = reinterpret_cast<float*>(smem4) + wave * 4096;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Ts[(tm * 32 + acc_row(r, g)) * 64 + tn * 32 + i] = acc[tm][tn][r];
+        const int c4 = (lane & 15) * 4;
+        const int colb = n0 + wn * 64 + c4;
+        const bool cok = colb < N;           // N % 4 == 0 (checked by the launcher)
+        const int colc = cok ? colb : 0;
+        float4 tv[16], rv[16];
+        float bvv[16], rsv[16], rtv[16];
+        int rows[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int rl = (lane >> 4) + 4 * j;
+            const int row = m0 + wm * 64 + rl;
+            rows[j] = row < M ? row : 0;
+            const float t0 = (bias ? bias : dummy)[bias ? rows[j] : 0];
+            const float t1 = (rsc ? rsc : dummy)[rsc ? rows[j] : 0];
+            const float t2 = (rsc ? rsh : dummy)[rsc ? rows[j] : 0];
+            bvv[j] = bias ? t0 : 0.f;
+            rsv[j] = rsc ? t1 : 1.f;
+            rtv[j] = rsc ? t2 : 0.f;
+            if (RES) rv[j] = *reinterpret_cast<const float4*>(R + (long)rows[j] * ldr + colc);
+            tv[j] = *reinterpret_cast<const float4*>(Ts + rl * 64 + c4);
+        }
+        G4T(51);
+#ifdef ACE_X_TRACE
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        G4T(52);
+#endif
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int row = m0 + wm * 64 + (lane >> 4) + 4 * j;
+            float o[4] = {tv[j].x, tv[j].y, tv[j].z, tv[j].w};
+            const float r4[4] = {RES ? rv[j].x : 0.f, RES ? rv[j].y : 0.f, RES ? rv[j].z : 0.f, RES ? rv[j].w : 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = fmaf(o[e] * inv_a, inv_b, bvv[j]);
+                if (RES) v += fmaf(r4[e], rsv[j], rtv[j]);
+                o[e] = act_apply(v, actk);
+            }
+            if (row < M && cok) {
+                *reinterpret_cast<float4*>(C + (long)row * ldc + colb) = make_float4(o[0], o[1], o[2], o[3]);
+                vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+            }
+        }
+    } else {
+        const int col0 = n0 + wn * 64 + i, col1 = col0 + 32;
+        const bool c0ok = col0 < N, c1ok = col1 < N;
+        _Float16* Chi = q.Chi + (long)batch * q.sCp;
+        _Float16* Clo = q.Clo + (long)batch * q.sCp;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int rbase = m0 + wm * 64 + tm * 32 + 8 * qd + 4 * g;
+                float bv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int rr = (rbase + e < M) ? rbase + e : 0;
+                    const float t0 = (bias ? bias : dummy)[bias ? rr : 0];
+                    bv[e] = bias ? t0 : 0.f;
+                }
+                if (rbase < M) {  // M % 8 == 0: the 4-row group is wholly inside; 8-byte half entries
+                    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                    half4 h0, l0, h1, l1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = act_apply(fmaf(acc[tm][0][4 * qd + e] * inv_a, inv_b, bv[e]), actk) * cscale;
+                        const float x1 = act_apply(fmaf(acc[tm][1][4 * qd + e] * inv_a, inv_b, bv[e]), actk) * cscale;
+                        const _Float16 a = (_Float16)x0, b = (_Float16)x1;
+                        h0[e] = a; l0[e] = (_Float16)(x0 - (float)a);
+                        h1[e] = b; l1[e] = (_Float16)(x1 - (float)b);
+                    }
+                    const long kgo = rbase >> 3;   // rbase = 8 (..) + 4 g
+                    const long e0 = (kgo * q.ldnc + col0) * 8 + 4 * g, e1 = (kgo * q.ldnc + col1) * 8 + 4 * g;
+                    if (c0ok) { *reinterpret_cast<half4*>(Chi + e0) = h0; *reinterpret_cast<half4*>(Clo + e0) = l0; }
+                    if (c1ok) { *reinterpret_cast<half4*>(Chi + e1) = h1; *reinterpret_cast<half4*>(Clo + e1) = l1; }
+                }
+            }
+        }
+    }
+    G4T(53);
+    if (q.omax && C) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        if (lane == 0) atomicMax(q.omax + (blockIdx.x & 63), __float_as_uint(vmax));
+    }
+#ifdef ACE_X_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G4T(54);
+#endif
+}
+
+// fp32 [K][N] (row pitch ldb) -> P-format fp16 hi/lo planes [ceil(K/8)][ldn][8], optional per-row affine (fused
+// instance norm), scaled by 2^(12 - exponent(slot)).  Thread = (k group, 4 consecutive columns).
+__global__ __launch_bounds__(256) void pack_pformat_kernel(const float* __restrict__ src, long ldb, long sSrc, int K,
+                                                            int N, const float* __restrict__ sc,
+                                                            const float* __restrict__ sh, long sbs,
+                                                            const unsigned* __restrict__ slot, _Float16* __restrict__ hi,
+                                                            _Float16* __restrict__ lo, long ldn, long sPl) {
+    const int lane = threadIdx.x & 63;
+    const float scale = ldexpf(1.0f, pow2_exponent_for(slot_reduce(slot, lane)));
+    const int nq = N / 4;
+    const int batch = blockIdx.y;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int kg = (int)(t / nq);
+    const int n = (int)(t % nq) * 4;
+    if (kg >= (K + 7) / 8) return;
+    const float* base = src + (long)batch * sSrc + n;
+    float4 v[8];
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * kg + e;
+        const int kc = k < K ? k : K - 1;
+        v[e] = *reinterpret_cast<const float4*>(base + (long)kc * ldb);
+        a[e] = sc ? sc[(long)batch * sbs + kc] * scale : scale;
+        b[e] = sc ? sh[(long)batch * sbs + kc] * scale : 0.f;
+        if (k >= K) { a[e] = 0.f; b[e] = 0.f; }
+    }
+    half8 h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float xs[4] = {v[e].x, v[e].y, v[e].z, v[e].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = __builtin_amdgcn_fmed3f(fmaf(xs[j], a[e], b[e]), -65504.f, 65504.f);
+            const _Float16 hh = (_Float16)x;
+            h[j][e] = hh;
+            l[j][e] = (_Float16)(x - (float)hh);
+        }
+    }
+    _Float16* ph = hi + (long)batch * sPl + ((long)kg * ldn + n) * 8;
+    _Float16* pl = lo + (long)batch * sPl + ((long)kg * ldn + n) * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<half8*>(ph + 8 * j) = h[j];
+        *reinterpret_cast<half8*>(pl + 8 * j) = l[j];
+    }
+}
+
+hipError_t launch_pack_pformat(const float* src, long ldb, long sSrc, int K, int N, int nbatch, const float* sc,
+                               const float* sh, long sbs, const unsigned* slot, void* hi, void* lo, long ldn, long sPl,
+                               hipStream_t s) {
+    if (N % 4 != 0 || !al16(src) || ldb % 4 != 0 || sSrc % 4 != 0) return hipErrorInvalidValue;
+    const long total = (long)((K + 7) / 8) * (N / 4);
+    dim3 grid((unsigned)((total + 255) / 256), (unsigned)nbatch);
+    hipLaunchKernelGGL(pack_pformat_kernel, grid, dim3(256), 0, s, src, ldb, sSrc, K, N, sc, sh, sbs, slot,
+                       static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), ldn, sPl);
+    return hipGetLastError();
+}
+
+template <int WM, int WN>
+static hipError_t launch_gemm4_cfg(const Gemm4Args& a, hipStream_t s) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr size_t lds = (size_t)2 * 2 * (BM * 32 + 32 * BN) * sizeof(_Float16) + 4 * 256;
+    const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
+    const long nblk = (long)tilesM * tilesN * a.nbatch;
+    if (nblk <= 0) return hipSuccess;
+    const bool res = a.R != nullptr, pk = a.Chi != nullptr;
+    static bool configured[4] = {false, false, false, false};
+    const void* fn = pk ? (res ? (const void*)gemm4_f16x3_kernel<WM, WN, true, true> : (const void*)gemm4_f16x3_kernel<WM, WN, false, true>)
+                        : (res ? (const void*)gemm4_f16x3_kernel<WM, WN, true, false> : (const void*)gemm4_f16x3_kernel<WM, WN, false, false>);
+    const int ci = (pk ? 2 : 0) + (res ? 1 : 0);
+    if (!configured[ci]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured[ci] = true;
+    }
+    dim3 grid((unsigned)nblk), block(64 * WM * WN);
+    if (pk && res) hipLaunchKernelGGL((gemm4_f16x3_kernel<WM, WN, true, true>), grid, block, lds, s, a, tilesM, tilesN);
+    else if (pk) hipLaunchKernelGGL((gemm4_f16x3_kernel<WM, WN, false, true>), grid, block, lds, s, a, tilesM, tilesN);
+    else if (res) hipLaunchKernelGGL((gemm4_f16x3_kernel<WM, WN, true, false>), grid, block, lds, s, a, tilesM, tilesN);
+    else hipLaunchKernelGGL((gemm4_f16x3_kernel<WM, WN, false, false>), grid, block, lds, s, a, tilesM, tilesN);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_f16x3_packed(const Gemm4Args& a, hipStream_t s) {
+    if (!al16(a.Ahi) || !al16(a.Alo) || !al16(a.Bhi) || !al16(a.Blo) || a.lda % 8 != 0 || a.sA % 8 != 0 || a.sB % 8 != 0)
+        return hipErrorInvalidValue;
+    if (a.Chi && (a.M % 8 != 0 || a.R || a.C)) return hipErrorInvalidValue;   // P-format output: no fp32 copy, no residual
+    if (!a.Chi && (!a.C || !al16(a.C) || a.ldc % 4 != 0 || a.sC % 4 != 0 || a.N % 4 != 0)) return hipErrorInvalidValue;
+    if (a.R && (!al16(a.R) || a.ldr % 4 != 0 || a.sR % 4 != 0)) return hipErrorInvalidValue;
+    const long waste128 = (long)((a.M + 127) / 128) * 128, waste64 = (long)((a.M + 63) / 64) * 64;
+    if (a.M >= 128 && waste128 <= waste64) return launch_gemm4_cfg<2, 2>(a, s);
+    return launch_gemm4_cfg<1, 4>(a, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1955,6 +2478,18 @@ __global__ __launch_bounds__(128) void fold_affine_kernel(const float* __restric
 hipError_t launch_fold_affine(const float* W, long ldw, const float* a, const float* b, const float* bias, float* Wf,
                               float* bf, int nsamples, int O, int I, hipStream_t s) {
     hipLaunchKernelGGL(fold_affine_kernel, dim3(O, nsamples), dim3(128), 0, s, W, ldw, a, b, bias, Wf, bf, O, I);
+    return hipGetLastError();
+}
+
+// slot reset as a kernel (not hipMemsetAsync): inside a captured graph a memset node is not ordered/coherent with the
+// device-scope atomics on the same words the way a kernel node is (observed: stale bounds on replay)
+__global__ void zero_u32_kernel(unsigned* p, long n) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) __hip_atomic_store(p + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+hipError_t launch_zero_u32(unsigned* p, long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n);
     return hipGetLastError();
 }
 

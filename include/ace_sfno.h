@@ -74,6 +74,13 @@ int ace_conv1x1(const float* x, const float* weight, const float* bias, float* y
 int ace_conv1x1_f16x3(const float* x, const float* weight, const float* bias, float* y, int n, int cin, int cout,
                       long hw, int act, void* stream);
 
+/* MLP.forward (fme/ace/models/modulus/layers.py:97-137): y = W2 act(W1 x + b1) + b2 on (n, cin, hw) -> (n, cout, hw),
+ * on the packed-operand f16x3 engine (the hidden activation is produced and consumed as pre-split fp16 planes and
+ * never exists in fp32).  Needs cin % 8 == 0, hid % 8 == 0, hw % 4 == 0.  Test / micro-benchmark entry: prepares the
+ * weight planes on every call and synchronises. */
+int ace_mlp_f16x3(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, int n,
+                  int cin, int hid, int cout, long hw, int act, void* stream);
+
 /* nn.InstanceNorm2d(C, eps, affine) (sfnonet.py:593-601) on (n, C, hw); gamma/beta may be NULL. */
 int ace_instance_norm(const float* x, const float* gamma, const float* beta, float eps, float* y, int n, int c,
                       long hw, void* stream);

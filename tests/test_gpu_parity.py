@@ -244,11 +244,12 @@ def test_graph_replay_matches_eager(dev, precision):
             net.forward_graph(x, out)
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
-        x.normal_()                      # same storage, new contents: replay must see them
-        ref2 = net(x).clone()
-        net.forward_graph(x, out)
-        torch.cuda.synchronize()
-        assert torch.equal(out, ref2)
+        for _ in range(8):               # same storage, new contents: every replay must see them (and must reset the
+            x.normal_()                  # dynamic-range slots itself: a stale bound only shows with fresh inputs)
+            ref2 = net(x).clone()
+            net.forward_graph(x, out)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref2)
 
 
 @pytest.mark.parametrize("scale", [1e-4, 1.0, 3e3])
@@ -287,6 +288,32 @@ def test_f16x3_conv_vs_fp64(dev):
         _lib.check(L.ace_conv1x1_f16x3(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), n, cin, cout, hw, act,
                                        _lib.current_stream()))
         assert rel_max(y, ref) <= OP_TOL
+
+
+def test_f16x3_packed_mlp_vs_fp64(dev):
+    """MLP (layers.py:97-137) on the packed-operand engine: P-format input, bound-scaled P-format hidden activation,
+    against fp64; includes ragged tiles (hw not a multiple of the tile), batch > 1 and wide dynamic range."""
+    from ace_amd import _lib
+    L = _lib.lib()
+    cases = [(1, 384, 768, 384, 8192, 1, 1.0), (2, 48, 40, 56, 164, 1, 50.0), (1, 136, 264, 72, 4132, 3, 1e-3),
+             (3, 8, 8, 8, 4, 2, 1.0), (1, 64, 128, 64, 1000, 1, 1e8), (1, 64, 128, 64, 1000, 1, 1e-12)]
+    for (n, cin, hid, cout, hw, act, xs) in cases:
+        g = torch.Generator().manual_seed(cin + hw)
+        x = torch.randn(n, cin, hw, generator=g) * xs
+        w1 = torch.nn.init.trunc_normal_(torch.empty(hid, cin), std=0.05, generator=g)
+        b1 = torch.randn(hid, generator=g) * 0.1 * xs
+        w2 = torch.nn.init.trunc_normal_(torch.empty(cout, hid), std=0.05, generator=g)
+        b2 = torch.randn(cout, generator=g) * 0.1 * xs
+        u = torch.nn.functional.conv1d(x.double(), w1.double()[:, :, None], b1.double())
+        u = {1: torch.nn.functional.gelu, 2: torch.relu, 3: torch.nn.functional.silu}[act](u)
+        ref = torch.nn.functional.conv1d(u, w2.double()[:, :, None], b2.double())
+        t = [v.to(dev) for v in (x, w1, b1, w2, b2)]
+        y = torch.empty(n, cout, hw, device=dev)
+        _lib.check(L.ace_mlp_f16x3(*[_lib.ptr(v) for v in t], _lib.ptr(y), n, cin, hid, cout, hw, act,
+                                   _lib.current_stream()))
+        assert rel_max(y, ref) <= OP_TOL, (n, cin, hid, cout, hw, act, xs, rel_max(y, ref))
+    with pytest.raises(ValueError):
+        _lib.check(L.ace_mlp_f16x3(*[_lib.ptr(v) for v in t], _lib.ptr(y), 1, 7, 8, 8, 4, 0, _lib.current_stream()))
 
 
 def test_race_screen(dev, precision):
