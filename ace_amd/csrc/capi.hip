@@ -138,8 +138,9 @@ static int run_dft_forward(const ace_sht_plan& pl, const float* x, const float* 
     return ACE_OK;
 }
 static int run_dft_inverse(const ace_sht_plan& pl, const float* X, const float* bias, float* y, int Bt, int C,
-                           hipStream_t s) {
+                           hipStream_t s, unsigned* ymax = nullptr) {
     DftArgs a;
+    a.omax = ymax;
     a.spec = X; a.y = y; a.tc = pl.gc.p; a.ts = pl.gs.p; a.ldt = pl.Kfp; a.bias = bias;
     a.Bt = Bt; a.C = C; a.H = pl.nlat; a.W = pl.nlon; a.Mm = pl.mmax;
     HIP_TRY(launch_dft_inverse(a, s));
@@ -420,6 +421,7 @@ struct Weight {
     DevBuf hi, lo;      // f16x3 mode: fp16 planes of the conv weight scaled by `ascale` (pitch halves)
     float ascale = 1.f;
     DevBuf thi, tlo;    // the same planes in the v4 engine's A-tile order (rows padded to 16)
+    float wabs = 0.f;   // conv weights: max |w|
     float winf = 0.f;   // conv weights: max row sum of |w| (bounds |W x| by winf * max|x|)
     float absmax = 0.f; // small parameters (biases): max |value|
 };
@@ -443,6 +445,10 @@ struct ace_sfno {
     // workspace
     DevBuf h0, h1, Y, T, R, U, X, D, E, stats;
     DevBuf P;  // f16x3: a C-channel activation as P-format fp16 hi/lo planes (input of the packed-operand GEMM)
+    DevBuf P2;           // second one: the block input h as written by the previous block's fc2 epilogue
+    DevBuf part;         // per-strip row statistics from the GEMM epilogues (fused instance norm), two tensors
+    DevBuf Wp0, Wp1;     // folded (norm affine) skip / fc1 weights as tiled fp16 planes, per sample
+    int nstrips = 0;
     DevBuf Wf0, bf0, Wf1, bf1;
     DevBuf amax;  // [8] uint words: bit patterns of max|X|, max|D|, max|E| of the current block (f16x3 dynamic range)  // instance-norm affine folded into inner_skip / mlp.fc1 weights, per sample
     bool taps_on = false;
@@ -551,12 +557,22 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     HIP_TRY(n->T.alloc(act));
     if (n->plan_data != n->plan_lg.get()) HIP_TRY(n->R.alloc(act));
     if (c.use_mlp) HIP_TRY(n->U.alloc((size_t)n->Bmax * n->hid * HW, true));
-    if (c.precision == 1) HIP_TRY(n->P.alloc(act, true));
+    if (c.precision == 1) {
+        HIP_TRY(n->P.alloc(act, true));
+        if (c.normalization_layer == 1 && c.use_mlp) {
+            HIP_TRY(n->P2.alloc(act, true));
+            n->nstrips = (int)((HW + 63) / 64) + 4;     // >= tilesN * WN of either tile shape
+            HIP_TRY(n->part.alloc((size_t)2 * n->Bmax * n->nstrips * C * 4, true));
+            const size_t cp = (size_t)((C + 31) & ~31);
+            HIP_TRY(n->Wp0.alloc((size_t)n->Bmax * ((C + 15) / 16 * 16) * cp, true));       // 2 planes of halves = 1 float per element
+            HIP_TRY(n->Wp1.alloc((size_t)n->Bmax * ((n->hid + 15) / 16 * 16) * cp, true));
+        }
+    }
     HIP_TRY(n->X.alloc(spec_x));
     HIP_TRY(n->D.alloc(spec_d));
     HIP_TRY(n->E.alloc(spec_d));
     HIP_TRY(n->stats.alloc((size_t)4 * n->Bmax * C));
-    HIP_TRY(n->amax.alloc((size_t)(16 + 8 * c.num_layers) * AMAX_SHARDS));
+    HIP_TRY(n->amax.alloc((size_t)(16 + 12 * c.num_layers) * AMAX_SHARDS));
     if (c.normalization_layer == 1) {
         const size_t cp = (size_t)((C + 31) & ~31);
         HIP_TRY(n->Wf0.alloc((size_t)n->Bmax * C * cp));
@@ -636,6 +652,7 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
         HIP_TRY(hipMemcpy(host.data(), w.buf.p, host.size() * sizeof(float), hipMemcpyDeviceToHost));
         float mx = 0.f;
         for (float v : host) mx = std::max(mx, std::fabs(v));
+        w.wabs = mx;
         w.winf = 0.f;
         for (int r = 0; r < w.rows; ++r) {
             double rs = 0.0;
@@ -741,6 +758,43 @@ static int conv_pk(const ace_sfno* n, const Weight& w, const float* bias, const 
     return ACE_OK;
 }
 
+struct PkOpts {
+    // A: static tiled planes of `w`, or per-sample folded planes (fhi/flo with scale slot fslot)
+    const Weight* w = nullptr;
+    const void* fhi = nullptr; const void* flo = nullptr; const unsigned* fslot = nullptr; long f_stride = 0;
+    const float* bias = nullptr; long sbias = 0;
+    const void* bhi = nullptr; const void* blo = nullptr; int cin = 0; const unsigned* in_slot = nullptr;
+    float* out = nullptr; int cout = 0; unsigned* omax = nullptr;
+    const float* R = nullptr; long r_bs = 0; const float* rsc = nullptr; const float* rsh = nullptr;
+    int act = ACT_NONE;
+    void* ohi = nullptr; void* olo = nullptr; float cb = 0.f; unsigned* cslot = nullptr;
+    const unsigned* cinb = nullptr; const unsigned* rmax = nullptr;
+    float* part = nullptr;
+};
+static int conv_pk2(const ace_sfno* n, const PkOpts& o, int batch, hipStream_t s) {
+    Gemm4Args a;
+    if (o.fhi) {
+        a.Ahi = static_cast<const _Float16*>(o.fhi); a.Alo = static_cast<const _Float16*>(o.flo);
+        a.sA = o.f_stride; a.amax = o.fslot;
+    } else {
+        a.Ahi = reinterpret_cast<const _Float16*>(o.w->thi.p); a.Alo = reinterpret_cast<const _Float16*>(o.w->tlo.p);
+        a.sA = 0; a.ascale = o.w->ascale;
+    }
+    a.lda = o.w->pitch; a.a_tiled = 1;
+    a.Bhi = static_cast<const _Float16*>(o.bhi); a.Blo = static_cast<const _Float16*>(o.blo);
+    a.ldn = n->HW; a.sB = (long)o.cin * n->HW; a.bmax = o.in_slot;
+    a.C = o.out; a.ldc = n->HW; a.sC = (long)o.cout * n->HW; a.omax = o.omax;
+    a.Chi = static_cast<_Float16*>(o.ohi); a.Clo = static_cast<_Float16*>(o.olo); a.ldnc = n->HW; a.sCp = (long)o.cout * n->HW;
+    a.cw = o.w->winf; a.cb = o.cb; a.cslot = o.cslot; a.cinb = o.cinb; a.rmax = o.rmax;
+    a.part = reinterpret_cast<float4*>(o.part);
+    a.bias = o.bias; a.sbias = o.sbias;
+    a.R = o.R; a.ldr = n->HW; a.sR = o.r_bs; a.rsc = o.rsc; a.rsh = o.rsh; a.srs = o.rsc ? o.cout : 0;
+    a.M = o.cout; a.N = (int)n->HW; a.K = o.cin; a.nbatch = batch;
+    a.act = o.act == ACT_GELU ? ACT_GELU_FAST : o.act;
+    HIP_TRY(launch_gemm_f16x3_packed(a, s));
+    return ACE_OK;
+}
+
 // hipEvent stage timer: one event after each launch group; the elapsed time between consecutive events
 // is charged to the stage that just ended (the reference's CUDATimer children: fme/core/benchmark/timer.py:105-168,
 // conditional_sfno/sfnonet.py:388-437, s2convolutions.py:372-431).
@@ -792,7 +846,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     const long actB = (long)C * HW;  // per-sample stride of a C-channel activation
     auto W = [&](const std::string& name) { return n->w(name); };
     // dynamic-range slots of the f16x3 engine (AMAX_SHARDS words each): 0 network input, 1..7 encoder/decoder hidden,
-    // 8 + i block input h_i, 16 + 8 i + {0 X, 1 D, 2 E, 3 N0, 4 T, 5 N1, 6 U} of block i
+    // 8 + i block input h_i, 16 + 12 i + {0 X, 1 D, 2 E, 3 N0, 4 T, 5 N1, 6 U, 7 Y, 8 folded skip weight, 9 folded fc1 weight}
     const bool f16 = c.precision == 1;
     unsigned* amax = reinterpret_cast<unsigned*>(n->amax.p);
     auto slot = [&](int k) -> unsigned* { return f16 ? amax + (size_t)k * AMAX_SHARDS : nullptr; };
@@ -829,6 +883,15 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     float* sh1 = sc1 + (size_t)n->Bmax * C;
     const bool norm = c.normalization_layer == 1;
 
+    // fused-norm state of the packed-operand path: does P2 hold the block input in P format / `part_h` its statistics?
+    bool have_ph = false, have_hstats = false;
+    float* part_h = n->part.p;
+    float* part_t = n->part.p ? n->part.p + (size_t)n->Bmax * n->nstrips * C * 4 : nullptr;
+    _Float16* PAh = reinterpret_cast<_Float16*>(n->P.p);                  // T planes / pack fallback
+    _Float16* PAl = PAh ? PAh + (size_t)n->Bmax * C * HW : nullptr;
+    _Float16* PBh = reinterpret_cast<_Float16*>(n->P2.p);                 // h planes
+    _Float16* PBl = PBh ? PBh + (size_t)n->Bmax * C * HW : nullptr;
+
     // ---- blocks (sfnonet.py:217-252)
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string p = "blocks." + std::to_string(i) + ".";
@@ -837,12 +900,16 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         const bool scale_residual = (&fwd != &inv);  // grids differ (s2convolutions.py:82-86)
 
         // norm0 as an affine applied on load by every consumer (never materialised)
-        const int sb = 16 + 8 * i;  // slot base of this block
+        const int sb = 16 + 12 * i;  // slot base of this block
         if (f16 && i + 1 >= 8) HIP_TRY(launch_zero_u32(hslot(i + 1), AMAX_SHARDS, s));
         const float *a0 = nullptr, *b0 = nullptr;
         if (norm) {
-            HIP_TRY(launch_instnorm_stats(h, W(p + "norm0.weight"), W(p + "norm0.bias"), 1e-6f, B, C, HW, sc0, sh0, s,
-                                          slot(sb + 3)));
+            if (have_hstats)   // statistics of h came out of the previous block's fc2 epilogue
+                HIP_TRY(launch_instnorm_finalize(reinterpret_cast<const float4*>(part_h), gemm4_strips(C, (int)HW), B, C, HW,
+                                                 W(p + "norm0.weight"), W(p + "norm0.bias"), 1e-6f, sc0, sh0, slot(sb + 3), s));
+            else
+                HIP_TRY(launch_instnorm_stats(h, W(p + "norm0.weight"), W(p + "norm0.bias"), 1e-6f, B, C, HW, sc0, sh0, s,
+                                              slot(sb + 3)));
             a0 = sc0; b0 = sh0;
             MARK(ST_NORM0);
         }
@@ -881,7 +948,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         MARK(ST_CONTRACT);
         ACE_TRY(run_legendre_inverse(inv, n->E.p, n->X.p, N2, s, emax));
         MARK(ST_LEGENDRE_INV);
-        ACE_TRY(run_dft_inverse(inv, n->X.p, W(p + "filter.filter.bias"), n->Y.p, B, C, s));
+        ACE_TRY(run_dft_inverse(inv, n->X.p, W(p + "filter.filter.bias"), n->Y.p, B, C, s, slot(sb + 7)));
         MARK(ST_DFT_INV);
 
         // x = act(filter + inner_skip(residual))   (sfnonet.py:229-232)
@@ -893,7 +960,75 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         const bool pk = skip_f16 && packed_ok(n, C) && (!c.use_mlp || n->hid % 8 == 0);
         _Float16* Ph = reinterpret_cast<_Float16*>(n->P.p);
         _Float16* Pl = Ph + (size_t)n->Bmax * C * HW;
-        if (pk) {
+        const bool fused = pk && norm && c.use_mlp && n->P2.p != nullptr;
+        if (fused) {
+            // Packed-operand path with the instance norms fused away: every conv input is P-format planes written by
+            // its producer's epilogue, the norm affine is folded into the consumer's weights, the norm statistics come
+            // out of the producer's epilogue.  No pass over an activation other than the GEMMs themselves.
+            const Weight& ws = *n->weights[n->index.at(p + "inner_skip.weight")];
+            const Weight& bsw = *n->weights[n->index.at(p + "inner_skip.bias")];
+            const Weight& w1 = *n->weights[n->index.at(p + "mlp.fwd.0.weight")];
+            const Weight& b1w = *n->weights[n->index.at(p + "mlp.fwd.0.bias")];
+            const Weight& w2 = *n->weights[n->index.at(p + "mlp.fwd.2.weight")];
+            const Weight& b2w = *n->weights[n->index.at(p + "mlp.fwd.2.bias")];
+            const long cp = ws.pitch;
+            _Float16* F0h = reinterpret_cast<_Float16*>(n->Wp0.p);
+            const long f0s = (long)((C + 15) / 16 * 16) * cp;
+            _Float16* F0l = F0h + (size_t)n->Bmax * f0s;
+            _Float16* F1h = reinterpret_cast<_Float16*>(n->Wp1.p);
+            const long f1s = (long)((n->hid + 15) / 16 * 16) * cp;
+            _Float16* F1l = F1h + (size_t)n->Bmax * f1s;
+            _Float16* Uh = reinterpret_cast<_Float16*>(n->U.p);
+            _Float16* Ul = Uh + (size_t)n->Bmax * n->hid * HW;
+            const bool last = (i + 1 == c.num_layers);
+            // inner skip: T = act(Y + Ws norm0(h) + bs), written as P-format planes only (+ its row statistics)
+            PkOpts o;
+            o.w = &ws; o.cin = C; o.cout = C; o.act = act;
+            o.R = n->Y.p; o.r_bs = actB;
+            o.ohi = PAh; o.olo = PAl; o.cb = bsw.absmax; o.cslot = slot(sb + 4); o.cinb = slot(sb + 3); o.rmax = slot(sb + 7);
+            o.part = part_t;
+            if (have_ph) {   // h planes from the previous fc2; the affine goes into the weights
+                HIP_TRY(launch_fold_affine_f16(ws.buf.p, ws.pitch, ws.wabs, ra, rb, bsw.buf.p, F0h, F0l, n->bf0.p, B, C, C, cp,
+                                               f0s, slot(sb + 8), s));
+                o.fhi = F0h; o.flo = F0l; o.fslot = slot(sb + 8); o.f_stride = f0s;
+                o.bias = n->bf0.p; o.sbias = C;
+                o.bhi = PBh; o.blo = PBl; o.in_slot = hslot(i);
+            } else {         // first block: normalise + split h in one pass
+                ACE_TRY(pack_act(n, res, actB, C, ra, rb, skip_max, PBh, PBl, B, s));
+                o.bias = bsw.buf.p;
+                o.bhi = PBh; o.blo = PBl; o.in_slot = skip_max;
+            }
+            ACE_TRY(conv_pk2(n, o, B, s));
+            MARK(ST_INNER_SKIP);
+            // norm1 statistics -> affine -> folded fc1 weights
+            HIP_TRY(launch_instnorm_finalize(reinterpret_cast<const float4*>(part_t), gemm4_strips(C, (int)HW), B, C, HW,
+                                             W(p + "norm1.weight"), W(p + "norm1.bias"), 1e-6f, sc1, sh1, slot(sb + 5), s));
+            HIP_TRY(launch_fold_affine_f16(w1.buf.p, w1.pitch, w1.wabs, sc1, sh1, b1w.buf.p, F1h, F1l, n->bf1.p, B, n->hid, C,
+                                           cp, f1s, slot(sb + 9), s));
+            MARK(ST_NORM1);
+            PkOpts f1;
+            f1.w = &w1; f1.fhi = F1h; f1.flo = F1l; f1.fslot = slot(sb + 9); f1.f_stride = f1s;
+            f1.bias = n->bf1.p; f1.sbias = n->hid;
+            f1.bhi = PAh; f1.blo = PAl; f1.cin = C; f1.in_slot = slot(sb + 4);
+            f1.cout = n->hid; f1.act = act;
+            f1.ohi = Uh; f1.olo = Ul; f1.cb = b1w.absmax; f1.cslot = slot(sb + 6); f1.cinb = slot(sb + 5);
+            ACE_TRY(conv_pk2(n, f1, B, s));
+            MARK(ST_MLP_FC1);
+            PkOpts f2;
+            f2.w = &w2; f2.bias = b2w.buf.p;
+            f2.bhi = Uh; f2.blo = Ul; f2.cin = n->hid; f2.in_slot = slot(sb + 6);
+            f2.out = hn; f2.cout = C; f2.act = ACT_NONE;
+            f2.R = res; f2.r_bs = actB; f2.rsc = ra; f2.rsh = rb;
+            if (!last) {   // next block: h planes + statistics, bound instead of the true max in the h slot
+                f2.ohi = PBh; f2.olo = PBl; f2.cb = b2w.absmax; f2.cslot = hslot(i + 1); f2.rmax = slot(sb + 3);
+                f2.part = part_h;
+            } else {
+                f2.omax = hslot(i + 1);
+            }
+            ACE_TRY(conv_pk2(n, f2, B, s));
+            have_ph = have_hstats = !last;
+        } else if (pk) {
+            have_ph = have_hstats = false;
             const Weight& ws = *n->weights[n->index.at(p + "inner_skip.weight")];
             ACE_TRY(pack_act(n, res, actB, C, ra, rb, skip_max, Ph, Pl, B, s));
             ACE_TRY(conv_pk(n, ws, W(p + "inner_skip.bias"), Ph, Pl, C, skip_max, n->T.p, C, n->Y.p, actB, nullptr, nullptr,
@@ -903,16 +1038,18 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             ACE_TRY(conv(n, wskip, res, actB, C, nullptr, 0, -1, n->T.p, C, n->Y.p, actB, nullptr, nullptr, act, B, s,
                          skip_f16 ? ra : nullptr, skip_f16 ? rb : nullptr, skip_max, nullptr, slot(sb + 4)));
         }
-        MARK(ST_INNER_SKIP);
+        if (!fused) MARK(ST_INNER_SKIP);
         // norm1 -> MLP -> + residual   (sfnonet.py:234-250)
         const float *a1 = nullptr, *b1 = nullptr;
-        if (norm) {
+        if (norm && !fused) {
             HIP_TRY(launch_instnorm_stats(n->T.p, W(p + "norm1.weight"), W(p + "norm1.bias"), 1e-6f, B, C, HW, sc1, sh1, s,
                                           slot(sb + 5)));
             a1 = sc1; b1 = sh1;
             MARK(ST_NORM1);
         }
-        if (c.use_mlp && pk) {
+        if (fused) {
+            // done above
+        } else if (c.use_mlp && pk) {
             // fc1 reads norm1(T) packed; its epilogue writes U = act(.) straight in P format (bound-scaled), which fc2
             // consumes by DMA: the hidden activation never exists in fp32
             const Weight& w1 = *n->weights[n->index.at(p + "mlp.fwd.0.weight")];

@@ -77,8 +77,16 @@ struct Gemm4Args {
     const unsigned* bmax = nullptr;
     float* C = nullptr; long ldc = 0; long sC = 0;                 // fp32 output (optional when PK)
     _Float16* Chi = nullptr; _Float16* Clo = nullptr; long ldnc = 0; long sCp = 0;  // P-format output over rows of C
-    float cw = 0.f, cb = 0.f;                   // PK: |C| <= cw * bound(B) + cb; published to cslot, scale derived from it
+    // PK: |C| <= cw * bound(conv input) + cb + bound(residual); published to cslot, the output scale is derived from it.
+    // bound(conv input) is read from `cinb` (e.g. the bound of the NORMALISED input when the norm is folded into A)
+    // or, if null, from bmax; bound(residual) from `rmax` or 0
+    float cw = 0.f, cb = 0.f;
     unsigned* cslot = nullptr;
+    const unsigned* cinb = nullptr;
+    const unsigned* rmax = nullptr;
+    // optional per-row statistics of the final values, one float4 (sum, sum sq, min, max) per (batch, 64-column strip,
+    // row): part[((batch * tilesN * WN + strip) * M + row)]
+    float4* part = nullptr;
     unsigned* omax = nullptr;                   // fp32 output: atomicMax of bits(max|C|)
     const float* bias = nullptr; long sbias = 0;
     const float* R = nullptr; long ldr = 0; long sR = 0;
@@ -88,6 +96,7 @@ struct Gemm4Args {
     int act = ACT_NONE;
 };
 hipError_t launch_gemm_f16x3_packed(const Gemm4Args& a, hipStream_t s);
+int gemm4_strips(int M, int N);
 hipError_t launch_split_f16_tiled(const float* src, long lds_, void* hi, void* lo, long ldd, long rows, int cols,
                                   float scale, hipStream_t s);
 // fp32 [K][N] -> P-format planes with optional per-row affine; scale = 2^(12 - exponent(slot))
@@ -107,7 +116,7 @@ struct DftArgs {
     const float* sc = nullptr; const float* sh = nullptr;  // forward: per-(b,c) affine on x (fused instance norm)
     const float* bias = nullptr;                           // inverse: per-c bias added to the output
     int Bt = 1, C = 0, H = 0, W = 0, Mm = 0;
-    unsigned* omax = nullptr;  // forward: atomicMax of bits(max|X|)
+    unsigned* omax = nullptr;  // atomicMax of bits(max|output|)
 };
 hipError_t launch_dft_forward(const DftArgs& a, hipStream_t s);
 hipError_t launch_dft_inverse(const DftArgs& a, hipStream_t s);
@@ -116,6 +125,15 @@ hipError_t launch_dft_inverse(const DftArgs& a, hipStream_t s);
 //   scale = gamma[c] * rsqrt(var + eps),  shift = beta[c] - mean * scale   (biased var, fp64 accumulation)
 hipError_t launch_instnorm_stats(const float* x, const float* gamma, const float* beta, float eps, int Bt, int C,
                                  long HW, float* scale, float* shift, hipStream_t s, unsigned* omax = nullptr);
+
+// fused instance norm, second half: reduce Gemm4Args::part statistics to the per-(sample, channel) affine (+ bound)
+hipError_t launch_instnorm_finalize(const float4* part, int nparts, int Bt, int C, long HW, const float* gamma,
+                                    const float* beta, float eps, float* scale, float* shift, unsigned* omax,
+                                    hipStream_t s);
+// W diag(a) as tiled fp16 hi/lo planes + folded bias, bound published to wslot (see kernels.hip)
+hipError_t launch_fold_affine_f16(const float* W, long ldw, float wmax, const float* a, const float* b, const float* bias,
+                                  void* hi, void* lo, float* bf, int nsamples, int O, int I, long ldd, long sPl,
+                                  unsigned* wslot, hipStream_t s);
 
 // layout converters between the internal spectral layout and the reference's (n, L, M) complex64
 hipError_t launch_spec_to_ref(const float* D, float* out, int Bt, int C, int L, int Mm, hipStream_t s);

@@ -1413,6 +1413,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
     // dynamic-range slots: loaded now, reduced after the first DMAs are in flight
     const unsigned raw_a = q.amax ? slot_load(q.amax + lane) : 0u;
     const unsigned raw_b = q.bmax ? slot_load(q.bmax + lane) : 0u;
+    const unsigned raw_c = q.cinb ? slot_load(q.cinb + lane) : 0u;
+    const unsigned raw_r = q.rmax ? slot_load(q.rmax + lane) : 0u;
 
     // ---- DMA descriptors of this wave's pieces (fixed over the k loop)
     const _Float16* Ahi = q.Ahi + (long)batch * q.sA;
@@ -1569,7 +1571,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
     if (q.bmax) { bbound = wave_max(raw_b); inv_b = ldexpf(1.0f, -pow2_exponent_for(bbound)); }
     float cscale = 1.f;
     if (PK) {  // bound of this launch's output, identical in every workgroup; consumers read it from cslot
-        const float cbound = fmaf(q.cw, bbound, q.cb);
+        const float inb = q.cinb ? wave_max(raw_c) : bbound;      // bound of the (normalised) conv input
+        const float resb = q.rmax ? wave_max(raw_r) : 0.f;        // bound of the residual term
+        const float cbound = fmaf(q.cw, inb, q.cb) + resb;
         cscale = ldexpf(1.0f, pow2_exponent_for(cbound));
         if (tid == 0) atomicMax(q.cslot + (blockIdx.x & 63), __float_as_uint(cbound));
     }
@@ -1594,7 +1598,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
     }
     G4T(50);
 
-    // ---- epilogue
+    // ---- epilogue, through LDS: each wave parks its 64x64 tile (accumulator layout) in its own 16 KiB of the now idle
+    // operand buffers.  No barrier: all LDS reads of the main loop completed before its last barrier, and waves use
+    // disjoint regions.
+    //   phase 2 - read back row-contiguous (4 rows x 256 B per wave instruction): scales, bias, residual (16-byte loads),
+    //             activation; optional fp32 store (16 B per lane); optional per-row statistics of the final values
+    //             (sum, sum of squares, min, max over this wave's 64 columns -> `part`, reduced later by
+    //             instnorm_finalize_kernel: the fused instance norm of the NEXT layer needs no pass over the tensor);
+    //   phase 3 - optional P-format output: final values go back to LDS and are re-read 8 rows x 1 column per lane,
+    //             split hi/lo and stored as whole 16-byte entries (1 KiB per wave instruction).
     float vmax = 0.f;
     float* C = q.C ? q.C + (long)batch * q.sC : nullptr;
     const float* R = RES ? q.R + (long)batch * q.sR : nullptr;
@@ -1604,11 +1616,43 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
     const float* dummy = reinterpret_cast<const float*>(q.Ahi);
     const long ldc = q.ldc, ldr = q.ldr;
     const int actk = q.act;
-    if (!PK) {
-        // fp32 output through LDS: each wave parks its 64x64 tile (accumulator layout) in its own 16 KiB of the now idle
-        // operand buffers and reads it back row-contiguous, so that residual loads and stores are 16 B per lane
-        // (4 rows x 256 B per wave instruction instead of 2 rows x 128 B) - 4x fewer vector-memory instructions.
-        // No barrier: all LDS reads of the main loop completed before its last barrier, and waves use disjoint regions.
+    float4* part = q.part ? q.part + ((long)batch * tilesN * WN + (long)tile_n * WN + wn) * q.M : nullptr;
+    if (PK && !RES && !C && !part) {
+        // only the P-format output (fc1 -> hidden activation): park, then lane = column, 8 rows per 16-byte entry
+        float* Ts = reinterpret_cast<float*>(smem4) + wave * 4096;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Ts[(tm * 32 + acc_row(r, g)) * 64 + tn * 32 + i] = acc[tm][tn][r];
+        _Float16* Chi = q.Chi + (long)batch * q.sCp;
+        _Float16* Clo = q.Clo + (long)batch * q.sCp;
+        const int col = n0 + wn * 64 + lane;
+        const bool colok = col < N;
+        // the 64 row biases of this wave: one coalesced load, broadcast per row with v_readlane
+        const int brow = m0 + wm * 64 + lane;
+        const float bl = bias ? bias[brow < M ? brow : 0] : 0.f;
+#pragma unroll
+        for (int rg = 0; rg < 8; ++rg) {
+            const int rbase = m0 + wm * 64 + 8 * rg;
+            half8 hh, ll;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float bvs = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bl), 8 * rg + e));
+                const float x = act_apply(fmaf(Ts[(8 * rg + e) * 64 + lane] * inv_a, inv_b, bvs), actk) * cscale;
+                const _Float16 a = (_Float16)x;
+                hh[e] = a;
+                ll[e] = (_Float16)(x - (float)a);
+            }
+            if (rbase < M && colok) {
+                const long eo = ((long)(rbase >> 3) * q.ldnc + col) * 8;
+                *reinterpret_cast<half8*>(Chi + eo) = hh;
+                *reinterpret_cast<half8*>(Clo + eo) = ll;
+            }
+        }
+    } else {
         float* Ts = reinterpret_cast<float*>(smem4) + wave * 4096;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
@@ -1645,7 +1689,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
 #endif
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int row = m0 + wm * 64 + (lane >> 4) + 4 * j;
+            const int rl = (lane >> 4) + 4 * j;
+            const int row = m0 + wm * 64 + rl;
             float o[4] = {tv[j].x, tv[j].y, tv[j].z, tv[j].w};
             const float r4[4] = {RES ? rv[j].x : 0.f, RES ? rv[j].y : 0.f, RES ? rv[j].z : 0.f, RES ? rv[j].w : 0.f};
 #pragma unroll
@@ -1654,49 +1699,51 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
                 if (RES) v += fmaf(r4[e], rsv[j], rtv[j]);
                 o[e] = act_apply(v, actk);
             }
-            if (row < M && cok) {
-                *reinterpret_cast<float4*>(C + (long)row * ldc + colb) = make_float4(o[0], o[1], o[2], o[3]);
-                vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+            const bool ok = row < M && cok;
+            if (C && ok) *reinterpret_cast<float4*>(C + (long)row * ldc + colb) = make_float4(o[0], o[1], o[2], o[3]);
+            if (ok) vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+            if (PK) *reinterpret_cast<float4*>(Ts + rl * 64 + c4) = make_float4(o[0], o[1], o[2], o[3]);
+            if (part) {   // wave-uniform branch
+                float sm = ok ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f;
+                float sq = ok ? fmaf(o[0], o[0], o[1] * o[1]) + fmaf(o[2], o[2], o[3] * o[3]) : 0.f;
+                float mn = ok ? fminf(fminf(o[0], o[1]), fminf(o[2], o[3])) : 3.0e38f;
+                float mx = ok ? fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3])) : -3.0e38f;
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) {   // the 16 lanes that share this row
+                    sm += __shfl_xor(sm, off, 64);
+                    sq += __shfl_xor(sq, off, 64);
+                    mn = fminf(mn, __shfl_xor(mn, off, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+                }
+                if ((lane & 15) == 0 && row < M) part[row] = make_float4(sm, sq, mn, mx);
             }
         }
-    } else {
-        const int col0 = n0 + wn * 64 + i, col1 = col0 + 32;
-        const bool c0ok = col0 < N, c1ok = col1 < N;
-        _Float16* Chi = q.Chi + (long)batch * q.sCp;
-        _Float16* Clo = q.Clo + (long)batch * q.sCp;
+        if (PK) {
+            _Float16* Chi = q.Chi + (long)batch * q.sCp;
+            _Float16* Clo = q.Clo + (long)batch * q.sCp;
+            const int col = n0 + wn * 64 + lane;
+            const bool colok = col < N;
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
+            for (int rg = 0; rg < 8; ++rg) {
+                const int rbase = m0 + wm * 64 + 8 * rg;
+                half8 hh, ll;
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int rbase = m0 + wm * 64 + tm * 32 + 8 * qd + 4 * g;
-                float bv[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int rr = (rbase + e < M) ? rbase + e : 0;
-                    const float t0 = (bias ? bias : dummy)[bias ? rr : 0];
-                    bv[e] = bias ? t0 : 0.f;
+                for (int e = 0; e < 8; ++e) {
+                    const float x = Ts[(8 * rg + e) * 64 + lane] * cscale;
+                    const _Float16 a = (_Float16)x;
+                    hh[e] = a;
+                    ll[e] = (_Float16)(x - (float)a);
                 }
-                if (rbase < M) {  // M % 8 == 0: the 4-row group is wholly inside; 8-byte half entries
-                    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-                    half4 h0, l0, h1, l1;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x0 = act_apply(fmaf(acc[tm][0][4 * qd + e] * inv_a, inv_b, bv[e]), actk) * cscale;
-                        const float x1 = act_apply(fmaf(acc[tm][1][4 * qd + e] * inv_a, inv_b, bv[e]), actk) * cscale;
-                        const _Float16 a = (_Float16)x0, b = (_Float16)x1;
-                        h0[e] = a; l0[e] = (_Float16)(x0 - (float)a);
-                        h1[e] = b; l1[e] = (_Float16)(x1 - (float)b);
-                    }
-                    const long kgo = rbase >> 3;   // rbase = 8 (..) + 4 g
-                    const long e0 = (kgo * q.ldnc + col0) * 8 + 4 * g, e1 = (kgo * q.ldnc + col1) * 8 + 4 * g;
-                    if (c0ok) { *reinterpret_cast<half4*>(Chi + e0) = h0; *reinterpret_cast<half4*>(Clo + e0) = l0; }
-                    if (c1ok) { *reinterpret_cast<half4*>(Chi + e1) = h1; *reinterpret_cast<half4*>(Clo + e1) = l1; }
+                if (rbase < M && colok) {   // M % 8 == 0: the 8-row group is wholly inside
+                    const long eo = ((long)(rbase >> 3) * q.ldnc + col) * 8;
+                    *reinterpret_cast<half8*>(Chi + eo) = hh;
+                    *reinterpret_cast<half8*>(Clo + eo) = ll;
                 }
             }
         }
     }
     G4T(53);
-    if (q.omax && C) {
+    if (q.omax) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
         if (lane == 0) atomicMax(q.omax + (blockIdx.x & 63), __float_as_uint(vmax));
@@ -1791,11 +1838,18 @@ static hipError_t launch_gemm4_cfg(const Gemm4Args& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// number of 64-column strips (= statistics partials per row) the launcher's tile choice produces for an M x N problem
+int gemm4_strips(int M, int N) {
+    const long waste128 = (long)((M + 127) / 128) * 128, waste64 = (long)((M + 63) / 64) * 64;
+    const bool big = M >= 128 && waste128 <= waste64;
+    return big ? ((N + 127) / 128) * 2 : ((N + 255) / 256) * 4;
+}
 hipError_t launch_gemm_f16x3_packed(const Gemm4Args& a, hipStream_t s) {
     if (!al16(a.Ahi) || !al16(a.Alo) || !al16(a.Bhi) || !al16(a.Blo) || a.lda % 8 != 0 || a.sA % 8 != 0 || a.sB % 8 != 0)
         return hipErrorInvalidValue;
-    if (a.Chi && (a.M % 8 != 0 || a.R || a.C)) return hipErrorInvalidValue;   // P-format output: no fp32 copy, no residual
-    if (!a.Chi && (!a.C || !al16(a.C) || a.ldc % 4 != 0 || a.sC % 4 != 0 || a.N % 4 != 0)) return hipErrorInvalidValue;
+    if (a.Chi && (a.M % 8 != 0 || !a.cslot)) return hipErrorInvalidValue;
+    if (!a.Chi && !a.C) return hipErrorInvalidValue;
+    if (a.N % 4 != 0 || (a.C && (!al16(a.C) || a.ldc % 4 != 0 || a.sC % 4 != 0))) return hipErrorInvalidValue;
     if (a.R && (!al16(a.R) || a.ldr % 4 != 0 || a.sR % 4 != 0)) return hipErrorInvalidValue;
     const long waste128 = (long)((a.M + 127) / 128) * 128, waste64 = (long)((a.M + 63) / 64) * 64;
     if (a.M >= 128 && waste128 <= waste64) return launch_gemm4_cfg<2, 2>(a, s);
@@ -2151,6 +2205,7 @@ __global__ __launch_bounds__(256) void dft_inverse_kernel(DftArgs p, int tilesM,
     }
 
     const int w0c = n0 + i, w1c = n0 + 32 + i;
+    float vmax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int nn = nn0 + wave * 32 + acc_row(r, h);
@@ -2164,9 +2219,20 @@ __global__ __launch_bounds__(256) void dft_inverse_kernel(DftArgs p, int tilesM,
             const int w = tn == 0 ? w0c : w1c;
             if (w >= Kf) continue;
             const float pv = P[tn][r], qv = Q[tn][r];
-            yrow[w] = (pv + qv) + bv;
-            if (w != 0 && 2 * w != p.W) yrow[p.W - w] = (pv - qv) + bv;
+            const float ya = (pv + qv) + bv;
+            yrow[w] = ya;
+            vmax = fmaxf(vmax, fabsf(ya));
+            if (w != 0 && 2 * w != p.W) {
+                const float yb = (pv - qv) + bv;
+                yrow[p.W - w] = yb;
+                vmax = fmaxf(vmax, fabsf(yb));
+            }
         }
+    }
+    if (p.omax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        if ((tid & 63) == 0) atomicMax(p.omax + (blockIdx.x & 63), __float_as_uint(vmax));
     }
 }
 
@@ -2253,6 +2319,122 @@ __global__ __launch_bounds__(512) void instnorm_stats_kernel(const float* __rest
             atomicMax(omax + (plane & 63), __float_as_uint(bound));
         }
     }
+}
+
+// Second half of the fused instance norm: reduce the per-strip row statistics written by the producing GEMM's epilogue
+// (Gemm4Args::part) to the per-(sample, channel) affine, in fp64 and in a fixed order (deterministic).
+__global__ __launch_bounds__(512) void instnorm_finalize_kernel(const float4* __restrict__ part, int nparts, int C,
+                                                                long HW, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps,
+                                                                float* __restrict__ scale, float* __restrict__ shift,
+                                                                unsigned* omax) {
+    // one workgroup per 16 channels (256 contiguous bytes per strip): thread = (channel sub-index, strip residue of 32);
+    // strips are summed thread-strided in fp64, then across the 32 residues in a fixed tree order
+    const int b = blockIdx.y;
+    const int cs = threadIdx.x & 15, pr = threadIdx.x >> 4;   // 0..15, 0..31
+    const int c = blockIdx.x * 16 + cs;
+    double s = 0.0, ss = 0.0;
+    float lo = 3.0e38f, hi = -3.0e38f;
+    if (c < C) {
+        const float4* base = part + (long)b * nparts * C + c;
+#pragma unroll 4
+        for (int p = pr; p < nparts; p += 32) {
+            const float4 v = base[(long)p * C];
+            s += (double)v.x;
+            ss += (double)v.y;
+            lo = fminf(lo, v.z);
+            hi = fmaxf(hi, v.w);
+        }
+    }
+    __shared__ double rs[32][16], rss[32][16];
+    __shared__ float rlo[32][16], rhi[32][16];
+    rs[pr][cs] = s; rss[pr][cs] = ss; rlo[pr][cs] = lo; rhi[pr][cs] = hi;
+    __syncthreads();
+    if (pr == 0 && c < C) {
+        for (int k = 1; k < 32; ++k) {
+            s += rs[k][cs]; ss += rss[k][cs];
+            lo = fminf(lo, rlo[k][cs]); hi = fmaxf(hi, rhi[k][cs]);
+        }
+        const double mean = s / (double)HW;
+        double var = ss / (double)HW - mean * mean;  // biased variance
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double g = gamma ? (double)gamma[c] : 1.0;
+        const double bt = beta ? (double)beta[c] : 0.0;
+        const double sc = g * rstd;
+        const float a = (float)sc, bb = (float)(bt - mean * sc);
+        scale[(long)b * C + c] = a;
+        shift[(long)b * C + c] = bb;
+        if (omax) atomicMax(omax + ((b * C + c) & 63), __float_as_uint(fmaxf(fabsf(fmaf(lo, a, bb)), fabsf(fmaf(hi, a, bb)))));
+    }
+}
+hipError_t launch_instnorm_finalize(const float4* part, int nparts, int Bt, int C, long HW, const float* gamma,
+                                    const float* beta, float eps, float* scale, float* shift, unsigned* omax,
+                                    hipStream_t s) {
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((unsigned)((C + 15) / 16), (unsigned)Bt), dim3(512), 0, s, part, nparts,
+                       C, HW, gamma, beta, eps, scale, shift, omax);
+    return hipGetLastError();
+}
+
+// Instance-norm affine folded into the conv that consumes the normalised tensor, for the packed-operand engine:
+//   Wf[o][i] = W[o][i] * a[i]   -> fp16 hi/lo planes in A-tile order (split_f16_tiled layout), scaled by 2^(12 - exponent(bound))
+//   bf[o]    = bias[o] + sum_i W[o][i] * b[i]
+// bound = max|W| * max|a| is published to `wslot` (the GEMM derives the same scale from it).  One workgroup per 16 output
+// rows; per sample.
+__global__ __launch_bounds__(256) void fold_affine_f16_kernel(const float* __restrict__ W, long ldw, float wmax,
+                                                              const float* __restrict__ a, const float* __restrict__ b,
+                                                              const float* __restrict__ bias, _Float16* __restrict__ hi,
+                                                              _Float16* __restrict__ lo, float* __restrict__ bf, int O,
+                                                              int I, long ldd, long sPl, unsigned* wslot) {
+    // workgroup = (16 output rows, one 32-column stage, sample): 512 plane elements, two per thread
+    const int rb = blockIdx.x, st = blockIdx.y, smp = blockIdx.z;
+    const float* as = a + (long)smp * I;
+    const float* bs = b + (long)smp * I;
+    __shared__ float red[4];
+    float am = 0.f;
+    for (int i = threadIdx.x; i < I * (int)gridDim.z; i += 256) am = fmaxf(am, fabsf(a[i]));   // over ALL samples: one scale
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+    __syncthreads();
+    am = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float bound = wmax * am;
+    const float scale = ldexpf(1.0f, pow2_exponent_for(bound));
+    if (rb == 0 && st == 0 && threadIdx.x == 0) atomicMax(wslot + (smp & 63), __float_as_uint(bound));
+    const long nst = ldd / 32;
+    _Float16* ph = hi + (long)smp * sPl + ((long)rb * nst + st) * 512;
+    _Float16* pl = lo + (long)smp * sPl + ((long)rb * nst + st) * 512;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = threadIdx.x + 256 * u;
+        const int e = t & 7, ps = (t >> 3) & 3, r = t >> 5;
+        const long row = (long)rb * 16 + r;
+        const int ls = ps ^ ((int)(row >> 2) & 3);
+        const int c = st * 32 + ls * 8 + e;
+        float x = 0.f;
+        if (row < O && c < I) x = __builtin_amdgcn_fmed3f(W[row * ldw + c] * as[c] * scale, -65504.f, 65504.f);
+        const _Float16 h = (_Float16)x;
+        ph[t] = h;
+        pl[t] = (_Float16)(x - (float)h);
+    }
+    if (st == 0) {  // folded bias: 16 rows, 16 threads per row
+        const int r = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+        const long row = (long)rb * 16 + r;
+        float acc = 0.f;
+        if (row < O)
+            for (int i = l16; i < I; i += 16) acc = fmaf(W[row * ldw + i], bs[i], acc);
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (l16 == 0 && row < O) bf[(long)smp * O + row] = (bias ? bias[row] : 0.f) + acc;
+    }
+}
+hipError_t launch_fold_affine_f16(const float* W, long ldw, float wmax, const float* a, const float* b, const float* bias,
+                                  void* hi, void* lo, float* bf, int nsamples, int O, int I, long ldd, long sPl,
+                                  unsigned* wslot, hipStream_t s) {
+    if (ldd % 32 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fold_affine_f16_kernel, dim3((unsigned)((O + 15) / 16), (unsigned)(ldd / 32), (unsigned)nsamples), dim3(256), 0, s, W, ldw,
+                       wmax, a, b, bias, static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), bf, O, I, ldd, sPl, wslot);
+    return hipGetLastError();
 }
 
 hipError_t launch_instnorm_stats(const float* x, const float* gamma, const float* beta, float eps, int Bt, int C,
