@@ -14,6 +14,9 @@ from .sfno import SphericalFourierNeuralOperatorBuilder, SphericalFourierNeuralO
 from .packer import Packer  # noqa: F401
 from .normalizer import StandardNormalizer  # noqa: F401
 from .step import SingleModuleStep, SingleModuleStepConfig, StepArgs, StepOutput  # noqa: F401
+from .checkpoint import LoadedStepper, load_stepper  # noqa: F401
+from .corrector import AtmosphereCorrectorConfig  # noqa: F401
+from .ocean import OceanConfig  # noqa: F401
 from .stepper import Stepper  # noqa: F401
 
 __version__ = "0.1.0"

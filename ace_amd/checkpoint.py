@@ -1,0 +1,173 @@
+"""Checkpoint ingestion: build an ``ace_amd.Stepper`` from a checkpoint written by ``fme``.
+
+Follows ``load_stepper`` / ``Stepper.from_state`` (fme/ace/stepper/single_module.py:1909-1927, 1358-1429):
+
+    checkpoint = torch.load(path)["stepper"]
+    new format   {"config": {"step": {"type", "config"}, ...}, "dataset_info": {...}, "step": <step state>, ...}
+                 step type "single_module"/"default" (fme/core/step/single_module.py:48-49) possibly wrapped in
+                 "multi_call" (fme/core/step/multi_call.py:60-85, state {"wrapped_step": ...}: :330-345)
+    legacy       {"config": SingleModuleStepperConfig fields, "module": state_dict, "normalizer", "img_shape" |
+                 "data_shapes", ...}   (single_module.py:1370-1413)
+
+Module weights are loaded with the strict ``load_state_dict`` the reference uses (fme/core/registry/module.py:102-112);
+the "module." prefix of wrapped modules is accepted (fme/core/distributed/non_distributed.py:15-28).
+
+What is NOT carried over (and why) is returned in ``LoadedStepper.ignored``: training history, loss configuration,
+parameter-init configuration, derived forcings, input masking, vertical coordinate / gridded operations (only needed by
+the conservation correctors, which are outside the hot path).  Features that change the rollout and are not
+implemented raise ``NotImplementedError`` unless ``ignore_unsupported=True``.
+"""
+import dataclasses
+import datetime
+import pathlib
+from typing import Any, Dict, List, Mapping, Optional, Tuple, Union
+
+import torch
+
+from .dataset_info import DatasetInfo
+from .registry import ModuleSelector
+from .step import NormalizationConfig, SingleModuleStepConfig
+from .stepper import Stepper
+
+_STEP_TYPES = ("single_module", "default")
+
+
+@dataclasses.dataclass
+class LoadedStepper:
+    stepper: Stepper
+    config: SingleModuleStepConfig
+    dataset_info: DatasetInfo
+    ignored: List[str]
+
+
+def _img_shape_from_dataset_state(ds: Mapping[str, Any]) -> Tuple[int, int]:
+    """DatasetInfo.from_state (fme/core/dataset_info.py:291-345): img_shape, or the lat/lon sizes of the coordinates."""
+    if ds.get("img_shape") is not None:
+        return tuple(int(v) for v in ds["img_shape"])
+    hc = ds.get("horizontal_coordinates")
+    if hc is not None:
+        if "lat" in hc and "lon" in hc:                      # LatLonCoordinates.get_state (coordinates.py:708-709)
+            return (int(len(hc["lat"])), int(len(hc["lon"])))
+        raise NotImplementedError("HEALPix coordinates are outside the accelerated hot path")
+    go = ds.get("gridded_operations")
+    if go is not None and "state" in go and "area_weights" in go["state"]:
+        aw = go["state"]["area_weights"]
+        return (int(aw.shape[-2]), int(aw.shape[-1]))
+    raise ValueError("checkpoint dataset_info carries neither img_shape nor horizontal coordinates")
+
+
+def _timestep_from_dataset_state(ds: Mapping[str, Any]) -> datetime.timedelta:
+    ts = ds.get("timestep")
+    if ts is None:
+        return datetime.timedelta(hours=6)
+    if isinstance(ts, datetime.timedelta):
+        return ts
+    return datetime.timedelta(microseconds=int(ts))          # encode_timestep: integer microseconds (fme/core/dataset/utils.py)
+
+
+def _normalization_from_state(norm: Mapping[str, Any]) -> NormalizationConfig:
+    """NetworkAndLossNormalizationConfig (fme/core/normalizer.py:318-358) -> the network normaliser; also accepts a
+    bare NormalizationConfig / StandardNormalizer state {"means", "stds"}."""
+    if "network" in norm:
+        norm = norm["network"]
+    means, stds = norm.get("means"), norm.get("stds")
+    if not means or not stds:
+        raise ValueError("checkpoint normalization carries no loaded means/stds (newer checkpoints embed them: "
+                         "StepperConfig.as_loaded_dict, single_module.py:582-584)")
+    f = lambda v: float(v.item()) if isinstance(v, torch.Tensor) else float(v)
+    return NormalizationConfig(means={k: f(v) for k, v in means.items()}, stds={k: f(v) for k, v in stds.items()})
+
+
+def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool = False):
+    """-> (SingleModuleStepConfig, DatasetInfo, module state dict, list of ignored items)."""
+    ignored: List[str] = []
+    cfg = state["config"]
+    if "step" in cfg:                                         # ---- new format
+        sel = cfg["step"]
+        step_type, step_cfg = sel["type"], dict(sel["config"])
+        step_state = state["step"]
+        if step_type == "multi_call":
+            if step_cfg.get("config") is not None:
+                if not ignore_unsupported:
+                    raise NotImplementedError("multi-call diagnostics are outside the accelerated hot path")
+                ignored.append("multi_call")
+            inner = step_cfg["wrapped_step"]
+            step_type, step_cfg = inner["type"], dict(inner["config"])
+            step_state = step_state["wrapped_step"]
+        if step_type not in _STEP_TYPES:
+            raise NotImplementedError(f"step type '{step_type}' is outside the accelerated hot path")
+        for k in ("input_masking", "derived_forcings"):
+            v = cfg.get(k)
+            if v not in (None, {}, {"insolation": None}):
+                ignored.append(k)
+        ds_state = state["dataset_info"]
+        normalization = _normalization_from_state(step_cfg["normalization"])
+    else:                                                     # ---- legacy single-module stepper
+        step_cfg = dict(cfg)
+        for k in ("parameter_init", "loss", "loss_normalization", "residual_normalization", "multi_call",
+                  "include_multi_call_in_loss", "crps_training"):
+            if step_cfg.pop(k, None) not in (None, {}, True, False):
+                ignored.append(k)
+        step_state = {"module": state["module"]}
+        ds_state = {"timestep": state.get("encoded_timestep")}
+        if "img_shape" in state:
+            ds_state["img_shape"] = state["img_shape"]
+        else:
+            for shape in state.get("data_shapes", {}).values():
+                if len(shape) == 4:
+                    ds_state["img_shape"] = shape[-2:]
+                    break
+        norm_state = state.get("normalizer", state.get("normalization"))
+        if norm_state is None:
+            raise ValueError(f"No normalizer state found, keys include {list(state.keys())}")
+        normalization = _normalization_from_state(norm_state)
+    step_cfg.pop("crps_training", None)
+    step_cfg.pop("normalization", None)
+    builder = step_cfg.pop("builder")
+    unsupported = []
+    for k in ("secondary_decoder", "global_mean_removal", "input_dropout"):
+        if step_cfg.get(k) is not None:
+            unsupported.append(k)
+    if step_cfg.get("include_channel_mask_inputs"):
+        unsupported.append("include_channel_mask_inputs")
+    if unsupported and not ignore_unsupported:
+        raise NotImplementedError("step options outside the accelerated hot path: " + ", ".join(unsupported))
+    for k in unsupported:
+        ignored.append(k)
+        step_cfg[k] = None if k != "include_channel_mask_inputs" else False
+    known = {f.name for f in dataclasses.fields(SingleModuleStepConfig)}
+    unknown = set(step_cfg) - known
+    if unknown:
+        raise ValueError(f"unknown step config fields: {sorted(unknown)}")
+    config = SingleModuleStepConfig(builder=ModuleSelector(type=builder["type"], config=dict(builder["config"])),
+                                    normalization=normalization, **step_cfg)
+    missing = config.corrector.unsupported()
+    if missing:
+        if not ignore_unsupported:
+            raise NotImplementedError("corrector options outside the accelerated hot path (need area weights / "
+                                      "vertical coordinate): " + ", ".join(missing))
+        ignored.extend(f"corrector.{m}" for m in missing)
+        config._ignore_unsupported = True
+    for k in ("vertical_coordinate", "gridded_operations", "mask_provider", "variable_metadata"):
+        if ds_state.get(k) is not None:
+            ignored.append(f"dataset_info.{k}")
+    labels = ds_state.get("all_labels") or None
+    dataset_info = DatasetInfo(_img_shape_from_dataset_state(ds_state), all_labels=set(labels) if labels else None,
+                               timestep=_timestep_from_dataset_state(ds_state))
+    if state.get("training_history"):
+        ignored.append("training_history")
+    return config, dataset_info, step_state, ignored
+
+
+def load_stepper(checkpoint: Union[str, pathlib.Path, Mapping[str, Any]], device=None,
+                 ignore_unsupported: bool = False) -> LoadedStepper:
+    """``fme.ace.stepper.load_stepper`` for the accelerated stepper.  ``checkpoint``: a path (torch.load) or the
+    already-loaded dict; either the whole checkpoint ({"stepper": ...}) or the stepper state itself."""
+    if not isinstance(checkpoint, Mapping):
+        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+    state = checkpoint["stepper"] if "stepper" in checkpoint else checkpoint
+    config, dataset_info, step_state, ignored = stepper_config_from_state(state, ignore_unsupported)
+    stepper = Stepper.from_config(config, dataset_info, device=device)
+    stepper.load_state({"step": step_state})
+    stepper.set_eval()
+    return LoadedStepper(stepper=stepper, config=config, dataset_info=dataset_info, ignored=ignored)

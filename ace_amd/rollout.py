@@ -26,6 +26,8 @@ class RolloutEngine:
         cfg = step.config
         if cfg.residual_prediction or cfg.prescribed_prognostic_names:
             raise NotImplementedError("residual_prediction / prescribed prognostics are not lowered into the engine")
+        if step._corrector is not None or step._ocean is not None:
+            raise NotImplementedError("corrector / ocean post-step hooks are not lowered into the engine; use Stepper")
         self.stepper = stepper
         self.net = step.module.torch_module
         self.B, self.T = batch, n_forward_steps

@@ -79,9 +79,22 @@ class SingleModuleStepConfig:
     input_dropout: Any = None
 
     def __post_init__(self):
-        for field in ("secondary_decoder", "ocean", "corrector", "global_mean_removal", "input_dropout"):
+        from .corrector import AtmosphereCorrectorConfig
+        from .ocean import OceanConfig
+        for field in ("secondary_decoder", "global_mean_removal", "input_dropout"):
             if getattr(self, field) is not None:
                 raise NotImplementedError(f"SingleModuleStepConfig.{field} is outside the accelerated hot path")
+        # ocean / corrector: dataclass instances or their state dicts (as found in a checkpoint's step config)
+        if isinstance(self.ocean, dict):
+            self.ocean = OceanConfig.from_state(self.ocean)
+        if self.ocean is not None and not isinstance(self.ocean, OceanConfig):
+            raise NotImplementedError("SingleModuleStepConfig.ocean must be an OceanConfig (prescribed SST) or its state")
+        if self.ocean is not None and self.ocean.slab is not None:
+            raise NotImplementedError("the slab ocean is outside the accelerated hot path")
+        if not isinstance(self.corrector, (AtmosphereCorrectorConfig, dict, type(None))):
+            raise NotImplementedError("SingleModuleStepConfig.corrector must be an AtmosphereCorrectorConfig or its state")
+        if self.corrector is None or isinstance(self.corrector, dict):
+            self.corrector = AtmosphereCorrectorConfig.from_state(self.corrector)
         if self.include_channel_mask_inputs:
             raise NotImplementedError("include_channel_mask_inputs is outside the accelerated hot path")
         for name in self.prescribed_prognostic_names:
@@ -103,7 +116,9 @@ class SingleModuleStepConfig:
 
     @property
     def input_names(self) -> List[str]:
-        return self.in_names
+        if self.ocean is None:
+            return self.in_names
+        return list(set(self.in_names).union(self.ocean.forcing_names))
 
     @property
     def output_names(self) -> List[str]:
@@ -115,8 +130,10 @@ class SingleModuleStepConfig:
 
     @property
     def next_step_input_names(self) -> List[str]:
-        input_only = set(self.input_names).difference(self.output_names)
-        return list(set(input_only).union(self.prescribed_prognostic_names))
+        result = set(self.input_names).difference(self.output_names)
+        if self.ocean is not None:
+            result = result.union(self.ocean.forcing_names)
+        return list(result.union(self.prescribed_prognostic_names))
 
     def get_next_step_forcing_names(self) -> List[str]:
         return self.next_step_forcing_names
@@ -131,8 +148,9 @@ def step_with_adjustments(input: TensorMapping, next_step_input_data: TensorMapp
                           network_calls: Callable[[TensorDict], TensorDict], normalizer: StandardNormalizer,
                           residual_prediction: bool, prognostic_names: List[str],
                           prescribed_prognostic_names: Optional[List[str]] = None,
-                          stepper_state=None) -> StepOutput:
-    """single_module.py:595-733 with corrector=None, ocean=None, global_mean_removal=None."""
+                          stepper_state=None, corrector=None, ocean=None) -> StepOutput:
+    """single_module.py:595-733 with global_mean_removal=None: normalise, network, (residual), denormalise, corrector,
+    ocean, prescribed prognostics - in the reference's order (single_module.py:669-716)."""
     if prescribed_prognostic_names is None:
         prescribed_prognostic_names = []
     input_norm = normalizer.normalize(input)
@@ -140,6 +158,10 @@ def step_with_adjustments(input: TensorMapping, next_step_input_data: TensorMapp
     if residual_prediction:
         output_norm = {**output_norm, **{k: input_norm[k] + output_norm[k] for k in prognostic_names}}
     output = normalizer.denormalize(output_norm)
+    if corrector is not None:
+        output = corrector(input, output, next_step_input_data)
+    if ocean is not None:
+        output = ocean(input, output, next_step_input_data)
     for name in prescribed_prognostic_names:
         if name in next_step_input_data:
             output = {**output, name: next_step_input_data[name]}
@@ -168,6 +190,10 @@ class SingleModuleStep:
         init_weights(self.modules)
         self._img_shape = dataset_info.img_shape
         self._config = config
+        self._corrector = config.corrector.get_corrector(dataset_info,
+                                                         ignore_unsupported=getattr(config, "_ignore_unsupported", False))
+        self._ocean = (config.ocean.build(list(config.in_names), list(config.out_names), dataset_info.timestep)
+                       if config.ocean is not None else None)
         self._timestep = dataset_info.timestep
         self.in_names = config.in_names
         self.out_names = config.out_names
@@ -217,7 +243,7 @@ class SingleModuleStep:
             normalizer=self.normalizer, residual_prediction=self._config.residual_prediction,
             prognostic_names=self.prognostic_names,
             prescribed_prognostic_names=self._config.prescribed_prognostic_names,
-            stepper_state=args.stepper_state,
+            stepper_state=args.stepper_state, corrector=self._corrector, ocean=self._ocean,
         )
 
     def get_state(self):

@@ -199,6 +199,9 @@ def test_step_config_validation_and_names():
                                        prescribed_prognostic_names=["zz"])
     with pytest.raises(NotImplementedError):
         ace_amd.SingleModuleStepConfig(builder=b, in_names=["a"], out_names=["a"], normalization=norm, ocean=object())
+    with pytest.raises(NotImplementedError):
+        ace_amd.SingleModuleStepConfig(builder=b, in_names=["a"], out_names=["a"], normalization=norm,
+                                       secondary_decoder={"x": 1})
 
 
 def test_stepper_loop_bookkeeping_with_a_stub_module():

@@ -15,13 +15,15 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_base_unifor
 
 // region_floats: size of the region each XCD-group of workgroups cycles through
 template <int MODE>  // 0 = LDS-DMA, 1 = VGPR loads
-__global__ __launch_bounds__(256) void probe(const float* __restrict__ src, long region_floats, int iters, float* sink) {
+__global__ __launch_bounds__(256) void probe(const float* __restrict__ src, long region_floats, int iters, float* sink, int share) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long base = ((long)blockIdx.x * 8192) % region_floats;  // each WG starts at a different 32 KB offset
+    // `share` workgroups (consecutive ids on one XCD: ids congruent mod 8) stream the SAME addresses
+    const long grp = ((long)(blockIdx.x >> 3) / share) * 8 + (blockIdx.x & 7);
+    const long base = (grp * 8192 * 64) % region_floats;  // distinct groups are 2 MiB apart
     float4 acc = {0, 0, 0, 0};
     for (int it = 0; it < iters; ++it) {
-        const long off = (base + (long)it * 8192) % region_floats;   // 32 KB per iteration per WG
+        const long off = (base + (long)it * 8192) % region_floats;   // 32 KB per iteration per WG (iters * 32 KB <= 2 MiB apart)
         const float* p = src + off + wave * 2048 + lane * 4;          // wave: 8 KB = 8 pieces of 1 KB
         if (MODE == 0) {
 #pragma unroll
@@ -48,23 +50,23 @@ int main() {
     hipMemset(src, 0, total * sizeof(float));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    const int iters = 200;
-    const long regions[] = {1L << 18 /*1 MiB*/, 1L << 20 /*4 MiB*/, 1L << 24 /*64 MiB*/, 1L << 27 /*512 MiB*/};
-    for (int wgs_per_cu = 1; wgs_per_cu <= 2; ++wgs_per_cu)
+    const int iters = 60;
+    const long regions[] = {1L << 24 /*64 MiB*/, 1L << 28 /*1 GiB: the whole buffer*/};
+    for (int share : {1, 2, 3, 6})
         for (long reg : regions)
-            for (int mode = 0; mode < 2; ++mode) {
+            for (int mode = 0; mode < 1; ++mode) {
+                const int wgs_per_cu = 2;
                 const int grid = 256 * wgs_per_cu;
                 for (int rep = 0; rep < 2; ++rep) {
                     hipEventRecord(e0);
-                    if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(grid), dim3(256), 65536, 0, src, reg, iters, sink);
-                    else hipLaunchKernelGGL(probe<1>, dim3(grid), dim3(256), 65536, 0, src, reg, iters, sink);
+                    hipLaunchKernelGGL(probe<0>, dim3(grid), dim3(256), 65536, 0, src, reg, iters, sink, share);
                     hipEventRecord(e1);
                     hipEventSynchronize(e1);
                 }
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 const double bytes = (double)grid * iters * 32768.0;
-                printf("wg/cu %d region %6ld KiB mode %s: %.1f us  %.2f TB/s  %.1f B/clk/CU @2.1GHz\n", wgs_per_cu, reg * 4 / 1024,
-                       mode == 0 ? "lds-dma" : "vgpr   ", ms * 1e3, bytes / ms / 1e9, bytes / (ms * 1e-3) / 256 / 2.1e9);
+                printf("share %d region %6ld KiB lds-dma: %.1f us  %.2f TB/s into CUs  %.1f B/clk/CU @2.1GHz  (distinct bytes %.2f TB/s)\n", share, reg * 4 / 1024,
+                       ms * 1e3, bytes / ms / 1e9, bytes / (ms * 1e-3) / 256 / 2.1e9, bytes / share / ms / 1e9);
             }
     return 0;
 }

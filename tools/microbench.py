@@ -91,3 +91,18 @@ if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1].startswith("h")
         conv16(768, 384, 64800, 1, 3, "f16x3 fc1")
     if which in ("hfc2", "hall"):
         conv16(384, 768, 64800, 0, 3, "f16x3 fc2")
+
+
+def mlp16(cin, hid, cout, hw, iters):
+    L = _lib.lib()
+    g = lambda *s: torch.randn(*s, device=dev)
+    x, w1, b1, w2, b2 = g(1, cin, hw), g(hid, cin) * 0.05, g(hid) * 0.1, g(cout, hid) * 0.05, g(cout) * 0.1
+    y = torch.empty(1, cout, hw, device=dev)
+    for _ in range(iters):
+        _lib.check(L.ace_mlp_f16x3(*[_lib.ptr(v) for v in (x, w1, b1, w2, b2, y)], 1, cin, hid, cout, hw, 1, _lib.current_stream()))
+    torch.cuda.synchronize()
+    print("packed mlp done (time it from the kernel trace)")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pmlp":
+    mlp16(384, 768, 384, 64800, 3)
