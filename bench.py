@@ -176,7 +176,7 @@ MEASURED_TRAFFIC = {}
 try:
     import json as _json
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as _f:
-        MEASURED_TRAFFIC = {tuple(k.split("|")): v for k, v in _json.load(_f).items()}
+        MEASURED_TRAFFIC = {tuple(k.split("|")): v for k, v in _json.load(_f).items() if not k.startswith("_")}
 except (OSError, ValueError):
     pass
 
