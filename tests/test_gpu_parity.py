@@ -232,6 +232,33 @@ def test_block_taps_vs_oracle(dev, precision):
     assert rel_max(y, ref) <= NET_TOL
 
 
+@pytest.mark.parametrize("offset", [0.0, 4.0])
+def test_packed_fused_path_vs_oracle(dev, precision, offset):
+    """The packed-operand path with fused instance norms (P-format planes from the producers' epilogues, norm affine
+    folded into tiled fp16 weights, statistics from the epilogue partials): C % 8 == 0 and H*W % 4 == 0, batch 3,
+    4 blocks (blocks 1.. take h in P format from the previous fc2), random norm gains/offsets, and an input with a
+    large mean (the folded affine then cancels a big constant) - per-block taps against the fp64 oracle."""
+    from oracle.sfno import SFNOConfig, SFNOOracle, init_state
+    cfg = SFNOConfig(in_chans=5, out_chans=4, img_shape=(24, 48), embed_dim=32, num_layers=4, operator_type="dhconv")
+    state = init_state(cfg, seed=11)
+    g = torch.Generator().manual_seed(12)
+    for k in state:
+        if ".norm" in k and k.endswith("weight"):
+            state[k] = 1.0 + 0.3 * torch.randn(state[k].shape, generator=g)
+        if ".norm" in k and k.endswith("bias"):
+            state[k] = 0.2 * torch.randn(state[k].shape, generator=g)
+    x = torch.randn(3, 5, 24, 48, generator=g) * 0.7 + offset
+    net = build_native_net(cfg, state, dev, precision)
+    with torch.no_grad():
+        y, taps = net.forward_with_taps(x.to(dev))
+        y2 = net(x.to(dev))
+    assert torch.equal(y, y2)
+    ref, rtaps = SFNOOracle(cfg, state, dtype=torch.float64).forward(x, return_blocks=True)
+    for i, rt in enumerate(rtaps):
+        assert rel_max(taps[i + 1], rt) <= NET_TOL, f"block {i}: {rel_max(taps[i + 1], rt)}"
+    assert rel_max(y, ref) <= NET_TOL
+
+
 def test_graph_replay_matches_eager(dev, precision):
     from oracle.sfno import SFNOConfig, init_state
     cfg = SFNOConfig(in_chans=4, out_chans=4, img_shape=(24, 48), embed_dim=16, num_layers=2, operator_type="dhconv")
