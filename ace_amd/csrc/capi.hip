@@ -87,6 +87,7 @@ struct ace_sht_plan {
     // f16x3 mode: hi/lo fp16 planes of wt / pt (same pitches, in halves) scaled by a power of two
     DevBuf wt_hi, wt_lo, pt_hi, pt_lo;
     float wt_scale = 1.f, pt_scale = 1.f;
+    float wt_winf = 0.f;   // max over (m, l) of sum_k |wt[m][l][k]|: |Legendre-forward output| <= wt_winf * max|X|
     bool f16 = false;
 };
 
@@ -115,6 +116,11 @@ static int plan_build(int nlat, int nlon, int lmax, int mmax, Grid g, std::uniqu
     if (f16) {
         p->f16 = true;
         p->wt_scale = pow2_scale_for(t.wt);
+        for (size_t r = 0; r < (size_t)t.mmax * t.lmax; ++r) {
+            double rs = 0.0;
+            for (int k = 0; k < t.nlat; ++k) rs += std::fabs((double)t.wt[r * t.Hp + k]);
+            p->wt_winf = std::max(p->wt_winf, (float)(rs * (1.0 + 1e-6)));
+        }
         p->pt_scale = pow2_scale_for(t.pt);
         const size_t hw = (t.wt.size() + 1) / 2, hp = (t.pt.size() + 1) / 2;
         HIP_TRY(p->wt_hi.alloc(hw, false)); HIP_TRY(p->wt_lo.alloc(hw, false));
@@ -148,14 +154,23 @@ static int run_dft_inverse(const ace_sht_plan& pl, const float* X, const float* 
 }
 // D[l][m][n2] = sum_k wt[m][l][k] X[m][k][n2]   (sht_fix.py:134-138), batched over m, rows l >= m only
 static int run_legendre_forward(const ace_sht_plan& pl, const float* X, float* D, long N2, hipStream_t s,
-                                const unsigned* xmax = nullptr, unsigned* dmax = nullptr) {
+                                const unsigned* xmax = nullptr, unsigned* dmax = nullptr, bool planes = false) {
     GemmArgs g;
-    g.omax = dmax;
+    g.omax = planes ? nullptr : dmax;
     g.A = pl.wt.p; g.lda = pl.Hp; g.sA = (long)pl.lmax * pl.Hp;
     g.B = X; g.ldb = N2; g.sB = (long)pl.nlat * N2;
     g.C = D; g.ldc = (long)pl.mmax * N2; g.sC = N2;
     g.M = pl.lmax; g.N = (int)N2; g.K = pl.nlat; g.nbatch = pl.mmax; g.a_kpad = pl.Hp;
     g.tri = TRI_ROWS_GE_BATCH;
+    if (planes) {
+        // D as fp16 hi/lo planes in D's own layout [l][m][n2] (the buffer holds two planes instead of one fp32 tensor):
+        // the dhconv contracts over n2's channel index, so this IS the v4 engine's A operand.  dmax receives the bound.
+        if (!(pl.f16 && xmax && dmax && gemm_f16x3_eligible(g))) return fail(ACE_ERR_STATE, "legendre planes path not eligible");
+        _Float16* Dh = reinterpret_cast<_Float16*>(D);
+        _Float16* Dl = Dh + (size_t)pl.lmax * pl.mmax * N2;
+        HIP_TRY(launch_gemm_f16x3_planes(g, pl.wt_hi.p, pl.wt_lo.p, pl.wt_scale, xmax, Dh, Dl, pl.wt_winf, dmax, s));
+        return ACE_OK;
+    }
     if (pl.f16 && xmax && gemm_f16x3_eligible(g)) {
         HIP_TRY(launch_gemm_f16x3(g, pl.wt_hi.p, pl.wt_lo.p, pl.wt_scale, 1.f, s, xmax, dmax));
         return ACE_OK;
@@ -917,7 +932,11 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         unsigned *xmax = slot(sb + 0), *dmax = slot(sb + 1), *emax = slot(sb + 2);
         ACE_TRY(run_dft_forward(fwd, h, a0, b0, n->X.p, B, C, s, xmax));
         MARK(ST_DFT_FWD);
-        ACE_TRY(run_legendre_forward(fwd, n->X.p, n->D.p, N2, s, xmax, dmax));
+        // packed dhconv: D goes from the Legendre epilogue to the filter GEMM as fp16 planes (never fp32)
+        static const bool no_pk_sht = getenv("ACE_NO_PK_SHT") != nullptr;   // A/B switch for measurements
+        const bool dplanes = f16 && !no_pk_sht && c.operator_type == 1 && n->wx_hi[i].p && !scale_residual && fwd.f16 &&
+                             N2 % 4 == 0 && (2 * C) % 32 == 0;
+        ACE_TRY(run_legendre_forward(fwd, n->X.p, n->D.p, N2, s, xmax, dmax, dplanes));
         MARK(ST_LEGENDRE_FWD);
         const float* res = h;           // residual = x_norm, applied as (h, a0, b0)
         const float *ra = a0, *rb = b0;
@@ -936,7 +955,19 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             g.M = n->Mm * B; g.N = 2 * C; g.K = 2 * C; g.nbatch = n->L; g.a_kpad = 2 * C;
             g.tri = TRI_ROWS_LE_BATCH; g.trimul = B;
             g.omax = emax;
-            if (f16 && n->wx_hi[i].p) {
+            if (dplanes) {
+                Gemm4Args a;
+                a.Ahi = reinterpret_cast<const _Float16*>(n->D.p);
+                a.Alo = a.Ahi + (size_t)n->L * n->Mm * N2;
+                a.lda = 2 * C; a.sA = (long)n->Mm * N2; a.amax = dmax;
+                a.Bhi = reinterpret_cast<const _Float16*>(n->wx_hi[i].p);
+                a.Blo = reinterpret_cast<const _Float16*>(n->wx_lo[i].p);
+                a.ldn = 2 * C; a.sB = (long)2 * C * 2 * C; a.bscale = n->wx_scale[i];
+                a.C = n->E.p; a.ldc = 2 * C; a.sC = (long)n->Mm * N2; a.omax = emax;
+                a.M = n->Mm * B; a.N = 2 * C; a.K = 2 * C; a.nbatch = n->L;
+                a.tri = TRI_ROWS_LE_BATCH; a.trimul = B;
+                HIP_TRY(launch_gemm_f16x3_packed(a, s));
+            } else if (f16 && n->wx_hi[i].p) {
                 HIP_TRY(launch_gemm_f16x3_adyn(g, n->wx_hi[i].p, n->wx_lo[i].p, 2 * C, (long)2 * C * 2 * C, n->wx_scale[i],
                                                dmax, emax, s));
             } else {

@@ -54,6 +54,10 @@ constexpr int AMAX_SHARDS = 64;
 hipError_t launch_gemm_f16x3(const GemmArgs& g, const void* Ahi, const void* Alo, float ascale, float bscale,
                              hipStream_t s, const unsigned* bmax = nullptr, unsigned* omax = nullptr,
                              const unsigned* bmax2 = nullptr);
+// same engine, C written as fp16 hi/lo planes in C's row-major layout (the v4 engine's A format), scaled from the bound
+// cw * bound(B) which is published to cslot
+hipError_t launch_gemm_f16x3_planes(const GemmArgs& g, const void* Ahi, const void* Alo, float ascale, const unsigned* bmax,
+                                    void* Chi, void* Clo, float cw, unsigned* cslot, hipStream_t s);
 // Mirrored roles: A = fp32 activations (row-major, split on the fly, scale from the `amax` slot), B = static operand
 // pre-packed as fp16 hi/lo planes [batch][K/8][ldn][8] scaled by the power of two `bscale_static`.
 hipError_t launch_gemm_f16x3_adyn(const GemmArgs& g, const void* Bhi, const void* Blo, long ldn, long sB_halves,

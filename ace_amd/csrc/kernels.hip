@@ -47,6 +47,14 @@ DEVINL unsigned slot_load(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// power of two that maps a bound to [2^11, 2^12) (fp16 keeps 11 more bits below; lo parts stay normal for every
+// element within 2^-13 of the bound and lose absolute, not relative, accuracy below that)
+DEVINL int pow2_exponent_for(float mx) {
+    int e = 0;
+    if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &e); e = 12 - e; }
+    return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+
 DEVINL float act_apply(float v, int act) {
     switch (act) {
         case ACT_GELU_FAST: return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
@@ -661,6 +669,12 @@ struct Gemm3Args {
     const unsigned* bmax = nullptr;
     const unsigned* bmax2 = nullptr;  // optional second source (B2 of the concat)
     unsigned* omax = nullptr;   // if set: atomicMax of the bit pattern of max|C| over this launch (64 shards)
+    // optional: write C as two fp16 planes (hi, lo) in C's own row-major layout instead of fp32 - the "A format" of the
+    // v4 engine (the consumer contracts over C's columns).  Scaled by 2^(12 - exponent(cw * bound(B))), bound published
+    // to cslot.  Vector epilogue only (N % 4 == 0, ldc % 4 == 0).
+    _Float16* Chi = nullptr; _Float16* Clo = nullptr;
+    float cw = 0.f;
+    unsigned* cslot = nullptr;
 };
 
 constexpr int G3_KAFF = 1024;  // largest K whose per-row affine is kept in LDS by the f16x3 engine
@@ -709,12 +723,14 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = (K - kbeg + BKT - 1) / BKT;
     float bscale_k = q.bscale, oscale_k = q.oscale;
+    float bbound_k = 0.f;
     if (q.bmax) {  // power of two that puts max|B| in [2^11, 2^12): exact to undo, no overflow, lo parts stay normal
         float mx = __uint_as_float(slot_load(q.bmax + lane));  // 64 shards (one per producer workgroup residue), reduce in the wave
         if (q.bmax2) mx = fmaxf(mx, __uint_as_float(slot_load(q.bmax2 + lane)));
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
         mx = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mx)));
+        bbound_k = mx;
         int e = 0;
         if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &e); e = 12 - e; }
         e = e > 100 ? 100 : (e < -100 ? -100 : e);
@@ -1018,6 +1034,94 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
     const float* dummy = B;
     const long ldc = p.ldc, ldr = p.ldr;
     const int actk = p.act;
+    const bool vec_epi = (N % 4 == 0) && (ldc % 4 == 0) && (p.sC % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                         (!RES || ((ldr % 4 == 0) && (p.sR % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.R) & 15) == 0)));
+    if (vec_epi) {
+        // through LDS (as the v4 engine): park the 64x64 tile in this wave's 16 KiB of the idle operand buffers, read it
+        // back row-contiguous: residual loads and stores are 16 B per lane.  The loader waves are done with LDS (their
+        // last barrier is the one the MMA waves just passed).
+        float cscale = 1.f;
+        if (q.Chi) {
+            const float cbound = q.cw * bbound_k;
+            cscale = ldexpf(1.0f, pow2_exponent_for(cbound));
+            if (tid == 0) atomicMax(q.cslot + (blockIdx.x & 63), __float_as_uint(cbound));
+        }
+        float* Ts = reinterpret_cast<float*>(smem3) + wave * 4096;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Ts[(tm * 32 + acc_row(r, g)) * 64 + tn * 32 + i] = acc[tm][tn][r];
+        const int c4 = (lane & 15) * 4;
+        const int colb = n0 + wn * 64 + c4;
+        const bool cok = colb < N;
+        const int colc = cok ? colb : 0;
+        _Float16* Ph = q.Chi ? q.Chi + (long)batch * p.sC : nullptr;
+        _Float16* Pl = q.Chi ? q.Clo + (long)batch * p.sC : nullptr;
+        // four rows at a time: this kernel is capped at 128 VGPRs (8 waves per workgroup, 2 workgroups per CU)
+#pragma unroll 1
+        for (int jb = 0; jb < 16; jb += 4) {
+            float4 tv[4], rv[4];
+            float bvv[4], rsv[4], rtv[4], osv[4], otv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int rl = (lane >> 4) + 4 * (jb + jj);
+                const int row = m0 + wm * 64 + rl;
+                const int rr = row < M ? row : 0;
+                const float t0 = (bias ? bias : dummy)[bias ? rr : 0];
+                const float t1 = (rsc ? rsc : dummy)[rsc ? rr : 0];
+                const float t2 = (rsc ? rsh : dummy)[rsc ? rr : 0];
+                const float t3 = (osc ? osc : dummy)[osc ? rr : 0];
+                const float t4 = (osc ? osh : dummy)[osc ? rr : 0];
+                bvv[jj] = bias ? t0 : 0.f;
+                rsv[jj] = rsc ? t1 : 1.f;
+                rtv[jj] = rsc ? t2 : 0.f;
+                osv[jj] = osc ? t3 : 1.f;
+                otv[jj] = osc ? t4 : 0.f;
+                if (RES) rv[jj] = *reinterpret_cast<const float4*>(R + (long)rr * ldr + colc);
+                tv[jj] = *reinterpret_cast<const float4*>(Ts + rl * 64 + c4);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int row = m0 + wm * 64 + (lane >> 4) + 4 * (jb + jj);
+                float o[4] = {tv[jj].x, tv[jj].y, tv[jj].z, tv[jj].w};
+                const float r4[4] = {RES ? rv[jj].x : 0.f, RES ? rv[jj].y : 0.f, RES ? rv[jj].z : 0.f, RES ? rv[jj].w : 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = fmaf(o[e], osc_acc, bvv[jj]);
+                    if (RES) v += fmaf(r4[e], rsv[jj], rtv[jj]);
+                    v = act_apply(v, actk);
+                    o[e] = fmaf(v, osv[jj], otv[jj]);
+                }
+                if (row < M && cok) {
+                    vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+                    if (Ph) {
+                        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                        half4 hh, ll;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x = o[e] * cscale;
+                            const _Float16 a = (_Float16)x;
+                            hh[e] = a;
+                            ll[e] = (_Float16)(x - (float)a);
+                        }
+                        *reinterpret_cast<half4*>(Ph + (long)row * ldc + colb) = hh;
+                        *reinterpret_cast<half4*>(Pl + (long)row * ldc + colb) = ll;
+                    } else {
+                        *reinterpret_cast<float4*>(C + (long)row * ldc + colb) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                }
+            }
+        }
+        if (q.omax) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+            if (lane == 0) atomicMax(q.omax + (blockIdx.x & 63), __float_as_uint(vmax));
+        }
+        return;
+    }
     const int col0 = n0 + wn * 64 + i, col1 = col0 + 32;
     const bool c0ok = col0 < N, c1ok = col1 < N;
     const int cc0 = c0ok ? col0 : 0, cc1 = c1ok ? col1 : 0;
@@ -1241,6 +1345,25 @@ hipError_t launch_gemm_f16x3(const GemmArgs& g, const void* Ahi, const void* Alo
     return launch_gemm3_cfg<1, 4>(a, s);
 }
 
+// as launch_gemm_f16x3, but C is written as fp16 hi/lo planes in C's own layout (see Gemm3Args::Chi)
+hipError_t launch_gemm_f16x3_planes(const GemmArgs& g, const void* Ahi, const void* Alo, float ascale, const unsigned* bmax,
+                                    void* Chi, void* Clo, float cw, unsigned* cslot, hipStream_t s) {
+    if (!bmax || !Chi || !Clo || !cslot || g.N % 4 != 0 || g.ldc % 4 != 0 || g.sC % 4 != 0 || g.R || !al16(Chi) || !al16(Clo))
+        return hipErrorInvalidValue;
+    Gemm3Args a;
+    a.g = g;
+    a.g.C = reinterpret_cast<float*>(Chi);   // only its alignment is looked at
+    a.Ahi = static_cast<const _Float16*>(Ahi);
+    a.Alo = static_cast<const _Float16*>(Alo);
+    a.bscale = 1.f;
+    a.oscale = 1.0f / ascale;
+    a.bmax = bmax;
+    a.Chi = static_cast<_Float16*>(Chi); a.Clo = static_cast<_Float16*>(Clo); a.cw = cw; a.cslot = cslot;
+    const long waste128 = (long)((g.M + 127) / 128) * 128, waste64 = (long)((g.M + 63) / 64) * 64;
+    if (g.M >= 128 && waste128 <= waste64) return launch_gemm3_cfg<2, 2>(a, s);
+    return launch_gemm3_cfg<1, 4>(a, s);
+}
+
 hipError_t launch_split_f16(const float* src, long lds_, void* hi, void* lo, long ldd, long rows, int cols, float scale,
                             hipStream_t s) {
     const long total = rows * ldd;
@@ -1339,13 +1462,6 @@ hipError_t launch_gemm_f16x3_adyn(const GemmArgs& g, const void* Bhi, const void
 // is issued right after that barrier.  Epilogue as v3, plus the optional P-format output over the rows of C.
 // ---------------------------------------------------------------------------------------------
 
-// power of two that maps a bound to [2^11, 2^12) (fp16 keeps 11 more bits below; lo parts stay normal for every
-// element within 2^-13 of the bound and lose absolute, not relative, accuracy below that)
-DEVINL int pow2_exponent_for(float mx) {
-    int e = 0;
-    if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &e); e = 12 - e; }
-    return e > 100 ? 100 : (e < -100 ? -100 : e);
-}
 DEVINL float slot_reduce(const unsigned* slot, int lane) {
     float mx = __uint_as_float(slot_load(slot + lane));
 #pragma unroll
@@ -1665,57 +1781,55 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
         const int colb = n0 + wn * 64 + c4;
         const bool cok = colb < N;           // N % 4 == 0 (checked by the launcher)
         const int colc = cok ? colb : 0;
-        float4 tv[16], rv[16];
-        float bvv[16], rsv[16], rtv[16];
-        int rows[16];
+        // four rows at a time: loads, math and stores of successive chunks overlap, and the register footprint stays small
+#pragma unroll 1
+        for (int jb = 0; jb < 16; jb += 4) {
+            float4 tv[4], rv[4];
+            float bvv[4], rsv[4], rtv[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int rl = (lane >> 4) + 4 * j;
-            const int row = m0 + wm * 64 + rl;
-            rows[j] = row < M ? row : 0;
-            const float t0 = (bias ? bias : dummy)[bias ? rows[j] : 0];
-            const float t1 = (rsc ? rsc : dummy)[rsc ? rows[j] : 0];
-            const float t2 = (rsc ? rsh : dummy)[rsc ? rows[j] : 0];
-            bvv[j] = bias ? t0 : 0.f;
-            rsv[j] = rsc ? t1 : 1.f;
-            rtv[j] = rsc ? t2 : 0.f;
-            if (RES) rv[j] = *reinterpret_cast<const float4*>(R + (long)rows[j] * ldr + colc);
-            tv[j] = *reinterpret_cast<const float4*>(Ts + rl * 64 + c4);
-        }
-        G4T(51);
-#ifdef ACE_X_TRACE
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        G4T(52);
-#endif
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int rl = (lane >> 4) + 4 * j;
-            const int row = m0 + wm * 64 + rl;
-            float o[4] = {tv[j].x, tv[j].y, tv[j].z, tv[j].w};
-            const float r4[4] = {RES ? rv[j].x : 0.f, RES ? rv[j].y : 0.f, RES ? rv[j].z : 0.f, RES ? rv[j].w : 0.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = fmaf(o[e] * inv_a, inv_b, bvv[j]);
-                if (RES) v += fmaf(r4[e], rsv[j], rtv[j]);
-                o[e] = act_apply(v, actk);
+            for (int jj = 0; jj < 4; ++jj) {
+                const int rl = (lane >> 4) + 4 * (jb + jj);
+                const int row = m0 + wm * 64 + rl;
+                const int rr = row < M ? row : 0;
+                const float t0 = (bias ? bias : dummy)[bias ? rr : 0];
+                const float t1 = (rsc ? rsc : dummy)[rsc ? rr : 0];
+                const float t2 = (rsc ? rsh : dummy)[rsc ? rr : 0];
+                bvv[jj] = bias ? t0 : 0.f;
+                rsv[jj] = rsc ? t1 : 1.f;
+                rtv[jj] = rsc ? t2 : 0.f;
+                if (RES) rv[jj] = *reinterpret_cast<const float4*>(R + (long)rr * ldr + colc);
+                tv[jj] = *reinterpret_cast<const float4*>(Ts + rl * 64 + c4);
             }
-            const bool ok = row < M && cok;
-            if (C && ok) *reinterpret_cast<float4*>(C + (long)row * ldc + colb) = make_float4(o[0], o[1], o[2], o[3]);
-            if (ok) vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
-            if (PK) *reinterpret_cast<float4*>(Ts + rl * 64 + c4) = make_float4(o[0], o[1], o[2], o[3]);
-            if (part) {   // wave-uniform branch
-                float sm = ok ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f;
-                float sq = ok ? fmaf(o[0], o[0], o[1] * o[1]) + fmaf(o[2], o[2], o[3] * o[3]) : 0.f;
-                float mn = ok ? fminf(fminf(o[0], o[1]), fminf(o[2], o[3])) : 3.0e38f;
-                float mx = ok ? fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3])) : -3.0e38f;
 #pragma unroll
-                for (int off = 8; off > 0; off >>= 1) {   // the 16 lanes that share this row
-                    sm += __shfl_xor(sm, off, 64);
-                    sq += __shfl_xor(sq, off, 64);
-                    mn = fminf(mn, __shfl_xor(mn, off, 64));
-                    mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            for (int jj = 0; jj < 4; ++jj) {
+                const int rl = (lane >> 4) + 4 * (jb + jj);
+                const int row = m0 + wm * 64 + rl;
+                float o[4] = {tv[jj].x, tv[jj].y, tv[jj].z, tv[jj].w};
+                const float r4[4] = {RES ? rv[jj].x : 0.f, RES ? rv[jj].y : 0.f, RES ? rv[jj].z : 0.f, RES ? rv[jj].w : 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = fmaf(o[e] * inv_a, inv_b, bvv[jj]);
+                    if (RES) v += fmaf(r4[e], rsv[jj], rtv[jj]);
+                    o[e] = act_apply(v, actk);
                 }
-                if ((lane & 15) == 0 && row < M) part[row] = make_float4(sm, sq, mn, mx);
+                const bool ok = row < M && cok;
+                if (C && ok) *reinterpret_cast<float4*>(C + (long)row * ldc + colb) = make_float4(o[0], o[1], o[2], o[3]);
+                if (ok) vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+                if (PK) *reinterpret_cast<float4*>(Ts + rl * 64 + c4) = make_float4(o[0], o[1], o[2], o[3]);
+                if (part) {   // wave-uniform branch
+                    float sm = ok ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f;
+                    float sq = ok ? fmaf(o[0], o[0], o[1] * o[1]) + fmaf(o[2], o[2], o[3] * o[3]) : 0.f;
+                    float mn = ok ? fminf(fminf(o[0], o[1]), fminf(o[2], o[3])) : 3.0e38f;
+                    float mx = ok ? fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3])) : -3.0e38f;
+#pragma unroll
+                    for (int off = 8; off > 0; off >>= 1) {   // the 16 lanes that share this row
+                        sm += __shfl_xor(sm, off, 64);
+                        sq += __shfl_xor(sq, off, 64);
+                        mn = fminf(mn, __shfl_xor(mn, off, 64));
+                        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+                    }
+                    if ((lane & 15) == 0 && row < M) part[row] = make_float4(sm, sq, mn, mx);
+                }
             }
         }
         if (PK) {
@@ -1816,7 +1930,7 @@ hipError_t launch_pack_pformat(const float* src, long ldb, long sSrc, int K, int
 template <int WM, int WN>
 static hipError_t launch_gemm4_cfg(const Gemm4Args& a, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr size_t lds = (size_t)2 * 2 * (BM * 32 + 32 * BN) * sizeof(_Float16) + 4 * 256;
+    constexpr size_t lds = (size_t)2 * 2 * (BM * 32 + 32 * BN) * sizeof(_Float16) + ((ACE_G4_PFD > 0 || ACE_G4_RTOUCH) ? 4 * 256 : 0);
     const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
     const long nblk = (long)tilesM * tilesN * a.nbatch;
     if (nblk <= 0) return hipSuccess;
