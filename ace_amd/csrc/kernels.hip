@@ -1966,7 +1966,8 @@ hipError_t launch_gemm_f16x3_packed(const Gemm4Args& a, hipStream_t s) {
     if (a.N % 4 != 0 || (a.C && (!al16(a.C) || a.ldc % 4 != 0 || a.sC % 4 != 0))) return hipErrorInvalidValue;
     if (a.R && (!al16(a.R) || a.ldr % 4 != 0 || a.sR % 4 != 0)) return hipErrorInvalidValue;
     const long waste128 = (long)((a.M + 127) / 128) * 128, waste64 = (long)((a.M + 63) / 64) * 64;
-    if (a.M >= 128 && waste128 <= waste64) return launch_gemm4_cfg<2, 2>(a, s);
+    static const int force = getenv("ACE_G4_TILE") ? atoi(getenv("ACE_G4_TILE")) : 0;   // A/B switch: 1 = 128x128, 2 = 64x256
+    if (force == 1 || (force == 0 && a.M >= 128 && waste128 <= waste64)) return launch_gemm4_cfg<2, 2>(a, s);
     return launch_gemm4_cfg<1, 4>(a, s);
 }
 
@@ -2138,7 +2139,34 @@ __global__ __launch_bounds__(256) void dft_forward_kernel(DftArgs p, int tilesM,
     const long N2 = (long)p.Bt * 2 * p.C;
     const int n = n0 + bcol;
     float vmax = 0.f;
-    if (n < ncols) {
+    if (VX && (p.C % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.spec_out) & 15) == 0)) {
+        // through LDS, one plane (Re, then Im) at a time: each wave parks its 64 (m) x 32 (n) tile and reads it back
+        // row-contiguous, so the stores are 16 B per lane (8 rows x 128 B per wave instruction instead of 2 x 128 B).
+        // The operand buffers are idle: the main loop ended on a barrier.
+        float* Ts = smem + wave * 2048;
+        const int c4 = (lane & 7) * 4;
+        const int nb = n0 + wave * 32 + c4;          // first of this lane's 4 columns (same kb: C % 4 == 0)
+        const int nbc = nb < ncols ? nb : 0;
+        const int cb = nbc % p.C, kbb = nbc / p.C;
+        float* ob = p.spec_out + (long)kbb * 2 * p.C + cb;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Ts[(tm * 32 + acc_row(r, h)) * 32 + i] = pl == 0 ? Re[tm][r] : Im[tm][r];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ml = (lane >> 3) + 8 * j;
+                const float4 v = *reinterpret_cast<const float4*>(Ts + ml * 32 + c4);
+                const int m = m0 + ml;
+                if (m < p.Mm && nb < ncols) {
+                    *reinterpret_cast<float4*>(ob + (long)m * p.H * N2 + pl * p.C) = v;
+                    vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                }
+            }
+        }
+    } else if (n < ncols) {
         const int c = n % p.C, kb = n / p.C;  // kb = k * Bt + b
         float* obase = p.spec_out + (long)kb * 2 * p.C + c;
 #pragma unroll
