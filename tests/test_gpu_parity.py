@@ -259,6 +259,32 @@ def test_packed_fused_path_vs_oracle(dev, precision, offset):
     assert rel_max(y, ref) <= NET_TOL
 
 
+def test_quarter_degree_grid(dev):
+    """BASELINE configs[3] geometry (0.25 degree: 721 x 1440, L = M = 721): the SHT pair and a small dhconv net against
+    the fp64 oracle - index arithmetic, odd nlat, table sizes (1.5 GB per transform) and ragged tiles at the large grid."""
+    import ace_amd
+    from oracle.sht import RealSHT as ORealSHT, InverseRealSHT as OInverseRealSHT
+    from oracle.sfno import SFNOConfig, SFNOOracle, init_state
+    H, W = 721, 1440
+    f = ace_amd.RealSHT(H, W, H, W // 2 + 1, "legendre-gauss")
+    i = ace_amd.InverseRealSHT(H, W, H, W // 2 + 1, "legendre-gauss")
+    x = torch.randn(2, H, W, generator=torch.Generator().manual_seed(0))
+    c = f(x.to(dev))
+    y = i(c)
+    oc = ORealSHT(H, W, H, W // 2 + 1, "legendre-gauss")(x.double())
+    oy = OInverseRealSHT(H, W, H, W // 2 + 1, "legendre-gauss")(oc)
+    assert rel_max(c, oc) <= SHT_TOL and rel_max(y, oy) <= SHT_TOL
+    cfg = SFNOConfig(in_chans=3, out_chans=2, img_shape=(H, W), embed_dim=16, num_layers=1, operator_type="dhconv")
+    st = init_state(cfg, seed=1)
+    xin = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(2))
+    ref = SFNOOracle(cfg, st, dtype=torch.float64).forward(xin)
+    for prec in ("f16x3", "fp32"):
+        net = build_native_net(cfg, st, dev, prec)
+        with torch.no_grad():
+            out = net(xin.to(dev))
+        assert rel_max(out, ref) <= NET_TOL, prec
+
+
 def test_graph_replay_matches_eager(dev, precision):
     from oracle.sfno import SFNOConfig, init_state
     cfg = SFNOConfig(in_chans=4, out_chans=4, img_shape=(24, 48), embed_dim=16, num_layers=2, operator_type="dhconv")
