@@ -457,6 +457,7 @@ struct ace_sfno {
     std::vector<DevBuf> wx;  // per block: dhconv weight expanded to real [L][2C][2C] (fp32 engines)
     std::vector<DevBuf> wx_hi, wx_lo;  // per block: the same operand k-packed as fp16 hi/lo planes (f16x3 engine)
     std::vector<float> wx_scale;
+    std::vector<char> wx_compact;   // per block: wx_hi/lo hold the compact (Wr | Wi) form of Gemm4Args::cplx
     // workspace
     DevBuf h0, h1, Y, T, R, U, X, D, E, stats;
     DevBuf P;  // f16x3: a C-channel activation as P-format fp16 hi/lo planes (input of the packed-operand GEMM)
@@ -563,6 +564,14 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     n->wx_hi.resize(c.num_layers);
     n->wx_lo.resize(c.num_layers);
     n->wx_scale.assign(c.num_layers, 1.f);
+    n->wx_compact.assign(c.num_layers, 0);
+    for (int i = 0; i < c.num_layers; ++i) {
+        // blocks whose input/output grid differs from the internal one keep D in fp32 (residual round trip) and use
+        // the expanded operand
+        const bool mixed = (n->plan_data != n->plan_lg.get()) && (i == 0 || i == c.num_layers - 1);
+        n->wx_compact[i] = (getenv("ACE_NO_PK_SHT") == nullptr && c.precision == 1 && c.operator_type == 1 && n->C % 128 == 0 && !mixed &&
+                            ((long)n->Bmax * 2 * n->C) % 4 == 0) ? 1 : 0;
+    }
     const size_t act = (size_t)n->Bmax * C * HW;
     const size_t spec_x = (size_t)n->Mm * n->H * n->Bmax * 2 * C;
     const size_t spec_d = (size_t)n->L * n->Mm * n->Bmax * 2 * C;
@@ -650,10 +659,16 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
             int e = 0;
             if (mx > 0.f && std::isfinite(mx)) { (void)std::frexp(mx, &e); e = 10 - e; }
             n->wx_scale[w.block] = std::ldexp(1.0f, e);
-            if (!n->wx_hi[w.block].p) HIP_TRY(n->wx_hi[w.block].alloc((cnt + 1) / 2, false));
-            if (!n->wx_lo[w.block].p) HIP_TRY(n->wx_lo[w.block].alloc((cnt + 1) / 2, false));
-            HIP_TRY(launch_pack_dhconv_f16(w.buf.p, n->wx_hi[w.block].p, n->wx_lo[w.block].p, n->C, n->C, n->L,
-                                           n->wx_scale[w.block], s));
+            const bool compact = n->wx_compact[w.block] != 0;
+            const size_t halves = compact ? cnt / 2 : cnt;
+            if (!n->wx_hi[w.block].p) HIP_TRY(n->wx_hi[w.block].alloc((halves + 1) / 2, false));
+            if (!n->wx_lo[w.block].p) HIP_TRY(n->wx_lo[w.block].alloc((halves + 1) / 2, false));
+            if (compact)
+                HIP_TRY(launch_pack_dhconv_f16c(w.buf.p, n->wx_hi[w.block].p, n->wx_lo[w.block].p, n->C, n->C, n->L,
+                                                n->wx_scale[w.block], s));
+            else
+                HIP_TRY(launch_pack_dhconv_f16(w.buf.p, n->wx_hi[w.block].p, n->wx_lo[w.block].p, n->C, n->C, n->L,
+                                               n->wx_scale[w.block], s));
         } else {
             DevBuf& wx = n->wx[w.block];
             if (!wx.p) HIP_TRY(wx.alloc(cnt, false));
@@ -963,10 +978,13 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 a.Bhi = reinterpret_cast<const _Float16*>(n->wx_hi[i].p);
                 a.Blo = reinterpret_cast<const _Float16*>(n->wx_lo[i].p);
                 a.ldn = 2 * C; a.sB = (long)2 * C * 2 * C; a.bscale = n->wx_scale[i];
+                if (n->wx_compact[i]) { a.cplx = C; a.ldn = C; a.sB = (long)2 * C * C; a.tile = 1; }
                 a.C = n->E.p; a.ldc = 2 * C; a.sC = (long)n->Mm * N2; a.omax = emax;
                 a.M = n->Mm * B; a.N = 2 * C; a.K = 2 * C; a.nbatch = n->L;
                 a.tri = TRI_ROWS_LE_BATCH; a.trimul = B;
                 HIP_TRY(launch_gemm_f16x3_packed(a, s));
+            } else if (f16 && n->wx_hi[i].p && n->wx_compact[i]) {
+                return fail(ACE_ERR_STATE, "compact dhconv operand without the packed path");
             } else if (f16 && n->wx_hi[i].p) {
                 HIP_TRY(launch_gemm_f16x3_adyn(g, n->wx_hi[i].p, n->wx_lo[i].p, 2 * C, (long)2 * C * 2 * C, n->wx_scale[i],
                                                dmax, emax, s));

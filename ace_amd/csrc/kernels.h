@@ -63,6 +63,8 @@ hipError_t launch_gemm_f16x3_planes(const GemmArgs& g, const void* Ahi, const vo
 hipError_t launch_gemm_f16x3_adyn(const GemmArgs& g, const void* Bhi, const void* Blo, long ldn, long sB_halves,
                                   float bscale_static, const unsigned* amax, unsigned* omax, hipStream_t s);
 hipError_t launch_pack_dhconv_f16(const float* w, void* hi, void* lo, int Cin, int Cout, int L, float scale, hipStream_t s);
+// compact form for Gemm4Args::cplx: planes [l][2 (re | im)][Cin/8][Cout][8]
+hipError_t launch_pack_dhconv_f16c(const float* w, void* hi, void* lo, int Cin, int Cout, int L, float scale, hipStream_t s);
 hipError_t launch_zero_u32(unsigned* p, long n, hipStream_t s);
 // max|x| of a plain tensor into a slot
 hipError_t launch_absmax(const float* x, long n, unsigned* omax, hipStream_t s);
@@ -76,6 +78,11 @@ struct Gemm4Args {
     const _Float16* Ahi = nullptr; const _Float16* Alo = nullptr; long lda = 0; long sA = 0;   // halves
     const _Float16* Bhi = nullptr; const _Float16* Blo = nullptr; long ldn = 0; long sB = 0;   // ldn entries per k group; sB halves
     int a_tiled = 0;                            // A planes are in split_f16_tiled order (lda = padded K)
+    // complex-structured B (dhconv): cplx = C > 0 means K = N = 2C and B = [[Wr, Wi], [-Wi, Wr]] is stored compactly as
+    // two C x C P-format blocks per batch (Wr then Wi; ldn = C, sB = 2 C C); the kernel picks the block per (k half,
+    // n half) and negates the A fragments for the (-Wi) quadrant.  Needs C % 128 == 0 and the 128 x 128 tile.
+    int cplx = 0;
+    int tile = 0;                               // 0 = pick by M, 1 = 128 x 128, 2 = 64 x 256
     float ascale = 1.f, bscale = 1.f;           // static power-of-two scales (used when the slot pointer is null)
     const unsigned* amax = nullptr;             // dynamic operands: slot holding the bound the producer scaled with
     const unsigned* bmax = nullptr;

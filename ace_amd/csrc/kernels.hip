@@ -1408,6 +1408,37 @@ hipError_t launch_pack_dhconv_f16(const float* w, void* hi, void* lo, int Cin, i
     return hipGetLastError();
 }
 
+// the same weight, compact: two Cin x Cout P-format blocks per l (re, then im); see Gemm4Args::cplx
+__global__ void pack_dhconv_f16c_kernel(const float* __restrict__ w, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                        int Cin, int Cout, int L, float scale) {
+    const long total = (long)L * 2 * Cin * Cout;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int e = t % 8;
+        long q = t / 8;
+        const int o = q % Cout;
+        q /= Cout;
+        const int kg = q % (Cin / 8);
+        q /= (Cin / 8);
+        const int blk = q % 2;
+        const int l = q / 2;
+        const int i = kg * 8 + e;
+        const float2 wv = *reinterpret_cast<const float2*>(w + (((long)i * Cout + o) * L + l) * 2);
+        const float v = __builtin_amdgcn_fmed3f((blk == 0 ? wv.x : wv.y) * scale, -65504.f, 65504.f);
+        const _Float16 h = (_Float16)v;
+        hi[t] = h;
+        lo[t] = (_Float16)(v - (float)h);
+    }
+}
+hipError_t launch_pack_dhconv_f16c(const float* w, void* hi, void* lo, int Cin, int Cout, int L, float scale, hipStream_t s) {
+    if (Cin % 8 != 0) return hipErrorInvalidValue;
+    const long total = (long)L * 2 * Cin * Cout;
+    long gsz = (total + 255) / 256;
+    if (gsz > 32768) gsz = 32768;
+    hipLaunchKernelGGL(pack_dhconv_f16c_kernel, dim3((unsigned)gsz), dim3(256), 0, s, w, static_cast<_Float16*>(hi),
+                       static_cast<_Float16*>(lo), Cin, Cout, L, scale);
+    return hipGetLastError();
+}
+
 // f16x3 with the roles mirrored: A = fp32 activations (split on the fly, dynamic scale from amax), B = packed static
 // operand (planes Bhi/Blo, [K/8][ldn][8] per batch with batch stride sB_halves).  Requirements: K % 32 == 0, lda % 4 == 0,
 // A 16B aligned.  g.B / g.ldb are ignored (ldn and the plane pointers describe B).
@@ -1559,12 +1590,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
     }
     int bkg[BCW];
     long bcol[BCW];
+    const int cplx = q.cplx;                    // complex-structured B: see Gemm4Args::cplx
+    const int nhalf = cplx ? n0 / cplx : 0;     // 0: real output columns, 1: imaginary (tiles never straddle)
 #pragma unroll
     for (int c = 0; c < BCW; ++c) {   // piece = one k group x 64 columns
         const int cb = wave + c * NW;
         bkg[c] = cb / (BN / 64);
         int nn = n0 + (cb % (BN / 64)) * 64 + lane;
         nn = nn < N ? nn : N - 1;
+        if (cplx) nn -= nhalf * cplx;
         bcol[c] = (long)nn * 8;
     }
     auto issue = [&](int k0, int buf) {
@@ -1582,7 +1616,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
             const int cb = wave + c * NW;
             int kg = k0 / 8 + bkg[c];
             kg = kg < nkg ? kg : nkg - 1;   // groups past K meet zero A columns (values there are finite)
-            const long off = (long)kg * ldn * 8 + bcol[c];
+            long off = (long)kg * ldn * 8 + bcol[c];
+            if (cplx) {                     // block (k half == n half ? Wr : Wi), k group inside the block
+                const int khalf = k0 >= cplx;
+                off = (long)(khalf != nhalf) * cplx * cplx + (long)(kg - khalf * (cplx / 8)) * ldn * 8 + bcol[c];
+            }
             glds16(reinterpret_cast<const float*>(Bhi + off), reinterpret_cast<float*>(Bb + cb * 512));
             glds16(reinterpret_cast<const float*>(Blo + off), reinterpret_cast<float*>(Bb + BPL + cb * 512));
         }
@@ -1606,7 +1644,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
     const int arow0 = wm * 64 + i, arow1 = arow0 + 32;
     const int key0 = (arow0 >> 2) & 3, key1 = (arow1 >> 2) & 3;
     const int bcol0 = wn * 64 + i, bcol1 = bcol0 + 32;
-    auto load_frags = [&](Frags4& f, int buf, int c) {
+    auto neg8 = [](half8 v) {   // -v: flip the eight sign bits
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 u = __builtin_bit_cast(u32x4, v);
+        u ^= 0x80008000u;
+        return __builtin_bit_cast(half8, u);
+    };
+    auto load_frags = [&](Frags4& f, int buf, int c, bool neg = false) {
         const _Float16* Ah = As + buf * 2 * APL;
         const _Float16* Al = Ah + APL;
         const _Float16* Bh = Bs + buf * 2 * BPL;
@@ -1620,7 +1664,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
         f.ah[1] = *reinterpret_cast<const half8*>(Ah + arow1 * 32 + 8 * (ls ^ key1));
         f.bl[0] = *reinterpret_cast<const half8*>(Bl + ((long)ls * BN + bcol0) * 8);
         f.bl[1] = *reinterpret_cast<const half8*>(Bl + ((long)ls * BN + bcol1) * 8);
+        if (neg) {   // wave-uniform: the (-Wi) quadrant of the complex-structured operand
+            f.al[0] = neg8(f.al[0]); f.al[1] = neg8(f.al[1]);
+            f.ah[0] = neg8(f.ah[0]); f.ah[1] = neg8(f.ah[1]);
+        }
     };
+    auto negq = [&](int kt) { return cplx != 0 && nhalf == 0 && kbeg + kt * BKT >= cplx; };
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1698,16 +1747,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     G4T(2);
-    if (nk > 0) load_frags(f0, 0, 0);
+    if (nk > 0) load_frags(f0, 0, 0, negq(0));
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        load_frags(f1, cur, 1);
+        load_frags(f1, cur, 1, negq(kt));
         mma(f0);
         interleave();
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NTOUCH) : "memory");   // all but the newest prefetch touch
         __syncthreads();
         if (kt + 2 < nk) issue(kbeg + (kt + 2) * BKT, cur);
-        if (kt + 1 < nk) load_frags(f0, cur ^ 1, 0);
+        if (kt + 1 < nk) load_frags(f0, cur ^ 1, 0, negq(kt + 1));
         mma(f1);
         interleave();
         G4T(3 + (kt < 40 ? kt : 40));
@@ -1966,7 +2015,9 @@ hipError_t launch_gemm_f16x3_packed(const Gemm4Args& a, hipStream_t s) {
     if (a.N % 4 != 0 || (a.C && (!al16(a.C) || a.ldc % 4 != 0 || a.sC % 4 != 0))) return hipErrorInvalidValue;
     if (a.R && (!al16(a.R) || a.ldr % 4 != 0 || a.sR % 4 != 0)) return hipErrorInvalidValue;
     const long waste128 = (long)((a.M + 127) / 128) * 128, waste64 = (long)((a.M + 63) / 64) * 64;
-    static const int force = getenv("ACE_G4_TILE") ? atoi(getenv("ACE_G4_TILE")) : 0;   // A/B switch: 1 = 128x128, 2 = 64x256
+    static const int env_force = getenv("ACE_G4_TILE") ? atoi(getenv("ACE_G4_TILE")) : 0;   // A/B switch: 1 = 128x128, 2 = 64x256
+    const int force = a.tile ? a.tile : env_force;
+    if (a.cplx && (a.cplx % 128 != 0 || a.K != 2 * a.cplx || a.N != 2 * a.cplx || a.ldn != a.cplx || force != 1)) return hipErrorInvalidValue;
     if (force == 1 || (force == 0 && a.M >= 128 && waste128 <= waste64)) return launch_gemm4_cfg<2, 2>(a, s);
     return launch_gemm4_cfg<1, 4>(a, s);
 }
