@@ -2516,22 +2516,22 @@ __global__ __launch_bounds__(512) void instnorm_stats_kernel(const float* __rest
 
 // Second half of the fused instance norm: reduce the per-strip row statistics written by the producing GEMM's epilogue
 // (Gemm4Args::part) to the per-(sample, channel) affine, in fp64 and in a fixed order (deterministic).
-__global__ __launch_bounds__(512) void instnorm_finalize_kernel(const float4* __restrict__ part, int nparts, int C,
+__global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float4* __restrict__ part, int nparts, int C,
                                                                 long HW, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float eps,
                                                                 float* __restrict__ scale, float* __restrict__ shift,
                                                                 unsigned* omax) {
-    // one workgroup per 16 channels (256 contiguous bytes per strip): thread = (channel sub-index, strip residue of 32);
-    // strips are summed thread-strided in fp64, then across the 32 residues in a fixed tree order
+    // one workgroup per 4 channels: thread = (channel sub-index, strip residue of 64); strips are summed thread-strided
+    // in fp64, then across the residues with a fixed shuffle tree and a fixed order over the 4 waves (deterministic)
     const int b = blockIdx.y;
-    const int cs = threadIdx.x & 15, pr = threadIdx.x >> 4;   // 0..15, 0..31
-    const int c = blockIdx.x * 16 + cs;
+    const int cs = threadIdx.x & 3, pr = threadIdx.x >> 2;   // 0..3, 0..63
+    const int c = blockIdx.x * 4 + cs;
     double s = 0.0, ss = 0.0;
     float lo = 3.0e38f, hi = -3.0e38f;
     if (c < C) {
         const float4* base = part + (long)b * nparts * C + c;
 #pragma unroll 4
-        for (int p = pr; p < nparts; p += 32) {
+        for (int p = pr; p < nparts; p += 64) {
             const float4 v = base[(long)p * C];
             s += (double)v.x;
             ss += (double)v.y;
@@ -2539,12 +2539,21 @@ __global__ __launch_bounds__(512) void instnorm_finalize_kernel(const float4* __
             hi = fmaxf(hi, v.w);
         }
     }
-    __shared__ double rs[32][16], rss[32][16];
-    __shared__ float rlo[32][16], rhi[32][16];
-    rs[pr][cs] = s; rss[pr][cs] = ss; rlo[pr][cs] = lo; rhi[pr][cs] = hi;
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1) {   // lanes of this wave with the same channel sub-index
+        s += __shfl_xor(s, off, 64);
+        ss += __shfl_xor(ss, off, 64);
+        lo = fminf(lo, __shfl_xor(lo, off, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    }
+    __shared__ double rs[4][4], rss[4][4];
+    __shared__ float rlo[4][4], rhi[4][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 4) { rs[wave][lane] = s; rss[wave][lane] = ss; rlo[wave][lane] = lo; rhi[wave][lane] = hi; }
     __syncthreads();
-    if (pr == 0 && c < C) {
-        for (int k = 1; k < 32; ++k) {
+    if (threadIdx.x < 4 && c < C) {
+        s = rs[0][cs]; ss = rss[0][cs]; lo = rlo[0][cs]; hi = rhi[0][cs];
+        for (int k = 1; k < 4; ++k) {
             s += rs[k][cs]; ss += rss[k][cs];
             lo = fminf(lo, rlo[k][cs]); hi = fmaxf(hi, rhi[k][cs]);
         }
@@ -2564,7 +2573,7 @@ __global__ __launch_bounds__(512) void instnorm_finalize_kernel(const float4* __
 hipError_t launch_instnorm_finalize(const float4* part, int nparts, int Bt, int C, long HW, const float* gamma,
                                     const float* beta, float eps, float* scale, float* shift, unsigned* omax,
                                     hipStream_t s) {
-    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((unsigned)((C + 15) / 16), (unsigned)Bt), dim3(512), 0, s, part, nparts,
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((unsigned)((C + 3) / 4), (unsigned)Bt), dim3(256), 0, s, part, nparts,
                        C, HW, gamma, beta, eps, scale, shift, omax);
     return hipGetLastError();
 }
