@@ -259,6 +259,29 @@ def test_packed_fused_path_vs_oracle(dev, precision, offset):
     assert rel_max(y, ref) <= NET_TOL
 
 
+@pytest.mark.parametrize("kw", [
+    dict(activation_function="silu"), dict(activation_function="relu", encoder_layers=2), dict(use_mlp=False),
+    dict(normalization_layer="none"), dict(num_layers=10), dict(mlp_ratio=1.0), dict(big_skip=False, pos_embed=False),
+    dict(hard_thresholding_fraction=0.6), dict(data_grid="equiangular", num_layers=3),
+    dict(embed_dim=128, num_layers=2),       # C % 128 == 0: the compact complex-structured filter operand
+    dict(embed_dim=128, num_layers=3, data_grid="equiangular"),   # ... mixed with expanded operands on the edge blocks
+])
+def test_packed_path_config_variants(dev, kw):
+    """every branch around the packed-operand path (C % 8 == 0, H*W % 4 == 0), f16x3 against the fp64 oracle: activations,
+    no MLP, no norm (pack passes instead of folds), > 8 blocks (slot recycling), mixed grids (fp32 D on the edge blocks),
+    truncated spectra, and the compact filter operand."""
+    from oracle.sfno import SFNOConfig, SFNOOracle, init_state
+    base = dict(in_chans=5, out_chans=4, img_shape=(24, 48), embed_dim=32, num_layers=3, operator_type="dhconv")
+    cfg = SFNOConfig(**{**base, **kw})
+    state = init_state(cfg, seed=5)
+    x = torch.randn(2, 5, 24, 48, generator=torch.Generator().manual_seed(6))
+    net = build_native_net(cfg, state, dev, "f16x3")
+    with torch.no_grad():
+        y = net(x.to(dev))
+    ref = SFNOOracle(cfg, state, dtype=torch.float64).forward(x)
+    assert rel_max(y, ref) <= NET_TOL, rel_max(y, ref)
+
+
 def test_quarter_degree_grid(dev):
     """BASELINE configs[3] geometry (0.25 degree: 721 x 1440, L = M = 721): the SHT pair and a small dhconv net against
     the fp64 oracle - index arithmetic, odd nlat, table sizes (1.5 GB per transform) and ragged tiles at the large grid."""
