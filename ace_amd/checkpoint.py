@@ -13,8 +13,8 @@ Module weights are loaded with the strict ``load_state_dict`` the reference uses
 the "module." prefix of wrapped modules is accepted (fme/core/distributed/non_distributed.py:15-28).
 
 What is NOT carried over (and why) is returned in ``LoadedStepper.ignored``: training history, loss configuration,
-parameter-init configuration, derived forcings, input masking, vertical coordinate / gridded operations (only needed by
-the conservation correctors, which are outside the hot path).  Features that change the rollout and are not
+parameter-init configuration, derived forcings, input masking.  Latitudes / area weights and the hybrid-sigma
+coefficients are kept for the conservation correctors (ace_amd/corrector.py).  Features that change the rollout and are not
 implemented raise ``NotImplementedError`` unless ``ignore_unsupported=True``.
 """
 import dataclasses
@@ -109,7 +109,12 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
             if step_cfg.pop(k, None) not in (None, {}, True, False):
                 ignored.append(k)
         step_state = {"module": state["module"]}
-        ds_state = {"timestep": state.get("encoded_timestep")}
+        ds_state = {"timestep": state.get("encoded_timestep"),
+                    "vertical_coordinate": state.get("sigma_coordinates", state.get("vertical_coordinate"))}
+        if "area" in state:
+            ds_state["gridded_operations"] = {"type": "LatLonOperations", "state": {"area_weights": state["area"]}}
+        elif "gridded_operations" in state:
+            ds_state["gridded_operations"] = state["gridded_operations"]
         if "img_shape" in state:
             ds_state["img_shape"] = state["img_shape"]
         else:
@@ -141,19 +146,25 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
         raise ValueError(f"unknown step config fields: {sorted(unknown)}")
     config = SingleModuleStepConfig(builder=ModuleSelector(type=builder["type"], config=dict(builder["config"])),
                                     normalization=normalization, **step_cfg)
-    missing = config.corrector.unsupported()
-    if missing:
-        if not ignore_unsupported:
-            raise NotImplementedError("corrector options outside the accelerated hot path (need area weights / "
-                                      "vertical coordinate): " + ", ".join(missing))
-        ignored.extend(f"corrector.{m}" for m in missing)
-        config._ignore_unsupported = True
-    for k in ("vertical_coordinate", "gridded_operations", "mask_provider", "variable_metadata"):
+    for k in ("mask_provider", "variable_metadata"):
         if ds_state.get(k) is not None:
             ignored.append(f"dataset_info.{k}")
     labels = ds_state.get("all_labels") or None
+    # geometry for the conservation correctors: latitudes (or legacy area weights) and hybrid-sigma coefficients
+    hc = ds_state.get("horizontal_coordinates") or {}
+    vc = ds_state.get("vertical_coordinate") or {}
+    go = ds_state.get("gridded_operations") or {}
+    area = go.get("state", {}).get("area_weights") if isinstance(go, Mapping) else None
     dataset_info = DatasetInfo(_img_shape_from_dataset_state(ds_state), all_labels=set(labels) if labels else None,
-                               timestep=_timestep_from_dataset_state(ds_state))
+                               timestep=_timestep_from_dataset_state(ds_state), lat=hc.get("lat"), lon=hc.get("lon"),
+                               ak=vc.get("ak"), bk=vc.get("bk"), area_weights=area)
+    missing = config.corrector.unsupported(dataset_info)
+    if missing:
+        if not ignore_unsupported:
+            raise NotImplementedError("corrector options that need latitudes / a hybrid-sigma vertical coordinate the "
+                                      "checkpoint's dataset_info does not carry: " + ", ".join(missing))
+        ignored.extend(f"corrector.{m}" for m in missing)
+        config._ignore_unsupported = True
     if state.get("training_history"):
         ignored.append("training_history")
     return config, dataset_info, step_state, ignored

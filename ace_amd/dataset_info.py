@@ -8,10 +8,41 @@ from typing import Optional, Set, Tuple
 
 class DatasetInfo:
     def __init__(self, img_shape: Tuple[int, int], all_labels: Optional[Set[str]] = None,
-                 timestep: datetime.timedelta = datetime.timedelta(hours=6)):
+                 timestep: datetime.timedelta = datetime.timedelta(hours=6), lat=None, lon=None, ak=None, bk=None,
+                 area_weights=None):
+        """``lat``/``lon`` (degrees; LatLonCoordinates, fme/core/coordinates.py:608-709) give the area weights of the
+        conservation correctors, ``ak``/``bk`` the hybrid sigma-pressure interfaces
+        (HybridSigmaPressureCoordinate, coordinates.py:150-280); all optional."""
         self._img_shape = (int(img_shape[-2]), int(img_shape[-1]))
         self._all_labels = set(all_labels) if all_labels else set()
         self._timestep = timestep
+        self._area_weights = None
+        self._vertical_coordinate = None
+        if area_weights is not None:
+            import torch
+            self._area_weights = torch.as_tensor(area_weights).detach().cpu()
+        elif lat is not None:
+            import torch
+            from .atmosphere import spherical_area_weights
+            lat = torch.as_tensor(lat).detach().cpu()
+            if len(lat) != self._img_shape[0]:
+                raise ValueError(f"{len(lat)} latitudes for an image of {self._img_shape[0]} rows")
+            nlon = len(lon) if lon is not None else self._img_shape[1]
+            self._area_weights = spherical_area_weights(lat, nlon)
+        if ak is not None and bk is not None:
+            import torch
+            from .atmosphere import HybridSigmaPressureCoordinate
+            self._vertical_coordinate = HybridSigmaPressureCoordinate(torch.as_tensor(ak).detach().cpu(),
+                                                                      torch.as_tensor(bk).detach().cpu())
+
+    @property
+    def area_weights(self):
+        """(nlat, nlon) weights summing to 1, or None (fme/core/metrics.py:14-32)."""
+        return self._area_weights
+
+    @property
+    def vertical_coordinate(self):
+        return self._vertical_coordinate
 
     @property
     def img_shape(self) -> Tuple[int, int]:

@@ -52,6 +52,12 @@ class StepArgs:
 
 
 @dataclasses.dataclass
+class StepperState:
+    """The per-sample state threaded from one step to the next (fme/core/step/args.py): here the corrector's."""
+    corrector_state: Any = None
+
+
+@dataclasses.dataclass
 class StepOutput:
     """output.py:12-28 (corrector diagnostics are always empty on this path)."""
 
@@ -159,7 +165,11 @@ def step_with_adjustments(input: TensorMapping, next_step_input_data: TensorMapp
         output_norm = {**output_norm, **{k: input_norm[k] + output_norm[k] for k in prognostic_names}}
     output = normalizer.denormalize(output_norm)
     if corrector is not None:
-        output = corrector(input, output, next_step_input_data)
+        cstate = stepper_state.corrector_state if stepper_state is not None else None
+        output, cstate = corrector(input, output, next_step_input_data, cstate)
+        if cstate is not None:      # keep the other fields of an incoming state (single_module.py:683-693)
+            stepper_state = (StepperState(corrector_state=cstate) if stepper_state is None
+                             else dataclasses.replace(stepper_state, corrector_state=cstate))
     if ocean is not None:
         output = ocean(input, output, next_step_input_data)
     for name in prescribed_prognostic_names:

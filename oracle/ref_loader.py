@@ -137,3 +137,77 @@ def load():
     )
     _loaded = ns
     return ns
+
+
+_corrector = None
+
+
+def load_corrector():
+    """The REAL reference post-step corrector stack under stubs (build container only): returns a namespace with
+    ``AtmosphereCorrectorConfig``, ``HybridSigmaPressureCoordinate``, ``LatLonCoordinates``, ``CorrectorState``.
+    Extra stubs on top of ``load()``: ``dacite`` (plain ``data_class(**data)``), ``fme.core.device`` helpers, a
+    non-distributed ``fme.core.distributed.Distributed`` (full slices, plain weighted mean), ``fme.core.dataset_info``
+    and ``fme.core.registry.corrector`` (only imported for their names); ``fme.core.typing_`` is the real module."""
+    global _corrector
+    if _corrector is not None:
+        return _corrector
+    load()
+    import torch
+
+    fme = sys.modules["fme"]
+    fme.get_device = lambda: torch.device("cpu")
+    for pkg in ["fme.core.corrector", "fme.core.registry"]:
+        if pkg not in sys.modules:
+            _ns(pkg, os.path.join(REF, *pkg.split(".")))
+    di = _ns("fme.core.dataset_info")
+    di.DatasetInfo = type("DatasetInfo", (), {})
+    rc = _ns("fme.core.registry.corrector")
+
+    class CorrectorSelector:
+        @classmethod
+        def register(cls, name):
+            return lambda c: c
+
+    rc.CorrectorSelector = CorrectorSelector
+    d = _ns("dacite")
+    d.Config = type("Config", (), {"__init__": lambda self, **kw: None})
+    d.from_dict = lambda data_class, data, config=None: data_class(**data)
+    ex = _ns("dacite.exceptions")
+    ex.DaciteError = type("DaciteError", (Exception,), {})
+    d.exceptions = ex
+    dv = _ns("fme.core.device")
+    dv.get_device = lambda: torch.device("cpu")
+    dv.using_gpu = lambda: False
+    dv.in_dataloader_worker = lambda: False
+    dv.using_srun = lambda: False
+    dv.move_tensordict_to_device = lambda x: x
+
+    class _Dist:
+        @classmethod
+        def get_instance(cls):
+            return cls()
+
+        def get_local_slices(self, shape, *a, **k):
+            return tuple(slice(None) for _ in shape)
+
+        def weighted_mean(self, data, weights, dim, keepdim=False):
+            return importlib.import_module("fme.core.metrics").weighted_mean(data, weights, dim=dim, keepdim=keepdim)
+
+        def spatial_reduce_sum(self, x):
+            return x
+
+        def zonal_mean(self, data):
+            return data.nanmean(dim=-1)
+
+    sys.modules["fme.core.distributed"].Distributed = _Dist
+    if "fme.core.typing_" in sys.modules:
+        del sys.modules["fme.core.typing_"]
+    importlib.import_module("fme.core.typing_")
+    coords = importlib.import_module("fme.core.coordinates")
+    atm = importlib.import_module("fme.core.corrector.atmosphere")
+    state = importlib.import_module("fme.core.corrector.state")
+    _corrector = types.SimpleNamespace(
+        AtmosphereCorrectorConfig=atm.AtmosphereCorrectorConfig, EnergyBudgetConfig=atm.EnergyBudgetConfig,
+        HybridSigmaPressureCoordinate=coords.HybridSigmaPressureCoordinate, LatLonCoordinates=coords.LatLonCoordinates,
+        CorrectorState=state.CorrectorState, module=atm)
+    return _corrector
