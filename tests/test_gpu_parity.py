@@ -282,6 +282,50 @@ def test_packed_path_config_variants(dev, kw):
     assert rel_max(y, ref) <= NET_TOL, rel_max(y, ref)
 
 
+def test_corrector_and_ocean_on_device(dev):
+    """the post-step hooks are plain torch ops on the device the state lives on: the ACE2-like corrector configuration
+    (fp64 global means on the GPU) and the prescribed-SST ocean against the reference's golden vectors."""
+    import datetime
+    import ace_amd
+    from ace_amd.corrector import AtmosphereCorrectorConfig
+    from ace_amd.ocean import OceanConfig
+    g = load_golden("gen_corrector.pt")
+    to = lambda d: {k: v.to(dev) for k, v in d.items()}
+    info = ace_amd.DatasetInfo((8, 16), timestep=datetime.timedelta(seconds=g["timestep_seconds"]), lat=g["lat"],
+                               lon=g["lon"], ak=g["ak"], bk=g["bk"])
+    cfg = AtmosphereCorrectorConfig(conserve_dry_air=True, moisture_budget_correction="advection_and_precipitation",
+                                    force_positive_names=["PRATEsfc", "specific_total_water_0", "specific_total_water_1"],
+                                    total_energy_budget_correction={"method": "constant_temperature"},
+                                    clip_frozen_precipitation=True)
+    c = cfg.get_corrector(info)
+    out0, st = c(to(g["input0"]), to(g["gen0"]), to(g["forcing"]), None)
+    out1, _ = c({**out0, **to(g["forcing"])}, to(g["gen1"]), to(g["forcing"]), st)
+    exp = g["expected"]["ace2_like"]
+    for k in exp["step0"]:   # budget residuals are differences of nearly cancelling terms: tolerance relative to the field
+        for got, want in ((out0[k], exp["step0"][k]), (out1[k], exp["step1"][k])):
+            torch.testing.assert_close(got.cpu(), want, rtol=2e-6, atol=2e-6 * float(want.abs().max()))
+    o = g["ocean"]
+    oc = OceanConfig("sst", "frac").build(["sst", "frac", "q"], ["sst", "q"])(to(o["input"]), to(o["gen"]), to(o["target"]))
+    assert torch.equal(oc["sst"].cpu(), o["expected"][False]["sst"])
+
+
+def test_graph_replay_packed_path_batch2(dev):
+    """hipGraph replay == eager on the packed path with batch 2 (per-sample folded weights, statistics partials) and
+    fresh inputs on every replay."""
+    from oracle.sfno import SFNOConfig, init_state
+    cfg = SFNOConfig(in_chans=4, out_chans=4, img_shape=(24, 48), embed_dim=32, num_layers=3, operator_type="dhconv")
+    net = build_native_net(cfg, init_state(cfg, seed=8), dev, "f16x3")
+    x = torch.randn(2, 4, 24, 48, device=dev)
+    out = torch.empty(2, 4, 24, 48, device=dev)
+    with torch.no_grad():
+        for _ in range(6):
+            x.normal_()
+            ref = net(x).clone()
+            net.forward_graph(x, out)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
+
+
 def test_quarter_degree_grid(dev):
     """BASELINE configs[3] geometry (0.25 degree: 721 x 1440, L = M = 721): the SHT pair and a small dhconv net against
     the fp64 oracle - index arithmetic, odd nlat, table sizes (1.5 GB per transform) and ragged tiles at the large grid."""
