@@ -26,8 +26,15 @@ class RolloutEngine:
         cfg = step.config
         if cfg.residual_prediction or cfg.prescribed_prognostic_names:
             raise NotImplementedError("residual_prediction / prescribed prognostics are not lowered into the engine")
-        if step._corrector is not None or step._ocean is not None:
-            raise NotImplementedError("corrector / ocean post-step hooks are not lowered into the engine; use Stepper")
+        # post-step hooks (corrector, prescribed-SST ocean): torch ops on the static buffers between the fused unpack of
+        # step s and the pack of step s + 1 - stream ordered, no host synchronisation.  The corrector state (dry-air
+        # reference mass) is seeded by the first step after load() and survives continue_from_last().
+        self._corrector = step._corrector
+        self._ocean = step._ocean
+        self._corrector_state = None
+        if (self._corrector is not None or self._ocean is not None) and graph == "window":
+            raise NotImplementedError("post-step hooks with graph='window': the dry-air reference of the first window "
+                                      "would be re-seeded on every replay; use graph='step' or None")
         self.stepper = stepper
         self.net = step.module.torch_module
         self.B, self.T = batch, n_forward_steps
@@ -46,6 +53,10 @@ class RolloutEngine:
         self.y = torch.zeros(B, len(self.out_names), H, W, **f32)   # network output (normalised)
         self.ic = {n: torch.zeros(B, 1, H, W, **f32) for n in self.prognostic}
         self.forcing = {n: torch.zeros(B, T + 1, H, W, **f32) for n in self.forcing_names}
+        # next-step data the hooks read that is not a network forcing input (e.g. the prescribed SST: prognostic AND target)
+        extra = set(cfg.ocean.forcing_names) if cfg.ocean is not None else set()
+        self.target_names = sorted(extra - set(self.forcing_names))
+        self.target = {n: torch.zeros(B, T + 1, H, W, **f32) for n in self.target_names}
         self.out = {n: torch.zeros(B, T, H, W, **f32) for n in self.out_names}
         norm = step.normalizer
         self.in_mean = torch.stack([norm.means[n].to(dev) for n in self.in_names]).contiguous()
@@ -94,12 +105,34 @@ class RolloutEngine:
         _lib.check(L.ace_unpack_denormalize(self.y.data_ptr(), self.out_mean.data_ptr(), self.out_std.data_ptr(),
                                             self._dst_ptr_addr[s], self._dst_strides.data_ptr(),
                                             self.B, nout, self.HW, stream))
+        if self._corrector is not None or self._ocean is not None:
+            self._apply_hooks(s)
+
+    def _apply_hooks(self, s: int):
+        """step_with_adjustments' tail (fme/core/step/single_module.py:669-716) on the window buffers of step s."""
+        inp = {n: (self.ic[n][:, 0] if s == 0 else self.out[n][:, s - 1]) for n in self.prognostic}
+        for n in self.forcing_names:
+            inp[n] = self.forcing[n][:, s + 1 if n in self.next_step_forcing else s]
+        gen = {n: self.out[n][:, s] for n in self.out_names}
+        nxt = {n: self.forcing[n][:, s + 1] for n in self.forcing_names}
+        nxt.update({n: self.target[n][:, s + 1] for n in self.target_names})
+        new = gen
+        if self._corrector is not None:
+            new, self._corrector_state = self._corrector(inp, new, nxt, self._corrector_state)
+        if self._ocean is not None:
+            new = self._ocean(inp, new, nxt)
+        for n in self.out_names:
+            if new[n] is not gen[n]:
+                gen[n].copy_(new[n])
 
     def load(self, initial_condition: Mapping[str, torch.Tensor], forcing: Mapping[str, torch.Tensor]):
         for n in self.prognostic:
             self.ic[n].copy_(initial_condition[n].reshape(self.B, 1, self.H, self.W))
         for n in self.forcing_names:
             self.forcing[n].copy_(forcing[n][:, : self.T + 1])
+        for n in self.target_names:
+            self.target[n].copy_(forcing[n][:, : self.T + 1])
+        self._corrector_state = None        # a new initial condition re-seeds the corrector
 
     def run_window(self):
         """Enqueue the T steps of the window on the current stream (no host synchronisation)."""
