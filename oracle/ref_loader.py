@@ -114,7 +114,18 @@ def load():
 
     timer = _ns("fme.core.benchmark.timer")
     timer.Timer = type("Timer", (), {})
-    timer.NullTimer = type("NullTimer", (), {})
+
+    class NullTimer:      # fme/core/benchmark/timer.py: a no-op timer whose children are no-op timers
+        def child(self, name):
+            return self
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+    timer.NullTimer = NullTimer
     timer.CUDATimer = type("CUDATimer", (), {})
 
     dev = _ns("fme.core.device")
@@ -211,3 +222,35 @@ def load_corrector():
         HybridSigmaPressureCoordinate=coords.HybridSigmaPressureCoordinate, LatLonCoordinates=coords.LatLonCoordinates,
         CorrectorState=state.CorrectorState, module=atm)
     return _corrector
+
+
+_csfno = None
+
+
+def load_csfno():
+    """The REAL NoiseConditionedSFNO (fme/ace/registry/stochastic_sfno.py + fme/core/models/conditional_sfno) under the
+    stubs of ``load_corrector`` plus SHT factories on the stub ``Distributed`` (the reference's own
+    ``fme.sht_fix.RealSHT/InverseRealSHT``).  Returns a namespace with ``Builder`` and ``DatasetInfo``-like helper."""
+    global _csfno
+    if _csfno is not None:
+        return _csfno
+    base = load()
+    load_corrector()
+    D = sys.modules["fme.core.distributed"].Distributed
+    D.get_sht = lambda self, nlat, nlon, lmax=None, mmax=None, grid="equiangular": base.RealSHT(
+        nlat, nlon, lmax=lmax, mmax=mmax, grid=grid)
+    D.get_isht = lambda self, nlat, nlon, lmax=None, mmax=None, grid="equiangular": base.InverseRealSHT(
+        nlat, nlon, lmax=lmax, mmax=mmax, grid=grid)
+    D.set_seed = lambda self, seed: None
+    for pkg in ["fme.core.models.conditional_sfno", "fme.ace.registry"]:
+        if pkg not in sys.modules:
+            _ns(pkg, os.path.join(REF, *pkg.split(".")))
+    reg = importlib.import_module("fme.ace.registry.stochastic_sfno")
+
+    class Info:
+        def __init__(self, img_shape):
+            self.img_shape = img_shape
+            self.all_labels = set()
+
+    _csfno = types.SimpleNamespace(Builder=reg.NoiseConditionedSFNOBuilder, Info=Info, module=reg)
+    return _csfno
