@@ -40,6 +40,8 @@ SIGNATURES = {
     "ace_conv1x1_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p]),
     "ace_mlp_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_long, c_int, c_void_p]),
     "ace_instance_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_long, c_void_p]),
+    "ace_conditional_layer_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                           c_int, c_int, c_int, c_long, c_void_p]),
     "ace_sfno_create": (c_int, [POINTER(AceSfnoConfig), POINTER(c_void_p)]),
     "ace_sfno_destroy": (None, [c_void_p]),
     "ace_sfno_set_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_long, c_void_p]),

@@ -408,6 +408,20 @@ extern "C" int ace_instance_norm(const float* x, const float* gamma, const float
     return ACE_OK;
 }
 
+extern "C" int ace_conditional_layer_norm(const float* x, const float* noise, const float* gamma, const float* beta,
+                                          const float* w_scale, const float* w_bias, float eps, float* y, int n, int c,
+                                          int noise_dim, long hw, void* stream) {
+    if (!x || !y || n <= 0 || c <= 0 || hw <= 0 || (w_scale && (!w_bias || !noise || noise_dim <= 0)))
+        return fail(ACE_ERR_INVALID, "ace_conditional_layer_norm: bad argument");
+    if (hw % 4 != 0) return fail(ACE_ERR_INVALID, "ace_conditional_layer_norm: needs hw % 4 == 0");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DevBuf stats;
+    HIP_TRY(stats.alloc((size_t)2 * n * hw, false));
+    HIP_TRY(launch_cond_layer_norm(x, noise, gamma, beta, w_scale, w_bias, eps, stats.p, y, n, c, noise_dim, hw, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return ACE_OK;
+}
+
 extern "C" int ace_pack_normalize(const float* const* srcs, const long* strides, const float* mean, const float* std_,
                                   float* dst, int batch, int nch, long hw, void* stream) {
     if (!srcs || !strides || !mean || !std_ || !dst) return fail(ACE_ERR_INVALID, "ace_pack_normalize: null argument");

@@ -146,6 +146,12 @@ hipError_t launch_fold_affine_f16(const float* W, long ldw, float wmax, const fl
                                   void* hi, void* lo, float* bf, int nsamples, int O, int I, long ldd, long sPl,
                                   unsigned* wslot, hipStream_t s);
 
+// conditional layer norm (per-pixel statistics over channels, noise-conditioned scale / bias; see kernels.hip).
+// stats: workspace of 2 * Bt * HW floats.  ws / wb (C x J) may be null (plain channel layer norm); gamma / beta may be null
+hipError_t launch_cond_layer_norm(const float* x, const float* noise, const float* gamma, const float* beta,
+                                  const float* ws, const float* wb, float eps, float* stats, float* y, int Bt, int C,
+                                  int J, long HW, hipStream_t s, unsigned* omax = nullptr);
+
 // layout converters between the internal spectral layout and the reference's (n, L, M) complex64
 hipError_t launch_spec_to_ref(const float* D, float* out, int Bt, int C, int L, int Mm, hipStream_t s);
 hipError_t launch_ref_to_spec(const float* in, float* E, int Bt, int C, int L, int Mm, hipStream_t s);

@@ -2865,6 +2865,130 @@ hipError_t launch_fold_affine(const float* W, long ldw, const float* a, const fl
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Conditional layer norm of the NoiseConditionedSFNO (fme/core/models/conditional_sfno/layers.py:95-141, 245-318):
+//   y[c][p] = ((x[c][p] - mean_p) * rstd_p * gamma_c + beta_c) * (1 + sum_j Ws[c][j] noise[j][p]) + sum_j Wb[c][j] noise[j][p]
+// with per-PIXEL statistics over the channels (biased variance, eps inside the sqrt).  Two kernels:
+//   cln_stats_kernel : mean / rstd per pixel; 8 channel groups x 64 pixel quads per workgroup, fp64 accumulation of
+//                      sum and sum of squares (one pass over x), reduced through LDS
+//   cln_apply_kernel : thread = 8 channels x 4 pixels; the two 1x1 "noise" convolutions are computed on the fly
+//                      (2 J FMAs per element; their weights for the 8 channels sit in LDS), fp32 output + max|y|
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void cln_stats_kernel(const float* __restrict__ x, int C, long HW, float eps,
+                                                        float* __restrict__ mean, float* __restrict__ rstd) {
+    const int b = blockIdx.y;
+    const int q = threadIdx.x & 63, cg = threadIdx.x >> 6;      // pixel quad, channel group (0..7)
+    const long p = ((long)blockIdx.x * 64 + q) * 4;
+    const bool ok = p < HW;                                     // HW % 4 == 0
+    const float* xb = x + (long)b * C * HW + (ok ? p : 0);
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    for (int c = cg; c < C; c += 8) {
+        const float4 v = *reinterpret_cast<const float4*>(xb + (long)c * HW);
+        const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += (double)xs[e]; ss[e] += (double)xs[e] * (double)xs[e]; }
+    }
+    __shared__ double rs[8][64][4], rss[8][64][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { rs[cg][q][e] = s[e]; rss[cg][q][e] = ss[e]; }
+    __syncthreads();
+    if (cg == 0 && ok) {
+        float m4[4], r4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            double a = 0.0, bq = 0.0;
+            for (int k = 0; k < 8; ++k) { a += rs[k][q][e]; bq += rss[k][q][e]; }
+            const double mu = a / C;
+            double var = bq / C - mu * mu;
+            if (var < 0.0) var = 0.0;
+            m4[e] = (float)mu;
+            r4[e] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        *reinterpret_cast<float4*>(mean + (long)b * HW + p) = make_float4(m4[0], m4[1], m4[2], m4[3]);
+        *reinterpret_cast<float4*>(rstd + (long)b * HW + p) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void cln_apply_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ ws, const float* __restrict__ wb,
+                                                        float* __restrict__ y, int C, int J, long HW, unsigned* omax) {
+    extern __shared__ float wsm[];                // [2][8][J]: scale / bias conv weights of this workgroup's 8 channels
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * 8;
+    for (int t = threadIdx.x; t < 2 * 8 * J; t += 256) {
+        const int which = t / (8 * J), r = (t / J) % 8, j = t % J;
+        const int c = c0 + r;
+        const float* src = which == 0 ? ws : wb;
+        wsm[t] = (src != nullptr && c < C) ? src[(long)c * J + j] : 0.f;
+    }
+    __syncthreads();
+    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    float vmax = 0.f;
+    if (p < HW) {
+        float sc[8][4], bi[8][4];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sc[r][e] = 1.f; bi[r][e] = 0.f; }
+        if (ws != nullptr) {
+            const float* nb = noise + (long)b * J * HW + p;
+            for (int j = 0; j < J; ++j) {
+                const float4 n4 = *reinterpret_cast<const float4*>(nb + (long)j * HW);
+                const float ns[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float a = wsm[r * J + j], bq = wsm[8 * J + r * J + j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { sc[r][e] = fmaf(a, ns[e], sc[r][e]); bi[r][e] = fmaf(bq, ns[e], bi[r][e]); }
+                }
+            }
+        }
+        const float4 m4 = *reinterpret_cast<const float4*>(mean + (long)b * HW + p);
+        const float4 r4 = *reinterpret_cast<const float4*>(rstd + (long)b * HW + p);
+        const float mu[4] = {m4.x, m4.y, m4.z, m4.w}, rs[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int c = c0 + r;
+            if (c >= C) break;
+            const float4 v = *reinterpret_cast<const float4*>(x + ((long)b * C + c) * HW + p);
+            const float xs[4] = {v.x, v.y, v.z, v.w};
+            const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = (xs[e] - mu[e]) * rs[e];
+                if (gamma) t = t * g + bt;
+                o[e] = t * sc[r][e] + bi[r][e];
+                vmax = fmaxf(vmax, fabsf(o[e]));
+            }
+            *reinterpret_cast<float4*>(y + ((long)b * C + c) * HW + p) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    if (omax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(omax + ((blockIdx.x + blockIdx.y) & 63), __float_as_uint(vmax));
+    }
+}
+
+hipError_t launch_cond_layer_norm(const float* x, const float* noise, const float* gamma, const float* beta,
+                                  const float* ws, const float* wb, float eps, float* stats, float* y, int Bt, int C,
+                                  int J, long HW, hipStream_t s, unsigned* omax) {
+    if (HW % 4 != 0 || !al16(x) || !al16(y) || !al16(stats) || (ws && (!noise || !al16(noise) || J <= 0 || J > 512)))
+        return hipErrorInvalidValue;
+    float* mean = stats;
+    float* rstd = stats + (long)Bt * HW;
+    hipLaunchKernelGGL(cln_stats_kernel, dim3((unsigned)((HW / 4 + 63) / 64), (unsigned)Bt), dim3(512), 0, s, x, C, HW, eps,
+                       mean, rstd);
+    const int Jm = ws ? J : 1;
+    hipLaunchKernelGGL(cln_apply_kernel, dim3((unsigned)((HW / 4 + 255) / 256), (unsigned)((C + 7) / 8), (unsigned)Bt),
+                       dim3(256), (size_t)2 * 8 * Jm * sizeof(float), s, x, noise, mean, rstd, gamma, beta, ws, wb, y, C, Jm,
+                       HW, omax);
+    return hipGetLastError();
+}
+
 // slot reset as a kernel (not hipMemsetAsync): inside a captured graph a memset node is not ordered/coherent with the
 // device-scope atomics on the same words the way a kernel node is (observed: stale bounds on replay)
 __global__ void zero_u32_kernel(unsigned* p, long n) {

@@ -85,6 +85,15 @@ int ace_mlp_f16x3(const float* x, const float* w1, const float* b1, const float*
 int ace_instance_norm(const float* x, const float* gamma, const float* beta, float eps, float* y, int n, int c,
                       long hw, void* stream);
 
+/* ConditionalLayerNorm.forward restricted to noise conditioning (fme/core/models/conditional_sfno/layers.py:95-141,
+ * 245-318): per-PIXEL layer norm over the c channels (biased variance, eps inside the sqrt, optional elementwise
+ * gamma/beta (c)), then y = y_norm * (1 + W_scale noise) + W_bias noise with the 1x1 convolutions W_scale, W_bias
+ * (c, noise_dim), noise (n, noise_dim, hw).  w_scale = w_bias = NULL: plain ChannelLayerNorm.  Needs hw % 4 == 0.
+ * Test / building-block entry: allocates its statistics workspace and synchronises. */
+int ace_conditional_layer_norm(const float* x, const float* noise, const float* gamma, const float* beta,
+                               const float* w_scale, const float* w_bias, float eps, float* y, int n, int c,
+                               int noise_dim, long hw, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * The network.  Replaces SphericalFourierNeuralOperatorNet.__init__/forward
  * (fme/ace/models/modulus/sfnonet.py:341-685, 713-749) as built by

@@ -70,6 +70,40 @@ def test_instance_norm(dev, n, c, hw):
 
 
 # ---------------------------------------------------------------------------------- SHT
+@pytest.mark.parametrize("n,c,j,hw,affine,cond", [(2, 16, 8, 288, True, True), (1, 384, 32, 4132, True, True),
+                                                   (3, 5, 4, 64, False, True), (2, 24, 0, 100, True, False)])
+def test_conditional_layer_norm(dev, n, c, j, hw, affine, cond):
+    """ConditionalLayerNorm with noise conditioning (conditional_sfno/layers.py:95-141, 245-318) against the reference's
+    torch formula in fp64."""
+    from ace_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(c + hw)
+    x = torch.randn(n, c, hw, generator=g) * 3.0 + 1.5
+    noise = torch.randn(n, max(j, 1), hw, generator=g)
+    gamma = 1.0 + 0.3 * torch.randn(c, generator=g)
+    beta = 0.2 * torch.randn(c, generator=g)
+    ws = 0.3 * torch.randn(c, max(j, 1), generator=g)
+    wb = 0.3 * torch.randn(c, max(j, 1), generator=g)
+    xd = x.double()
+    mean = xd.mean(dim=1, keepdim=True)
+    var = xd.var(dim=1, keepdim=True, unbiased=False)
+    ref = (xd - mean) * torch.rsqrt(var + 1e-5)
+    if affine:
+        ref = ref * gamma.double()[None, :, None] + beta.double()[None, :, None]
+    if cond:
+        scale = 1.0 + torch.einsum("cj,njp->ncp", ws.double(), noise.double())
+        bias = torch.einsum("cj,njp->ncp", wb.double(), noise.double())
+        ref = ref * scale + bias
+    t = [v.to(dev) for v in (x, noise, gamma, beta, ws, wb)]
+    y = torch.empty(n, c, hw, device=dev)
+    null = ctypes.c_void_p(0)
+    _lib.check(L.ace_conditional_layer_norm(_lib.ptr(t[0]), _lib.ptr(t[1]) if cond else null,
+                                            _lib.ptr(t[2]) if affine else null, _lib.ptr(t[3]) if affine else null,
+                                            _lib.ptr(t[4]) if cond else null, _lib.ptr(t[5]) if cond else null,
+                                            1e-5, _lib.ptr(y), n, c, j, hw, _lib.current_stream()))
+    assert rel_max(y, ref) <= OP_TOL
+
+
 def test_sht_golden_regression(dev):
     """fme/core/benchmark/testdata/{sht,inverse_sht}-regression.pt (lobatto 9x18)."""
     import ace_amd
