@@ -23,6 +23,7 @@ class AceSfnoConfig(ctypes.Structure):
         ("normalization_layer", c_int), ("activation_function", c_int), ("use_mlp", c_int),
         ("mlp_ratio", c_float), ("encoder_layers", c_int), ("pos_embed", c_int), ("big_skip", c_int),
         ("data_grid", c_int), ("max_batch", c_int), ("precision", c_int),
+        ("noise_embed_dim", c_int), ("affine_norms", c_int), ("normalize_big_skip", c_int), ("filter_num_groups", c_int),
     ]
 
 
@@ -49,6 +50,7 @@ SIGNATURES = {
     "ace_sfno_weight_name": (c_char_p, [c_void_p, c_int]),
     "ace_sfno_weight_numel": (c_long, [c_void_p, c_int]),
     "ace_sfno_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ace_sfno_forward_conditioned": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ace_sfno_num_stages": (c_int, []),
     "ace_sfno_stage_name": (c_char_p, [c_int]),
     "ace_sfno_forward_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, POINTER(c_float), POINTER(c_int)]),

@@ -446,6 +446,7 @@ struct Weight {
     bool set = false;
     int block = -1;
     bool is_filter = false;
+    long ext_numel = 0;  // numel of the caller's tensor when it differs from the library copy (grouped csfno filter)
     int rows = 0, cols = 0, pitch = 0;  // conv weights (rows x cols), pitch = cols rounded up to 32
     DevBuf hi, lo;      // f16x3 mode: fp16 planes of the conv weight scaled by `ascale` (pitch halves)
     float ascale = 1.f;
@@ -475,6 +476,8 @@ struct ace_sfno {
     // workspace
     DevBuf h0, h1, Y, T, R, U, X, D, E, stats;
     DevBuf P;  // f16x3: a C-channel activation as P-format fp16 hi/lo planes (input of the packed-operand GEMM)
+    DevBuf cln_stats;    // conditional layer norm: per-pixel mean | rstd
+    DevBuf inN;          // conditional layer norm of the network input (normalize_big_skip)
     DevBuf P2;           // second one: the block input h as written by the previous block's fc2 epilogue
     DevBuf part;         // per-strip row statistics from the GEMM epilogues (fused instance norm), two tensors
     DevBuf Wp0, Wp1;     // folded (norm affine) skip / fc1 weights as tiled fp16 planes, per sample
@@ -513,8 +516,16 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     if (c.in_chans <= 0 || c.out_chans <= 0 || c.embed_dim <= 0 || c.num_layers <= 0 || c.nlat < 2 || c.nlon < 2)
         return fail(ACE_ERR_INVALID, "non-positive dimension in ace_sfno_config");
     if (c.operator_type != 0 && c.operator_type != 1) return fail(ACE_ERR_INVALID, "Unsupported operator type");
-    if (c.normalization_layer != 0 && c.normalization_layer != 1)
-        return fail(ACE_ERR_INVALID, "normalization_layer must be 'none' or 'instance_norm'");
+    if (c.normalization_layer < 0 || c.normalization_layer > 2)
+        return fail(ACE_ERR_INVALID, "normalization_layer must be 'none', 'instance_norm' or conditional layer norm");
+    const bool cln = c.normalization_layer == 2;
+    if (cln) {
+        if (c.operator_type != 1) return fail(ACE_ERR_INVALID, "Only 'dhconv' operator_type is supported for NoiseConditionedSFNO models.");
+        if (c.noise_embed_dim < 0 || c.noise_embed_dim > 512) return fail(ACE_ERR_INVALID, "noise_embed_dim must be in [0, 512]");
+        if (c.filter_num_groups < 1 || c.embed_dim % c.filter_num_groups != 0)
+            return fail(ACE_ERR_INVALID, "embed_dim must be divisible by filter_num_groups");
+        if (((long)c.nlat * c.nlon) % 4 != 0) return fail(ACE_ERR_INVALID, "conditional layer norm needs nlat * nlon % 4 == 0");
+    }
     if (c.activation_function < 1 || c.activation_function > 3)
         return fail(ACE_ERR_INVALID, "Unknown activation function");
     if (c.data_grid != GRID_LEGENDRE_GAUSS && c.data_grid != GRID_EQUIANGULAR)
@@ -553,12 +564,22 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string p = "blocks." + std::to_string(i) + ".";
         if (c.normalization_layer == 1) { add_weight(n.get(), p + "norm0.weight", C); add_weight(n.get(), p + "norm0.bias", C); }
+        auto add_cln = [&](const std::string& q, long ch) {   // ConditionalLayerNorm parameters in state_dict order
+            if (c.noise_embed_dim > 0) {
+                add_weight(n.get(), q + "W_scale_2d.weight", ch * c.noise_embed_dim);
+                add_weight(n.get(), q + "W_bias_2d.weight", ch * c.noise_embed_dim);
+            }
+            if (c.affine_norms) { add_weight(n.get(), q + "norm.weight", ch); add_weight(n.get(), q + "norm.bias", ch); }
+        };
+        if (cln) add_cln(p + "norm0.", C);
         const long fw = c.operator_type == 1 ? C * C * n->L * 2 : C * C * (long)n->L * n->Mm * 2;
         add_weight(n.get(), p + "filter.filter.weight", fw, i, true);
+        if (cln) n->weights.back()->ext_numel = fw / c.filter_num_groups;   // (G, L, C/G, C/G, 2)
         add_weight(n.get(), p + "filter.filter.bias", C);
         add_conv_weight(n.get(), p + "inner_skip.weight", (int)C, (int)C);
         add_weight(n.get(), p + "inner_skip.bias", C);
         if (c.normalization_layer == 1) { add_weight(n.get(), p + "norm1.weight", C); add_weight(n.get(), p + "norm1.bias", C); }
+        if (cln) add_cln(p + "norm1.", C);
         if (c.use_mlp) {
             add_conv_weight(n.get(), p + "mlp.fwd.0.weight", n->hid, (int)C);
             add_weight(n.get(), p + "mlp.fwd.0.bias", n->hid);
@@ -573,6 +594,13 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
         cur = C;
     }
     add_conv_weight(n.get(), "decoder." + std::to_string(2 * c.encoder_layers) + ".weight", c.out_chans, (int)cur);
+    if (cln && c.normalize_big_skip && c.big_skip) {
+        if (c.noise_embed_dim > 0) {
+            add_weight(n.get(), "norm_big_skip.W_scale_2d.weight", (long)c.in_chans * c.noise_embed_dim);
+            add_weight(n.get(), "norm_big_skip.W_bias_2d.weight", (long)c.in_chans * c.noise_embed_dim);
+        }
+        if (c.affine_norms) { add_weight(n.get(), "norm_big_skip.norm.weight", c.in_chans); add_weight(n.get(), "norm_big_skip.norm.bias", c.in_chans); }
+    }
 
     n->wx.resize(c.num_layers);
     n->wx_hi.resize(c.num_layers);
@@ -610,6 +638,10 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     HIP_TRY(n->D.alloc(spec_d));
     HIP_TRY(n->E.alloc(spec_d));
     HIP_TRY(n->stats.alloc((size_t)4 * n->Bmax * C));
+    if (cln) {
+        HIP_TRY(n->cln_stats.alloc((size_t)2 * n->Bmax * HW));
+        if (c.normalize_big_skip && c.big_skip) HIP_TRY(n->inN.alloc((size_t)n->Bmax * c.in_chans * HW));
+    }
     HIP_TRY(n->amax.alloc((size_t)(16 + 12 * c.num_layers) * AMAX_SHARDS));
     if (c.normalization_layer == 1) {
         const size_t cp = (size_t)((C + 31) & ~31);
@@ -638,7 +670,7 @@ extern "C" const char* ace_sfno_weight_name(const ace_sfno* n, int i) {
 }
 extern "C" long ace_sfno_weight_numel(const ace_sfno* n, int i) {
     if (!n || i < 0 || i >= (int)n->weights.size()) return -1;
-    return n->weights[i]->numel;
+    return n->weights[i]->ext_numel ? n->weights[i]->ext_numel : n->weights[i]->numel;
 }
 
 extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* src, long numel, void* stream) {
@@ -646,15 +678,22 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
     auto it = n->index.find(name);
     if (it == n->index.end()) return fail(ACE_ERR_INVALID, std::string("unknown parameter '") + name + "'");
     Weight& w = *n->weights[it->second];
-    if (numel != w.numel)
+    const long expect = w.ext_numel ? w.ext_numel : w.numel;
+    if (numel != expect)
         return fail(ACE_ERR_INVALID, std::string("size mismatch for ") + name + ": expected " +
-                                         std::to_string(w.numel) + " elements, got " + std::to_string(numel));
+                                         std::to_string(expect) + " elements, got " + std::to_string(numel));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (w.ext_numel) {   // grouped csfno filter: (G, L, C/G, C/G, 2) -> dense (Cin, Cout, L, 2), then as any dhconv weight
+        if (!w.buf.p) HIP_TRY(w.buf.alloc((size_t)w.numel, false));
+        HIP_TRY(launch_csfno_weight_to_dense(src, w.buf.p, n->C, n->cfg.filter_num_groups, n->L, s));
+        src = nullptr;
+        numel = w.numel;
+    }
     if (w.pitch > 0) {
         if (!w.buf.p) HIP_TRY(w.buf.alloc((size_t)w.rows * w.pitch, true));  // zero padding columns
         HIP_TRY(hipMemcpy2DAsync(w.buf.p, sizeof(float) * w.pitch, src, sizeof(float) * w.cols, sizeof(float) * w.cols,
                                  w.rows, hipMemcpyDeviceToDevice, s));
-    } else {
+    } else if (src) {
         if (!w.buf.p) HIP_TRY(w.buf.alloc((size_t)numel, false));
         HIP_TRY(hipMemcpyAsync(w.buf.p, src, sizeof(float) * numel, hipMemcpyDeviceToDevice, s));
     }
@@ -882,7 +921,8 @@ struct StageTimer {
 };
 #define MARK(st) do { if (tm) tm->push(st); } while (0)
 
-static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStream_t s, StageTimer* tm = nullptr) {
+static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStream_t s, StageTimer* tm = nullptr,
+                        const float* noise = nullptr) {
     const ace_sfno_config& c = n->cfg;
     const int C = n->C, Cin = c.in_chans, act = c.activation_function;
     const long HW = n->HW;
@@ -926,6 +966,18 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     float* sc1 = sh0 + (size_t)n->Bmax * C;
     float* sh1 = sc1 + (size_t)n->Bmax * C;
     const bool norm = c.normalization_layer == 1;
+    // NoiseConditionedSFNO: conditional layer norms are materialised in place (fp32) with their true max in the slot of
+    // the instance-norm bound; the convolutions then run on the on-the-fly-split engine (v3) / the fp32 engines
+    const bool cln = c.normalization_layer == 2;
+    const float* skip_in = in;               // second source of the big-skip concat
+    const unsigned* skip_in_slot = slot(0);
+    if (cln && c.big_skip && c.normalize_big_skip) {
+        HIP_TRY(launch_cond_layer_norm(in, noise, W("norm_big_skip.norm.weight"), W("norm_big_skip.norm.bias"),
+                                       W("norm_big_skip.W_scale_2d.weight"), W("norm_big_skip.W_bias_2d.weight"), 1e-5f,
+                                       n->cln_stats.p, n->inN.p, B, Cin, c.noise_embed_dim, HW, s, slot(7)));
+        skip_in = n->inN.p;
+        skip_in_slot = slot(7);
+    }
 
     // fused-norm state of the packed-operand path: does P2 hold the block input in P format / `part_h` its statistics?
     bool have_ph = false, have_hstats = false;
@@ -947,6 +999,12 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         const int sb = 16 + 12 * i;  // slot base of this block
         if (f16 && i + 1 >= 8) HIP_TRY(launch_zero_u32(hslot(i + 1), AMAX_SHARDS, s));
         const float *a0 = nullptr, *b0 = nullptr;
+        if (cln) {   // x_norm = CLN0(h; noise), in place: the block never needs the un-normalised h again (sfnonet.py:388-437)
+            HIP_TRY(launch_cond_layer_norm(h, noise, W(p + "norm0.norm.weight"), W(p + "norm0.norm.bias"),
+                                           W(p + "norm0.W_scale_2d.weight"), W(p + "norm0.W_bias_2d.weight"), 1e-5f,
+                                           n->cln_stats.p, h, B, C, c.noise_embed_dim, HW, s, slot(sb + 3)));
+            MARK(ST_NORM0);
+        }
         if (norm) {
             if (have_hstats)   // statistics of h came out of the previous block's fc2 epilogue
                 HIP_TRY(launch_instnorm_finalize(reinterpret_cast<const float4*>(part_h), gemm4_strips(C, (int)HW), B, C, HW,
@@ -1018,9 +1076,9 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         ConvW wskip = conv_weight(n, p + "inner_skip.weight", p + "inner_skip.bias");
         // B of the inner skip: the normalised block input (bound from the norm statistics) or, without a norm, the raw
         // block input; the spectrally round-tripped residual of mixed-grid blocks has no range slot -> fp32 engine
-        const unsigned* skip_max = scale_residual ? nullptr : (norm ? slot(sb + 3) : hslot(i));
+        const unsigned* skip_max = scale_residual ? nullptr : ((norm || cln) ? slot(sb + 3) : hslot(i));
         const bool skip_f16 = f16 && skip_max != nullptr;
-        const bool pk = skip_f16 && packed_ok(n, C) && (!c.use_mlp || n->hid % 8 == 0);
+        const bool pk = skip_f16 && !cln && packed_ok(n, C) && (!c.use_mlp || n->hid % 8 == 0);
         _Float16* Ph = reinterpret_cast<_Float16*>(n->P.p);
         _Float16* Pl = Ph + (size_t)n->Bmax * C * HW;
         const bool fused = pk && norm && c.use_mlp && n->P2.p != nullptr;
@@ -1104,6 +1162,12 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         if (!fused) MARK(ST_INNER_SKIP);
         // norm1 -> MLP -> + residual   (sfnonet.py:234-250)
         const float *a1 = nullptr, *b1 = nullptr;
+        if (cln) {
+            HIP_TRY(launch_cond_layer_norm(n->T.p, noise, W(p + "norm1.norm.weight"), W(p + "norm1.norm.bias"),
+                                           W(p + "norm1.W_scale_2d.weight"), W(p + "norm1.W_bias_2d.weight"), 1e-5f,
+                                           n->cln_stats.p, n->T.p, B, C, c.noise_embed_dim, HW, s, slot(sb + 5)));
+            MARK(ST_NORM1);
+        }
         if (norm && !fused) {
             HIP_TRY(launch_instnorm_stats(n->T.p, W(p + "norm1.weight"), W(p + "norm1.bias"), 1e-6f, B, C, HW, sc1, sh1, s,
                                           slot(sb + 5)));
@@ -1131,7 +1195,8 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             ConvW wfc1 = conv_weight(n, p + "mlp.fwd.0.weight", p + "mlp.fwd.0.bias");
             if (a1 && !f16) ACE_TRY(fold(n, wfc1, n->hid, C, a1, b1, n->Wf1.p, n->bf1.p, B, s, &wfc1));
             ACE_TRY(conv(n, wfc1, n->T.p, actB, C, nullptr, 0, -1, n->U.p, n->hid, nullptr, 0, nullptr, nullptr, act, B, s,
-                         f16 ? a1 : nullptr, f16 ? b1 : nullptr, norm ? slot(sb + 5) : slot(sb + 4), nullptr, slot(sb + 6)));
+                         f16 ? a1 : nullptr, f16 ? b1 : nullptr, (norm || cln) ? slot(sb + 5) : slot(sb + 4), nullptr,
+                         slot(sb + 6)));
             MARK(ST_MLP_FC1);
             ACE_TRY(conv(n, conv_weight(n, p + "mlp.fwd.2.weight", p + "mlp.fwd.2.bias"), n->U.p, (long)n->hid * HW,
                          n->hid, nullptr, 0, -1, hn, C, res, actB, ra, rb, ACT_NONE, B, s, nullptr, nullptr, slot(sb + 6),
@@ -1151,8 +1216,8 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         const std::string p = "decoder." + std::to_string(2 * j);
         const bool cat = (j == 0 && c.big_skip);
         ACE_TRY(conv(n, conv_weight(n, p + ".weight", p + ".bias"), cur, cur_bs, cat ? C + Cin : curC,
-                     cat ? in : nullptr, (long)Cin * HW, C, ping[j & 1], C, nullptr, 0, nullptr, nullptr, act, B, s, nullptr,
-                     nullptr, j == 0 ? (c.use_mlp ? hslot(c.num_layers) : nullptr) : slot(3 + j), slot(0), slot(4 + j)));
+                     cat ? skip_in : nullptr, (long)Cin * HW, C, ping[j & 1], C, nullptr, 0, nullptr, nullptr, act, B, s, nullptr,
+                     nullptr, j == 0 ? (c.use_mlp ? hslot(c.num_layers) : nullptr) : slot(3 + j), skip_in_slot, slot(4 + j)));
         cur = ping[j & 1]; cur_bs = actB; curC = C;
     }
     ACE_TRY(conv(n, conv_weight(n, "decoder." + std::to_string(2 * c.encoder_layers) + ".weight", ""), cur, cur_bs, curC,
@@ -1174,7 +1239,18 @@ static int check_ready(ace_sfno* n, const float* in, float* out, int batch) {
 
 extern "C" int ace_sfno_forward(ace_sfno* n, const float* in, float* out, int batch, void* stream) {
     ACE_TRY(check_ready(n, in, out, batch));
+    if (n->cfg.normalization_layer == 2)
+        return fail(ACE_ERR_STATE, "this net is noise conditioned: call ace_sfno_forward_conditioned");
     return forward_impl(n, in, out, batch, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ace_sfno_forward_conditioned(ace_sfno* n, const float* in, const float* noise, float* out, int batch,
+                                            void* stream) {
+    ACE_TRY(check_ready(n, in, out, batch));
+    if (n->cfg.normalization_layer != 2)
+        return fail(ACE_ERR_STATE, "ace_sfno_forward_conditioned needs a net created with conditional layer norms");
+    if (!noise && n->cfg.noise_embed_dim > 0) return fail(ACE_ERR_INVALID, "null noise");
+    return forward_impl(n, in, out, batch, static_cast<hipStream_t>(stream), nullptr, noise);
 }
 
 extern "C" int ace_sfno_num_stages(void) { return ST_COUNT; }
@@ -1182,6 +1258,7 @@ extern "C" const char* ace_sfno_stage_name(int i) { return (i >= 0 && i < ST_COU
 extern "C" int ace_sfno_forward_timed(ace_sfno* n, const float* in, float* out, int batch, void* stream, float* ms_host,
                                       int* calls_host) {
     ACE_TRY(check_ready(n, in, out, batch));
+    if (n->cfg.normalization_layer == 2) return fail(ACE_ERR_STATE, "this net is noise conditioned: call ace_sfno_forward_conditioned");
     if (!ms_host) return fail(ACE_ERR_INVALID, "null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     StageTimer tm(s);
@@ -1209,6 +1286,7 @@ extern "C" int ace_sfno_get_tap(ace_sfno* n, int i, float* dst, int batch, void*
 
 extern "C" int ace_sfno_forward_graph(ace_sfno* n, const float* in, float* out, int batch, void* stream) {
     ACE_TRY(check_ready(n, in, out, batch));
+    if (n->cfg.normalization_layer == 2) return fail(ACE_ERR_STATE, "this net is noise conditioned: call ace_sfno_forward_conditioned");
     if (n->taps_on) return fail(ACE_ERR_STATE, "disable taps before using the graph path");
     hipStream_t s = static_cast<hipStream_t>(stream);
     GraphKey key{in, out, batch};

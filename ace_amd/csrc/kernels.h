@@ -63,6 +63,8 @@ hipError_t launch_gemm_f16x3_planes(const GemmArgs& g, const void* Ahi, const vo
 hipError_t launch_gemm_f16x3_adyn(const GemmArgs& g, const void* Bhi, const void* Blo, long ldn, long sB_halves,
                                   float bscale_static, const unsigned* amax, unsigned* omax, hipStream_t s);
 hipError_t launch_pack_dhconv_f16(const float* w, void* hi, void* lo, int Cin, int Cout, int L, float scale, hipStream_t s);
+// NoiseConditionedSFNO filter weight (G, L, C/G, C/G, 2) -> dense (Cin, Cout, L, 2)
+hipError_t launch_csfno_weight_to_dense(const float* w, float* dense, int C, int G, int L, hipStream_t s);
 // compact form for Gemm4Args::cplx: planes [l][2 (re | im)][Cin/8][Cout][8]
 hipError_t launch_pack_dhconv_f16c(const float* w, void* hi, void* lo, int Cin, int Cout, int L, float scale, hipStream_t s);
 hipError_t launch_zero_u32(unsigned* p, long n, hipStream_t s);

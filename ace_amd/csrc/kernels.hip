@@ -1375,6 +1375,33 @@ hipError_t launch_split_f16(const float* src, long lds_, void* hi, void* lo, lon
     return hipGetLastError();
 }
 
+// NoiseConditionedSFNO filter weight (G, L, C/G [out], C/G [in], 2) (conditional_sfno/s2convolutions.py:232-239,
+// einsum "bgixy,gxoi->bgoxy") -> the dense layout (Cin, Cout, L, 2) the rest of the library works with; entries that
+// couple different groups are zero
+__global__ void csfno_weight_to_dense_kernel(const float* __restrict__ w, float* __restrict__ dense, int C, int G, int L) {
+    const long total = (long)C * C * L;
+    const int Cg = C / G;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int l = t % L;
+        const int o = (t / L) % C;
+        const int i = t / ((long)L * C);
+        float2 v = make_float2(0.f, 0.f);
+        if (i / Cg == o / Cg) {
+            const int g = i / Cg;
+            v = *reinterpret_cast<const float2*>(w + ((((long)g * L + l) * Cg + (o % Cg)) * Cg + (i % Cg)) * 2);
+        }
+        *reinterpret_cast<float2*>(dense + t * 2) = v;
+    }
+}
+hipError_t launch_csfno_weight_to_dense(const float* w, float* dense, int C, int G, int L, hipStream_t s) {
+    if (G < 1 || C % G != 0) return hipErrorInvalidValue;
+    const long total = (long)C * C * L;
+    long gsz = (total + 255) / 256;
+    if (gsz > 32768) gsz = 32768;
+    hipLaunchKernelGGL(csfno_weight_to_dense_kernel, dim3((unsigned)gsz), dim3(256), 0, s, w, dense, C, G, L);
+    return hipGetLastError();
+}
+
 // dhconv weight (Cin, Cout, L, 2) -> per-l real 2Cin x 2Cout operand in the f16x3 engine's k-packed form:
 //   planes hi/lo [l][K/8][ldn][8] halves, K = 2 Cin (rows (ri, i)), ldn = 2 Cout (columns (r', o)), values scaled by `scale`
 //   [ out_re | out_im ] = [ x_re | x_im ] * [[ w_re, w_im ], [ -w_im, w_re ]]
@@ -2909,11 +2936,11 @@ __global__ __launch_bounds__(512) void cln_stats_kernel(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void cln_apply_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+__global__ __launch_bounds__(256) void cln_apply_kernel(const float* x, const float* __restrict__ noise,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ ws, const float* __restrict__ wb,
-                                                        float* __restrict__ y, int C, int J, long HW, unsigned* omax) {
+                                                        float* y, int C, int J, long HW, unsigned* omax) {   // y may alias x
     extern __shared__ float wsm[];                // [2][8][J]: scale / bias conv weights of this workgroup's 8 channels
     const int b = blockIdx.z;
     const int c0 = blockIdx.y * 8;

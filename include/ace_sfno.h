@@ -108,7 +108,7 @@ typedef struct ace_sfno_config {
     int scale_factor;             /* only 1 is supported */
     float hard_thresholding_fraction;
     int operator_type;            /* 0 = "diagonal", 1 = "dhconv" */
-    int normalization_layer;      /* 0 = "none", 1 = "instance_norm" */
+    int normalization_layer;      /* 0 = "none", 1 = "instance_norm", 2 = conditional layer norm (NoiseConditionedSFNO) */
     int activation_function;      /* 1 = "gelu", 2 = "relu", 3 = "silu" */
     int use_mlp;
     float mlp_ratio;
@@ -119,6 +119,11 @@ typedef struct ace_sfno_config {
     int precision;                /* 0 = exact fp32 MFMA everywhere (the reference's arithmetic);
                                      1 = "f16x3": 1x1 convolutions on compensated fp16 MFMA (hi/lo split of both
                                      operands, 3 exact-product MFMAs, fp32 accumulate): fp32-class accuracy */
+    /* NoiseConditionedSFNO (fme/ace/registry/stochastic_sfno.py:266-397; normalization_layer == 2) */
+    int noise_embed_dim;          /* channels of the conditioning noise */
+    int affine_norms;             /* elementwise gamma/beta in the layer norms */
+    int normalize_big_skip;       /* conditional layer norm on the big-skip input */
+    int filter_num_groups;        /* groups of the spectral filter (weight (G, L, C/G, C/G, 2)); >= 1 */
 } ace_sfno_config;
 
 int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** net);
@@ -139,6 +144,14 @@ long ace_sfno_weight_numel(const ace_sfno* net, int i);
 /* Module.__call__ (fme/core/registry/module.py:74-86): in (batch, in_chans, nlat, nlon) ->
  * out (batch, out_chans, nlat, nlon).  No allocation, no host synchronisation: capture-safe. */
 int ace_sfno_forward(ace_sfno* net, const float* in, float* out, int batch, void* stream);
+
+/* NoiseConditionedModel.forward -> conditional SphericalFourierNeuralOperatorNet.forward
+ * (fme/ace/registry/stochastic_sfno.py:128-172, fme/core/models/conditional_sfno/sfnonet.py:770-824) for a net created
+ * with normalization_layer == 2: `noise` is the (batch, noise_embed_dim, nlat, nlon) conditioning field on the device
+ * (the host side draws it - gaussian, or isotropic through ace_sht_inverse - as the reference does).  Parameters use
+ * the conditional model's state_dict names without the "conditional_model." prefix.  Same stream / allocation rules as
+ * ace_sfno_forward; ace_sfno_forward itself fails for such a net. */
+int ace_sfno_forward_conditioned(ace_sfno* net, const float* in, const float* noise, float* out, int batch, void* stream);
 
 /* Measurement: ace_sfno_forward with a hipEvent after every launch group on `stream` (the reference's
  * CUDATimer children, fme/core/benchmark/timer.py:105-168; block children conditional_sfno/sfnonet.py:388-437,

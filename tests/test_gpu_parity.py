@@ -360,6 +360,59 @@ def test_graph_replay_packed_path_batch2(dev):
             assert torch.equal(out, ref)
 
 
+def _csfno_noise(cfg, batch, seed):
+    """the conditioning noise exactly as the reference forward draws it after torch.manual_seed(seed) (CPU)"""
+    from oracle.csfno import isotropic_noise
+    from oracle.sht import InverseRealSHT as OInv
+    torch.manual_seed(seed)
+    h, w = cfg.img_shape
+    if cfg.noise_type == "isotropic":
+        isht = OInv(h, w, lmax=h, mmax=w // 2 + 1, grid=cfg.data_grid, dtype=torch.float32)
+        return isotropic_noise((batch, cfg.noise_embed_dim), h, w // 2 + 1, isht, torch.float32)
+    return torch.randn(torch.Size([batch, cfg.noise_embed_dim, h, w]), dtype=torch.float32)
+
+
+@pytest.mark.parametrize("name", ["isotropic_affine_bigskipnorm", "gaussian_groups2", "equiangular_nomlp"])
+def test_noise_conditioned_sfno_vs_reference(dev, name, precision):
+    """NoiseConditionedSFNO through the registry and the C ABI against the outputs of the real
+    reference module (tests/golden/gen_csfno.pt) and the fp64 oracle, with the reference's own noise draw."""
+    import ace_amd
+    from oracle.csfno import CSFNOConfig, CSFNOOracle
+    case = load_golden("gen_csfno.pt")[name]
+    cfg = CSFNOConfig(in_chans=5, out_chans=4, img_shape=(12, 24), **case["kwargs"])
+    noise = _csfno_noise(cfg, 2, case["forward_seed"])
+    sel = ace_amd.ModuleSelector(type="NoiseConditionedSFNO", config=dict(case["kwargs"]))
+    mod = sel.build(5, 4, ace_amd.DatasetInfo((12, 24)))
+    net = mod.torch_module
+    assert list(net.state_dict()) == list(case["state"])          # the reference's names, in its order
+    net.load_state_dict(case["state"], strict=True)
+    net.to(dev).set_precision(precision)
+    with torch.no_grad():
+        y = net(case["x"].to(dev), noise=noise.to(dev))
+        y2 = net(case["x"].to(dev), noise=noise.to(dev))
+    assert torch.equal(y, y2)
+    assert rel_max(y, case["y"]) <= NET_TOL
+    ref64 = CSFNOOracle(cfg, case["state"], dtype=torch.float64).forward(case["x"], noise=noise)
+    assert rel_max(y, ref64) <= NET_TOL
+    with torch.no_grad():                                         # own noise draw: runs, finite, differs per call
+        a, b = net(case["x"].to(dev)), net(case["x"].to(dev))
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
+
+
+def test_noise_conditioned_sfno_errors(dev):
+    import ace_amd
+    sel = ace_amd.ModuleSelector(type="NoiseConditionedSFNO", config={"embed_dim": 8, "noise_embed_dim": 4, "num_layers": 1})
+    net = sel.build(2, 2, ace_amd.DatasetInfo((8, 16))).torch_module.to(dev)
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 2, 8, 16, device=dev), noise=torch.zeros(1, 3, 8, 16, device=dev))
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 2, 8, 16))
+    with pytest.raises(NotImplementedError):
+        ace_amd.ModuleSelector(type="NoiseConditionedSFNO", config={"lora_rank": 2}).build(2, 2, ace_amd.DatasetInfo((8, 16)))
+    with pytest.raises(ValueError):
+        ace_amd.ModuleSelector(type="NoiseConditionedSFNO", config={"separable": True})
+
+
 def test_quarter_degree_grid(dev):
     """BASELINE configs[3] geometry (0.25 degree: 721 x 1440, L = M = 721): the SHT pair and a small dhconv net against
     the fp64 oracle - index arithmetic, odd nlat, table sizes (1.5 GB per transform) and ragged tiles at the large grid."""
