@@ -33,7 +33,8 @@ WORKER = textwrap.dedent(
     wrapped = d.wrap_module(torch.nn.Linear(2, 2))
     assert list(wrapped.state_dict())[0].startswith("module.")
     d.shutdown()
-    print("RANK_OK", d.rank)
+    sys.stdout.write("RANK_OK %d" % d.rank + chr(10))   # one write per rank: the two ranks share the pipe
+    sys.stdout.flush()
     """
 )
 
