@@ -51,6 +51,7 @@ SIGNATURES = {
     "ace_sfno_weight_numel": (c_long, [c_void_p, c_int]),
     "ace_sfno_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ace_sfno_forward_conditioned": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ace_sfno_forward_conditioned_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "ace_sfno_num_stages": (c_int, []),
     "ace_sfno_stage_name": (c_char_p, [c_int]),
     "ace_sfno_forward_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, POINTER(c_float), POINTER(c_int)]),

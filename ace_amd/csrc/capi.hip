@@ -1267,6 +1267,19 @@ extern "C" int ace_sfno_forward_timed(ace_sfno* n, const float* in, float* out, 
     return ACE_OK;
 }
 
+extern "C" int ace_sfno_forward_conditioned_timed(ace_sfno* n, const float* in, const float* noise, float* out, int batch,
+                                                  void* stream, float* ms_host, int* calls_host) {
+    ACE_TRY(check_ready(n, in, out, batch));
+    if (n->cfg.normalization_layer != 2)
+        return fail(ACE_ERR_STATE, "ace_sfno_forward_conditioned_timed needs a net created with conditional layer norms");
+    if (!ms_host || (!noise && n->cfg.noise_embed_dim > 0)) return fail(ACE_ERR_INVALID, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    StageTimer tm(s);
+    ACE_TRY(forward_impl(n, in, out, batch, s, &tm, noise));
+    HIP_TRY(tm.finish(ms_host, calls_host));
+    return ACE_OK;
+}
+
 extern "C" int ace_sfno_set_taps(ace_sfno* n, int enable) {
     if (!n) return fail(ACE_ERR_INVALID, "null argument");
     if (enable && n->taps.empty()) {

@@ -37,6 +37,9 @@ class RolloutEngine:
                                       "would be re-seeded on every replay; use graph='step' or None")
         self.stepper = stepper
         self.net = step.module.torch_module
+        self._conditioned = hasattr(self.net, "draw_noise")
+        if self._conditioned and graph == "window":
+            raise NotImplementedError("graph='window' with a noise-conditioned net: the noise draw is not captured")
         self.B, self.T = batch, n_forward_steps
         self.H, self.W = step._img_shape
         self.HW = self.H * self.W
@@ -100,8 +103,13 @@ class RolloutEngine:
         _lib.check(L.ace_pack_normalize(self._src_ptr_addr[s], self._src_stride_addr[s],
                                         self.in_mean.data_ptr(), self.in_std.data_ptr(), self.x.data_ptr(),
                                         self.B, nin, self.HW, stream))
-        fwd = L.ace_sfno_forward_graph if use_library_graph else L.ace_sfno_forward
-        _lib.check(fwd(self.net._native, self.x.data_ptr(), self.y.data_ptr(), self.B, stream))
+        if self._conditioned:   # NoiseConditionedSFNO: fresh conditioning noise every step (stochastic_sfno.py:128-146)
+            noise = self.net.draw_noise(self.B, self.device)
+            _lib.check(L.ace_sfno_forward_conditioned(self.net._native, self.x.data_ptr(), noise.data_ptr(), self.y.data_ptr(),
+                                                      self.B, stream))
+        else:
+            fwd = L.ace_sfno_forward_graph if use_library_graph else L.ace_sfno_forward
+            _lib.check(fwd(self.net._native, self.x.data_ptr(), self.y.data_ptr(), self.B, stream))
         _lib.check(L.ace_unpack_denormalize(self.y.data_ptr(), self.out_mean.data_ptr(), self.out_std.data_ptr(),
                                             self._dst_ptr_addr[s], self._dst_strides.data_ptr(),
                                             self.B, nout, self.HW, stream))

@@ -152,6 +152,9 @@ int ace_sfno_forward(ace_sfno* net, const float* in, float* out, int batch, void
  * the conditional model's state_dict names without the "conditional_model." prefix.  Same stream / allocation rules as
  * ace_sfno_forward; ace_sfno_forward itself fails for such a net. */
 int ace_sfno_forward_conditioned(ace_sfno* net, const float* in, const float* noise, float* out, int batch, void* stream);
+/* ... with the per-stage hipEvent timing of ace_sfno_forward_timed (synchronises). */
+int ace_sfno_forward_conditioned_timed(ace_sfno* net, const float* in, const float* noise, float* out, int batch,
+                                       void* stream, float* ms_per_stage, int* calls_per_stage);
 
 /* Measurement: ace_sfno_forward with a hipEvent after every launch group on `stream` (the reference's
  * CUDATimer children, fme/core/benchmark/timer.py:105-168; block children conditional_sfno/sfnonet.py:388-437,
