@@ -147,8 +147,13 @@ class AtmosphereCorrectorConfig:
     total_energy_budget_correction: Optional[Any] = None
     keep_gradient_through_clamps: bool = False
     clip_frozen_precipitation: bool = False
+    # CorrectorConfigABC (fme/core/corrector/registry.py:14-62): a training-epoch schedule; the corrector is always
+    # applied in eval mode (validation, inline and standalone inference), so inference ignores the value.
+    corrector_disabled_epochs: int = 0
 
     def __post_init__(self):
+        if self.corrector_disabled_epochs < 0:
+            raise ValueError(f"corrector_disabled_epochs must be non-negative, got {self.corrector_disabled_epochs}")
         if self.moisture_budget_correction is not None and self.moisture_budget_correction not in _MOISTURE_TERMS:
             raise ValueError(f"moisture_budget_correction must be one of {_MOISTURE_TERMS}")
         if isinstance(self.total_energy_budget_correction, Mapping):
@@ -159,7 +164,12 @@ class AtmosphereCorrectorConfig:
         if state is None:
             return cls()
         state = dict(state)
-        if set(state) == {"type", "config"}:           # CorrectorSelector form (fme/core/registry/corrector.py)
+        if "type" in state and "config" in state:      # CorrectorSelector form (fme/core/registry/corrector.py:11-45)
+            if set(state) - {"type", "config", "corrector_disabled_epochs"}:
+                raise ValueError(f"unknown corrector selector fields: {sorted(state)}")
+            if state.get("corrector_disabled_epochs", 0) != 0:
+                raise ValueError("corrector_disabled_epochs must be set on the wrapped corrector config (inside "
+                                 "`config:`), not on the CorrectorSelector.")
             if state["type"] != "atmosphere_corrector":
                 raise NotImplementedError(f"corrector type '{state['type']}' is outside the accelerated hot path")
             state = dict(state["config"])

@@ -254,3 +254,79 @@ def load_csfno():
 
     _csfno = types.SimpleNamespace(Builder=reg.NoiseConditionedSFNOBuilder, Info=Info, module=reg)
     return _csfno
+
+
+_stepper = None
+
+
+def load_stepper_ref():
+    """The REAL reference stepper stack (fme/ace/stepper/single_module.py ``Stepper`` / ``StepperConfig``,
+    fme/core/step/{step,single_module,multi_call}.py, the real corrector / module registries, the real
+    ``fme.core.dataset_info.DatasetInfo``) under stubs - build container only.  On top of ``load_csfno()``:
+    ``dacite`` becomes oracle/_minidacite.py, the IO / logging third-party packages the stepper module imports for
+    type names only (xarray, zarr, cftime, netCDF4, wandb, dask, h5netcdf) become permissive empty modules, the stub
+    ``Distributed`` gains the non-distributed ``wrap_module`` (a holder whose state-dict keys carry the ``module.``
+    prefix, fme/core/distributed/non_distributed.py:15-28), and every module that registers itself with a registry is
+    re-imported against the real ``CorrectorSelector`` / ``ModuleSelector``.  Used by tests/golden/make_golden_checkpoint.py
+    to emit a checkpoint state and a short rollout from the reference itself."""
+    global _stepper
+    if _stepper is not None:
+        return _stepper
+    load_csfno()
+    import torch
+
+    from . import _minidacite
+
+    d = sys.modules["dacite"]
+    ex = sys.modules["dacite.exceptions"]
+    d.from_dict, d.Config = _minidacite.from_dict, _minidacite.Config
+    for n in ["DaciteError", "UnexpectedDataError", "WrongTypeError", "MissingValueError", "UnionMatchError"]:
+        setattr(ex, n, getattr(_minidacite, n))
+        setattr(d, n, getattr(_minidacite, n))
+    for pkg in ["fme.core.step", "fme.core.generics", "fme.core.dataset", "fme.ace.stepper"]:
+        if pkg not in sys.modules:
+            _ns(pkg, os.path.join(REF, *pkg.split(".")))
+
+    class _Permissive(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            t = type(name, (), {"__init__": lambda self, *a, **k: None})
+            setattr(self, name, t)
+            return t
+
+    for extra in ["xarray", "zarr", "cftime", "netCDF4", "wandb", "dask", "h5netcdf", "xarray.coding",
+                  "xarray.coding.times", "dask.array"]:
+        if extra not in sys.modules:
+            m = _Permissive(extra)
+            m.__path__ = []
+            sys.modules[extra] = m
+    for k in [k for k in sys.modules
+              if k.startswith(("fme.core.registry.", "fme.core.corrector.", "fme.ace.registry."))
+              or k in ("fme.core.dataset_info", "fme.core.ocean")]:
+        del sys.modules[k]
+    R = sys.modules["fme.core.registry"]
+    R.CorrectorSelector = importlib.import_module("fme.core.registry.corrector").CorrectorSelector
+    R.ModuleSelector = importlib.import_module("fme.core.registry.module").ModuleSelector
+
+    class _Holder(torch.nn.Module):
+        def __init__(self, module):
+            super().__init__()
+            self.module = module
+
+        def forward(self, *a, **k):
+            return self.module(*a, **k)
+
+    sys.modules["fme.core.distributed"].Distributed.wrap_module = lambda self, m: _Holder(m)
+    di = importlib.import_module("fme.core.dataset_info")
+    importlib.import_module("fme.core.corrector.atmosphere")
+    importlib.import_module("fme.ace.registry.sfno")
+    importlib.import_module("fme.ace.registry.stochastic_sfno")
+    sm = importlib.import_module("fme.ace.stepper.single_module")
+    coords = importlib.import_module("fme.core.coordinates")
+    opt = importlib.import_module("fme.core.optimization")
+    _stepper = types.SimpleNamespace(
+        StepperConfig=sm.StepperConfig, Stepper=sm.Stepper, DatasetInfo=di.DatasetInfo,
+        LatLonCoordinates=coords.LatLonCoordinates, HybridSigmaPressureCoordinate=coords.HybridSigmaPressureCoordinate,
+        NullOptimization=opt.NullOptimization, module=sm)
+    return _stepper

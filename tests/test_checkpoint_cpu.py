@@ -185,3 +185,62 @@ def test_step_hook_order_corrector_then_ocean_then_prescribed():
     with pytest.raises(NotImplementedError):
         ace_amd.SingleModuleStepConfig(builder=cfg.builder, in_names=IN, out_names=OUT, normalization=norm,
                                        corrector={"conserve_dry_air": True}).get_step(ace_amd.DatasetInfo((4, 8)))
+
+
+# ---- format pinned on the reference itself: tests/golden/gen_checkpoint.pt holds Stepper.get_state() of REAL reference
+# steppers (tests/golden/make_golden_checkpoint.py, oracle/ref_loader.load_stepper_ref)
+def _golden_checkpoint():
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gen_checkpoint.pt")
+    return torch.load(path, map_location="cpu", weights_only=True)
+
+
+def test_reference_checkpoint_state_is_ingested():
+    g = _golden_checkpoint()["ace2_like"]
+    state = g["state"]
+    assert set(state) == {"config", "dataset_info", "step", "training_history"}
+    loaded = load_stepper({"stepper": state}, device="cpu")
+    assert loaded.ignored == []
+    ref_cfg = state["config"]["step"]["config"]
+    cfg = loaded.config
+    assert cfg.in_names == ref_cfg["in_names"] and cfg.out_names == ref_cfg["out_names"]
+    assert cfg.next_step_forcing_names == ["DSWRFtoa"]
+    assert cfg.ocean.surface_temperature_name == "surface_temperature" and cfg.ocean.ocean_fraction_name == "ocean_fraction"
+    c = cfg.corrector
+    assert c.conserve_dry_air and c.moisture_budget_correction == "advection_and_precipitation"
+    assert c.total_energy_budget_correction.method == "constant_temperature"
+    assert c.total_energy_budget_correction.constant_unaccounted_heating == pytest.approx(0.1)
+    assert c.force_positive_names == ref_cfg["corrector"]["config"]["force_positive_names"]
+    # every default the reference serialises for the builder is understood by the native builder
+    assert cfg.builder.type == "SphericalFourierNeuralOperatorNet"
+    for k, v in ref_cfg["builder"]["config"].items():
+        assert cfg.builder.config[k] == v, k
+    # weights: the reference's names (with the wrapper's "module." prefix) map one-to-one onto the native module
+    ref_w = {k[len("module."):]: v for k, v in state["step"]["module"].items() if k != "label_encoding"}
+    got_w = loaded.stepper.modules[0].state_dict()
+    got_w = {k[len("module."):] if k.startswith("module.") else k: v for k, v in got_w.items()}
+    assert set(ref_w) == set(got_w)
+    for k in ref_w:
+        assert torch.equal(ref_w[k], got_w[k].cpu()), k
+    # normaliser and geometry
+    norm = loaded.stepper._step_obj.normalizer
+    for n, m in ref_cfg["normalization"]["network"]["means"].items():
+        assert float(norm.means[n]) == pytest.approx(m, rel=1e-7)
+        assert float(norm.stds[n]) == pytest.approx(ref_cfg["normalization"]["network"]["stds"][n], rel=1e-7)
+    info = loaded.dataset_info
+    assert info.img_shape == (8, 16) and info.timestep == datetime.timedelta(hours=6)
+    assert torch.equal(info.vertical_coordinate.ak, state["dataset_info"]["vertical_coordinate"]["ak"])
+    assert torch.equal(info.vertical_coordinate.bk, state["dataset_info"]["vertical_coordinate"]["bk"])
+
+
+def test_reference_multi_call_noise_conditioned_checkpoint_is_ingested():
+    state = _golden_checkpoint()["multi_call_csfno"]["state"]
+    assert state["config"]["step"]["type"] == "multi_call" and list(state["step"]) == ["wrapped_step"]
+    loaded = load_stepper(state, device="cpu")
+    assert loaded.config.builder.type == "NoiseConditionedSFNO"
+    ref_w = {k[len("module."):]: v for k, v in state["step"]["wrapped_step"]["module"].items() if k != "label_encoding"}
+    got_w = loaded.stepper.modules[0].state_dict()
+    got_w = {k[len("module."):] if k.startswith("module.") else k: v for k, v in got_w.items()}
+    assert set(ref_w) == set(got_w)
+    for k in ref_w:
+        assert torch.equal(ref_w[k], got_w[k].cpu()), k
