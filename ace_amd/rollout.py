@@ -7,6 +7,8 @@ Per step s the engine enqueues
   2. the SFNO forward      (`graph="step"`: the library's captured hipGraph; `graph="window"`: steps 1-3
                            of the whole window live in one torch-captured hipGraph; `graph=None`: eager launches)
   3. ace_unpack_denormalize  network output -> out[name][:, s] (denormalised), which is also step s+1's state
+     (residual_prediction: the normalised prognostic inputs are added to the network output first; post-step hooks and
+     prescribed prognostics then edit out[name][:, s] in place)
 so the numbers are bit-identical to `Stepper.predict` (same kernels, same (x-mean)/std and y*std+mean roundings).
 Nothing is allocated and the host never synchronises inside the window."""
 
@@ -24,8 +26,6 @@ class RolloutEngine:
             raise ValueError("graph must be None, 'step' or 'window'")
         step = stepper._step_obj
         cfg = step.config
-        if cfg.residual_prediction or cfg.prescribed_prognostic_names:
-            raise NotImplementedError("residual_prediction / prescribed prognostics are not lowered into the engine")
         # post-step hooks (corrector, prescribed-SST ocean): torch ops on the static buffers between the fused unpack of
         # step s and the pack of step s + 1 - stream ordered, no host synchronisation.  The corrector state (dry-air
         # reference mass) is seeded by the first step after load() and survives continue_from_last().
@@ -58,6 +58,8 @@ class RolloutEngine:
         self.forcing = {n: torch.zeros(B, T + 1, H, W, **f32) for n in self.forcing_names}
         # next-step data the hooks read that is not a network forcing input (e.g. the prescribed SST: prognostic AND target)
         extra = set(cfg.ocean.forcing_names) if cfg.ocean is not None else set()
+        extra |= set(cfg.prescribed_prognostic_names)
+        self.prescribed = list(cfg.prescribed_prognostic_names)
         self.target_names = sorted(extra - set(self.forcing_names))
         self.target = {n: torch.zeros(B, T + 1, H, W, **f32) for n in self.target_names}
         self.out = {n: torch.zeros(B, T, H, W, **f32) for n in self.out_names}
@@ -91,6 +93,11 @@ class RolloutEngine:
         self._src_ptr_addr = [self._src_ptrs.data_ptr() + 8 * s * nin for s in range(T)]
         self._src_stride_addr = [self._src_strides.data_ptr() + 8 * s * nin for s in range(T)]
         self._dst_ptr_addr = [self._dst_ptrs.data_ptr() + 8 * s * nout for s in range(T)]
+        # residual prediction (single_module.py:663-664): normalised prognostic inputs are added to the network output
+        self._res_in = self._res_out = None
+        if cfg.residual_prediction:
+            self._res_in = torch.tensor([self.in_names.index(n) for n in self.prognostic], **i64)
+            self._res_out = torch.tensor([self.out_names.index(n) for n in self.prognostic], **i64)
         self._window_graph = None
         self.net._ensure_native(dev, B)
         self.net.sync_weights()
@@ -110,11 +117,15 @@ class RolloutEngine:
         else:
             fwd = L.ace_sfno_forward_graph if use_library_graph else L.ace_sfno_forward
             _lib.check(fwd(self.net._native, self.x.data_ptr(), self.y.data_ptr(), self.B, stream))
+        if self._res_in is not None:
+            self.y.index_add_(1, self._res_out, self.x.index_select(1, self._res_in))
         _lib.check(L.ace_unpack_denormalize(self.y.data_ptr(), self.out_mean.data_ptr(), self.out_std.data_ptr(),
                                             self._dst_ptr_addr[s], self._dst_strides.data_ptr(),
                                             self.B, nout, self.HW, stream))
         if self._corrector is not None or self._ocean is not None:
             self._apply_hooks(s)
+        for n in self.prescribed:     # after the ocean (single_module.py:700-716): overwritten from the data of step s + 1
+            self.out[n][:, s].copy_(self.target[n][:, s + 1] if n in self.target else self.forcing[n][:, s + 1])
 
     def _apply_hooks(self, s: int):
         """step_with_adjustments' tail (fme/core/step/single_module.py:669-716) on the window buffers of step s."""

@@ -29,10 +29,10 @@ class NormalizationConfig:
     fill_nans_on_normalize: bool = False
     fill_nans_on_denormalize: bool = False
 
-    def build(self, names: List[str]) -> StandardNormalizer:
+    def build(self, names: List[str], device=None) -> StandardNormalizer:
         means = {k: torch.tensor(self.means[k], dtype=torch.float) for k in names}
         stds = {k: torch.tensor(self.stds[k], dtype=torch.float) for k in names}
-        return StandardNormalizer(means, stds, self.fill_nans_on_normalize, self.fill_nans_on_denormalize)
+        return StandardNormalizer(means, stds, self.fill_nans_on_normalize, self.fill_nans_on_denormalize, device=device)
 
 
 class StepArgs:

@@ -29,7 +29,7 @@ class Stepper:
 
     @classmethod
     def from_config(cls, config: SingleModuleStepConfig, dataset_info, device=None) -> "Stepper":
-        normalizer = config.normalization.build(config._normalize_names)
+        normalizer = config.normalization.build(config._normalize_names, device=device)
         return cls(SingleModuleStep(config, dataset_info, normalizer, device=device))
 
     # -- properties (single_module.py:960-1043)

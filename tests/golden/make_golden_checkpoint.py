@@ -5,6 +5,8 @@ under stubs (oracle/ref_loader.load_stepper_ref) - build container only.  Writes
                 atmosphere corrector (dry air, moisture budget, energy budget, positivity), a prescribed-SST ocean and a
                 next-step forcing, the (initial condition, forcing) it was run on and the reference's own
                 ``predict_generator`` output of every step of a 3-step rollout on CPU
+  "residual_prescribed"  the same for residual_prediction=True with a prescribed prognostic (equiangular data grid, no
+                big skip, no position embedding, no hooks)
   "multi_call_csfno"  the state of a multi_call-wrapped NoiseConditionedSFNO stepper (state ingestion only: its
                 rollout draws noise from the global torch RNG)
 
@@ -105,6 +107,20 @@ def main():
         assert all(torch.isfinite(s[k]).all() for s in steps), k
     out["ace2_like"] = {"state": plain(stepper.get_state()), "ic": ic, "forcing": forcing, "steps": steps}
     print("ace2_like: outputs", sorted(steps[0]), "| PRESsfc step2 mean", float(steps[-1]["PRESsfc"].mean()))
+
+    # ---- residual prediction + a prescribed prognostic, equiangular data grid, no hooks
+    sfno_eq = {"type": "SphericalFourierNeuralOperatorNet",
+               "config": {"embed_dim": 12, "num_layers": 2, "operator_type": "dhconv", "data_grid": "equiangular",
+                          "big_skip": False, "pos_embed": False}}
+    cfg3 = {"step": step_config(sfno_eq, residual_prediction=True, prescribed_prognostic_names=["surface_temperature"])}
+    torch.manual_seed(4)
+    stepper3 = ref.StepperConfig.from_stepper_state({"config": cfg3}).get_stepper(dataset_info=info)
+    steps3 = []
+    with torch.no_grad():
+        for res in stepper3.predict_generator(ic, forcing, T, ref.NullOptimization(), labels=None):
+            steps3.append({k: v.clone() for k, v in res.output.items()})
+    out["residual_prescribed"] = {"state": plain(stepper3.get_state()), "ic": ic, "forcing": forcing, "steps": steps3}
+    print("residual_prescribed: PRESsfc step2 mean", float(steps3[-1]["PRESsfc"].mean()))
 
     # ---- multi_call-wrapped noise-conditioned stepper (state only)
     csfno = {"type": "NoiseConditionedSFNO",

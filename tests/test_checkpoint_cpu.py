@@ -244,3 +244,23 @@ def test_reference_multi_call_noise_conditioned_checkpoint_is_ingested():
     assert set(ref_w) == set(got_w)
     for k in ref_w:
         assert torch.equal(ref_w[k], got_w[k].cpu()), k
+
+
+@pytest.mark.parametrize("case", ["ace2_like", "residual_prescribed"])
+def test_oracle_rollout_restates_the_reference_stepper(case):
+    """oracle network + host step logic (normalise, residual, corrector, ocean, prescribed prognostics) in fp32 on CPU
+    against the rollout the REAL reference stepper produced for the fixture: identical to the last bit in the build
+    container (same torch CPU kernels, same operation order); held to 1e-6 of the field maximum here so that a
+    different CPU / thread count cannot fail it - except the ill-conditioned advective tendency (see conditioning_floor)."""
+    from _util import conditioning_floor, oracle_checkpoint_rollout
+    g = _golden_checkpoint()[case]
+    got = oracle_checkpoint_rollout(g, torch.float32)
+    floor = conditioning_floor(g)
+    nbit = 0
+    for s, want_all in enumerate(g["steps"]):
+        assert set(want_all) == set(got[s])
+        for k, want in want_all.items():
+            err = float((got[s][k] - want).abs().max() / want.abs().max())
+            assert err <= max(1e-6, 3.0 * floor[s][k]), (k, s, err)
+            nbit += int(torch.equal(got[s][k], want))
+    print(f"{case}: {nbit} of {sum(len(x) for x in g['steps'])} (step, field) pairs bit-identical")

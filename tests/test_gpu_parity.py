@@ -13,7 +13,7 @@ import ctypes
 import pytest
 import torch
 
-from _util import build_native_net, load_golden, rel_l2, rel_max
+from _util import build_native_net, conditioning_floor, load_golden, rel_l2, rel_max
 
 pytestmark = pytest.mark.gpu
 
@@ -669,17 +669,23 @@ def test_rollout_engine_matches_stepper(dev, graph):
         assert rel_max(state[k], ref_state[k]) <= 2e-6
 
 
-@pytest.mark.parametrize("engine", [None, "step"])
-def test_reference_checkpoint_rollout_matches_reference_stepper(dev, precision, engine):
+@pytest.mark.parametrize("case,engine", [("ace2_like", "stepper"), ("ace2_like", None), ("ace2_like", "step"),
+                                         ("residual_prescribed", "stepper"), ("residual_prescribed", None),
+                                         ("residual_prescribed", "step"), ("residual_prescribed", "window")])
+def test_reference_checkpoint_rollout_matches_reference_stepper(dev, precision, case, engine):
     """End-to-end drop-in check against the REAL reference stepper (tests/golden/gen_checkpoint.pt, emitted by
     fme.ace.stepper.Stepper on CPU): load its get_state() with ace_amd.load_stepper, roll 3 steps with the ACE2-style
     corrector (dry air, moisture and energy budgets, positivity), the prescribed-SST ocean and a next-step forcing,
     and compare every output of every step with the reference's own predict_generator.  Tolerance: 1e-5 of the
-    field's range per step (north_star), 3e-5 by step 3 (the error of step s is carried through s more networks);
-    the budget-closing fields are differences of nearly cancelling terms, hence relative to the field maximum."""
+    field's maximum per step (north_star), 3e-5 by step 3 (the error of step s is carried through s more networks),
+    or - for an ill-conditioned field - 3x the distance of the reference's own fp32 result from exact arithmetic
+    (conditioning_floor: from step 2 on the advective moisture tendency is a residual of nearly cancelling terms and
+    the reference's fp32 value is itself 3e-4 / 8e-4 of the field maximum away from the fp64 evaluation).
+    Second case: residual_prediction with a prescribed prognostic (equiangular grid, no big skip / position embedding).
+    engine: "stepper" = the dict-of-tensors Stepper.predict, otherwise the static-buffer RolloutEngine's graph mode."""
     import ace_amd
     from ace_amd.rollout import RolloutEngine
-    g = load_golden("gen_checkpoint.pt")["ace2_like"]
+    g = load_golden("gen_checkpoint.pt")[case]
     loaded = ace_amd.load_stepper(g["state"], device=dev)
     assert loaded.ignored == []
     stepper = loaded.stepper
@@ -687,16 +693,24 @@ def test_reference_checkpoint_rollout_matches_reference_stepper(dev, precision, 
     ic = {k: v.to(dev) for k, v in g["ic"].items()}
     forcing = {k: v.to(dev) for k, v in g["forcing"].items()}
     T = len(g["steps"])
-    if engine is None:
+    if engine == "stepper":
         out, state = stepper.predict(ic, forcing)
     else:
         out, state = RolloutEngine(stepper, batch=2, n_forward_steps=T, graph=engine).predict(ic, forcing)
     torch.cuda.synchronize()
     assert set(out) == set(g["steps"][0])
+    if case == "residual_prescribed":
+        assert torch.equal(out["surface_temperature"], forcing["surface_temperature"][:, 1:])
+    floor = conditioning_floor(g)
+    worst = []
     for s, want_all in enumerate(g["steps"]):
         for k, want in want_all.items():
             got = out[k][:, s].cpu()
             err = float((got - want).abs().max()) / float(want.abs().max())
-            assert err <= NET_TOL * (s + 1), (k, s, err)
+            tol = max(NET_TOL * (s + 1), 3.0 * floor[s][k])
+            worst.append((err / tol, err, tol, k, s))
+    worst.sort(reverse=True)
+    print("worst (err/tol, err, tol, field, step):", worst[:3])
+    assert worst[0][0] <= 1.0, worst[:5]
     for k, v in state.items():
         assert torch.equal(v[:, 0], out[k][:, -1])
