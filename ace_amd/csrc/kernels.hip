@@ -65,6 +65,19 @@ DEVINL float act_apply(float v, int act) {
     }
 }
 
+// Activation chosen once per kernel instead of once per element: inside an epilogue loop a runtime `switch (act)` puts
+// a branch chain between every LDS read and its use (the reads serialise on s_waitcnt, nothing is batched).  A < 0: the
+// runtime code (rare activations).
+template <int A>
+DEVINL float act_const(float v, int act_rt) { return A < 0 ? act_apply(v, act_rt) : act_apply(v, A); }
+template <int A> struct ActTag { static constexpr int value = A; };
+template <class F>
+DEVINL void dispatch_act(int act, F&& f) {
+    if (act == ACT_NONE) f(ActTag<ACT_NONE>{});
+    else if (act == ACT_GELU_FAST) f(ActTag<ACT_GELU_FAST>{});
+    else f(ActTag<-1>{});
+}
+
 // Workgroup b is observed to run on XCD b % 8.  Give each XCD a contiguous chunk of
 // logical tiles so tiles that share an operand panel also share an L2 (speed only;
 // bijective for any nblk).
@@ -1061,6 +1074,8 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
         _Float16* Ph = q.Chi ? q.Chi + (long)batch * p.sC : nullptr;
         _Float16* Pl = q.Chi ? q.Clo + (long)batch * p.sC : nullptr;
         // four rows at a time: this kernel is capped at 128 VGPRs (8 waves per workgroup, 2 workgroups per CU)
+        dispatch_act(actk, [&](auto at) {
+        constexpr int AC = decltype(at)::value;
 #pragma unroll 1
         for (int jb = 0; jb < 16; jb += 4) {
             float4 tv[4], rv[4];
@@ -1092,7 +1107,7 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
                 for (int e = 0; e < 4; ++e) {
                     float v = fmaf(o[e], osc_acc, bvv[jj]);
                     if (RES) v += fmaf(r4[e], rsv[jj], rtv[jj]);
-                    v = act_apply(v, actk);
+                    v = act_const<AC>(v, actk);
                     o[e] = fmaf(v, osv[jj], otv[jj]);
                 }
                 if (row < M && cok) {
@@ -1115,6 +1130,7 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
                 }
             }
         }
+        });
         if (q.omax) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
@@ -1540,6 +1556,9 @@ extern "C" int ace_debug_g4_trace(void* dst) { return (int)hipMemcpyFromSymbol(d
 #ifndef ACE_G4_RTOUCH
 #define ACE_G4_RTOUCH 0
 #endif
+#ifndef ACE_G4_PIN
+#define ACE_G4_PIN 1
+#endif
 struct Frags4 { half8 ah[2], al[2], bh[2], bl[2]; };  // one 16-deep k half: [tile]
 
 template <int WM, int WN, bool RES, bool PK>
@@ -1780,6 +1799,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
         load_frags(f1, cur, 1, negq(kt));
         mma(f0);
         interleave();
+#if ACE_G4_PIN
+        __builtin_amdgcn_sched_barrier(0);   // keep the 12 MFMAs above the wait: without it the scheduler sinks 11 of them below
+#endif                                       // the barrier and the DMA of the next stage gets half the lookahead
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NTOUCH) : "memory");   // all but the newest prefetch touch
         __syncthreads();
         if (kt + 2 < nk) issue(kbeg + (kt + 2) * BKT, cur);
@@ -1826,24 +1848,30 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
         // the 64 row biases of this wave: one coalesced load, broadcast per row with v_readlane
         const int brow = m0 + wm * 64 + lane;
         const float bl = bias ? bias[brow < M ? brow : 0] : 0.f;
+        dispatch_act(actk, [&](auto at) {
+            constexpr int AC = decltype(at)::value;
 #pragma unroll
-        for (int rg = 0; rg < 8; ++rg) {
-            const int rbase = m0 + wm * 64 + 8 * rg;
-            half8 hh, ll;
+            for (int rg = 0; rg < 8; ++rg) {
+                const int rbase = m0 + wm * 64 + 8 * rg;
+                float tv[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float bvs = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bl), 8 * rg + e));
-                const float x = act_apply(fmaf(Ts[(8 * rg + e) * 64 + lane] * inv_a, inv_b, bvs), actk) * cscale;
-                const _Float16 a = (_Float16)x;
-                hh[e] = a;
-                ll[e] = (_Float16)(x - (float)a);
+                for (int e = 0; e < 8; ++e) tv[e] = Ts[(8 * rg + e) * 64 + lane];
+                half8 hh, ll;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float bvs = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bl), 8 * rg + e));
+                    const float x = act_const<AC>(fmaf(tv[e] * inv_a, inv_b, bvs), actk) * cscale;
+                    const _Float16 a = (_Float16)x;
+                    hh[e] = a;
+                    ll[e] = (_Float16)(x - (float)a);
+                }
+                if (rbase < M && colok) {
+                    const long eo = ((long)(rbase >> 3) * q.ldnc + col) * 8;
+                    *reinterpret_cast<half8*>(Chi + eo) = hh;
+                    *reinterpret_cast<half8*>(Clo + eo) = ll;
+                }
             }
-            if (rbase < M && colok) {
-                const long eo = ((long)(rbase >> 3) * q.ldnc + col) * 8;
-                *reinterpret_cast<half8*>(Chi + eo) = hh;
-                *reinterpret_cast<half8*>(Clo + eo) = ll;
-            }
-        }
+        });
     } else {
         float* Ts = reinterpret_cast<float*>(smem4) + wave * 4096;
 #pragma unroll
@@ -1858,6 +1886,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
         const bool cok = colb < N;           // N % 4 == 0 (checked by the launcher)
         const int colc = cok ? colb : 0;
         // four rows at a time: loads, math and stores of successive chunks overlap, and the register footprint stays small
+        dispatch_act(actk, [&](auto at) {
+        constexpr int AC = decltype(at)::value;
 #pragma unroll 1
         for (int jb = 0; jb < 16; jb += 4) {
             float4 tv[4], rv[4];
@@ -1886,7 +1916,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
                 for (int e = 0; e < 4; ++e) {
                     float v = fmaf(o[e] * inv_a, inv_b, bvv[jj]);
                     if (RES) v += fmaf(r4[e], rsv[jj], rtv[jj]);
-                    o[e] = act_apply(v, actk);
+                    o[e] = act_const<AC>(v, actk);
                 }
                 const bool ok = row < M && cok;
                 if (C && ok) *reinterpret_cast<float4*>(C + (long)row * ldc + colb) = make_float4(o[0], o[1], o[2], o[3]);
@@ -1908,6 +1938,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
                 }
             }
         }
+        });
         if (PK) {
             _Float16* Chi = q.Chi + (long)batch * q.sCp;
             _Float16* Clo = q.Clo + (long)batch * q.sCp;

@@ -39,6 +39,29 @@ __global__ __launch_bounds__(256) void k16(float* out, const float* in, int iter
     if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
 }
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+// fp16 32x32x16 (the instruction of the f16x3 engines): NACC independent accumulators, operands from memory (random fp16)
+template <int NACC>
+__global__ __launch_bounds__(256) void kh(float* out, const float* in, int iters, unsigned long long* clk) {
+    f32x16 acc[NACC];
+    for (int a = 0; a < NACC; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    half8 av, bv;
+    for (int e = 0; e < 8; ++e) {
+        av[e] = (_Float16)in[(threadIdx.x * 8 + e) & 511];
+        bv[e] = (_Float16)in[(threadIdx.x * 8 + e + 77) & 511];
+    }
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[a], 0, 0, 0);
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+    for (int a = 0; a < NACC; ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
+}
+
 template <typename F>
 void run(const char* name, F launch, double flops_per_block_iter, int blocks, int iters) {
     hipEvent_t e0, e1;
@@ -74,6 +97,10 @@ int main() {
             unsigned long long c = 0;
             run("mfma_f32_32x32x2 x4acc", [&](int it) { hipLaunchKernelGGL(k32<4>, dim3(blocks), dim3(256), 0, 0, out, in, it, clk); },
                 4.0 * 4 * 2 * 32 * 32 * 2, blocks, iters);
+            hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
+            printf("  cycles/mfma(wave) %.1f\n", (double)c / (iters * 4.0));
+            run("mfma_f32_32x32x16_f16 x4acc", [&](int it) { hipLaunchKernelGGL(kh<4>, dim3(blocks), dim3(256), 0, 0, out, in, it, clk); },
+                4.0 * 4 * 2 * 32 * 32 * 16, blocks, iters);
             hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
             printf("  cycles/mfma(wave) %.1f\n", (double)c / (iters * 4.0));
             run("mfma_f32_16x16x4 x4acc", [&](int it) { hipLaunchKernelGGL(k16<4>, dim3(blocks), dim3(256), 0, 0, out, in, it, clk); },

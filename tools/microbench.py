@@ -105,4 +105,4 @@ def mlp16(cin, hid, cout, hw, iters):
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pmlp":
-    mlp16(384, 768, 384, 64800, 3)
+    mlp16(384, 768, 384, 64800, int(sys.argv[2]) if len(sys.argv) > 2 else 3)
