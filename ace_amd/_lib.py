@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libace_sfno.so")
+LIB_PATH = os.environ.get("ACE_SFNO_LIB") or os.path.join(HERE, "libace_sfno.so")   # ACE_SFNO_LIB: A/B a variant build
 
 ACE_OK, ACE_ERR_INVALID, ACE_ERR_RUNTIME, ACE_ERR_STATE = 0, -1, -2, -3
 

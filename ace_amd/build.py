@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libace_sfno.so")
-SOURCES = ["kernels.hip", "capi.hip", "tables.cpp"]
+SOURCES = ["kernels.hip", "fft.hip", "capi.hip", "tables.cpp"]
 HEADERS = ["kernels.h", "tables.h", os.path.join("..", "..", "include", "ace_sfno.h")]
 
 

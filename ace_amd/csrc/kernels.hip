@@ -1964,10 +1964,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
         }
     }
     G4T(53);
-    if (q.omax) {
+    if (q.omax) {   // one atomic per workgroup: the 64 slots share two cache lines and same-line atomics serialise
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
-        if (lane == 0) atomicMax(q.omax + (blockIdx.x & 63), __float_as_uint(vmax));
+        float* red = reinterpret_cast<float*>(smem4);
+        __syncthreads();
+        if (lane == 0) red[wave] = vmax;
+        __syncthreads();
+        if (tid == 0) {
+            float m = red[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
+            atomicMax(q.omax + (blockIdx.x & 63), __float_as_uint(m));
+        }
     }
 #ifdef ACE_X_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2299,6 +2308,8 @@ __global__ __launch_bounds__(256) void dft_forward_kernel(DftArgs p, int tilesM,
 }
 
 hipError_t launch_dft_forward(const DftArgs& a, hipStream_t s) {
+    hipError_t ferr = hipSuccess;
+    if (launch_dft_forward_fft(a, s, &ferr)) return ferr;
     constexpr int BM = 64, BN = 128;
     const int ncols = a.H * a.Bt * a.C;
     const int tilesM = (a.Mm + BM - 1) / BM, tilesN = (ncols + BN - 1) / BN;
@@ -2480,10 +2491,13 @@ __global__ __launch_bounds__(256) void dft_inverse_kernel(DftArgs p, int tilesM,
             }
         }
     }
-    if (p.omax) {
+    if (p.omax) {   // one atomic per workgroup
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
-        if ((tid & 63) == 0) atomicMax(p.omax + (blockIdx.x & 63), __float_as_uint(vmax));
+        __syncthreads();
+        if ((tid & 63) == 0) smem[tid >> 6] = vmax;
+        __syncthreads();
+        if (tid == 0) atomicMax(p.omax + (blockIdx.x & 63), __float_as_uint(fmaxf(fmaxf(smem[0], smem[1]), fmaxf(smem[2], smem[3]))));
     }
 }
 
