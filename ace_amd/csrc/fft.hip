@@ -218,6 +218,157 @@ hipError_t launch_fwd(const DftArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+
+// ---- inverse ----------------------------------------------------------------------------------------------------------
+// y[n] = sum_k F[k] e^(+2 pi i k n / W) with F the Hermitian extension of the stored half spectrum S[m], m < Mm
+// (F[0] = Re S[0], F[W/2] = Re S[W/2]: irfft ignores those imaginary parts, fft.py:78-96; zero beyond Mm).  With
+// k = k1 + N1 k2, n = N2 a + b:
+//     T[k1][b] = sum_k2 F[k1 + N1 k2] w_N2^(-k2 b)            N2-point inverse DFTs (radix 2 x N2/2), k1 <= N1/2 only:
+//     U[k1][b] = w_W^(-k1 b) T[k1][b]                         U[N1 - k1][b] = conj U[k1][b]
+//     y[N2 a + b] = Re U[0] + (-1)^a Re U[N1/2] + 2 sum_{0<k1<N1/2} Re(w_N1^(-k1 a) U[k1][b])      (pairs a, N1 - a share sums)
+// grid = (ceil(C / 16), H, Bt); block = 16 * max(N2, N1/2 + 1).  The spectral-filter bias is added on the way out.
+template <int W>
+__device__ constexpr RootTab<W> kRoots{1.0};
+
+template <int N1, int N2>
+__global__ __launch_bounds__(FFT_ROWS * (N2 > N1 / 2 + 1 ? N2 : N1 / 2 + 1)) void dft_inverse_fft_kernel(DftArgs p) {
+    constexpr int W = N1 * N2, R = FFT_ROWS, H1 = N1 / 2 + 1, M2 = N2 / 2, NT = R * (N2 > H1 ? N2 : H1);
+    constexpr int PITCH = W + 1;
+    static_assert(N1 % 2 == 0 && N2 % 2 == 0 && N1 >= 4, "even factors");
+    constexpr int YS = R * PITCH, US = 2 * R * H1 * N2;
+    __shared__ __attribute__((aligned(16))) float smem[YS > US ? YS : US];
+    float* ys = smem;
+    v2f* Us = reinterpret_cast<v2f*>(smem);
+
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * R, k = blockIdx.y, b = blockIdx.z;
+    const int kb = k * p.Bt + b;
+    const long HW = (long)p.H * W;
+    const long N2c = (long)p.Bt * 2 * p.C;
+
+    // ---- step A: thread (k1, r): the N2 inputs F[k1 + N1 k2] straight from memory (64-byte runs over r), N2-point inverse DFT
+    {
+        const int r = tid % R, k1 = tid / R;
+        if (k1 < H1) {
+            int c = c0 + r;
+            c = c < p.C ? c : p.C - 1;
+            const float* sb = p.spec + (long)kb * 2 * p.C + c;
+            v2f f[N2];
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) {
+                const int kk = k1 + N1 * k2;
+                const bool mir = 2 * kk > W;
+                const int m = mir ? W - kk : kk;
+                float re = 0.f, im = 0.f;
+                if (m < p.Mm) {
+                    const float* s = sb + (long)m * p.H * N2c;
+                    re = s[0];
+                    im = s[p.C];
+                }
+                if (m == 0 || 2 * m == W) im = 0.f;
+                f[k2] = v2f{re, mir ? -im : im};
+            }
+            // radix 2: even / odd k2 -> two (N2/2)-point inverse DFTs, then T[j] = E[j] + w O[j], T[j + N2/2] = E[j] - w O[j]
+            constexpr RootTab<M2> TM{};
+            constexpr RootTab<N2> T2{};
+#pragma unroll
+            for (int j = 0; j < M2; ++j) {
+                v2f e = {0.f, 0.f}, o = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < M2; ++i) {
+                    const int q = (i * j) % M2;
+                    const v2f w = {TM.re[q], -TM.im[q]};     // w_M2^(-i j)
+                    const v2f wp = {TM.im[q], TM.re[q]};     // i * w
+                    e += v2f{f[2 * i].x, f[2 * i].x} * w;
+                    e += v2f{f[2 * i].y, f[2 * i].y} * wp;
+                    o += v2f{f[2 * i + 1].x, f[2 * i + 1].x} * w;
+                    o += v2f{f[2 * i + 1].y, f[2 * i + 1].y} * wp;
+                }
+                const float wr = T2.re[j], wi = -T2.im[j];   // w_N2^(-j)
+                const v2f wo = {o.x * wr - o.y * wi, o.x * wi + o.y * wr};
+                const v2f t0 = e + wo, t1 = e - wo;
+                // twiddle w_W^(-k1 b): runtime index (k1 varies over the workgroup)
+                const int j0 = k1 * j, j1 = k1 * (j + M2);
+                const float a0 = kRoots<W>.re[j0], b0 = -kRoots<W>.im[j0];
+                const float a1 = kRoots<W>.re[j1], b1 = -kRoots<W>.im[j1];
+                Us[(r * H1 + k1) * N2 + j] = v2f{t0.x * a0 - t0.y * b0, t0.x * b0 + t0.y * a0};
+                Us[(r * H1 + k1) * N2 + j + M2] = v2f{t1.x * a1 - t1.y * b1, t1.x * b1 + t1.y * a1};
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- step B: thread (b1, r): N1 real outputs y[N2 a + b1] from U[0 .. N1/2][b1]
+    {
+        const int r = tid % R, b1 = tid / R;
+        const bool act = b1 < N2;
+        v2f u[H1];
+#pragma unroll
+        for (int k1 = 0; k1 < H1; ++k1) u[k1] = act ? Us[(r * H1 + k1) * N2 + b1] : v2f{0.f, 0.f};
+        __syncthreads();   // the output rows alias U
+        if (act) {
+            constexpr RootTab<N1> T1{};
+            const int cr = c0 + r < p.C ? c0 + r : p.C - 1;
+            const float bias = p.bias ? p.bias[cr] : 0.f;
+            float* yr = ys + r * PITCH + b1;
+            float s0 = u[0].x + u[N1 / 2].x + bias, sh = u[0].x + ((N1 / 2) % 2 ? -u[N1 / 2].x : u[N1 / 2].x) + bias;
+#pragma unroll
+            for (int k1 = 1; k1 < N1 / 2; ++k1) {
+                s0 += 2.f * u[k1].x;
+                sh += (k1 % 2 ? -2.f : 2.f) * u[k1].x;
+            }
+            yr[0] = s0;
+            yr[N2 * (N1 / 2)] = sh;
+#pragma unroll
+            for (int a = 1; a < N1 / 2; ++a) {
+                // (P, Q) = sum_k1 (Ur, Ui) * (2 cos, -2 sin)(2 pi k1 a / N1);  w_N1^j = (cos, -sin)
+                v2f pq = {u[0].x + (a % 2 ? -u[N1 / 2].x : u[N1 / 2].x) + bias, 0.f};
+#pragma unroll
+                for (int k1 = 1; k1 < N1 / 2; ++k1) {
+                    const int j = (k1 * a) % N1;
+                    pq += u[k1] * v2f{2.f * T1.re[j], 2.f * T1.im[j]};
+                }
+                yr[N2 * a] = pq.x + pq.y;
+                yr[N2 * (N1 - a)] = pq.x - pq.y;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- rows -> memory, 16 B per lane
+    float vmax = 0.f;
+    for (int idx = tid; idx < R * (W / 4); idx += NT) {
+        const int r = idx / (W / 4), j = idx % (W / 4);
+        const int c = c0 + r;
+        if (c < p.C) {
+            const float* d = ys + r * PITCH + 4 * j;
+            const float4 v = make_float4(d[0], d[1], d[2], d[3]);
+            *reinterpret_cast<float4*>(p.y + ((long)b * p.C + c) * HW + (long)k * W + 4 * j) = v;
+            vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+    }
+    if (p.omax) {   // one atomic per workgroup
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        __syncthreads();
+        if ((tid & 63) == 0) smem[tid >> 6] = vmax;
+        __syncthreads();
+        if (tid == 0) {
+            float m = 0.f;
+            for (int w = 0; w < (NT + 63) / 64; ++w) m = fmaxf(m, smem[w]);
+            atomicMax(p.omax + ((blockIdx.x + blockIdx.y) & 63), __float_as_uint(m));
+        }
+    }
+}
+
+template <int N1, int N2>
+hipError_t launch_inv(const DftArgs& a, hipStream_t s) {
+    constexpr int H1 = N1 / 2 + 1, NT = FFT_ROWS * (N2 > H1 ? N2 : H1);
+    dim3 grid((unsigned)((a.C + FFT_ROWS - 1) / FFT_ROWS), (unsigned)a.H, (unsigned)a.Bt), block(NT);
+    hipLaunchKernelGGL((dft_inverse_fft_kernel<N1, N2>), grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
 bool fft_enabled() {
     static const bool on = [] {
         const char* e = std::getenv("ACE_NO_FFT");
@@ -237,6 +388,18 @@ bool launch_dft_forward_fft(const DftArgs& a, hipStream_t s, hipError_t* err) {
         case 48: *err = launch_fwd<8, 6>(a, s); return true;
         case 24: *err = launch_fwd<6, 4>(a, s); return true;
         case 16: *err = launch_fwd<4, 4>(a, s); return true;
+        default: return false;
+    }
+}
+
+bool launch_dft_inverse_fft(const DftArgs& a, hipStream_t s, hipError_t* err) {
+    if (!fft_enabled() || (reinterpret_cast<uintptr_t>(a.y) & 15) != 0 || a.Mm > a.W / 2 + 1 || a.H > 65535 || a.Bt > 65535)
+        return false;
+    switch (a.W) {
+        case 360: *err = launch_inv<20, 18>(a, s); return true;
+        case 48: *err = launch_inv<8, 6>(a, s); return true;
+        case 24: *err = launch_inv<6, 4>(a, s); return true;
+        case 16: *err = launch_inv<4, 4>(a, s); return true;
         default: return false;
     }
 }

@@ -135,6 +135,7 @@ hipError_t launch_dft_forward(const DftArgs& a, hipStream_t s);
 hipError_t launch_dft_inverse(const DftArgs& a, hipStream_t s);
 // two-level FFT forms on the vector ALUs (fft.hip); return false when the size / alignment is not covered
 bool launch_dft_forward_fft(const DftArgs& a, hipStream_t s, hipError_t* err);
+bool launch_dft_inverse_fft(const DftArgs& a, hipStream_t s, hipError_t* err);
 
 // per-(b,c) instance-norm statistics over H*W -> affine (scale, shift):
 //   scale = gamma[c] * rsqrt(var + eps),  shift = beta[c] - mean * scale   (biased var, fp64 accumulation)

@@ -2502,6 +2502,8 @@ __global__ __launch_bounds__(256) void dft_inverse_kernel(DftArgs p, int tilesM,
 }
 
 hipError_t launch_dft_inverse(const DftArgs& a, hipStream_t s) {
+    hipError_t ferr = hipSuccess;
+    if (launch_dft_inverse_fft(a, s, &ferr)) return ferr;
     constexpr int BM = 128, BN = 64;
     const int nrows = a.H * a.Bt * a.C;
     const int Kf = a.W / 2 + 1;
