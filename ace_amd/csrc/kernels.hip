@@ -1559,9 +1559,6 @@ extern "C" int ace_debug_g4_trace(void* dst) { return (int)hipMemcpyFromSymbol(d
 #ifndef ACE_G4_PIN
 #define ACE_G4_PIN 1
 #endif
-#ifndef ACE_G4_RING
-#define ACE_G4_RING 0   // 128x128 tile: four 16-deep LDS slots refilled as soon as their fragments are in registers (3 in flight)
-#endif
 struct Frags4 { half8 ah[2], al[2], bh[2], bl[2]; };  // one 16-deep k half: [tile]
 
 template <int WM, int WN, bool RES, bool PK>
@@ -1770,76 +1767,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
             glds4(Rt + (long)row * q.ldr + col, Scratch + wave * 128);
         }
     }
-    // ---- ring variant (128 x 128 only): slot = 16 KiB = {A hi, A lo: [4 row blocks][2 k groups][32 rows][8], B hi, B lo:
-    // [2 k groups][128 cols][8]}.  Every fragment read of a wave is 1 KiB contiguous (conflict free) and every DMA piece
-    // (32 rows x 16 k of A, or one k group x 64 columns of B) is 1 KiB contiguous in LDS; the lane picks its own source.
-    constexpr bool RING = (ACE_G4_RING != 0) && WM == 2 && WN == 2;
-    constexpr int SLOT = 8192;                    // halves per slot
-    const int nh = 2 * nk;
-    long ra_off0 = 0, ra_off1 = 0;                // this lane's A source for the first / second half of a 32-deep stage
-    long rb_col = 0;
-    if (RING) {
-        const int R = m0 + wave * 32 + (lane & 31), gk = lane >> 5;
-        if (a_tiled) {
-            const int nrb = (q.M + 15) / 16;
-            int blk = R >> 4;
-            blk = blk < nrb ? blk : nrb - 1;
-            const long base = (long)blk * lda * 16 + (R & 15) * 32;
-            const int key = (R >> 2) & 3;
-            ra_off0 = base + 8 * (gk ^ key);
-            ra_off1 = base + 8 * ((2 + gk) ^ key);
-        } else {
-            const int Rc = R < M ? R : M - 1;
-            ra_off0 = (long)Rc * lda + 8 * gk;
-            ra_off1 = ra_off0 + 16;
-        }
-        int nn = n0 + (wave & 1) * 64 + lane;
-        nn = nn < N ? nn : N - 1;
-        if (cplx) nn -= nhalf * cplx;
-        rb_col = (long)nn * 8;
-    }
-    auto issue_half = [&](int hh, int slot) {     // 4 DMA instructions per wave: A hi, A lo (32 rows), B hi, B lo (64 columns)
-        _Float16* Sb = smem4 + slot * SLOT;
-        const int k0 = kbeg + hh * 16;
-        const long ao = (a_tiled ? (long)(k0 >> 5) * 512 : (long)(k0 & ~31)) + ((k0 & 16) ? ra_off1 : ra_off0);
-        glds16(reinterpret_cast<const float*>(Ahi + ao), reinterpret_cast<float*>(Sb + wave * 512));
-        glds16(reinterpret_cast<const float*>(Alo + ao), reinterpret_cast<float*>(Sb + 2048 + wave * 512));
-        const int kgl = wave >> 1;                // k group of this wave's B piece within the half
-        int kg = k0 / 8 + kgl;
-        kg = kg < nkg ? kg : nkg - 1;
-        long off = (long)kg * ldn * 8 + rb_col;
-        if (cplx) {
-            const int khalf = k0 >= cplx;
-            off = (long)(khalf != nhalf) * cplx * cplx + (long)(kg - khalf * (cplx / 8)) * ldn * 8 + rb_col;
-        }
-        glds16(reinterpret_cast<const float*>(Bhi + off), reinterpret_cast<float*>(Sb + 4096 + kgl * 1024 + (wave & 1) * 512));
-        glds16(reinterpret_cast<const float*>(Blo + off), reinterpret_cast<float*>(Sb + 6144 + kgl * 1024 + (wave & 1) * 512));
-    };
-    auto load_frags_ring = [&](Frags4& f, int slot, bool neg) {
-        const _Float16* Sb = smem4 + slot * SLOT;
-        const int ao = ((wm * 4 + g) * 32 + i) * 8;           // row block 2 wm (+ 2 * 32 * 8 halves for the next one)
-        const int bo = 4096 + (g * 128 + wn * 64 + i) * 8;
-        f.al[0] = *reinterpret_cast<const half8*>(Sb + 2048 + ao);
-        f.al[1] = *reinterpret_cast<const half8*>(Sb + 2048 + ao + 512);
-        f.bh[0] = *reinterpret_cast<const half8*>(Sb + bo);
-        f.bh[1] = *reinterpret_cast<const half8*>(Sb + bo + 256);
-        f.ah[0] = *reinterpret_cast<const half8*>(Sb + ao);
-        f.ah[1] = *reinterpret_cast<const half8*>(Sb + ao + 512);
-        f.bl[0] = *reinterpret_cast<const half8*>(Sb + 2048 + bo);
-        f.bl[1] = *reinterpret_cast<const half8*>(Sb + 2048 + bo + 256);
-        if (neg) {
-            f.al[0] = neg8(f.al[0]); f.al[1] = neg8(f.al[1]);
-            f.ah[0] = neg8(f.ah[0]); f.ah[1] = neg8(f.ah[1]);
-        }
-    };
-    if (RING) {
-#pragma unroll
-        for (int hh = 0; hh < 4; ++hh)
-            if (hh < nh) issue_half(hh, hh);
-    } else {
-        if (nk > 0) issue(kbeg, 0);
-        if (nk > 1) issue(kbeg + BKT, 1);
-    }
+    if (nk > 0) issue(kbeg, 0);
+    if (nk > 1) issue(kbeg + BKT, 1);
     // scales: the producer of a dynamic operand scaled it by 2^(12 - exponent(bound)); undo both here (exact)
     auto wave_max = [&](unsigned raw) {
         float mx = __uint_as_float(raw);
@@ -1860,58 +1789,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
         if (tid == 0) atomicMax(q.cslot + (blockIdx.x & 63), __float_as_uint(cbound));
     }
     constexpr int NTOUCH = PFD > 0 ? 1 : 0;   // prefetch touches per issue() that may stay outstanding
-    if (RING) {
-        // Half h: its fragments are in registers.  After 4 of its 12 MFMAs: wait until half h + 1 has landed (the two
-        // halves behind it stay in flight), barrier (every wave has read slot h), refill slot h with half h + 4, read the
-        // fragments of h + 1 under the remaining 8 MFMAs.
-        auto mma_first = [&](const Frags4& f) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[a], f.bh[b], acc[a][b], 0, 0, 0);
-        };
-        auto mma_rest = [&](const Frags4& f) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bl[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bh[b], acc[a][b], 0, 0, 0);
-        };
-        auto neg_half = [&](int h) { return cplx != 0 && nhalf == 0 && kbeg + h * 16 >= cplx; };
-        auto half_iter = [&](Frags4& fc, Frags4& fn, int h) {
-            mma_first(fc);
-            __builtin_amdgcn_sched_barrier(0);
-            if (h + 1 < nh) {
-                const int rem = nh - h - 2;       // halves behind h + 1 that were issued already (at most 2)
-                if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (h + 4 < nh) issue_half(h + 4, h & 3);
-                load_frags_ring(fn, (h + 1) & 3, neg_half(h + 1));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mma_rest(fc);
-        };
-        if (nh > 0) {
-            if (nh >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            load_frags_ring(f0, 0, neg_half(0));
-        }
-        for (int h = 0; h < nh; h += 2) {
-            half_iter(f0, f1, h);
-            half_iter(f1, f0, h + 1);
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();   // the epilogue parks accumulators over the whole ring
-    } else {
     if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PCS + NTOUCH) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1932,7 +1809,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
         mma(f1);
         interleave();
         G4T(3 + (kt < 40 ? kt : 40));
-    }
     }
     G4T(50);
 
