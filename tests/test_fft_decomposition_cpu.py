@@ -1,0 +1,88 @@
+"""The index algebra of ace_amd/csrc/fft.hip (two-level Cooley-Tukey form of the longitude DFT), restated in numpy and
+checked against the direct sums the matrix kernels / the reference compute (fme/fft.py:61-96 under sht_fix's 2 pi scaling):
+the Hermitian shortcuts (k1 > N1/2 from conj(.) w_N2^b; inverse only k1 <= N1/2), the mirrored reads of the half spectrum,
+the dropped imaginary parts at m = 0 / Nyquist, the truncation at mmax and the paired (P, Q) outputs.  The kernels
+themselves are exercised by the GPU SHT / network tests at W = 16, 24, 48 and 360."""
+import numpy as np
+import pytest
+
+CASES = [(360, 20, 18), (48, 8, 6), (24, 6, 4), (16, 4, 4)]   # the instantiated factorisations W = N1 * N2
+
+
+def w(j, n):
+    return np.exp(-2j * np.pi * (j % n) / n)
+
+
+def forward_two_level(x, N1, N2, Mm):
+    W = N1 * N2
+    H1 = N1 // 2 + 1
+    Z = np.zeros((N2, H1), complex)
+    for b in range(N2):
+        for k1 in range(H1):
+            Z[b, k1] = sum(x[N2 * a + b] * w(a * k1, N1) for a in range(N1)) * (2 * np.pi / W) * w(b * k1, W)
+    X = np.zeros(Mm, complex)
+    for k1 in range(N1):
+        cj = k1 > N1 // 2
+        z = [np.conj(Z[b, N1 - k1]) * w(b, N2) if cj else Z[b, k1] for b in range(N2)]
+        for k2 in range(N2 // 2 + 1):
+            m = k1 + N1 * k2
+            if m < Mm:
+                X[m] = sum(z[b] * w(b * k2, N2) for b in range(N2))
+    return X
+
+
+def inverse_two_level(S, N1, N2, Mm):
+    W = N1 * N2
+    H1, M2 = N1 // 2 + 1, N2 // 2
+    U = np.zeros((H1, N2), complex)
+    for k1 in range(H1):
+        f = np.zeros(N2, complex)
+        for k2 in range(N2):
+            kk = k1 + N1 * k2
+            mir = 2 * kk > W
+            m = W - kk if mir else kk
+            re, im = (S[m].real, S[m].imag) if m < Mm else (0.0, 0.0)
+            if m == 0 or 2 * m == W:
+                im = 0.0
+            f[k2] = complex(re, -im if mir else im)
+        for j in range(M2):
+            e = sum(f[2 * i] * np.conj(w(i * j, M2)) for i in range(M2))
+            o = sum(f[2 * i + 1] * np.conj(w(i * j, M2)) for i in range(M2)) * np.conj(w(j, N2))
+            U[k1, j] = (e + o) * np.conj(w(k1 * j, W))
+            U[k1, j + M2] = (e - o) * np.conj(w(k1 * (j + M2), W))
+    y = np.zeros(W)
+    hN = N1 // 2
+    for b in range(N2):
+        u = U[:, b]
+        y[b] = u[0].real + u[hN].real + 2 * sum(u[k].real for k in range(1, hN))
+        y[N2 * hN + b] = u[0].real + (-1) ** hN * u[hN].real + sum((-2 if k % 2 else 2) * u[k].real for k in range(1, hN))
+        for a in range(1, hN):
+            P = u[0].real + (-1) ** a * u[hN].real + sum(2 * u[k].real * w(k * a, N1).real for k in range(1, hN))
+            Q = sum(2 * u[k].imag * w(k * a, N1).imag for k in range(1, hN))
+            y[N2 * a + b], y[N2 * (N1 - a) + b] = P + Q, P - Q
+    return y
+
+
+@pytest.mark.parametrize("W,N1,N2", CASES)
+def test_forward_two_level_equals_scaled_rfft(W, N1, N2):
+    rng = np.random.default_rng(W)
+    x = rng.standard_normal(W)
+    for Mm in (W // 2 + 1, W // 2 - 1, 3):
+        got = forward_two_level(x, N1, N2, Mm)
+        ref = 2 * np.pi * np.fft.rfft(x, norm="forward")[:Mm]
+        assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    assert forward_two_level(x, N1, N2, W // 2 + 1)[0].imag == 0.0
+
+
+@pytest.mark.parametrize("W,N1,N2", CASES)
+def test_inverse_two_level_equals_irfft_of_truncated_spectrum(W, N1, N2):
+    rng = np.random.default_rng(W + 1)
+    S = rng.standard_normal(W // 2 + 1) + 1j * rng.standard_normal(W // 2 + 1)
+    for Mm in (W // 2 + 1, W // 2 - 1, 3):
+        T = np.zeros(W // 2 + 1, complex)
+        T[:Mm] = S[:Mm]
+        T[0] = T[0].real                       # irfft ignores these imaginary parts (fft.py:78-96)
+        T[-1] = T[-1].real
+        ref = np.fft.irfft(T, n=W, norm="forward")
+        got = inverse_two_level(S, N1, N2, Mm)
+        assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
