@@ -18,6 +18,7 @@ from .checkpoint import LoadedStepper, load_stepper  # noqa: F401
 from .csfno import NoiseConditionedSFNO, NoiseConditionedSFNOBuilder  # noqa: F401
 from .corrector import AtmosphereCorrectorConfig  # noqa: F401
 from .ocean import OceanConfig  # noqa: F401
-from .stepper import Stepper  # noqa: F401
+from .stepper import PrognosticState, Stepper  # noqa: F401
+from .inference import EnginePredict, ForcingWindows, InferenceData, Looper, TensorFileWriter, run_inference  # noqa: F401
 
 __version__ = "0.1.0"

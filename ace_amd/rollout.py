@@ -174,11 +174,19 @@ class RolloutEngine:
                 self._enqueue_step(s, self.graph_mode == "step")
 
     def predict(self, initial_condition, forcing) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
-        """Same contract as Stepper.predict for one window of n_forward_steps."""
+        """Same contract as Stepper.predict for one window of n_forward_steps (a ``PrognosticState`` initial condition
+        carries the corrector state of the previous window in; the returned state carries this window's out)."""
+        from .step import StepperState
+        from .stepper import PrognosticState
         with torch.no_grad():
             self.load(initial_condition, forcing)
+            carried = getattr(initial_condition, "stepper_state", None)
+            if carried is not None:
+                self._corrector_state = carried.corrector_state
             self.run_window()
-        state = {n: self.out[n][:, -1:] for n in self.prognostic}
+        state = PrognosticState({n: self.out[n][:, -1:] for n in self.prognostic})
+        if self._corrector_state is not None:
+            state.stepper_state = StepperState(corrector_state=self._corrector_state)
         return self.out, state
 
     def continue_from_last(self):

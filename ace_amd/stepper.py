@@ -18,6 +18,13 @@ TensorMapping = Mapping[str, torch.Tensor]
 TensorDict = Dict[str, torch.Tensor]
 
 
+class PrognosticState(dict):
+    """name -> (B, 1, H, W) prognostic tensors plus the opaque per-sample ``stepper_state`` that rides with them from
+    window to window (the reference keeps it on the BatchData of the prognostic state)."""
+
+    stepper_state = None
+
+
 class Stepper:
     TIME_DIM = 1
     CHANNEL_DIM = -3
@@ -89,7 +96,9 @@ class Stepper:
                 n_forward_steps: Optional[int] = None) -> Tuple[TensorDict, TensorDict]:
         """single_module.py:1169-1259 on plain dicts: initial_condition name -> (B, 1, H, W) prognostic state,
         forcing name -> (B, 1 + n_forward_steps, H, W).  Returns (output name -> (B, n_forward_steps, H, W),
-        final prognostic state name -> (B, 1, H, W))."""
+        final prognostic state name -> (B, 1, H, W)).  The returned state is a ``PrognosticState`` (a dict) that carries
+        the per-sample ``stepper_state`` (corrector dry-air reference) the way the reference's does
+        (fme/ace/data_loading/batch_data.py:214-235): feed it back as the next window's initial condition."""
         any_forcing = next(iter(forcing.values()))
         if n_forward_steps is None:
             n_forward_steps = any_forcing.shape[self.TIME_DIM] - self.n_ic_timesteps
@@ -97,9 +106,11 @@ class Stepper:
             if v.shape[self.TIME_DIM] != self.n_ic_timesteps:
                 raise ValueError(f"Initial condition must have {self.n_ic_timesteps} timesteps, got {v.shape[1]}.")
         with torch.no_grad():
-            outs = list(self.predict_generator(initial_condition, forcing, n_forward_steps))
+            outs = list(self.predict_generator(initial_condition, forcing, n_forward_steps,
+                                               stepper_state=getattr(initial_condition, "stepper_state", None)))
         data = {k: torch.stack([o.output[k] for o in outs], dim=self.TIME_DIM) for k in outs[0].output}
-        prognostic_state = {k: data[k][:, -1:] for k in self.prognostic_names}
+        prognostic_state = PrognosticState({k: data[k][:, -1:] for k in self.prognostic_names})
+        prognostic_state.stepper_state = outs[-1].stepper_state
         return data, prognostic_state
 
     def get_state(self):

@@ -714,3 +714,38 @@ def test_reference_checkpoint_rollout_matches_reference_stepper(dev, precision, 
     assert worst[0][0] <= 1.0, worst[:5]
     for k, v in state.items():
         assert torch.equal(v[:, 0], out[k][:, -1])
+
+
+@pytest.mark.parametrize("how", ["stepper", "engine"])
+def test_windowed_inference_matches_reference_continuous_rollout(dev, how, tmp_path):
+    """run_inference over forcing windows of 2 + 1 steps (ace_amd/inference.py: window feeder with the one-ahead upload,
+    Looper, restart dump) == the REAL reference stepper's continuous 3-step rollout of tests/golden/gen_checkpoint.pt: the
+    dry-air reference mass of the corrector has to ride on the prognostic state from window to window, as the reference's
+    stepper_state does (fme/ace/data_loading/batch_data.py:214-235)."""
+    import ace_amd
+    from ace_amd.inference import EnginePredict, ForcingWindows, InferenceData, TensorFileWriter, run_inference
+    g = load_golden("gen_checkpoint.pt")["ace2_like"]
+    stepper = ace_amd.load_stepper(g["state"], device=dev).stepper
+    ic = {k: v.to(dev) for k, v in g["ic"].items()}
+    T = len(g["steps"])
+    loader = ForcingWindows(g["forcing"], total_forward_steps=T, forward_steps_in_memory=2, device=dev)
+    assert len(loader) == 2
+    predict = stepper.predict if how == "stepper" else EnginePredict(stepper, batch=2, graph="step")
+    writer = TensorFileWriter(str(tmp_path))
+    state = run_inference(predict, InferenceData(ic, loader), writer=writer)
+    torch.cuda.synchronize()
+    series = torch.load(tmp_path / "autoregressive_predictions.pt", weights_only=True)
+    floor = conditioning_floor(g)
+    for s, want_all in enumerate(g["steps"]):
+        for k, want in want_all.items():
+            err = float((series[k][:, s] - want).abs().max()) / float(want.abs().max())
+            assert err <= max(NET_TOL * (s + 1), 3.0 * floor[s][k]), (k, s, err)
+    restart = torch.load(tmp_path / "restart.pt", weights_only=True)
+    assert set(restart) == set(stepper.prognostic_names)
+    for k, v in restart.items():
+        assert torch.equal(v, series[k][:, -1:]) and torch.equal(v, state[k].cpu())
+    # the dry-air reference seeded by the first window is still the one on the final state (carried, not re-seeded)
+    cs = state.stepper_state.corrector_state
+    assert cs is not None and cs.global_dry_air_mass is not None
+    first = run_inference(predict, InferenceData(ic, ForcingWindows(g["forcing"], 1, 1, device=dev)))
+    assert torch.equal(cs.global_dry_air_mass, first.stepper_state.corrector_state.global_dry_air_mass)

@@ -1,0 +1,93 @@
+"""Window I/O around the rollout (ace_amd/inference.py) on CPU with a stand-in predict function: the forcing-window rule of
+InferenceDataset (fme/ace/data_loading/inference.py:291-357), the Looper / run_inference call order
+(fme/core/generics/inference.py:25-66, 117-166), the writer files and the state that rides on the prognostic state."""
+import os
+
+import pytest
+import torch
+
+from ace_amd.inference import ForcingWindows, InferenceData, Looper, TensorFileWriter, run_inference
+from ace_amd.stepper import PrognosticState
+
+
+def fake_predict(ic, forcing, compute_derived_variables=False):
+    """x_{t+1} = x_t + f_t ; diagnostic d_{t+1} = 2 f_{t+1}; counts the windows on the carried state."""
+    x = ic["x"][:, 0]
+    f = forcing["f"]
+    outs = []
+    for t in range(f.shape[1] - 1):
+        x = x + f[:, t]
+        outs.append(x)
+    out = {"x": torch.stack(outs, dim=1), "d": 2 * f[:, 1:]}
+    state = PrognosticState({"x": out["x"][:, -1:]})
+    state.stepper_state = (getattr(ic, "stepper_state", None) or 0) + 1
+    return out, state
+
+
+def test_forcing_windows_follow_the_reference_rule():
+    f = torch.arange(3 * 11, dtype=torch.float32).reshape(3, 11, 1, 1).expand(3, 11, 2, 4).contiguous()
+    fw = ForcingWindows({"f": f}, total_forward_steps=10, forward_steps_in_memory=4, device="cpu")
+    assert len(fw) == 3
+    wins = list(fw)
+    assert [w["f"].shape[1] for w in wins] == [5, 5, 3]            # T + 1, T + 1, cut at total + 1
+    assert torch.equal(wins[0]["f"][:, -1], wins[1]["f"][:, 0])    # consecutive windows share one time level
+    assert torch.equal(wins[2]["f"], f[:, 8:11])
+    sub = list(ForcingWindows({"f": f}, 10, 4, device="cpu", members=[0, 2]))     # member g on rank g % world
+    assert torch.equal(sub[1]["f"], f[[0, 2], 4:9])
+    assert len(ForcingWindows({"f": f}, 8, 4, device="cpu")) == 2
+    with pytest.raises(ValueError, match="number of forward inference steps"):
+        ForcingWindows({"f": f}, 11, 4, device="cpu")
+    with pytest.raises(ValueError):
+        ForcingWindows({"f": f[:, :, 0]}, 4, 2, device="cpu")
+
+
+def test_looper_chains_windows_through_the_prognostic_state():
+    torch.manual_seed(0)
+    f = torch.randn(2, 8, 3, 5)
+    ic = {"x": torch.randn(2, 1, 3, 5)}
+    one, _ = fake_predict(ic, {"f": f})
+    looper = Looper(fake_predict, InferenceData(ic, ForcingWindows({"f": f}, 7, 3, device="cpu")))
+    assert len(looper) == 3
+    wins = list(looper)
+    assert [w["x"].shape[1] for w in wins] == [3, 3, 1]
+    torch.testing.assert_close(torch.cat([w["x"] for w in wins], dim=1), one["x"])
+    assert torch.equal(torch.cat([w["d"] for w in wins], dim=1), one["d"])
+    final = looper.get_prognostic_state()
+    assert torch.equal(final["x"], wins[-1]["x"][:, -1:]) and final.stepper_state == 3
+
+
+def test_run_inference_call_order_and_files(tmp_path):
+    calls = []
+
+    class Agg:
+        def record_initial_condition(self, initial_condition):
+            calls.append("agg.ic")
+            return ["ic"]
+
+        def record_batch(self, data):
+            calls.append(f"agg.batch{data['x'].shape[1]}")
+            return ["b"]
+
+    class Writer(TensorFileWriter):
+        def write(self, data, filename):
+            calls.append("write." + filename)
+            super().write(data, filename)
+
+        def append_batch(self, batch):
+            calls.append("append")
+            super().append_batch(batch)
+
+    f = torch.randn(1, 6, 2, 2)
+    ic = {"x": torch.zeros(1, 1, 2, 2)}
+    logs = []
+    state = run_inference(fake_predict, InferenceData(ic, ForcingWindows({"f": f}, 5, 2, device="cpu")), Agg(),
+                          Writer(str(tmp_path), names=["x"]), logs.extend)
+    assert calls == ["agg.ic", "write.initial_condition.nc", "append", "agg.batch2", "append", "agg.batch2", "append",
+                     "agg.batch1", "write.restart.nc"]
+    assert logs == ["ic", "b", "b", "b"]
+    restart = torch.load(os.path.join(tmp_path, "restart.pt"), weights_only=True)
+    assert set(restart) == {"x"} and torch.equal(restart["x"], state["x"]) and restart["x"].shape == (1, 1, 2, 2)
+    series = torch.load(os.path.join(tmp_path, "autoregressive_predictions.pt"), weights_only=True)
+    assert set(series) == {"x"} and series["x"].shape == (1, 5, 2, 2)
+    torch.testing.assert_close(series["x"][:, -1:], restart["x"])
+    assert torch.equal(torch.load(os.path.join(tmp_path, "initial_condition.pt"), weights_only=True)["x"], ic["x"])
