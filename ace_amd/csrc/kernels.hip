@@ -1690,6 +1690,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
     const int arow0 = wm * 64 + i, arow1 = arow0 + 32;
     const int key0 = (arow0 >> 2) & 3, key1 = (arow1 >> 2) & 3;
     const int bcol0 = wn * 64 + i, bcol1 = bcol0 + 32;
+    // Triangular launches (dhconv: rows m <= l) leave whole 64-row strips of a 128-row tile beyond M: such a wave keeps
+    // its DMA share and the barriers but issues no fragment reads, no MFMAs and no epilogue (25 % of the dhconv's waves).
+    const bool strip_on = m0 + wm * 64 < M;
     auto neg8 = [](half8 v) {   // -v: flip the eight sign bits
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         u32x4 u = __builtin_bit_cast(u32x4, v);
@@ -1697,6 +1700,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
         return __builtin_bit_cast(half8, u);
     };
     auto load_frags = [&](Frags4& f, int buf, int c, bool neg = false) {
+        if (!strip_on) return;
         const _Float16* Ah = As + buf * 2 * APL;
         const _Float16* Al = Ah + APL;
         const _Float16* Bh = Bs + buf * 2 * BPL;
@@ -1724,6 +1728,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     auto mma = [&](const Frags4& f) {  // 12 MFMAs: small cross terms first, the hi.hi term last
+        if (!strip_on) return;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1831,7 +1836,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
     const long ldc = q.ldc, ldr = q.ldr;
     const int actk = q.act;
     float4* part = q.part ? q.part + ((long)batch * tilesN * WN + (long)tile_n * WN + wn) * q.M : nullptr;
-    if (PK && !RES && !C && !part) {
+    if (!strip_on) {
+        // nothing to write: every row of this wave's strip is beyond M
+    } else if (PK && !RES && !C && !part) {
         // only the P-format output (fc1 -> hidden activation): park, then lane = column, 8 rows per 16-byte entry
         float* Ts = reinterpret_cast<float*>(smem4) + wave * 4096;
 #pragma unroll
