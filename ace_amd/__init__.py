@@ -14,7 +14,7 @@ from .sfno import SphericalFourierNeuralOperatorBuilder, SphericalFourierNeuralO
 from .packer import Packer  # noqa: F401
 from .normalizer import StandardNormalizer  # noqa: F401
 from .step import SingleModuleStep, SingleModuleStepConfig, StepArgs, StepOutput  # noqa: F401
-from .checkpoint import LoadedStepper, load_stepper  # noqa: F401
+from .checkpoint import LoadedStepper, StepperOverrideConfig, apply_stepper_override, load_stepper  # noqa: F401
 from .csfno import NoiseConditionedSFNO, NoiseConditionedSFNOBuilder  # noqa: F401
 from .corrector import AtmosphereCorrectorConfig  # noqa: F401
 from .ocean import OceanConfig  # noqa: F401

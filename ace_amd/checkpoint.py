@@ -170,15 +170,43 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
     return config, dataset_info, step_state, ignored
 
 
-def load_stepper(checkpoint: Union[str, pathlib.Path, Mapping[str, Any]], device=None,
+@dataclasses.dataclass
+class StepperOverrideConfig:
+    """single_module.py:1848-1870: inference-time overrides of a serialized stepper; ``"keep"`` leaves the option alone.
+    ``multi_call``: "keep" or None (multi-call diagnostics are outside the accelerated path either way);
+    ``derived_forcings``: "keep" only."""
+
+    ocean: Any = "keep"
+    multi_call: Any = "keep"
+    derived_forcings: Any = "keep"
+    prescribed_prognostic_names: Any = "keep"
+
+
+def apply_stepper_override(stepper: Stepper, override_config: Optional[StepperOverrideConfig] = None) -> None:
+    """single_module.py:1929-1960."""
+    if override_config is None:
+        override_config = StepperOverrideConfig()
+    if override_config.ocean != "keep":
+        stepper.replace_ocean(override_config.ocean)
+    if override_config.multi_call not in ("keep", None):
+        raise NotImplementedError("multi-call diagnostics are outside the accelerated hot path")
+    if override_config.derived_forcings != "keep":
+        raise NotImplementedError("derived forcings are outside the accelerated hot path")
+    if override_config.prescribed_prognostic_names != "keep":
+        stepper.replace_prescribed_prognostic_names(override_config.prescribed_prognostic_names)
+
+
+def load_stepper(checkpoint: Union[str, pathlib.Path, Mapping[str, Any]],
+                 override_config: Optional[StepperOverrideConfig] = None, device=None,
                  ignore_unsupported: bool = False) -> LoadedStepper:
-    """``fme.ace.stepper.load_stepper`` for the accelerated stepper.  ``checkpoint``: a path (torch.load) or the
-    already-loaded dict; either the whole checkpoint ({"stepper": ...}) or the stepper state itself."""
+    """``fme.ace.stepper.load_stepper`` (single_module.py:1909-1927) for the accelerated stepper.  ``checkpoint``: a path
+    (torch.load) or the already-loaded dict; either the whole checkpoint ({"stepper": ...}) or the stepper state itself."""
     if not isinstance(checkpoint, Mapping):
         checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
     state = checkpoint["stepper"] if "stepper" in checkpoint else checkpoint
     config, dataset_info, step_state, ignored = stepper_config_from_state(state, ignore_unsupported)
     stepper = Stepper.from_config(config, dataset_info, device=device)
     stepper.load_state({"step": step_state})
+    apply_stepper_override(stepper, override_config)
     stepper.set_eval()
-    return LoadedStepper(stepper=stepper, config=config, dataset_info=dataset_info, ignored=ignored)
+    return LoadedStepper(stepper=stepper, config=stepper._step_obj.config, dataset_info=dataset_info, ignored=ignored)

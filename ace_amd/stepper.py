@@ -64,6 +64,28 @@ class Stepper:
     def _input_only_names(self) -> set:
         return set(self._step_obj.input_names).difference(self._step_obj.output_names)
 
+    # -- inference-time replacements (single_module.py:967-996): same weights, new post-step behaviour
+    def replace_ocean(self, ocean):
+        """Replace the ocean model (an ``OceanConfig``, its state dict, or None)."""
+        import dataclasses
+        step = self._step_obj
+        keep = getattr(step._config, "_ignore_unsupported", False)
+        step._config = dataclasses.replace(step._config, ocean=ocean)      # __post_init__ validates / converts
+        step._config._ignore_unsupported = keep
+        cfg = step._config
+        step._ocean = (cfg.ocean.build(list(cfg.in_names), list(cfg.out_names), step._timestep)
+                       if cfg.ocean is not None else None)
+
+    def replace_prescribed_prognostic_names(self, names: List[str]) -> None:
+        import dataclasses
+        step = self._step_obj
+        keep = getattr(step._config, "_ignore_unsupported", False)
+        step._config = dataclasses.replace(step._config, prescribed_prognostic_names=list(names))
+        step._config._ignore_unsupported = keep
+
+    def get_prescribed_prognostic_names(self) -> List[str]:
+        return list(self._step_obj.config.prescribed_prognostic_names)
+
     def set_eval(self):
         for m in self.modules:
             m.eval()

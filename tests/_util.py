@@ -54,6 +54,21 @@ def build_native_net(cfg, state, device="cuda", precision=None):
     return net.to(device).eval()
 
 
+def checkpoint_case(golden: dict, name: str) -> dict:
+    """one case of tests/golden/gen_checkpoint.pt; "<base>_override" re-uses the state / inputs of <base> with the
+    StepperOverrideConfig fields stored under "override" and its own reference rollout"""
+    case = golden[name]
+    if "override" in case:
+        base = golden[name[: -len("_override")]]
+        case = {**base, "steps": case["steps"], "override": case["override"]}
+    return case
+
+
+def checkpoint_override(case: dict):
+    import ace_amd
+    return ace_amd.StepperOverrideConfig(**case["override"]) if "override" in case else None
+
+
 def oracle_checkpoint_rollout(case: dict, dtype=torch.float32):
     """CPU rollout of one case of tests/golden/gen_checkpoint.pt: the oracle network (oracle/sfno.py) evaluated in
     `dtype` under the host-side step logic (ace_amd.step.step_with_adjustments: normalise, residual, corrector, ocean,
@@ -63,7 +78,7 @@ def oracle_checkpoint_rollout(case: dict, dtype=torch.float32):
     from ace_amd.step import step_with_adjustments
     from oracle.sfno import SFNOConfig, SFNOOracle
 
-    loaded = ace_amd.load_stepper(case["state"], device="cpu")
+    loaded = ace_amd.load_stepper(case["state"], override_config=checkpoint_override(case), device="cpu")
     step, cfg = loaded.stepper._step_obj, loaded.config
     fields = {f.name for f in dataclasses.fields(SFNOConfig)}
     ocfg = SFNOConfig(in_chans=len(cfg.in_names), out_chans=len(cfg.out_names), img_shape=loaded.dataset_info.img_shape,

@@ -7,6 +7,8 @@ under stubs (oracle/ref_loader.load_stepper_ref) - build container only.  Writes
                 ``predict_generator`` output of every step of a 3-step rollout on CPU
   "residual_prescribed"  the same for residual_prediction=True with a prescribed prognostic (equiangular data grid, no
                 big skip, no position embedding, no hooks)
+  "ace2_like_override"  the first stepper re-loaded with ``StepperOverrideConfig(ocean=None, prescribed_prognostic_names=
+                ["surface_temperature"])`` and its 3-step rollout
   "multi_call_csfno"  the state of a multi_call-wrapped NoiseConditionedSFNO stepper (state ingestion only: its
                 rollout draws noise from the global torch RNG)
 
@@ -121,6 +123,20 @@ def main():
             steps3.append({k: v.clone() for k, v in res.output.items()})
     out["residual_prescribed"] = {"state": plain(stepper3.get_state()), "ic": ic, "forcing": forcing, "steps": steps3}
     print("residual_prescribed: PRESsfc step2 mean", float(steps3[-1]["PRESsfc"].mean()))
+
+    # ---- inference-time override of the first stepper (load_stepper(path, StepperOverrideConfig(...)), single_module.py:1909-1960):
+    # no ocean, the surface temperature prescribed from the forcing record instead
+    sm = ref.module
+    over = {"ocean": None, "prescribed_prognostic_names": ["surface_temperature"]}
+    stepper4 = sm.Stepper.from_state(out["ace2_like"]["state"])
+    sm.apply_stepper_override(stepper4, sm.StepperOverrideConfig(**over))
+    steps4 = []
+    with torch.no_grad():
+        for res in stepper4.predict_generator(ic, forcing, T, ref.NullOptimization(), labels=None):
+            steps4.append({k: v.clone() for k, v in res.output.items()})
+    out["ace2_like_override"] = {"override": over, "steps": steps4}
+    print("ace2_like_override: max |dT_sfc| vs no override",
+          float((steps4[-1]["air_temperature_1"] - steps[-1]["air_temperature_1"]).abs().max()))
 
     # ---- multi_call-wrapped noise-conditioned stepper (state only)
     csfno = {"type": "NoiseConditionedSFNO",

@@ -246,14 +246,40 @@ def test_reference_multi_call_noise_conditioned_checkpoint_is_ingested():
         assert torch.equal(ref_w[k], got_w[k].cpu()), k
 
 
-@pytest.mark.parametrize("case", ["ace2_like", "residual_prescribed"])
+def test_stepper_override_config():
+    """load_stepper(path, StepperOverrideConfig(...)) / apply_stepper_override (single_module.py:1848-1960)."""
+    from ace_amd.checkpoint import StepperOverrideConfig, apply_stepper_override
+    state = _golden_checkpoint()["ace2_like"]["state"]
+    kept = load_stepper(state, device="cpu")
+    assert kept.config.ocean is not None and kept.stepper.get_prescribed_prognostic_names() == []
+    over = load_stepper(state, StepperOverrideConfig(ocean=None, prescribed_prognostic_names=["surface_temperature"]),
+                        device="cpu")
+    assert over.config.ocean is None and over.stepper._step_obj._ocean is None
+    assert over.stepper.get_prescribed_prognostic_names() == ["surface_temperature"]
+    assert "surface_temperature" in over.stepper._step_obj.next_step_input_names
+    assert "ocean_fraction" in over.config.in_names          # still a network input: only the SST prescription is gone
+    for k, v in kept.stepper.modules[0].state_dict().items():     # the weights are untouched
+        assert torch.equal(v, over.stepper.modules[0].state_dict()[k])
+    apply_stepper_override(over.stepper, StepperOverrideConfig(
+        ocean={"surface_temperature_name": "surface_temperature", "ocean_fraction_name": "ocean_fraction"}))
+    assert over.stepper._step_obj._ocean is not None
+    with pytest.raises(ValueError, match="must be in out_names"):
+        over.stepper.replace_prescribed_prognostic_names(["HGTsfc"])
+    with pytest.raises(NotImplementedError):
+        apply_stepper_override(over.stepper, StepperOverrideConfig(derived_forcings={"insolation": None}))
+    with pytest.raises(NotImplementedError):
+        apply_stepper_override(over.stepper, StepperOverrideConfig(multi_call={"forcing_name": "co2"}))
+    apply_stepper_override(over.stepper, StepperOverrideConfig(multi_call=None))
+
+
+@pytest.mark.parametrize("case", ["ace2_like", "residual_prescribed", "ace2_like_override"])
 def test_oracle_rollout_restates_the_reference_stepper(case):
     """oracle network + host step logic (normalise, residual, corrector, ocean, prescribed prognostics) in fp32 on CPU
     against the rollout the REAL reference stepper produced for the fixture: identical to the last bit in the build
     container (same torch CPU kernels, same operation order); held to 1e-6 of the field maximum here so that a
     different CPU / thread count cannot fail it - except the ill-conditioned advective tendency (see conditioning_floor)."""
-    from _util import conditioning_floor, oracle_checkpoint_rollout
-    g = _golden_checkpoint()[case]
+    from _util import checkpoint_case, conditioning_floor, oracle_checkpoint_rollout
+    g = checkpoint_case(_golden_checkpoint(), case)
     got = oracle_checkpoint_rollout(g, torch.float32)
     floor = conditioning_floor(g)
     nbit = 0

@@ -13,7 +13,8 @@ import ctypes
 import pytest
 import torch
 
-from _util import build_native_net, conditioning_floor, load_golden, rel_l2, rel_max
+from _util import (build_native_net, checkpoint_case, checkpoint_override, conditioning_floor, load_golden, rel_l2,
+                   rel_max)
 
 pytestmark = pytest.mark.gpu
 
@@ -671,7 +672,8 @@ def test_rollout_engine_matches_stepper(dev, graph):
 
 @pytest.mark.parametrize("case,engine", [("ace2_like", "stepper"), ("ace2_like", None), ("ace2_like", "step"),
                                          ("residual_prescribed", "stepper"), ("residual_prescribed", None),
-                                         ("residual_prescribed", "step"), ("residual_prescribed", "window")])
+                                         ("residual_prescribed", "step"), ("residual_prescribed", "window"),
+                                         ("ace2_like_override", "stepper"), ("ace2_like_override", "step")])
 def test_reference_checkpoint_rollout_matches_reference_stepper(dev, precision, case, engine):
     """End-to-end drop-in check against the REAL reference stepper (tests/golden/gen_checkpoint.pt, emitted by
     fme.ace.stepper.Stepper on CPU): load its get_state() with ace_amd.load_stepper, roll 3 steps with the ACE2-style
@@ -682,11 +684,12 @@ def test_reference_checkpoint_rollout_matches_reference_stepper(dev, precision, 
     (conditioning_floor: from step 2 on the advective moisture tendency is a residual of nearly cancelling terms and
     the reference's fp32 value is itself 3e-4 / 8e-4 of the field maximum away from the fp64 evaluation).
     Second case: residual_prediction with a prescribed prognostic (equiangular grid, no big skip / position embedding).
+    Third case: the first checkpoint loaded with StepperOverrideConfig(ocean=None, prescribed_prognostic_names=[SST]).
     engine: "stepper" = the dict-of-tensors Stepper.predict, otherwise the static-buffer RolloutEngine's graph mode."""
     import ace_amd
     from ace_amd.rollout import RolloutEngine
-    g = load_golden("gen_checkpoint.pt")[case]
-    loaded = ace_amd.load_stepper(g["state"], device=dev)
+    g = checkpoint_case(load_golden("gen_checkpoint.pt"), case)
+    loaded = ace_amd.load_stepper(g["state"], override_config=checkpoint_override(g), device=dev)
     assert loaded.ignored == []
     stepper = loaded.stepper
     stepper._step_obj.module.torch_module.set_precision(precision)
@@ -699,7 +702,7 @@ def test_reference_checkpoint_rollout_matches_reference_stepper(dev, precision, 
         out, state = RolloutEngine(stepper, batch=2, n_forward_steps=T, graph=engine).predict(ic, forcing)
     torch.cuda.synchronize()
     assert set(out) == set(g["steps"][0])
-    if case == "residual_prescribed":
+    if case in ("residual_prescribed", "ace2_like_override"):
         assert torch.equal(out["surface_temperature"], forcing["surface_temperature"][:, 1:])
     floor = conditioning_floor(g)
     worst = []
