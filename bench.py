@@ -47,7 +47,7 @@ def stage_model(C=384, H=180, W=360, L=180, M=181, hid=768, cin=44, cout=50):
         # name: (flops, hbm_bytes)  - dense counts; the triangular (l >= m) work actually done is ~half for legendre
         "forward_transform.dft": (fft_flops, act + coef),
         "forward_transform.legendre": (2 * 2 * C * M * L * H, 2 * coef + tab),
-        "dhconv": (8 * C * C * L * M, 2 * coef + 4 * C * C * L * 4),
+        "dhconv": (8 * C * C * L * M, 2 * coef + 2 * C * C * L * 4),      # coef_in + Wf (212 MB) + coef_out
         "inverse_transform.legendre": (2 * 2 * C * M * L * H, 2 * coef + tab),
         "inverse_transform.dft": (fft_flops, act + coef),
         "inner_skip+activation": (2 * C * C * H * W, 3 * act),
