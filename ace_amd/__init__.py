@@ -18,6 +18,7 @@ from .checkpoint import LoadedStepper, StepperOverrideConfig, apply_stepper_over
 from .csfno import NoiseConditionedSFNO, NoiseConditionedSFNOBuilder  # noqa: F401
 from .corrector import AtmosphereCorrectorConfig  # noqa: F401
 from .ocean import OceanConfig  # noqa: F401
+from .derived_variables import AtmosphericDeriveFn, compute_derived_quantities  # noqa: F401
 from .stepper import PrognosticState, Stepper  # noqa: F401
 from .inference import EnginePredict, ForcingWindows, InferenceData, Looper, TensorFileWriter, run_inference  # noqa: F401
 

@@ -46,6 +46,8 @@ ATMOSPHERE_FIELD_NAME_PREFIXES = {
     "toa_down_sw_radiative_flux": ["DSWRFtoa", "SOLIN"],
     "air_temperature": ["air_temperature_", "T_"],
     "frozen_precipitation_rate": ["total_frozen_precipitation_rate"],
+    "eastward_wind_at_10m": ["UGRD10m"],
+    "northward_wind_at_10m": ["VGRD10m"],
 }
 _LEVEL = re.compile(r"_(\d+)$")
 
@@ -294,6 +296,11 @@ class AtmosphereData:
     def total_energy_ace2(self) -> torch.Tensor:
         return (self.air_temperature * SPECIFIC_HEAT_OF_DRY_AIR_CONST_VOLUME
                 + self.specific_total_water * LATENT_HEAT_OF_VAPORIZATION + self.height_at_midpoint * GRAVITY)
+
+    @property
+    def windspeed_at_10m(self) -> torch.Tensor:
+        """atmosphere_data.py:367-373."""
+        return torch.sqrt(self._get("eastward_wind_at_10m") ** 2 + self._get("northward_wind_at_10m") ** 2)
 
     @property
     def total_energy_ace2_path(self) -> torch.Tensor:

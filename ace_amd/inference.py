@@ -12,7 +12,7 @@ Mirrors, on plain ``name -> tensor`` dicts:
 
 netCDF / xarray are not on the path (and not in this image): ``TensorFileWriter`` keeps the reference's writer interface and file
 stems but stores ``torch.save`` archives (``restart.pt`` holds exactly the prognostic names and shapes ``restart.nc`` would).
-Derived variables (``compute_derived_variables``) are outside the accelerated path: the outputs are the stepper's ``out_names``.
+Derived variables (``compute_derived_variables``) are torch ops on the window's output series (ace_amd/derived_variables.py).
 
 The feeder keeps one window ahead: while window i runs on the compute stream, window i + 1 is copied host -> HBM from pinned
 memory on a side stream (85 MB for a 40-step window of 8 forcing fields at 1 degree: ~2 ms at PCIe rates against ~330 ms of
@@ -99,8 +99,9 @@ class InferenceData:
 class Looper:
     """fme/core/generics/inference.py:25-66."""
 
-    def __init__(self, predict: Callable, data: InferenceData):
+    def __init__(self, predict: Callable, data: InferenceData, compute_derived_variables: bool = False):
         self._predict = predict
+        self._derived = compute_derived_variables      # the reference always asks for them (inference.py:58-62)
         self._prognostic_state = data.initial_condition
         self._len = len(data.loader)
         self._loader = iter(data.loader)
@@ -113,7 +114,10 @@ class Looper:
 
     def __next__(self) -> TensorDict:
         forcing = next(self._loader)
-        output, self._prognostic_state = self._predict(self._prognostic_state, forcing)
+        if self._derived:
+            output, self._prognostic_state = self._predict(self._prognostic_state, forcing, compute_derived_variables=True)
+        else:
+            output, self._prognostic_state = self._predict(self._prognostic_state, forcing)
         return output
 
     def get_prognostic_state(self) -> TensorDict:
@@ -157,12 +161,13 @@ class TensorFileWriter:
 
 
 def run_inference(predict: Callable, data: InferenceData, aggregator=None, writer=None,
-                  record_logs: Optional[Callable[[Any], None]] = None):
+                  record_logs: Optional[Callable[[Any], None]] = None, compute_derived_variables: bool = False):
     """fme/core/generics/inference.py:117-166 (same call order; ``aggregator`` / ``record_logs`` optional here).
-    Returns the final prognostic state."""
+    ``compute_derived_variables``: ask ``predict`` for the derived output variables (ace_amd/derived_variables.py) as the
+    reference's Looper always does.  Returns the final prognostic state."""
     if writer is None:
         writer = NullDataWriter()
-    looper = Looper(predict=predict, data=data)
+    looper = Looper(predict=predict, data=data, compute_derived_variables=compute_derived_variables)
     if aggregator is not None:
         logs = aggregator.record_initial_condition(initial_condition=data.initial_condition)
         if record_logs is not None:
@@ -202,4 +207,8 @@ class EnginePredict:
         out, state = eng.predict(initial_condition, forcing)
         kept = type(state)({k: v.clone() for k, v in state.items()})
         kept.stepper_state = getattr(state, "stepper_state", None)
-        return {k: v.clone() for k, v in out.items()}, kept
+        out = {k: v.clone() for k, v in out.items()}
+        if compute_derived_variables:
+            from .stepper import derive_over_window
+            out = derive_over_window(self._stepper.derive_func, out, initial_condition, forcing, 1, n_steps)
+        return out, kept

@@ -205,6 +205,7 @@ class SingleModuleStep:
         self._ocean = (config.ocean.build(list(config.in_names), list(config.out_names), dataset_info.timestep)
                        if config.ocean is not None else None)
         self._timestep = dataset_info.timestep
+        self._vertical_coordinate = getattr(dataset_info, "vertical_coordinate", None)   # derived variables only
         self.in_names = config.in_names
         self.out_names = config.out_names
 

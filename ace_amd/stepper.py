@@ -25,6 +25,21 @@ class PrognosticState(dict):
     stepper_state = None
 
 
+def derive_over_window(derive_func, data: TensorDict, initial_condition: TensorMapping, forcing: TensorMapping,
+                       n_ic: int, n_forward_steps: int) -> TensorDict:
+    """single_module.py:1236-1245: prepend the initial condition (names it does not hold are NaN there,
+    batch_data.py:889-913), compute the derived variables against the forcing of the same time levels, drop the initial
+    time level again."""
+    example = next(iter(initial_condition.values()))
+    full = {}
+    for k, v in data.items():
+        head = initial_condition[k] if k in initial_condition else torch.full_like(example, float("nan"))
+        full[k] = torch.cat([head.to(v.device), v], dim=1)
+    f = {k: v[:, : n_ic + n_forward_steps] for k, v in forcing.items()}
+    derived = derive_func(full, f)
+    return {k: v[:, n_ic:] for k, v in {**full, **derived}.items() if k in full or k not in f}
+
+
 class Stepper:
     TIME_DIM = 1
     CHANNEL_DIM = -3
@@ -114,8 +129,15 @@ class Stepper:
             stepper_state = result.stepper_state
             yield result
 
+    @property
+    def derive_func(self):
+        """single_module.py:606-613, 895-897: the derived-variable function of the dataset's vertical coordinate."""
+        from .derived_variables import AtmosphericDeriveFn
+        return AtmosphericDeriveFn(self._step_obj._vertical_coordinate, self._step_obj._timestep)
+
     def predict(self, initial_condition: TensorMapping, forcing: TensorMapping,
-                n_forward_steps: Optional[int] = None) -> Tuple[TensorDict, TensorDict]:
+                n_forward_steps: Optional[int] = None, compute_derived_variables: bool = False
+                ) -> Tuple[TensorDict, TensorDict]:
         """single_module.py:1169-1259 on plain dicts: initial_condition name -> (B, 1, H, W) prognostic state,
         forcing name -> (B, 1 + n_forward_steps, H, W).  Returns (output name -> (B, n_forward_steps, H, W),
         final prognostic state name -> (B, 1, H, W)).  The returned state is a ``PrognosticState`` (a dict) that carries
@@ -131,6 +153,8 @@ class Stepper:
             outs = list(self.predict_generator(initial_condition, forcing, n_forward_steps,
                                                stepper_state=getattr(initial_condition, "stepper_state", None)))
         data = {k: torch.stack([o.output[k] for o in outs], dim=self.TIME_DIM) for k in outs[0].output}
+        if compute_derived_variables:
+            data = derive_over_window(self.derive_func, data, initial_condition, forcing, self.n_ic_timesteps, n_forward_steps)
         prognostic_state = PrognosticState({k: data[k][:, -1:] for k in self.prognostic_names})
         prognostic_state.stepper_state = outs[-1].stepper_state
         return data, prognostic_state

@@ -56,6 +56,19 @@ def test_looper_chains_windows_through_the_prognostic_state():
     assert torch.equal(final["x"], wins[-1]["x"][:, -1:]) and final.stepper_state == 3
 
 
+def test_looper_asks_for_derived_variables_when_told():
+    seen = []
+
+    def predict(ic, forcing, compute_derived_variables=False):
+        seen.append(compute_derived_variables)
+        return fake_predict(ic, forcing)
+
+    data = lambda: InferenceData({"x": torch.zeros(1, 1, 2, 2)}, ForcingWindows({"f": torch.zeros(1, 3, 2, 2)}, 2, 1, device="cpu"))
+    run_inference(predict, data())
+    run_inference(predict, data(), compute_derived_variables=True)
+    assert seen == [False, False, True, True]
+
+
 def test_run_inference_call_order_and_files(tmp_path):
     calls = []
 
