@@ -1559,6 +1559,9 @@ extern "C" int ace_debug_g4_trace(void* dst) { return (int)hipMemcpyFromSymbol(d
 #ifndef ACE_G4_PIN
 #define ACE_G4_PIN 1
 #endif
+#ifndef ACE_G4_REGEPI
+#define ACE_G4_REGEPI 0   // P-format-only epilogue from registers (v_permlane32_swap): written, lane mapping probed, NOT yet
+#endif                    // validated on the GPU (round 2: tools/ab.sh with -DACE_G4_REGEPI=1)
 struct Frags4 { half8 ah[2], al[2], bh[2], bl[2]; };  // one 16-deep k half: [tile]
 
 template <int WM, int WN, bool RES, bool PK>
@@ -1838,6 +1841,55 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
     float4* part = q.part ? q.part + ((long)batch * tilesN * WN + (long)tile_n * WN + wn) * q.M : nullptr;
     if (!strip_on) {
         // nothing to write: every row of this wave's strip is beyond M
+    } else if (ACE_G4_REGEPI && PK && !RES && !C && !part) {
+        // Register-only variant.  A lane of the 32x32 accumulator tile holds rows {0-3, 8-11, 16-19, 24-27} (+4 in the upper
+        // half-wave) of its column; v_permlane32_swap(vdst, src) exchanges vdst[32..63] with src[0..31] (probed:
+        // tools/permlane_probe.hip), so swapping r(4j+e) pairs (r0<->r4 .. r3<->r7, r8<->r12 .. r11<->r15) leaves rows
+        // 8g .. 8g+7 in r0..r7 and rows 16+8g .. 16+8g+7 in r8..r15: whole 8-row P entries, no LDS.
+        _Float16* Chi = q.Chi + (long)batch * q.sCp;
+        _Float16* Clo = q.Clo + (long)batch * q.sCp;
+        const int brow = m0 + wm * 64 + lane;
+        const float bl = bias ? bias[brow < M ? brow : 0] : 0.f;
+        dispatch_act(actk, [&](auto at) {
+            constexpr int AC = decltype(at)::value;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    f32x16 v = acc[tm][tn];
+#pragma unroll
+                    for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[8 * hq + e]),
+                                                                             __float_as_uint(v[8 * hq + 4 + e]), false, false);
+                            v[8 * hq + e] = __uint_as_float(sw[0]);
+                            v[8 * hq + 4 + e] = __uint_as_float(sw[1]);
+                        }
+                    const int col = n0 + wn * 64 + tn * 32 + i;
+#pragma unroll
+                    for (int hq = 0; hq < 2; ++hq) {
+                        const int rl = tm * 32 + hq * 16 + g * 8;       // first of this lane's 8 rows within the wave's 64
+                        const int rbase = m0 + wm * 64 + rl;
+                        half8 hh, ll;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            // bias of row rl + e: the two half-waves need different rows of the coalesced load
+                            const float b0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bl), tm * 32 + hq * 16 + e));
+                            const float b1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bl), tm * 32 + hq * 16 + 8 + e));
+                            const float x = act_const<AC>(fmaf(v[8 * hq + e] * inv_a, inv_b, g ? b1 : b0), actk) * cscale;
+                            const _Float16 a = (_Float16)x;
+                            hh[e] = a;
+                            ll[e] = (_Float16)(x - (float)a);
+                        }
+                        if (rbase < M && col < N) {
+                            const long eo = ((long)(rbase >> 3) * q.ldnc + col) * 8;
+                            *reinterpret_cast<half8*>(Chi + eo) = hh;
+                            *reinterpret_cast<half8*>(Clo + eo) = ll;
+                        }
+                    }
+                }
+        });
     } else if (PK && !RES && !C && !part) {
         // only the P-format output (fc1 -> hidden activation): park, then lane = column, 8 rows per 16-byte entry
         float* Ts = reinterpret_cast<float*>(smem4) + wave * 4096;
