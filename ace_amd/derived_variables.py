@@ -12,85 +12,46 @@ from .atmosphere import AtmosphereData
 TensorDict = Dict[str, torch.Tensor]
 DerivedVariableFunc = Callable[[AtmosphereData, datetime.timedelta], torch.Tensor]
 
-_DERIVED_VARIABLE_REGISTRY: MutableMapping[str, DerivedVariableFunc] = {}
+def _stepwise_change(series: torch.Tensor) -> torch.Tensor:
+    """x[t] - x[t-1] along the time axis, zero at the first time level (nothing to difference against)."""
+    out = torch.zeros_like(series)
+    out[:, 1:] = series[:, 1:] - series[:, :-1]
+    return out
 
 
-def register(func: DerivedVariableFunc) -> DerivedVariableFunc:
-    label = func.__name__
-    if label in _DERIVED_VARIABLE_REGISTRY:
-        raise ValueError(f"Function {label} has already been added to registry.")
-    _DERIVED_VARIABLE_REGISTRY[label] = func
-    return func
+def _twp_budget_residual(d: AtmosphereData, dt: datetime.timedelta) -> torch.Tensor:
+    """d(TWP)/dt - (E - P + advective tendency); defined from the second time level on."""
+    sources = d.evaporation_rate - d.precipitation_rate + d.tendency_of_total_water_path_due_to_advection
+    twp = d.total_water_path
+    out = torch.zeros_like(twp)
+    out[:, 1:] = (twp[:, 1:] - twp[:, :-1]) / dt.total_seconds() - sources[:, 1:]
+    return out
+
+
+def _energy_path_tendency(d: AtmosphereData, dt: datetime.timedelta) -> torch.Tensor:
+    return _stepwise_change(d.total_energy_ace2_path) / dt.total_seconds()
+
+
+# name -> function, in the reference's registration order (derived_variables.py:44-167): the order is the order in which the
+# variables are appended to the output dict, which downstream writers keep
+_DERIVED_VARIABLE_REGISTRY: MutableMapping[str, DerivedVariableFunc] = {
+    "surface_pressure_due_to_dry_air": lambda d, dt: d.surface_pressure_due_to_dry_air,
+    "surface_pressure_due_to_dry_air_absolute_tendency": lambda d, dt: _stepwise_change(d.surface_pressure_due_to_dry_air).abs(),
+    "total_water_path": lambda d, dt: d.total_water_path,
+    "total_water_path_budget_residual": _twp_budget_residual,
+    "net_energy_flux_toa_into_atmosphere": lambda d, dt: d.net_top_of_atmosphere_energy_flux,
+    "net_energy_flux_sfc_into_atmosphere": lambda d, dt: -d.net_surface_energy_flux,     # stored positive into the surface
+    "net_energy_flux_into_atmospheric_column": lambda d, dt: d.net_energy_flux_into_atmosphere,
+    "total_energy_ace2_path": lambda d, dt: d.total_energy_ace2_path,
+    "total_energy_ace2_path_tendency": _energy_path_tendency,
+    "implied_tendency_of_total_energy_ace2_path_due_to_advection":
+        lambda d, dt: _energy_path_tendency(d, dt) - d.net_energy_flux_into_atmosphere,   # residual of the column budget
+    "windspeed_at_10m": lambda d, dt: d.windspeed_at_10m,
+}
 
 
 def get_derived_variable_names():
     return list(_DERIVED_VARIABLE_REGISTRY)
-
-
-@register
-def surface_pressure_due_to_dry_air(data, timestep):
-    return data.surface_pressure_due_to_dry_air
-
-
-@register
-def surface_pressure_due_to_dry_air_absolute_tendency(data, timestep):
-    ps_dry = data.surface_pressure_due_to_dry_air
-    out = torch.zeros_like(ps_dry)
-    out[:, 1:] = torch.diff(ps_dry, n=1, dim=1).abs()
-    return out
-
-
-@register
-def total_water_path(data, timestep):
-    return data.total_water_path
-
-
-@register
-def total_water_path_budget_residual(data, timestep):
-    twp = data.total_water_path
-    tendency = (twp[:, 1:] - twp[:, :-1]) / (timestep.total_seconds())
-    out = torch.zeros_like(twp)          # no budget residual on the initial step
-    out[:, 1:] = tendency - (data.evaporation_rate[:, 1:] - data.precipitation_rate[:, 1:]
-                             + data.tendency_of_total_water_path_due_to_advection[:, 1:])
-    return out
-
-
-@register
-def net_energy_flux_toa_into_atmosphere(data, timestep):
-    return data.net_top_of_atmosphere_energy_flux
-
-
-@register
-def net_energy_flux_sfc_into_atmosphere(data, timestep):
-    return -data.net_surface_energy_flux   # the property is positive into the surface
-
-
-@register
-def net_energy_flux_into_atmospheric_column(data, timestep):
-    return data.net_energy_flux_into_atmosphere
-
-
-@register
-def total_energy_ace2_path(data, timestep):
-    return data.total_energy_ace2_path
-
-
-@register
-def total_energy_ace2_path_tendency(data, timestep):
-    mse = total_energy_ace2_path(data, timestep)
-    out = torch.zeros_like(mse)
-    out[:, 1:] = torch.diff(mse, n=1, dim=1) / timestep.total_seconds()
-    return out
-
-
-@register
-def implied_tendency_of_total_energy_ace2_path_due_to_advection(data, timestep):
-    return total_energy_ace2_path_tendency(data, timestep) - data.net_energy_flux_into_atmosphere
-
-
-@register
-def windspeed_at_10m(data, timestep):
-    return data.windspeed_at_10m
 
 
 def _compute_derived_variable(data: TensorDict, vertical_coordinate, timestep: datetime.timedelta, label: str,
