@@ -104,3 +104,43 @@ def test_run_inference_call_order_and_files(tmp_path):
     assert set(series) == {"x"} and series["x"].shape == (1, 5, 2, 2)
     torch.testing.assert_close(series["x"][:, -1:], restart["x"])
     assert torch.equal(torch.load(os.path.join(tmp_path, "initial_condition.pt"), weights_only=True)["x"], ic["x"])
+
+
+def test_forcing_windows_tile_the_record_for_any_lengths():
+    """property: for every (total, T) the windows are [iT, min(iT + T, total)] inclusive, consecutive windows share exactly
+    one time level, and together they cover every time level once (plus the shared ones)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(total=st.integers(1, 40), T=st.integers(1, 12))
+    def check(total, T):
+        f = torch.arange(total + 1, dtype=torch.float32).reshape(1, total + 1, 1, 1)
+        wins = [w["f"][0, :, 0, 0].tolist() for w in ForcingWindows({"f": f}, total, T, device="cpu")]
+        assert len(wins) == -(-total // T)
+        assert wins[0][0] == 0 and wins[-1][-1] == total
+        for a, b in zip(wins, wins[1:]):
+            assert a[-1] == b[0] and len(a) == T + 1
+        steps = [x for w in wins for x in w[1:]]
+        assert steps == list(map(float, range(1, total + 1)))
+
+    check()
+
+
+def test_documented_switches_exist_in_the_code():
+    """every ACE_* environment switch DESIGN.md documents is read somewhere in the sources (and vice versa for getenv)"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    documented = set(re.findall(r"`(ACE_[A-Z0-9_]+)(?:=[^`]*)?`", design))
+    src = ""
+    for sub in ("ace_amd", os.path.join("ace_amd", "csrc")):
+        d = os.path.join(root, sub)
+        for f in os.listdir(d):
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src += open(os.path.join(d, f)).read()
+    read_by_code = set(re.findall(r'getenv\("(ACE_[A-Z0-9_]+)"\)', src)) | set(re.findall(r'environ[^"\n]*"(ACE_[A-Z0-9_]+)"', src))
+    compile_time = set(re.findall(r"#ifndef (ACE_[A-Z0-9_]+)", src))
+    missing = {n for n in documented if n not in read_by_code and n not in compile_time and n not in src}
+    assert not missing, f"documented but not in the sources: {sorted(missing)}"
+    undocumented = {n for n in read_by_code if n not in design}
+    assert not undocumented, f"read by the code but not documented in DESIGN.md: {sorted(undocumented)}"
