@@ -13,7 +13,8 @@ Module weights are loaded with the strict ``load_state_dict`` the reference uses
 the "module." prefix of wrapped modules is accepted (fme/core/distributed/non_distributed.py:15-28).
 
 What is NOT carried over (and why) is returned in ``LoadedStepper.ignored``: training history, loss configuration,
-parameter-init configuration, derived forcings, input masking.  Latitudes / area weights and the hybrid-sigma
+parameter-init configuration, an empty mask provider; derived forcings, input masking and a mask provider with masks
+raise unless ``ignore_unsupported=True``.  Latitudes / area weights and the hybrid-sigma
 coefficients are kept for the conservation correctors (ace_amd/corrector.py).  Features that change the rollout and are not
 implemented raise ``NotImplementedError`` unless ``ignore_unsupported=True``.
 """
@@ -75,7 +76,10 @@ def _normalization_from_state(norm: Mapping[str, Any]) -> NormalizationConfig:
         raise ValueError("checkpoint normalization carries no loaded means/stds (newer checkpoints embed them: "
                          "StepperConfig.as_loaded_dict, single_module.py:582-584)")
     f = lambda v: float(v.item()) if isinstance(v, torch.Tensor) else float(v)
-    return NormalizationConfig(means={k: f(v) for k, v in means.items()}, stds={k: f(v) for k, v in stds.items()})
+    # fme/core/normalizer.py:41-42, 212-242: the NaN fills travel with the normaliser and change what the network sees
+    return NormalizationConfig(means={k: f(v) for k, v in means.items()}, stds={k: f(v) for k, v in stds.items()},
+                               fill_nans_on_normalize=bool(norm.get("fill_nans_on_normalize", False)),
+                               fill_nans_on_denormalize=bool(norm.get("fill_nans_on_denormalize", False)))
 
 
 def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool = False):
@@ -96,9 +100,14 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
             step_state = step_state["wrapped_step"]
         if step_type not in _STEP_TYPES:
             raise NotImplementedError(f"step type '{step_type}' is outside the accelerated hot path")
+        # both change the rollout in the reference (input_process_func on every step, single_module.py:615-632; forcings
+        # computed from the time axis): never dropped silently
         for k in ("input_masking", "derived_forcings"):
             v = cfg.get(k)
             if v not in (None, {}, {"insolation": None}):
+                if not ignore_unsupported:
+                    raise NotImplementedError(f"StepperConfig.{k} is configured in this checkpoint and is outside the "
+                                              "accelerated hot path (pass ignore_unsupported=True to drop it)")
                 ignored.append(k)
         ds_state = state["dataset_info"]
         normalization = _normalization_from_state(step_cfg["normalization"])
@@ -146,9 +155,15 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
         raise ValueError(f"unknown step config fields: {sorted(unknown)}")
     config = SingleModuleStepConfig(builder=ModuleSelector(type=builder["type"], config=dict(builder["config"])),
                                     normalization=normalization, **step_cfg)
-    for k in ("mask_provider", "variable_metadata"):
-        if ds_state.get(k) is not None:
-            ignored.append(f"dataset_info.{k}")
+    mp = ds_state.get("mask_provider")
+    if mp is not None:
+        # a provider with masks drives the reference's output masking (single_module.py _output_masking): results differ
+        if isinstance(mp, Mapping) and mp.get("masks") and not ignore_unsupported:
+            raise NotImplementedError("dataset_info.mask_provider carries masks (output masking) - outside the accelerated "
+                                      "hot path (pass ignore_unsupported=True to drop it)")
+        ignored.append("dataset_info.mask_provider")
+    if ds_state.get("variable_metadata") is not None:
+        ignored.append("dataset_info.variable_metadata")
     labels = ds_state.get("all_labels") or None
     # geometry for the conservation correctors: latitudes (or legacy area weights) and hybrid-sigma coefficients
     hc = ds_state.get("horizontal_coordinates") or {}

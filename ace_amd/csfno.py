@@ -164,6 +164,7 @@ class NoiseConditionedSFNO(nn.Module):
     def sync_weights(self, force: bool = False):
         L = _lib.lib()
         stream = _lib.current_stream()
+        changed = 0
         for name, p in self.state_dict(keep_vars=True).items():
             stamp = (p.data_ptr(), p._version)
             if not force and self._uploaded.get(name) == stamp:
@@ -174,6 +175,8 @@ class NoiseConditionedSFNO(nn.Module):
             native_name = name[len("conditional_model."):] if name.startswith("conditional_model.") else name
             _lib.check(L.ace_sfno_set_weight(self._native, native_name.encode(), _lib.ptr(t), t.numel(), stream))
             self._uploaded[name] = stamp
+            changed += 1
+        return changed
 
     # ------------------------------------------------------------------ noise (stochastic_sfno.py:21-47, 128-146)
     def draw_noise(self, batch: int, device: torch.device) -> torch.Tensor:

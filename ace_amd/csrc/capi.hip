@@ -762,7 +762,11 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
         for (float v : host) w.absmax = std::max(w.absmax, std::fabs(v));
     }
     w.set = true;
-    // parameters changed: captured graphs still point at the same library buffers, so they stay valid
+    // Captured graphs keep pointing at the same library buffers, but the host-side scalars derived from the weights
+    // (ascale, winf, wabs, bias bounds, filter scale) are baked into their kernel arguments by value: drop the graphs so
+    // that the next ace_sfno_forward_graph re-captures with the new scalars.
+    for (auto& kv : n->graphs) (void)hipGraphExecDestroy(kv.second);
+    n->graphs.clear();
     return ACE_OK;
 }
 

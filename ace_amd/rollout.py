@@ -64,6 +64,10 @@ class RolloutEngine:
         self.target = {n: torch.zeros(B, T + 1, H, W, **f32) for n in self.target_names}
         self.out = {n: torch.zeros(B, T, H, W, **f32) for n in self.out_names}
         norm = step.normalizer
+        if norm.fill_nans_on_normalize or norm.fill_nans_on_denormalize:
+            # normalizer.py:212-242: the fused pack/unpack kernels do not replace NaNs
+            raise NotImplementedError("RolloutEngine: fill_nans_on_normalize / fill_nans_on_denormalize are not implemented "
+                                      "in the fused pack/unpack kernels; use Stepper.predict")
         self.in_mean = torch.stack([norm.means[n].to(dev) for n in self.in_names]).contiguous()
         self.in_std = torch.stack([norm.stds[n].to(dev) for n in self.in_names]).contiguous()
         self.out_mean = torch.stack([norm.means[n].to(dev) for n in self.out_names]).contiguous()
@@ -155,6 +159,16 @@ class RolloutEngine:
 
     def run_window(self):
         """Enqueue the T steps of the window on the current stream (no host synchronisation)."""
+        # parameters changed since the last window (load_state_dict / stepper.load_state): upload them; the library drops
+        # its captured per-step graphs itself, the window graph captured here is dropped too
+        if self.net.sync_weights():
+            self._window_graph = None
+        step = self.stepper._step_obj   # Stepper.replace_ocean / overrides after construction take effect here
+        if step._ocean is not self._ocean or step._corrector is not self._corrector:
+            if self.graph_mode == "window" and (step._ocean is not None or step._corrector is not None):
+                raise NotImplementedError("post-step hooks with graph='window'")
+            self._ocean, self._corrector = step._ocean, step._corrector
+            self._window_graph = None
         if self.graph_mode == "window":
             if self._window_graph is None:
                 # warm up outside capture (first-touch allocations inside torch), then capture once

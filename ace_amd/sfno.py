@@ -314,6 +314,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         """Upload parameters that changed since the last upload (load_state_dict, optimiser step, .to())."""
         L = _lib.lib()
         stream = _lib.current_stream()
+        changed = 0
         for name, p in self.state_dict(keep_vars=True).items():
             stamp = (p.data_ptr(), p._version)
             if not force and self._uploaded.get(name) == stamp:
@@ -323,6 +324,8 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
                 t = t.float().contiguous()
             _lib.check(L.ace_sfno_set_weight(self._native, name.encode(), _lib.ptr(t), t.numel(), stream))
             self._uploaded[name] = stamp
+            changed += 1
+        return changed
 
     def _prepare(self, x: torch.Tensor):
         if x.dim() != 4 or x.shape[1] != self.in_chans or tuple(x.shape[-2:]) != self.img_shape:
@@ -346,11 +349,13 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
                                                _lib.current_stream()))
         return out
 
-    def forward_graph(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-        """hipGraph replay of forward on STATIC buffers (same x/out storage every call)."""
+    def forward_graph(self, x: torch.Tensor, out: torch.Tensor, sync: bool = True) -> torch.Tensor:
+        """hipGraph replay of forward on STATIC buffers (same x/out storage every call).  ``sync``: upload parameters that
+        changed since the last call first (version stamps; a changed weight drops the library's captured graphs) - a
+        rollout loop passes False after syncing once per window."""
         assert x.is_contiguous() and out.is_contiguous() and x.dtype == out.dtype == torch.float32
         self._ensure_native(x.device, x.shape[0])
-        if not self._uploaded:
+        if sync or not self._uploaded:
             self.sync_weights()
         _lib.check(_lib.lib().ace_sfno_forward_graph(self._native, _lib.ptr(x), _lib.ptr(out), x.shape[0],
                                                      _lib.current_stream()))
