@@ -32,6 +32,7 @@ SIGNATURES = {
     "ace_last_error": (c_char_p, []),
     "ace_version": (c_int, []),
     "ace_sht_plan_create": (c_int, [c_int, c_int, c_int, c_int, c_char_p, POINTER(c_void_p)]),
+    "ace_sht_plan_create_ex": (c_int, [c_int, c_int, c_int, c_int, c_char_p, c_int, POINTER(c_void_p)]),
     "ace_sht_plan_destroy": (None, [c_void_p]),
     "ace_sht_plan_dims": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "ace_sht_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

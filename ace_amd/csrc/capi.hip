@@ -14,6 +14,7 @@
 
 #include "../../include/ace_sfno.h"
 #include "kernels.h"
+#include "strip_pack.h"
 #include "tables.h"
 
 using namespace ace;
@@ -89,6 +90,10 @@ struct ace_sht_plan {
     float wt_scale = 1.f, pt_scale = 1.f;
     float wt_winf = 0.f;   // max over (m, l) of sum_k |wt[m][l][k]|: |Legendre-forward output| <= wt_winf * max|X|
     bool f16 = false;
+    // strip kernels (strip.hip): wt / pt as pre-packed MFMA A fragments + per-m block offsets (nlat, lmax <= 192)
+    DevBuf wt_frag, pt_frag, wt_off, pt_off;
+    bool strip = false;
+    DevBuf slots;   // standalone transforms in f16x3 mode: dynamic-range slots (max|X|, max|coefficients|)
 };
 
 static float pow2_scale_for(const std::vector<float>& v) {  // puts max|v| in [2^9, 2^10)
@@ -128,6 +133,23 @@ static int plan_build(int nlat, int nlon, int lmax, int mmax, Grid g, std::uniqu
         HIP_TRY(launch_split_f16(p->wt.p, t.Hp, p->wt_hi.p, p->wt_lo.p, t.Hp, (long)t.mmax * t.lmax, t.Hp, p->wt_scale, nullptr));
         HIP_TRY(launch_split_f16(p->pt.p, t.Lp, p->pt_hi.p, p->pt_lo.p, t.Lp, (long)t.mmax * t.nlat, t.Lp, p->pt_scale, nullptr));
         HIP_TRY(hipDeviceSynchronize());
+        if (t.nlat <= 192 && t.lmax <= 192) {
+            auto up = [](const StripPack& sp, DevBuf& frag, DevBuf& off) -> hipError_t {
+                hipError_t e = frag.alloc((sp.frags.size() + 1) / 2, false);   // halves -> floats
+                if (e != hipSuccess) return e;
+                e = hipMemcpy(frag.p, sp.frags.data(), sp.frags.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+                if (e != hipSuccess) return e;
+                e = off.alloc(sp.tile_off.size(), false);
+                if (e != hipSuccess) return e;
+                return hipMemcpy(off.p, sp.tile_off.data(), sp.tile_off.size() * sizeof(int), hipMemcpyHostToDevice);
+            };
+            StripPack sp;
+            pack_legendre_strip(t.wt.data(), t.mmax, t.lmax, t.nlat, t.Hp, 0, p->wt_scale, sp);
+            HIP_TRY(up(sp, p->wt_frag, p->wt_off));
+            pack_legendre_strip(t.pt.data(), t.mmax, t.nlat, t.lmax, t.Lp, 1, p->pt_scale, sp);
+            HIP_TRY(up(sp, p->pt_frag, p->pt_off));
+            p->strip = true;
+        }
     }
     out = std::move(p);
     return ACE_OK;
@@ -162,6 +184,25 @@ static int run_legendre_forward(const ace_sht_plan& pl, const float* X, float* D
     g.C = D; g.ldc = (long)pl.mmax * N2; g.sC = N2;
     g.M = pl.lmax; g.N = (int)N2; g.K = pl.nlat; g.nbatch = pl.mmax; g.a_kpad = pl.Hp;
     g.tri = TRI_ROWS_GE_BATCH;
+    if (pl.strip && xmax) {   // register-resident strip kernel (strip.hip)
+        LegStripArgs a;
+        a.B = X; a.b_kstride = N2; a.b_moff = (long)pl.nlat * N2;
+        a.A = reinterpret_cast<const _Float16*>(pl.wt_frag.p); a.tile_off = reinterpret_cast<const int*>(pl.wt_off.p);
+        a.ascale = pl.wt_scale; a.bmax = xmax;
+        a.c_rstride = (long)pl.mmax * N2; a.c_moff = N2;
+        a.N = (int)N2; a.K = pl.nlat; a.R = pl.lmax; a.nbatch = pl.mmax; a.mode = 0;
+        if (planes) {
+            a.Chi = reinterpret_cast<_Float16*>(D);
+            a.Clo = a.Chi + (size_t)pl.lmax * pl.mmax * N2;
+            a.cw = pl.wt_winf; a.cslot = dmax;
+        } else {
+            a.C = D; a.omax = dmax;
+        }
+        if (legendre_strip_eligible(a)) {
+            HIP_TRY(launch_legendre_strip(a, s));
+            return ACE_OK;
+        }
+    }
     if (planes) {
         // D as fp16 hi/lo planes in D's own layout [l][m][n2] (the buffer holds two planes instead of one fp32 tensor):
         // the dhconv contracts over n2's channel index, so this IS the v4 engine's A operand.  dmax receives the bound.
@@ -187,6 +228,18 @@ static int run_legendre_inverse(const ace_sht_plan& pl, const float* E, float* X
     g.C = X; g.ldc = N2; g.sC = (long)pl.nlat * N2;
     g.M = pl.nlat; g.N = (int)N2; g.K = pl.lmax; g.nbatch = pl.mmax; g.a_kpad = pl.Lp;
     g.tri = TRI_K_GE_BATCH;
+    if (pl.strip && emax) {   // register-resident strip kernel (strip.hip)
+        LegStripArgs a;
+        a.B = E; a.b_kstride = (long)pl.mmax * N2; a.b_moff = N2;
+        a.A = reinterpret_cast<const _Float16*>(pl.pt_frag.p); a.tile_off = reinterpret_cast<const int*>(pl.pt_off.p);
+        a.ascale = pl.pt_scale; a.bmax = emax;
+        a.C = X; a.c_rstride = N2; a.c_moff = (long)pl.nlat * N2;
+        a.N = (int)N2; a.K = pl.lmax; a.R = pl.nlat; a.nbatch = pl.mmax; a.mode = 1;
+        if (legendre_strip_eligible(a)) {
+            HIP_TRY(launch_legendre_strip(a, s));
+            return ACE_OK;
+        }
+    }
     if (pl.f16 && emax && gemm_f16x3_eligible(g)) {
         HIP_TRY(launch_gemm_f16x3(g, pl.pt_hi.p, pl.pt_lo.p, pl.pt_scale, 1.f, s, emax, nullptr));
         return ACE_OK;
@@ -195,15 +248,21 @@ static int run_legendre_inverse(const ace_sht_plan& pl, const float* E, float* X
     return ACE_OK;
 }
 
-extern "C" int ace_sht_plan_create(int nlat, int nlon, int lmax, int mmax, const char* grid, ace_sht_plan** plan) {
+extern "C" int ace_sht_plan_create_ex(int nlat, int nlon, int lmax, int mmax, const char* grid, int precision,
+                                      ace_sht_plan** plan) {
     if (!plan || !grid) return fail(ACE_ERR_INVALID, "null argument");
+    if (precision != 0 && precision != 1) return fail(ACE_ERR_INVALID, "precision must be 0 (fp32) or 1 (f16x3)");
     Grid g;
     if (std::string(grid) == "healpix") return fail(ACE_ERR_INVALID, "'healpix' grid not supported");
     if (!parse_grid(grid, &g)) return fail(ACE_ERR_INVALID, "Unknown quadrature mode");
     std::unique_ptr<ace_sht_plan> p;
-    ACE_TRY(plan_build(nlat, nlon, lmax, mmax, g, p));
+    ACE_TRY(plan_build(nlat, nlon, lmax, mmax, g, p, precision == 1));
+    if (precision == 1) HIP_TRY(p->slots.alloc((size_t)2 * AMAX_SHARDS));
     *plan = p.release();
     return ACE_OK;
+}
+extern "C" int ace_sht_plan_create(int nlat, int nlon, int lmax, int mmax, const char* grid, ace_sht_plan** plan) {
+    return ace_sht_plan_create_ex(nlat, nlon, lmax, mmax, grid, 0, plan);
 }
 extern "C" void ace_sht_plan_destroy(ace_sht_plan* plan) { delete plan; }
 extern "C" int ace_sht_plan_dims(const ace_sht_plan* p, int* nlat, int* nlon, int* lmax, int* mmax) {
@@ -223,8 +282,13 @@ extern "C" int ace_sht_forward(ace_sht_plan* p, const float* x, float* coeffs, i
     HIP_TRY(p->D.ensure((size_t)p->lmax * p->mmax * N2));
     // coefficients with l < m are never written by the triangular Legendre stage: they are zero
     HIP_TRY(hipMemsetAsync(p->D.p, 0, (size_t)p->lmax * p->mmax * N2 * sizeof(float), s));
-    ACE_TRY(run_dft_forward(*p, x, nullptr, nullptr, p->X.p, 1, n, s));
-    ACE_TRY(run_legendre_forward(*p, p->X.p, p->D.p, N2, s));
+    unsigned* xmax = nullptr;
+    if (p->f16 && p->slots.p) {
+        xmax = reinterpret_cast<unsigned*>(p->slots.p);
+        HIP_TRY(launch_zero_u32(xmax, 2 * AMAX_SHARDS, s));
+    }
+    ACE_TRY(run_dft_forward(*p, x, nullptr, nullptr, p->X.p, 1, n, s, xmax));
+    ACE_TRY(run_legendre_forward(*p, p->X.p, p->D.p, N2, s, xmax, xmax ? xmax + AMAX_SHARDS : nullptr));
     HIP_TRY(launch_spec_to_ref(p->D.p, coeffs, 1, n, p->lmax, p->mmax, s));
     return ACE_OK;
 }
@@ -235,7 +299,13 @@ extern "C" int ace_sht_inverse(ace_sht_plan* p, const float* coeffs, float* x, i
     HIP_TRY(p->X.ensure((size_t)p->mmax * p->nlat * N2));
     HIP_TRY(p->D.ensure((size_t)p->lmax * p->mmax * N2));
     HIP_TRY(launch_ref_to_spec(coeffs, p->D.p, 1, n, p->lmax, p->mmax, s));
-    ACE_TRY(run_legendre_inverse(*p, p->D.p, p->X.p, N2, s));
+    unsigned* emax = nullptr;
+    if (p->f16 && p->slots.p) {   // f16x3: range of the coefficients (entries with l < m are zero after the conversion)
+        emax = reinterpret_cast<unsigned*>(p->slots.p);
+        HIP_TRY(launch_zero_u32(emax, 2 * AMAX_SHARDS, s));
+        HIP_TRY(launch_absmax(p->D.p, (long)p->lmax * p->mmax * N2, emax, s));
+    }
+    ACE_TRY(run_legendre_inverse(*p, p->D.p, p->X.p, N2, s, emax));
     ACE_TRY(run_dft_inverse(*p, p->X.p, nullptr, x, 1, n, s));
     return ACE_OK;
 }

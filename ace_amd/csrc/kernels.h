@@ -117,6 +117,29 @@ hipError_t launch_pack_pformat(const float* src, long ldb, long sSrc, int K, int
                                const float* sh, long sbs, const unsigned* slot, void* hi, void* lo, long ldn, long sPl,
                                hipStream_t s);
 
+// "Strip" Legendre kernels (strip.hip): the data operand (a 32-column strip of X_m / E_m over the whole contraction) is
+// resident in registers, the table arrives as pre-packed MFMA A fragments (strip_pack.h).  Batched over m.
+struct LegStripArgs {
+    const float* B = nullptr;        // fp32 data operand: element (m, k, n) at m * b_moff + k * b_kstride + n
+    long b_kstride = 0, b_moff = 0;
+    const _Float16* A = nullptr;     // packed table fragments, scaled by the power of two `ascale`
+    const int* tile_off = nullptr;   // per m: first k-step block (device array)
+    float ascale = 1.f;
+    const unsigned* bmax = nullptr;  // dynamic-range slot holding max|B| (required)
+    // output: fp32 C, or fp16 hi/lo planes (element (m, row, n) at m * c_moff + row * c_rstride + n in either form)
+    float* C = nullptr; _Float16* Chi = nullptr; _Float16* Clo = nullptr;
+    long c_rstride = 0, c_moff = 0;
+    float cw = 0.f; unsigned* cslot = nullptr;   // planes: |C| <= cw * bound(B), published to cslot
+    unsigned* omax = nullptr;                    // fp32: atomicMax of bits(max|C|)
+    int N = 0;        // columns
+    int K = 0;        // contraction extent (forward: nlat, inverse: lmax)
+    int R = 0;        // row extent (forward: lmax, inverse: nlat)
+    int nbatch = 0;   // mmax
+    int mode = 0;     // 0 forward (rows l >= m), 1 inverse (contraction over l >= m)
+};
+bool legendre_strip_eligible(const LegStripArgs& a);
+hipError_t launch_legendre_strip(const LegStripArgs& a, hipStream_t s);
+
 // Spectral-space layout used between the kernels ("channel-fastest planar"):
 //   X[m][k][b][ri][c]  (after the longitude DFT)     index ((m*H + k)*Bt + b)*2C + ri*C + c
 //   D[l][m][b][ri][c]  (after the Legendre stage)    index ((l*Mm + m)*Bt + b)*2C + ri*C + c

@@ -1,0 +1,134 @@
+// Operand packing of the "strip" Legendre kernels (strip.hip): host-side, header-only, no HIP dependency so that the
+// index algebra can be exercised on the CPU (tests/emul/strip_emul.cpp).
+//
+// The strip kernels keep the DATA operand (a 32-column strip of X_m or E_m, all of K) in registers as MFMA B fragments
+// and stream the TABLE operand (wt_m / pt_m) through LDS as ready-made MFMA A fragments:
+//
+//   fragment (m, tile t, k-step jj) = 64 lanes x 8 halves, lane = i + 32 g:
+//       forward  (sht_fix.py:134-138)  row l = row0(m) + 32 t + i,  column k = 16 jj + 8 g + e        value wt[m][l][k]
+//       inverse  (sht_fix.py:208-219)  row k = 32 t + i,            column l = 16 (j0(m) + jj) + 8 g + e   value pt[m][k][l]
+//   i.e. exactly what lane (i, g) feeds to v_mfma_f32_32x32x16_f16 as its A operand.  A k-step block is the hi fragment
+//   (1 KiB) followed by the lo fragment (1 KiB); a tile is nks4(m) consecutive k-step blocks, so one tile is one
+//   contiguous run that a wave moves to LDS with 1-KiB global_load_lds pieces and reads back with conflict-free
+//   ds_read_b128 at lane * 16 B.  Rows outside the triangle (l < m), beyond the table, and padded k-steps are zero.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace ace {
+
+struct StripGeom {   // per-m geometry shared by the packer, the kernel and the emulator
+    int row0;    // first output row of tile 0
+    int ntiles;  // 32-row output tiles
+    int j0;      // first resident k16-step
+    int nks;     // k16-steps that carry data
+    int nks4;    // nks rounded up to 4 (the kernel works in groups of four k-steps)
+    int klo;     // first valid contraction index
+};
+
+// mode 0: forward (rows l in [m, R), contraction over k in [0, K));  mode 1: inverse (rows k in [0, R), contraction
+// over l in [m, K))
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline StripGeom strip_geom(int mode, int m, int R, int K) {
+    StripGeom g;
+    if (mode == 0) {
+        g.row0 = (m / 32) * 32;
+        g.ntiles = (R - g.row0 + 31) / 32;
+        g.j0 = 0;
+        g.nks = (K + 15) / 16;
+        g.klo = 0;
+    } else {
+        g.row0 = 0;
+        g.ntiles = (R + 31) / 32;
+        g.j0 = m / 16;
+        g.nks = (K + 15) / 16 - g.j0;
+        g.klo = m;
+    }
+    if (g.ntiles < 0) g.ntiles = 0;
+    if (g.nks < 0) g.nks = 0;
+    g.nks4 = (g.nks + 3) & ~3;
+    return g;
+}
+
+// fp32 -> fp16 bits, round to nearest even (normal / subnormal / overflow to inf); host only
+inline uint16_t f32_to_f16_bits(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t em = x & 0x7fffffffu;
+    if (em >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((em > 0x7f800000u) ? 0x200u : 0u));
+    if (em >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);   // >= 65520 rounds to inf
+    if (em < 0x33000001u) return (uint16_t)sign;                 // < 2^-25 (or exactly 2^-25: ties to even = 0)
+    int e = (int)(em >> 23) - 127;
+    uint32_t man = (em & 0x7fffffu) | 0x800000u;                 // 24-bit significand
+    int shift;                                                   // bits dropped from the 24-bit significand
+    uint32_t base;
+    if (e >= -14) { shift = 13; base = (uint32_t)(e + 15) << 10; man &= 0x7fffffu; }
+    else { shift = 13 + (-14 - e); base = 0; }
+    uint32_t q = man >> shift;
+    const uint32_t rem = man & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) ++q;            // carries propagate into the exponent correctly
+    return (uint16_t)(sign | (base + q));
+}
+inline float f16_bits_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t e = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    float v;
+    if (e == 0) v = std::ldexp((float)man, -24);
+    else if (e == 31) v = man ? NAN : INFINITY;
+    else v = std::ldexp((float)(man | 0x400u), (int)e - 25);
+    uint32_t b;
+    std::memcpy(&b, &v, 4);
+    b |= sign;
+    std::memcpy(&v, &b, 4);
+    return v;
+}
+
+struct StripPack {
+    std::vector<uint16_t> frags;   // fp16 bits: [k-step block][hi 512 | lo 512]
+    std::vector<int> tile_off;     // per m: index of the first k-step block of tile 0
+    long blocks = 0;
+};
+
+// tab: forward wt[m][l][pitch] (rows = l, cols = k); inverse pt[m][k][pitch] (rows = k, cols = l).
+// nrows / ncols: logical extents (forward: L, H; inverse: H, L).  Values are multiplied by `scale` (a power of two).
+inline void pack_legendre_strip(const float* tab, int mmax, int nrows, int ncols, int pitch, int mode, float scale,
+                                StripPack& out) {
+    out.tile_off.assign((size_t)mmax, 0);
+    long blocks = 0;
+    for (int m = 0; m < mmax; ++m) {
+        const StripGeom g = strip_geom(mode, m, nrows, ncols);
+        out.tile_off[m] = (int)blocks;
+        blocks += (long)g.ntiles * g.nks4;
+    }
+    out.blocks = blocks;
+    out.frags.assign((size_t)blocks * 1024, 0);
+    for (int m = 0; m < mmax; ++m) {
+        const StripGeom g = strip_geom(mode, m, nrows, ncols);
+        for (int t = 0; t < g.ntiles; ++t)
+            for (int jj = 0; jj < g.nks; ++jj) {
+                uint16_t* blk = out.frags.data() + ((size_t)out.tile_off[m] + (size_t)t * g.nks4 + jj) * 1024;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, gg = lane >> 5;
+                    const int row = g.row0 + 32 * t + i;
+                    for (int e = 0; e < 8; ++e) {
+                        const int col = 16 * (g.j0 + jj) + 8 * gg + e;
+                        float v = 0.f;
+                        // the contraction index is l for the inverse (valid from m), the row index is l for the forward
+                        const bool ok = row < nrows && col < ncols && (mode == 0 ? row >= m : col >= m);
+                        if (ok) v = tab[((size_t)m * nrows + row) * pitch + col] * scale;
+                        const uint16_t hi = f32_to_f16_bits(v);
+                        const uint16_t lo = f32_to_f16_bits(v - f16_bits_to_f32(hi));
+                        blk[lane * 8 + e] = hi;
+                        blk[512 + lane * 8 + e] = lo;
+                    }
+                }
+            }
+    }
+}
+
+}  // namespace ace

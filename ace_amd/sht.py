@@ -3,6 +3,7 @@
 and triangular Legendre quadrature on the fp32 MFMA tile engine."""
 
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -13,9 +14,15 @@ from . import _lib
 class _Plan:
     """Owns an ace_sht_plan (tables live on the current device)."""
 
-    def __init__(self, nlat, nlon, lmax, mmax, grid):
+    def __init__(self, nlat, nlon, lmax, mmax, grid, precision=None):
         handle = ctypes.c_void_p()
-        _lib.check(_lib.lib().ace_sht_plan_create(nlat, nlon, lmax or 0, mmax or 0, grid.encode(), ctypes.byref(handle)))
+        # arithmetic of the Legendre stage: "fp32" (exact, the reference's) or "f16x3" (the network's default mode);
+        # not part of the reference API, selected by ACE_SHT_PRECISION or the module attribute `precision`
+        precision = precision or os.environ.get("ACE_SHT_PRECISION", "fp32")
+        if precision not in ("fp32", "f16x3"):
+            raise ValueError("precision must be 'fp32' or 'f16x3'")
+        _lib.check(_lib.lib().ace_sht_plan_create_ex(nlat, nlon, lmax or 0, mmax or 0, grid.encode(),
+                                                     1 if precision == "f16x3" else 0, ctypes.byref(handle)))
         self.handle = handle
         d = [ctypes.c_int() for _ in range(4)]
         _lib.check(_lib.lib().ace_sht_plan_dims(handle, *[ctypes.byref(v) for v in d]))
@@ -43,8 +50,9 @@ def _default_dims(nlat, nlon, lmax, mmax, grid):
 class RealSHT(nn.Module):
     """Forward real SHT over the last two dimensions: (..., nlat, nlon) -> (..., lmax, mmax) complex64."""
 
-    def __init__(self, nlat, nlon, lmax=None, mmax=None, grid="lobatto", norm="ortho", csphase=True):
+    def __init__(self, nlat, nlon, lmax=None, mmax=None, grid="lobatto", norm="ortho", csphase=True, precision=None):
         super().__init__()
+        self.precision = precision   # None: ACE_SHT_PRECISION or "fp32"; "f16x3": the network's default arithmetic
         if norm != "ortho" or not csphase:
             raise NotImplementedError("only norm='ortho', csphase=True (the reference's usage) is implemented")
         self.nlat, self.nlon, self.grid, self.norm, self.csphase = nlat, nlon, grid, norm, csphase
@@ -53,7 +61,7 @@ class RealSHT(nn.Module):
 
     def _get_plan(self):
         if self._plan is None:
-            self._plan = _Plan(self.nlat, self.nlon, self.lmax, self.mmax, self.grid)
+            self._plan = _Plan(self.nlat, self.nlon, self.lmax, self.mmax, self.grid, getattr(self, "precision", None))
         return self._plan
 
     def extra_repr(self):
@@ -77,8 +85,9 @@ class RealSHT(nn.Module):
 class InverseRealSHT(nn.Module):
     """Inverse real SHT: (..., lmax, mmax) complex64 -> (..., nlat, nlon)."""
 
-    def __init__(self, nlat, nlon, lmax=None, mmax=None, grid="lobatto", norm="ortho", csphase=True):
+    def __init__(self, nlat, nlon, lmax=None, mmax=None, grid="lobatto", norm="ortho", csphase=True, precision=None):
         super().__init__()
+        self.precision = precision   # None: ACE_SHT_PRECISION or "fp32"; "f16x3": the network's default arithmetic
         if norm != "ortho" or not csphase:
             raise NotImplementedError("only norm='ortho', csphase=True (the reference's usage) is implemented")
         self.nlat, self.nlon, self.grid, self.norm, self.csphase = nlat, nlon, grid, norm, csphase
@@ -87,7 +96,7 @@ class InverseRealSHT(nn.Module):
 
     def _get_plan(self):
         if self._plan is None:
-            self._plan = _Plan(self.nlat, self.nlon, self.lmax, self.mmax, self.grid)
+            self._plan = _Plan(self.nlat, self.nlon, self.lmax, self.mmax, self.grid, getattr(self, "precision", None))
         return self._plan
 
     def extra_repr(self):

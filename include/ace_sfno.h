@@ -43,6 +43,10 @@ int ace_version(void);
 typedef struct ace_sht_plan ace_sht_plan;
 
 int ace_sht_plan_create(int nlat, int nlon, int lmax, int mmax, const char* grid, ace_sht_plan** plan);
+/* Same, with the arithmetic of the Legendre stage chosen: precision 0 = exact fp32 MFMA (ace_sht_plan_create),
+ * 1 = "f16x3" (error-compensated fp16 MFMA with dynamic range tracking, fp32-class accuracy; the mode the network
+ * runs in by default - DESIGN.md 3.1).  Not part of the reference API (fme/sht_fix.py has one arithmetic). */
+int ace_sht_plan_create_ex(int nlat, int nlon, int lmax, int mmax, const char* grid, int precision, ace_sht_plan** plan);
 void ace_sht_plan_destroy(ace_sht_plan* plan);
 int ace_sht_plan_dims(const ace_sht_plan* plan, int* nlat, int* nlon, int* lmax, int* mmax);
 

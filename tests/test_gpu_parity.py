@@ -124,15 +124,16 @@ def test_sht_golden_regression(dev):
     (12, 24, 8, 9, "legendre-gauss", 4), (45, 90, None, None, "legendre-gauss", 16), (13, 27, None, None, "equiangular", 2),
     (64, 128, 40, 50, "legendre-gauss", 7),
 ])
-def test_sht_vs_oracle(dev, nlat, nlon, lmax, mmax, grid, n):
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_sht_vs_oracle(dev, nlat, nlon, lmax, mmax, grid, n, precision):
     import ace_amd
     import oracle
     x = torch.randn(n, nlat, nlon, generator=torch.Generator().manual_seed(nlat))
     o_f = oracle.RealSHT(nlat, nlon, lmax, mmax, grid, dtype=torch.float64)
     o_i = oracle.InverseRealSHT(nlat, nlon, lmax, mmax, grid, dtype=torch.float64)
     c_ref = o_f(x)
-    sht = ace_amd.RealSHT(nlat, nlon, lmax, mmax, grid)
-    isht = ace_amd.InverseRealSHT(nlat, nlon, lmax, mmax, grid)
+    sht = ace_amd.RealSHT(nlat, nlon, lmax, mmax, grid, precision=precision)
+    isht = ace_amd.InverseRealSHT(nlat, nlon, lmax, mmax, grid, precision=precision)
     c = sht(x.to(dev))
     assert rel_max(c, c_ref) <= OP_TOL
     # arbitrary (non band-limited, l<m populated) coefficients through the inverse
@@ -157,13 +158,14 @@ def test_sht_leading_dims_and_empty(dev):
         ace_amd.RealSHT(12, 24, grid="healpix")
 
 
-def test_sht_180x360_vs_reference(dev):
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_sht_180x360_vs_reference(dev, precision):
     """coefficients and round trip emitted by the reference itself (tests/golden/make_golden.py)."""
     import ace_amd
     d = load_golden("gen_sht_180x360.pt")
     x = torch.randn(3, 180, 360, generator=torch.Generator().manual_seed(d["seed"]))
-    sht = ace_amd.RealSHT(180, 360, lmax=180, mmax=181, grid="legendre-gauss")
-    isht = ace_amd.InverseRealSHT(180, 360, lmax=180, mmax=181, grid="legendre-gauss")
+    sht = ace_amd.RealSHT(180, 360, lmax=180, mmax=181, grid="legendre-gauss", precision=precision)
+    isht = ace_amd.InverseRealSHT(180, 360, lmax=180, mmax=181, grid="legendre-gauss", precision=precision)
     c = sht(x.to(dev))
     assert rel_max(c, d["coeffs"]) <= SHT_TOL
     assert rel_max(isht(c), d["roundtrip"]) <= SHT_TOL
@@ -180,12 +182,13 @@ def test_constant_field(dev, grid, constant):
     assert torch.all(coeffs[1:].abs() < 1e-6)
 
 
-def test_full_size_properties(dev):
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_full_size_properties(dev, precision):
     """ACE2 shape (384 fields of 180x360): round-trip idempotence (fme/test_harmonics.py:35-42), linearity and
     the triangular zero pattern, where the CPU oracle would take minutes."""
     import ace_amd
-    sht = ace_amd.RealSHT(180, 360, lmax=180, mmax=181, grid="legendre-gauss")
-    isht = ace_amd.InverseRealSHT(180, 360, lmax=180, mmax=181, grid="legendre-gauss")
+    sht = ace_amd.RealSHT(180, 360, lmax=180, mmax=181, grid="legendre-gauss", precision=precision)
+    isht = ace_amd.InverseRealSHT(180, 360, lmax=180, mmax=181, grid="legendre-gauss", precision=precision)
     g = torch.Generator(device="cuda").manual_seed(5)
     x = torch.randn(384, 180, 360, device=dev, generator=g)
     y = torch.randn(384, 180, 360, device=dev, generator=g)

@@ -1,0 +1,19 @@
+"""Index algebra of the strip Legendre kernel (ace_amd/csrc/strip.hip) on the CPU: tests/emul/strip_emul.cpp restates the
+kernel's lane / fragment / tile / store mapping on top of the real operand packer (ace_amd/csrc/strip_pack.h) and
+compares with direct sums, forward and inverse, ragged and full shapes (incl. 180 x 180 x 181)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_strip_kernel_index_algebra(tmp_path):
+    exe = str(tmp_path / "strip_emul")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "emul", "strip_emul.cpp")], check=True)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "worst" in res.stdout
