@@ -50,7 +50,9 @@ inline StripGeom strip_geom(int mode, int m, int R, int K) {
     }
     if (g.ntiles < 0) g.ntiles = 0;
     if (g.nks < 0) g.nks = 0;
-    g.nks4 = (g.nks + 3) & ~3;
+    // at least one (all-zero) group: a wavenumber with nothing to contract (inverse, m >= 16 ceil(L / 16)) still has to
+    // write its zeros
+    g.nks4 = g.nks > 0 ? (g.nks + 3) & ~3 : 4;
     return g;
 }
 

@@ -122,7 +122,7 @@ int main() {
     struct Case { int mode, H, L, M, N; } cases[] = {
         {0, 20, 18, 12, 40},  {1, 20, 18, 12, 40},  {0, 45, 45, 46, 32},   {1, 45, 45, 46, 32},  {0, 64, 40, 50, 128},
         {1, 64, 40, 50, 128}, {0, 9, 8, 10, 6},     {1, 9, 8, 10, 6},      {0, 180, 180, 181, 128}, {1, 180, 180, 181, 128},
-        {0, 100, 90, 51, 256}, {1, 100, 90, 51, 256},
+        {0, 100, 90, 51, 256}, {1, 100, 90, 51, 256}, {0, 16, 16, 17, 48}, {1, 16, 16, 17, 48}, {0, 64, 48, 60, 32}, {1, 64, 48, 60, 32},
     };
     double worst = 0.0;
     for (auto& c : cases) {
