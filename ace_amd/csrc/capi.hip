@@ -521,6 +521,7 @@ struct Weight {
     DevBuf hi, lo;      // f16x3 mode: fp16 planes of the conv weight scaled by `ascale` (pitch halves)
     float ascale = 1.f;
     DevBuf thi, tlo;    // the same planes in the v4 engine's A-tile order (rows padded to 16)
+    DevBuf frag;        // mlp.fwd.2: packed MFMA A fragments streamed by 32-column chunk (fused MLP, mlp_strip.hip)
     float wabs = 0.f;   // conv weights: max |w|
     float winf = 0.f;   // conv weights: max row sum of |w| (bounds |W x| by winf * max|x|)
     float absmax = 0.f; // small parameters (biases): max |value|
@@ -551,6 +552,7 @@ struct ace_sfno {
     DevBuf P2;           // second one: the block input h as written by the previous block's fc2 epilogue
     DevBuf part;         // per-strip row statistics from the GEMM epilogues (fused instance norm), two tensors
     DevBuf Wp0, Wp1;     // folded (norm affine) skip / fc1 weights as tiled fp16 planes, per sample
+    DevBuf Wq1;          // folded fc1 weights as packed MFMA A fragments, per sample (fused MLP)
     int nstrips = 0;
     DevBuf Wf0, bf0, Wf1, bf1;
     DevBuf amax;  // [8] uint words: bit patterns of max|X|, max|D|, max|E| of the current block (f16x3 dynamic range)  // instance-norm affine folded into inner_skip / mlp.fc1 weights, per sample
@@ -697,7 +699,9 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
         HIP_TRY(n->P.alloc(act, true));
         if (c.normalization_layer == 1 && c.use_mlp) {
             HIP_TRY(n->P2.alloc(act, true));
-            n->nstrips = (int)((HW + 63) / 64) + 4;     // >= tilesN * WN of either tile shape
+            n->nstrips = (int)((HW + 31) / 32) + 8;     // >= tilesN * WN of either tile shape and the fused MLP's 32-pixel strips
+            if (mlp_strip_eligible((int)C, n->hid, ACT_GELU))
+                HIP_TRY(n->Wq1.alloc((size_t)n->Bmax * n->hid * C, true));   // hi + lo halves = one float per element
             HIP_TRY(n->part.alloc((size_t)2 * n->Bmax * n->nstrips * C * 4, true));
             const size_t cp = (size_t)((C + 31) & ~31);
             HIP_TRY(n->Wp0.alloc((size_t)n->Bmax * ((C + 15) / 16 * 16) * cp, true));       // 2 planes of halves = 1 float per element
@@ -823,6 +827,13 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
         if (!w.thi.p) HIP_TRY(w.thi.alloc((thalves + 1) / 2, false));
         if (!w.tlo.p) HIP_TRY(w.tlo.alloc((thalves + 1) / 2, false));
         HIP_TRY(launch_split_f16_tiled(w.buf.p, w.pitch, w.thi.p, w.tlo.p, w.pitch, w.rows, w.cols, w.ascale, s));
+        const std::string& wn = w.name;
+        if (wn.size() > 16 && wn.compare(wn.size() - 16, 16, "mlp.fwd.2.weight") == 0 &&
+            mlp_strip_eligible(w.rows, w.cols, ACT_GELU)) {
+            if (!w.frag.p) HIP_TRY(w.frag.alloc((size_t)w.rows * w.cols, false));
+            HIP_TRY(launch_pack_conv_frag(w.buf.p, w.pitch, w.rows, w.cols, 1, nullptr, 0.f, w.ascale, nullptr, w.frag.p,
+                                          0, 1, s));
+        }
         HIP_TRY(hipStreamSynchronize(s));
     }
     if (w.pitch == 0 && !w.is_filter && numel <= (1 << 16)) {  // biases: bound used by the P-format producers
@@ -1055,6 +1066,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
 
     // fused-norm state of the packed-operand path: does P2 hold the block input in P format / `part_h` its statistics?
     bool have_ph = false, have_hstats = false;
+    int h_nparts = 0;   // statistics partials per row in part_h (depends on which kernel produced them)
     float* part_h = n->part.p;
     float* part_t = n->part.p ? n->part.p + (size_t)n->Bmax * n->nstrips * C * 4 : nullptr;
     _Float16* PAh = reinterpret_cast<_Float16*>(n->P.p);                  // T planes / pack fallback
@@ -1081,7 +1093,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         }
         if (norm) {
             if (have_hstats)   // statistics of h came out of the previous block's fc2 epilogue
-                HIP_TRY(launch_instnorm_finalize(reinterpret_cast<const float4*>(part_h), gemm4_strips(C, (int)HW), B, C, HW,
+                HIP_TRY(launch_instnorm_finalize(reinterpret_cast<const float4*>(part_h), h_nparts, B, C, HW,
                                                  W(p + "norm0.weight"), W(p + "norm0.bias"), 1e-6f, sc0, sh0, slot(sb + 3), s));
             else
                 HIP_TRY(launch_instnorm_stats(h, W(p + "norm0.weight"), W(p + "norm0.bias"), 1e-6f, B, C, HW, sc0, sh0, s,
@@ -1200,6 +1212,33 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                                              W(p + "norm1.weight"), W(p + "norm1.bias"), 1e-6f, sc1, sh1, slot(sb + 5), s));
             HIP_TRY(launch_fold_affine_f16(w1.buf.p, w1.pitch, w1.wabs, sc1, sh1, b1w.buf.p, F1h, F1l, n->bf1.p, B, n->hid, C,
                                            cp, f1s, slot(sb + 9), s));
+            const bool strip_mlp = c.activation_function == ACT_GELU && mlp_strip_eligible(C, n->hid, ACT_GELU) &&
+                                   n->Wq1.p != nullptr && w2.frag.p != nullptr;
+            if (strip_mlp) {
+                // fused MLP (mlp_strip.hip): fc1, GELU and fc2 in one launch, the hidden activation stays in registers
+                _Float16* Q1 = reinterpret_cast<_Float16*>(n->Wq1.p);
+                const long q1s = (long)n->hid * C * 2;
+                HIP_TRY(launch_pack_conv_frag(w1.buf.p, w1.pitch, n->hid, C, 0, sc1, w1.wabs, 1.f, slot(sb + 9), Q1, q1s, B, s));
+                MARK(ST_NORM1);
+                MlpStripArgs m;
+                m.Xhi = PAh; m.Xlo = PAl; m.ldn = HW; m.sX = (long)C * HW; m.xslot = slot(sb + 4);
+                m.A1 = Q1; m.sA1 = q1s; m.a1slot = slot(sb + 9); m.b1 = n->bf1.p; m.sb1 = n->hid;
+                m.A2 = reinterpret_cast<const _Float16*>(w2.frag.p); m.a2scale = w2.ascale; m.b2 = b2w.buf.p;
+                m.cw1 = w1.winf; m.cb1 = b1w.absmax; m.cinb = slot(sb + 5);
+                m.cw2 = w2.winf; m.cb2 = b2w.absmax; m.rmax = slot(sb + 3);
+                m.R = res; m.sR = actB; m.rsc = ra; m.rsh = rb; m.srs = C;
+                m.C = hn; m.sC = actB;
+                m.Cch = C; m.hid = n->hid; m.HW = (int)HW; m.nbatch = B; m.act = ACT_GELU;
+                if (!last) {
+                    m.Chi = PBh; m.Clo = PBl; m.sCp = (long)C * HW; m.cslot = hslot(i + 1);
+                    m.part = reinterpret_cast<float4*>(part_h); m.nstrips32 = (int)((HW + 127) / 128) * 4;
+                } else {
+                    m.omax = hslot(i + 1);
+                }
+                HIP_TRY(launch_mlp_strip(m, s));
+                MARK(ST_MLP_FC1);
+                h_nparts = (int)((HW + 127) / 128) * 4;
+            } else {
             MARK(ST_NORM1);
             PkOpts f1;
             f1.w = &w1; f1.fhi = F1h; f1.flo = F1l; f1.fslot = slot(sb + 9); f1.f_stride = f1s;
@@ -1221,6 +1260,8 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 f2.omax = hslot(i + 1);
             }
             ACE_TRY(conv_pk2(n, f2, B, s));
+            h_nparts = gemm4_strips(C, (int)HW);
+            }
             have_ph = have_hstats = !last;
         } else if (pk) {
             have_ph = have_hstats = false;

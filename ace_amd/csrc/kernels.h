@@ -140,6 +140,29 @@ struct LegStripArgs {
 bool legendre_strip_eligible(const LegStripArgs& a);
 hipError_t launch_legendre_strip(const LegStripArgs& a, hipStream_t s);
 
+// Fused MLP (mlp_strip.hip): h' = W2 act(W1f P(T) + b1f) + b2 + (rsc h + rsh), the hidden activation stays on chip.
+struct MlpStripArgs {
+    const _Float16* Xhi = nullptr; const _Float16* Xlo = nullptr; long ldn = 0; long sX = 0;   // P-format input planes
+    const unsigned* xslot = nullptr;       // bound the producer scaled the input planes with
+    const _Float16* A1 = nullptr; long sA1 = 0; const unsigned* a1slot = nullptr;   // folded fc1 weights, packed fragments
+    const float* b1 = nullptr; long sb1 = 0;                                       // folded fc1 bias, per sample
+    const _Float16* A2 = nullptr; float a2scale = 1.f; const float* b2 = nullptr;   // fc2 weights (packed fragments), bias
+    float cw1 = 0.f, cb1 = 0.f; const unsigned* cinb = nullptr;   // |U| <= cw1 * bound(normalised input) + cb1
+    float cw2 = 0.f, cb2 = 0.f; const unsigned* rmax = nullptr;   // |h'| <= cw2 * bound(U) + cb2 + bound(residual)
+    const float* R = nullptr; long sR = 0; const float* rsc = nullptr; const float* rsh = nullptr; long srs = 0;
+    float* C = nullptr; long sC = 0;
+    _Float16* Chi = nullptr; _Float16* Clo = nullptr; long sCp = 0; unsigned* cslot = nullptr;
+    float4* part = nullptr; int nstrips32 = 0;   // per-(sample, 32-pixel strip, row) statistics
+    unsigned* omax = nullptr;
+    int Cch = 0, hid = 0, HW = 0, nbatch = 1, act = ACT_NONE;
+};
+hipError_t launch_mlp_strip(const MlpStripArgs& a, hipStream_t s);
+bool mlp_strip_eligible(int C, int hid, int act);
+// conv weight (O x I) -> packed MFMA A fragments (fp16 hi/lo), optionally W diag(a) per sample with the scale derived from
+// wmax * max|a| (published to wslot); order 0: streamed by 32-row chunk (fc1), 1: streamed by 32-column chunk (fc2)
+hipError_t launch_pack_conv_frag(const float* W, long ldw, int O, int I, int order, const float* a, float wmax,
+                                 float scale_static, unsigned* wslot, void* dst, long sDst, int nsamples, hipStream_t s);
+
 // Spectral-space layout used between the kernels ("channel-fastest planar"):
 //   X[m][k][b][ri][c]  (after the longitude DFT)     index ((m*H + k)*Bt + b)*2C + ri*C + c
 //   D[l][m][b][ri][c]  (after the Legendre stage)    index ((l*Mm + m)*Bt + b)*2C + ri*C + c

@@ -1,0 +1,431 @@
+// Fused MLP for gfx950: h' = W2 . GELU(W1f . P(T) + b1f) + b2 + (a0 h + b0)   (fme/ace/models/modulus/layers.py:117-137 with the
+// block's outer skip, sfnonet.py:234-250), one launch, the hidden activation U never leaves the chip.
+//
+// A wave owns a 32-pixel strip for the whole MLP:
+//   * the strip of the input (P-format fp16 hi/lo planes written by the inner-skip GEMM) is loaded once as MFMA B fragments
+//     and stays in registers (C = 384: 24 k-steps x 8 VGPRs);
+//   * the hidden dimension is walked in chunks of 32 units: fc1 of the chunk (24 k-steps x 3 MFMAs into one 32 x 32 tile),
+//     bias + GELU + hi/lo split IN REGISTERS - after four v_permlane32_swap the accumulator tile IS the B operand of two
+//     k-steps of fc2 - then fc2 of the chunk (12 output tiles x 2 k-steps x 3 MFMAs into the 12 resident accumulators);
+//   * both weight matrices stream through LDS as pre-packed A fragments (strip_pack.h layout), one 48 KiB slot each,
+//     shared by the four waves of the workgroup: the slot of W1 is refilled while fc2 runs and vice versa;
+//   * the epilogue (bias, residual with its own affine, fp32 store, P-format planes of h', row statistics of the next
+//     instance norm) runs from the 12 accumulators.
+// One wave per SIMD (the strip + the 12 accumulators need ~430 registers of the unified 512-entry file).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace ace {
+namespace {
+
+#define MDEV __device__ __forceinline__
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char* lds_cptr;
+
+MDEV unsigned slot_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+MDEV int pow2_exponent_for(float mx) {
+    int e = 0;
+    if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &e); e = 12 - e; }
+    return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+MDEV float wave_max_bits(unsigned raw) {
+    float mx = __uint_as_float(raw);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mx)));
+}
+MDEV void glds16(const void* gsrc, const char* lds_dst_uniform) {
+    unsigned keep;
+    const unsigned addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cptr)lds_dst_uniform);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(addr)
+                 : "memory");
+}
+MDEV float fast_erf(float x) {   // kernels.hip: max abs error 1.1e-7
+    const float t = fminf(fabsf(x), 4.0f);
+    float q = -1.150086973e-05f;
+    q = fmaf(q, t, 1.518900972e-04f);
+    q = fmaf(q, t, -8.436889620e-04f);
+    q = fmaf(q, t, 2.264559502e-03f);
+    q = fmaf(q, t, -7.151089812e-05f);
+    q = fmaf(q, t, -2.773463540e-02f);
+    q = fmaf(q, t, 1.483123451e-01f);
+    q = fmaf(q, t, 9.184418917e-01f);
+    q = fmaf(q, t, 1.627907395e+00f);
+    q = q * t;
+    return copysignf(1.0f - __builtin_amdgcn_exp2f(-q), x);
+}
+template <int ACT>
+MDEV float act_fn(float v) {
+    if (ACT == ACT_GELU_FAST || ACT == ACT_GELU) return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
+    if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
+    return v;
+}
+
+// After the four swaps a lane (i, g) holds rows 8 g .. 8 g + 7 in r0..r7 and rows 16 + 8 g .. + 7 in r8..r15 of its column
+// (v_permlane32_swap exchanges vdst[32..63] with src[0..31]; validated on the part through gemm4's ACE_G4_REGEPI build).
+MDEV void rows_to_kgroups(f32x16& v) {
+#pragma unroll
+    for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[8 * hq + e]), __float_as_uint(v[8 * hq + 4 + e]), false, false);
+            v[8 * hq + e] = __uint_as_float(sw[0]);
+            v[8 * hq + 4 + e] = __uint_as_float(sw[1]);
+        }
+}
+
+template <int I0, int I1, class F>
+MDEV void static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        static_for<I0 + 1, I1>(f);
+    }
+}
+
+// Row statistics of an 8-row x 32-column block held as v[0..7] per lane (lane = column, the 32 lanes of one half-wave):
+// butterfly with halving - after the offsets 16, 8, 4 every lane holds ONE partially reduced row (row index = bits 4..2 of
+// the lane, bit-reversed order handled by the caller through the returned row id), offsets 2 and 1 finish it.
+// 9 exchanges per quantity instead of 40.
+template <class Op>
+MDEV float reduce8(const float (&v)[8], int i, Op op, int* row_of_lane) {
+    float a[4];
+    const bool up16 = (i & 16) != 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float mine = up16 ? v[4 + r] : v[r];        // rows this lane keeps
+        const float send = up16 ? v[r] : v[4 + r];        // rows the partner keeps
+        a[r] = op(mine, __shfl_xor(send, 16, 64));
+    }
+    float b[2];
+    const bool up8 = (i & 8) != 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const float mine = up8 ? a[2 + r] : a[r];
+        const float send = up8 ? a[r] : a[2 + r];
+        b[r] = op(mine, __shfl_xor(send, 8, 64));
+    }
+    const bool up4 = (i & 4) != 0;
+    const float mine = up4 ? b[1] : b[0];
+    const float send = up4 ? b[0] : b[1];
+    float c = op(mine, __shfl_xor(send, 4, 64));
+    c = op(c, __shfl_xor(c, 2, 64));
+    c = op(c, __shfl_xor(c, 1, 64));
+    *row_of_lane = (up16 ? 4 : 0) + (up8 ? 2 : 0) + (up4 ? 1 : 0);
+    return c;
+}
+
+// NC = C / 32: KS1 = 2 NC k16-steps of fc1, NT2 = NC 32-row output tiles of fc2; a W1 chunk (32 hidden rows x C) and a W2
+// chunk (C rows x 32 hidden) are NC * 4 KiB each
+template <int NC, int ACT, bool PK>
+__global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
+    constexpr int KS1 = 2 * NC, NT2 = NC;
+    constexpr int SLOT1 = KS1 * 2048, SLOT2 = NT2 * 2 * 2048;
+    constexpr int MLP_LDS = SLOT1 + SLOT2;
+    __shared__ __attribute__((aligned(16))) char smem[MLP_LDS];
+    char* s1 = smem;
+    char* s2 = smem + SLOT1;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, g = lane >> 5;
+    const int strips = (p.HW + 127) / 128;
+    const int smp = blockIdx.x / strips;
+    const int n0 = (blockIdx.x % strips) * 128 + wave * 32;
+    const int n = n0 + i;
+    const int nc = n < p.HW ? n : p.HW - 1;
+    const int nchunks = p.hid / 32;
+
+    const unsigned raw_x = slot_load(p.xslot + lane);
+    const unsigned raw_a = slot_load(p.a1slot + lane);
+    const unsigned raw_c = slot_load(p.cinb + lane);
+    const unsigned raw_r = PK ? slot_load(p.rmax + lane) : 0u;
+
+    const _Float16* A1 = p.A1 + (long)smp * p.sA1;
+    auto issue1 = [&](int c) {   // 2 KS1 pieces, KS1 / 2 = NC per wave
+        const _Float16* src = A1 + (long)c * (KS1 * 1024) + lane * 8;
+#pragma unroll
+        for (int q = 0; q < KS1 / 2; ++q) {
+            const int pc = wave + 4 * q;
+            glds16(src + pc * 512, s1 + pc * 1024);
+        }
+    };
+    auto issue2 = [&](int c) {
+        const _Float16* src = p.A2 + (long)c * (NT2 * 2 * 1024) + lane * 8;
+#pragma unroll
+        for (int q = 0; q < NT2; ++q) {
+            const int pc = wave + 4 * q;
+            glds16(src + pc * 512, s2 + pc * 1024);
+        }
+    };
+    issue1(0);
+    issue2(0);
+
+    // ---- resident input strip (already split and k-packed by its producer)
+    half8 xh[KS1], xl[KS1];
+    {
+        const _Float16* Xh = p.Xhi + (long)smp * p.sX;
+        const _Float16* Xl = p.Xlo + (long)smp * p.sX;
+#pragma unroll
+        for (int j = 0; j < KS1; ++j) {
+            const long off = ((long)(2 * j + g) * p.ldn + nc) * 8;
+            xh[j] = *reinterpret_cast<const half8*>(Xh + off);
+            xl[j] = *reinterpret_cast<const half8*>(Xl + off);
+        }
+    }
+    const float xbound = wave_max_bits(raw_x);
+    const float inv_x = ldexpf(1.0f, -pow2_exponent_for(xbound));
+    const float inv_a1 = ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_a)));
+    const float s_fc1 = inv_x * inv_a1;
+    // bound of the hidden activation, identical in every workgroup: |U| <= cw1 * bound(norm1(T)) + cb1
+    const float ubound = fmaf(p.cw1, wave_max_bits(raw_c), p.cb1);
+    const int eu = pow2_exponent_for(ubound);
+    const float uscale = ldexpf(1.0f, eu);
+    const float s_fc2 = ldexpf(1.0f, -eu) / p.a2scale;
+
+    f32x16 out[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[t][r] = 0.f;
+
+    const float* b1 = p.b1 + (long)smp * p.sb1;
+    // LDS-DMA bookkeeping (the only vector-memory operations inside the loop besides four bias loads, no stores, so the
+    // counted wait is exact): W1(c+1) is issued in the middle of chunk c (after the GELU, before fc2), W2(c+1) at its end.
+    // At the top of chunk c+1 the queue is [W1(c+1): NC pieces][W2(c+1): NC pieces] - vmcnt(NC) retires exactly W1(c+1).
+    for (int c = 0; c < nchunks; ++c) {
+        // ---- fc1 of chunk c
+        if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // both first chunks and the input strip
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NC) : "memory");         // W1(c); W2(c) may still be in flight
+        __syncthreads();                       // W1 chunk c landed in every wave's share
+        f32x16 u0, u1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { u0[r] = 0.f; u1[r] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < KS1; ++j) {
+            const half8 ah = *reinterpret_cast<const half8*>(s1 + j * 2048 + lane * 16);
+            const half8 al = *reinterpret_cast<const half8*>(s1 + j * 2048 + 1024 + lane * 16);
+            u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[j], u0, 0, 0, 0);
+            u1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[j], u1, 0, 0, 0);
+            u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[j], u0, 0, 0, 0);
+        }
+        f32x16 u = u0 + u1;
+        // bias of this lane's rows after the swap: rows 8 g + e (e < 8) and 16 + 8 g + e
+        const f32x4 bA = *reinterpret_cast<const f32x4*>(b1 + 32 * c + 8 * g);
+        const f32x4 bB = *reinterpret_cast<const f32x4*>(b1 + 32 * c + 8 * g + 4);
+        const f32x4 bC = *reinterpret_cast<const f32x4*>(b1 + 32 * c + 16 + 8 * g);
+        const f32x4 bD = *reinterpret_cast<const f32x4*>(b1 + 32 * c + 16 + 8 * g + 4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W2(c) (issued a whole fc1 ago) and the bias loads
+        __syncthreads();                       // every wave is done with the W1 slot; W2 chunk c landed
+        rows_to_kgroups(u);
+        half8 uh[2], ul[2];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float bv0 = e < 4 ? bA[e & 3] : bB[e & 3];
+            const float bv1 = e < 4 ? bC[e & 3] : bD[e & 3];
+            const float y0 = act_fn<ACT>(fmaf(u[e], s_fc1, bv0)) * uscale;
+            const float y1 = act_fn<ACT>(fmaf(u[8 + e], s_fc1, bv1)) * uscale;
+            const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
+            uh[0][e] = h0; ul[0][e] = (_Float16)(y0 - (float)h0);
+            uh[1][e] = h1; ul[1][e] = (_Float16)(y1 - (float)h1);
+        }
+        // refill the W1 slot now: after the bias has been consumed (hipcc waits vmcnt(0) at the first use of a plain load and
+        // would drain a DMA issued before it), with the whole fc2 of this chunk to land
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < nchunks) issue1(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- fc2 of chunk c: NT2 output tiles x 2 k-steps
+#pragma unroll
+        for (int t = 0; t < NT2; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const half8 ah = *reinterpret_cast<const half8*>(s2 + (t * 2 + kk) * 2048 + lane * 16);
+                const half8 al = *reinterpret_cast<const half8*>(s2 + (t * 2 + kk) * 2048 + 1024 + lane * 16);
+                out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, uh[kk], out[t], 0, 0, 0);
+                out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ul[kk], out[t], 0, 0, 0);
+                out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, uh[kk], out[t], 0, 0, 0);
+            }
+        if (c + 1 < nchunks) {
+            __syncthreads();                   // every wave is done with the W2 slot
+            issue2(c + 1);
+        }
+    }
+
+    // ---- epilogue: rows of tile t are output channels 32 t + acc_row(r, g); lane column = pixel n
+    float cscale = 1.f;
+    if (PK) {
+        const float resb = wave_max_bits(raw_r);
+        const float cbound = fmaf(p.cw2, ubound, p.cb2) + resb;
+        cscale = ldexpf(1.0f, pow2_exponent_for(cbound));
+        if (tid == 0) atomicMax(p.cslot + (blockIdx.x & 63), __float_as_uint(cbound));
+    }
+    const float* R = p.R + (long)smp * p.sR + nc;
+    const float* rsc = p.rsc ? p.rsc + (long)smp * p.srs : nullptr;
+    const float* rsh = p.rsc ? p.rsh + (long)smp * p.srs : nullptr;
+    float* Cc = p.C + (long)smp * p.sC + nc;
+    float vmax = 0.f;
+    const bool nok = n < p.HW;
+    const long HW = p.HW;
+    static_for<0, NT2>([&](auto tt) {
+        constexpr int t = decltype(tt)::value;
+        f32x16 v = out[t];
+        rows_to_kgroups(v);      // rows 8 g + e and 16 + 8 g + e: whole P entries, 8 consecutive channel rows
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+            const int row0 = 32 * t + 16 * hq + 8 * g;
+            const f32x4 b2a = *reinterpret_cast<const f32x4*>(p.b2 + row0);
+            const f32x4 b2b = *reinterpret_cast<const f32x4*>(p.b2 + row0 + 4);
+            f32x4 sa = {1.f, 1.f, 1.f, 1.f}, sb = sa, ta = {0.f, 0.f, 0.f, 0.f}, tb = ta;
+            if (rsc) {
+                sa = *reinterpret_cast<const f32x4*>(rsc + row0); sb = *reinterpret_cast<const f32x4*>(rsc + row0 + 4);
+                ta = *reinterpret_cast<const f32x4*>(rsh + row0); tb = *reinterpret_cast<const f32x4*>(rsh + row0 + 4);
+            }
+            float res[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) res[e] = R[(long)(row0 + e) * HW];
+            float val[8];
+            half8 hh, ll;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float bb = e < 4 ? b2a[e & 3] : b2b[e & 3];
+                const float rs = e < 4 ? sa[e & 3] : sb[e & 3];
+                const float rt = e < 4 ? ta[e & 3] : tb[e & 3];
+                val[e] = fmaf(v[8 * hq + e], s_fc2, bb) + fmaf(res[e], rs, rt);
+                if (nok) Cc[(long)(row0 + e) * HW] = val[e];
+                vmax = fmaxf(vmax, nok ? fabsf(val[e]) : 0.f);
+                if (PK) {
+                    const float xs = val[e] * cscale;
+                    const _Float16 a = (_Float16)xs;
+                    hh[e] = a;
+                    ll[e] = (_Float16)(xs - (float)a);
+                }
+            }
+            if (PK && nok) {
+                const long eo = ((long)(row0 >> 3) * HW + n) * 8;
+                *reinterpret_cast<half8*>(p.Chi + (long)smp * p.sCp + eo) = hh;
+                *reinterpret_cast<half8*>(p.Clo + (long)smp * p.sCp + eo) = ll;
+            }
+            if (p.part) {   // wave-uniform: row statistics over this wave's 32 pixels (sum, sum of squares, min, max)
+                float q1[8], q2[8], q3[8], q4[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    q1[e] = nok ? val[e] : 0.f;
+                    q2[e] = nok ? val[e] * val[e] : 0.f;
+                    q3[e] = nok ? val[e] : 3.0e38f;
+                    q4[e] = nok ? val[e] : -3.0e38f;
+                }
+                int rl;
+                const float sm = reduce8(q1, i, [](float a, float b) { return a + b; }, &rl);
+                const float sq = reduce8(q2, i, [](float a, float b) { return a + b; }, &rl);
+                const float mn = reduce8(q3, i, [](float a, float b) { return fminf(a, b); }, &rl);
+                const float mx = reduce8(q4, i, [](float a, float b) { return fmaxf(a, b); }, &rl);
+                if ((i & 3) == 0)
+                    p.part[((long)smp * p.nstrips32 + (n0 >> 5)) * p.Cch + row0 + rl] = make_float4(sm, sq, mn, mx);
+            }
+        }
+    });
+    if (p.omax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        float* red = reinterpret_cast<float*>(smem);
+        __syncthreads();
+        if (lane == 0) red[wave] = vmax;
+        __syncthreads();
+        if (tid == 0) atomicMax(p.omax + (blockIdx.x & 63), __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+    }
+}
+
+}  // namespace
+
+// A-fragment packing of a conv weight W (O x I, row pitch ldw), optionally with a per-input-channel scale folded in
+// (instance-norm affine: W diag(a)), as fp16 hi/lo blocks of 64 lanes x 8 halves (strip_pack.h layout: lane = i + 32 g holds
+// row 32 T + i, columns 16 J + 8 g .. + 7):
+//   order 0 (streamed by output-row chunk, fc1): block (T, J) at T * (I / 16) + J
+//   order 1 (streamed by 32-column chunk, fc2):  block (T, J) at ((J / 2) * (O / 32) + T) * 2 + (J % 2)
+// O % 32 == 0, I % 16 == 0.  scale: a power of two, or derived from `bound` = wmax * max|a| (published to wslot).
+__global__ __launch_bounds__(256) void pack_conv_frag_kernel(const float* __restrict__ W, long ldw, int O, int I, int order,
+                                                             const float* __restrict__ a, float wmax, float scale_static,
+                                                             unsigned* wslot, _Float16* __restrict__ dst, long sDst) {
+    const int smp = blockIdx.y;
+    float scale = scale_static;
+    if (a) {   // one scale for all samples (as fold_affine_f16_kernel)
+        __shared__ float red[4];
+        float am = 0.f;
+        for (int q = threadIdx.x; q < I * (int)gridDim.y; q += 256) am = fmaxf(am, fabsf(a[q]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+        __syncthreads();
+        am = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float bound = wmax * am;
+        scale = ldexpf(1.0f, pow2_exponent_for(bound));
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(wslot + (smp & 63), __float_as_uint(bound));
+    }
+    const int nJ = I / 16, nT = O / 32;
+    const int blk = blockIdx.x;                 // one workgroup = one (T, J) block: 512 elements, two per thread
+    const int T = blk / nJ, J = blk % nJ;
+    const long bidx = order == 0 ? (long)T * nJ + J : ((long)(J / 2) * nT + T) * 2 + (J % 2);
+    _Float16* out = dst + (long)smp * sDst + bidx * 1024;
+    const float* as = a ? a + (long)smp * I : nullptr;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = threadIdx.x + 256 * u;    // = lane * 8 + e
+        const int e = t & 7, lane = t >> 3, i = lane & 31, g = lane >> 5;
+        const int row = 32 * T + i, col = 16 * J + 8 * g + e;
+        float x = W[(long)row * ldw + col] * scale;
+        if (as) x *= as[col];
+        x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+        const _Float16 h = (_Float16)x;
+        out[t] = h;
+        out[512 + t] = (_Float16)(x - (float)h);
+    }
+}
+
+hipError_t launch_pack_conv_frag(const float* W, long ldw, int O, int I, int order, const float* a, float wmax,
+                                 float scale_static, unsigned* wslot, void* dst, long sDst, int nsamples, hipStream_t s) {
+    if (O % 32 != 0 || I % 16 != 0 || (order == 1 && I % 32 != 0) || (a && !wslot)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((O / 32) * (I / 16)), (unsigned)nsamples);
+    hipLaunchKernelGGL(pack_conv_frag_kernel, grid, dim3(256), 0, s, W, ldw, O, I, order, a, wmax, scale_static, wslot,
+                       static_cast<_Float16*>(dst), sDst);
+    return hipGetLastError();
+}
+
+bool mlp_strip_eligible(int C, int hid, int act) {
+    static const bool off = std::getenv("ACE_NO_MLP_STRIP") != nullptr;   // A/B switch for measurements
+    if (off) return false;
+    if (!(act == ACT_GELU || act == ACT_GELU_FAST)) return false;
+    return (C == 128 || C == 256 || C == 384) && hid % 32 == 0 && hid >= 32;
+}
+
+template <int NC>
+static hipError_t launch_mlp_nc(const MlpStripArgs& a, hipStream_t s) {
+    const int strips = (a.HW + 127) / 128;
+    dim3 grid((unsigned)(strips * a.nbatch)), block(256);
+    if (a.Chi) hipLaunchKernelGGL((mlp_strip_kernel<NC, ACT_GELU_FAST, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((mlp_strip_kernel<NC, ACT_GELU_FAST, false>), grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mlp_strip(const MlpStripArgs& a, hipStream_t s) {
+    if (!mlp_strip_eligible(a.Cch, a.hid, a.act) || !a.C || !a.R) return hipErrorInvalidValue;
+    if (a.Chi && (!a.cslot || !a.rmax)) return hipErrorInvalidValue;
+    switch (a.Cch / 32) {
+        case 4: return launch_mlp_nc<4>(a, s);
+        case 8: return launch_mlp_nc<8>(a, s);
+        case 12: return launch_mlp_nc<12>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ace

@@ -1,0 +1,147 @@
+"""Parity at the HEADLINE shape (BASELINE.json configs[1]: ACE2-shape SFNO, embed 384, 8 layers, dhconv, 44/50 channels,
+180x360): the whole network against values emitted by the real reference (tests/golden/make_golden_headline.py), the
+fused MLP and the packed path at C = 384 / 128 against fp64, and a one-year (1460-step) hipGraph rollout."""
+import hashlib
+import os
+
+import pytest
+import torch
+
+from _util import build_native_net, load_golden, rel_max
+
+pytestmark = pytest.mark.gpu
+NET_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def headline():
+    from oracle.sfno import SFNOConfig, init_state
+    d = load_golden("gen_sfno_headline_384x8.pt")
+    cfg = SFNOConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in d["cfg"].items()})
+    state = init_state(cfg, seed=d["seed"])
+    chk = sum(float(v.double().abs().sum()) for v in state.values())
+    assert abs(chk - d["state_checksum"]) <= 1e-9 * abs(d["state_checksum"]), "weight generator drifted from the fixture"
+    x = torch.randn(d["batch"], cfg.in_chans, *cfg.img_shape, generator=torch.Generator().manual_seed(d["seed"] + 1000))
+    assert abs(float(x.double().abs().sum()) - d["x_checksum"]) <= 1e-9 * d["x_checksum"]
+    return d, cfg, state, x
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_headline_network_vs_reference(dev, headline, precision):
+    """C = 384 x 8 layers x 180x360, B = 2, against the reference's own output: 32768 sampled values and per-channel
+    statistics, in max|err| / max|ref| (north_star tolerance 1e-5)."""
+    d, cfg, state, x = headline
+    net = build_native_net(cfg, state, dev, precision)
+    with torch.no_grad():
+        y = net(x.to(dev))
+        y2 = net(x.to(dev))
+    assert torch.equal(y, y2)                                    # deterministic
+    assert torch.isfinite(y).all()
+    ys = y.reshape(-1)[d["sample_index"].to(dev)].cpu()
+    err = float((ys.double() - d["sample_value"].double()).abs().max() / d["y_absmax"])
+    print(f"headline {precision}: sampled rel err vs reference {err:.3e}")
+    assert err <= NET_TOL
+    mean = y.double().mean(dim=(0, 2, 3)).cpu()
+    amax = y.abs().amax(dim=(0, 2, 3)).cpu()
+    assert float((mean - d["y_channel_mean"].double()).abs().max()) <= NET_TOL * d["y_absmax"]
+    assert float((amax - d["y_channel_absmax"]).abs().max()) <= 10 * NET_TOL * d["y_absmax"]
+    # batched == per sample (the per-sample folded weights and statistics must not mix samples)
+    with torch.no_grad():
+        y0 = net(x[:1].to(dev))
+    assert rel_max(y0, y[:1]) <= 2e-6
+    # the graph path replays the same kernels
+    out = torch.empty_like(y)
+    xd = x.to(dev).contiguous()
+    with torch.no_grad():
+        net.forward_graph(xd, out)
+        net.forward_graph(xd, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, y)
+
+
+@pytest.mark.parametrize("C,hw", [(384, (45, 90)), (128, (24, 48)), (256, (20, 40))])
+def test_fused_mlp_shapes_vs_fp64(dev, C, hw):
+    """the fused MLP kernel (mlp_strip.hip: C in {128, 256, 384}) inside 3-block nets, batch 3, ragged last workgroup,
+    random norm gains - per-block taps against the fp64 oracle."""
+    from oracle.sfno import SFNOConfig, SFNOOracle, init_state
+    cfg = SFNOConfig(in_chans=6, out_chans=5, img_shape=hw, embed_dim=C, num_layers=3, operator_type="dhconv")
+    state = init_state(cfg, seed=17)
+    g = torch.Generator().manual_seed(18)
+    for k in state:
+        if ".norm" in k and k.endswith("weight"):
+            state[k] = 1.0 + 0.3 * torch.randn(state[k].shape, generator=g)
+        if ".norm" in k and k.endswith("bias"):
+            state[k] = 0.2 * torch.randn(state[k].shape, generator=g)
+    x = torch.randn(3, 6, *hw, generator=g) * 0.8 + 0.5
+    net = build_native_net(cfg, state, dev, "f16x3")
+    with torch.no_grad():
+        y, taps = net.forward_with_taps(x.to(dev))
+    ref, rtaps = SFNOOracle(cfg, state, dtype=torch.float64).forward(x, return_blocks=True)
+    for i, rt in enumerate(rtaps):
+        assert rel_max(taps[i + 1], rt) <= NET_TOL, f"block {i}: {rel_max(taps[i + 1], rt)}"
+    assert rel_max(y, ref) <= NET_TOL
+
+
+def test_weight_update_after_graph_capture(dev):
+    """ace_sfno_set_weight drops captured graphs: scales baked into kernel arguments must follow a weight update."""
+    from oracle.sfno import SFNOConfig, init_state
+    cfg = SFNOConfig(in_chans=4, out_chans=3, img_shape=(24, 48), embed_dim=32, num_layers=2, operator_type="dhconv")
+    state = init_state(cfg, seed=2)
+    net = build_native_net(cfg, state, dev, "f16x3")
+    x = torch.randn(1, 4, 24, 48, generator=torch.Generator().manual_seed(3)).to(dev)
+    out = torch.empty(1, 3, 24, 48, device=dev)
+    with torch.no_grad():
+        net.forward_graph(x, out)
+        big = {k: (v * 8.0 if k.endswith("mlp.fwd.0.weight") or k.endswith("inner_skip.weight") else v) for k, v in state.items()}
+        net.load_state_dict(big, strict=True)
+        net.forward_graph(x, out)
+        torch.cuda.synchronize()
+        eager = net(x)
+    assert torch.equal(out, eager)
+
+
+def test_one_year_graph_rollout(dev):
+    """configs[1]: 1460 forward steps of the ACE2-shape network from a hipGraph-captured step (20 windows of 73 steps on
+    static buffers): every value finite, the dynamic-range machinery healthy for the whole year (outputs of the last
+    window keep their spread), two runs bit-identical; reports the drift of the state after 4 and 1460 steps."""
+    import bench
+    from ace_amd.rollout import RolloutEngine
+    stepper, forcing, prog, diag = bench.build_stepper(dev, seed=0)
+    T, nwin = 73, 20
+    eng = RolloutEngine(stepper, batch=1, n_forward_steps=T, graph="step")
+    g = torch.Generator().manual_seed(7)
+    ic = {n: torch.randn(1, 1, *bench.IMG, generator=g).to(dev) for n in prog}
+    fc = {n: torch.randn(1, T + 1, *bench.IMG, generator=g).to(dev) for n in forcing}
+
+    def run():
+        eng.load(ic, fc)
+        stats = {}
+        with torch.no_grad():
+            for w in range(nwin):
+                eng.run_window()
+                if w == 0:
+                    stats[4] = torch.stack([eng.out[n][0, 3] for n in prog]).clone()
+                if w + 1 < nwin:
+                    eng.continue_from_last()
+        torch.cuda.synchronize()
+        stats[T * nwin] = torch.stack([eng.out[n][0, -1] for n in prog]).clone()
+        return stats
+
+    a = run()
+    b = run()
+    x0 = torch.stack([ic[n][0, 0] for n in prog])
+    for k in a:
+        assert torch.isfinite(a[k]).all(), f"non-finite state after {k} steps"
+        assert torch.equal(a[k], b[k]), f"replay not deterministic after {k} steps"
+        drift = float((a[k] - x0).double().pow(2).mean().sqrt() / x0.double().pow(2).mean().sqrt())
+        print(f"rollout: {k} steps, rms drift from the initial state {drift:.4f}, state rms {float(a[k].double().pow(2).mean().sqrt()):.4f}, "
+              f"absmax {float(a[k].abs().max()):.3f}")
+    last = a[T * nwin]
+    assert float(last.std()) > 1e-6, "state collapsed: dynamic-range slots lost the signal"
+    assert float(last.abs().max()) < 1e6, "state blew up"

@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Per-kernel means of rocprofv3 counter_collection.csv (one pass), or --merge DIR: merge the per-pass summaries and derive
+HBM bytes per launch (gfx950: FETCH_SIZE counts wide coalesced reads at half size -> bytes = 2 * FETCH_SIZE KB + WRITE_SIZE KB,
+MI355X_MICROARCH.md 'HBM'), L2 hit rate and MFMA-busy share."""
+import collections
+import csv
+import json
+import os
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name).replace("void ", "").replace("ace::", "")
+    return re.sub(r"\(.*", "", name)[:80]
+
+
+def one(path):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"]) + " g" + r.get("Grid_Size", r.get("Grid_Size_X", "?"))
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = {}
+    for k, d in acc.items():
+        out[k] = {c: sum(v) / len(v) for c, v in d.items()}
+        out[k]["_dispatches"] = max(len(v) for v in d.values())
+    return out
+
+
+def merge(d):
+    tot = collections.defaultdict(dict)
+    for f in sorted(os.listdir(d)):
+        if f.endswith(".json"):
+            try:
+                for k, v in json.load(open(os.path.join(d, f))).items():
+                    tot[k].update(v)
+            except ValueError:
+                pass
+    for k, v in tot.items():
+        if "FETCH_SIZE" in v or "WRITE_SIZE" in v:
+            # KB units; reads x2 (gfx950 correction for 16-byte-per-lane streaming reads)
+            v["hbm_read_MB_corrected"] = round(2 * v.get("FETCH_SIZE", 0.0) * 1024 / 1e6, 2)
+            v["hbm_write_MB"] = round(v.get("WRITE_SIZE", 0.0) * 1024 / 1e6, 2)
+            v["hbm_traffic_MB"] = round(v["hbm_read_MB_corrected"] + v["hbm_write_MB"], 2)
+        if "TCC_HIT_sum" in v and v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0) > 0:
+            v["l2_hit_rate"] = round(v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 4)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in v and v.get("GRBM_GUI_ACTIVE", 0) > 0:
+            # busy cycles are summed over the SIMDs that report (256 CUs x 4 SIMDs); share of the kernel's active cycles
+            v["mfma_busy_share"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] * 1024), 4)
+    return dict(sorted(tot.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "--merge":
+        print(json.dumps(merge(sys.argv[2]), indent=1))
+    else:
+        print(json.dumps(one(sys.argv[1]), indent=1))
