@@ -126,16 +126,21 @@ MDEV float reduce8(const float (&v)[8], int i, Op op, int* row_of_lane) {
     return c;
 }
 
-// NC = C / 32: KS1 = 2 NC k16-steps of fc1, NT2 = NC 32-row output tiles of fc2; a W1 chunk (32 hidden rows x C) and a W2
-// chunk (C rows x 32 hidden) are NC * 4 KiB each
+// NC = C / 32: KS1 = 2 NC k16-steps of fc1, NT2 = NC 32-row output tiles of fc2.  The two weight matrices are one stream
+// of GROUPS of NC k-step blocks (NC * 2 KiB): per hidden chunk c the groups 4c, 4c+1 are the two k-halves of the W1 chunk
+// (32 hidden rows x C) and 4c+2, 4c+3 the two row-halves of the W2 chunk (C rows x 32 hidden).  A ring of six groups in
+// LDS keeps five groups (> 1 chunk, ~3 us of MFMA work) in flight: an LDS-DMA piece issued under full-chip load lands
+// 2 - 3 us later (r02 measurement: with one group of lookahead the kernel waited half of its time).
 template <int NC, int ACT, bool PK>
 __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
     constexpr int KS1 = 2 * NC, NT2 = NC;
-    constexpr int SLOT1 = KS1 * 2048, SLOT2 = NT2 * 2 * 2048;
-    constexpr int MLP_LDS = SLOT1 + SLOT2;
-    __shared__ __attribute__((aligned(16))) char smem[MLP_LDS];
-    char* s1 = smem;
-    char* s2 = smem + SLOT1;
+    constexpr int GRP = NC * 2048;          // bytes per group
+    constexpr int NSLOT = 6, AHEAD = NSLOT - 1;
+    constexpr int PW = NC / 2;              // 1-KiB pieces per wave per group
+    constexpr int RING = NSLOT * GRP;
+    constexpr int B1MAX = 4096;             // hidden units whose folded bias is kept in LDS
+    __shared__ __attribute__((aligned(16))) char smem[RING + B1MAX * 4];
+    float* b1s = reinterpret_cast<float*>(smem + RING);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -146,6 +151,7 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
     const int n = n0 + i;
     const int nc = n < p.HW ? n : p.HW - 1;
     const int nchunks = p.hid / 32;
+    const int ngroups = 4 * nchunks;
 
     const unsigned raw_x = slot_load(p.xslot + lane);
     const unsigned raw_a = slot_load(p.a1slot + lane);
@@ -153,24 +159,21 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
     const unsigned raw_r = PK ? slot_load(p.rmax + lane) : 0u;
 
     const _Float16* A1 = p.A1 + (long)smp * p.sA1;
-    auto issue1 = [&](int c) {   // 2 KS1 pieces, KS1 / 2 = NC per wave
-        const _Float16* src = A1 + (long)c * (KS1 * 1024) + lane * 8;
+    const _Float16* A2 = p.A2;
+    auto issue = [&](int q) {   // group q -> ring slot q % NSLOT; groups past the end re-fetch the last one (keeps the count uniform)
+        const int qq = q < ngroups ? q : ngroups - 1;
+        const int c = qq >> 2, ph = qq & 3;
+        const _Float16* src = (ph < 2 ? A1 + (long)c * (KS1 * 1024) + (long)ph * (NC * 1024)
+                                      : A2 + (long)c * (NT2 * 2 * 1024) + (long)(ph - 2) * (NC * 1024)) + lane * 8;
+        const char* dst = smem + (q % NSLOT) * GRP;
 #pragma unroll
-        for (int q = 0; q < KS1 / 2; ++q) {
-            const int pc = wave + 4 * q;
-            glds16(src + pc * 512, s1 + pc * 1024);
+        for (int k = 0; k < PW; ++k) {
+            const int pc = wave + 4 * k;
+            glds16(src + pc * 512, dst + pc * 1024);
         }
     };
-    auto issue2 = [&](int c) {
-        const _Float16* src = p.A2 + (long)c * (NT2 * 2 * 1024) + lane * 8;
-#pragma unroll
-        for (int q = 0; q < NT2; ++q) {
-            const int pc = wave + 4 * q;
-            glds16(src + pc * 512, s2 + pc * 1024);
-        }
-    };
-    issue1(0);
-    issue2(0);
+    issue(0);
+    issue(1);
 
     // ---- resident input strip (already split and k-packed by its producer)
     half8 xh[KS1], xl[KS1];
@@ -183,6 +186,10 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
             xh[j] = *reinterpret_cast<const half8*>(Xh + off);
             xl[j] = *reinterpret_cast<const half8*>(Xl + off);
         }
+    }
+    {   // folded fc1 bias of this sample -> LDS (read back per chunk with ds_read: no vector-memory load inside the loop)
+        const float* b1 = p.b1 + (long)smp * p.sb1;
+        for (int k = tid; k < p.hid; k += 256) b1s[k] = b1[k];
     }
     const float xbound = wave_max_bits(raw_x);
     const float inv_x = ldexpf(1.0f, -pow2_exponent_for(xbound));
@@ -200,34 +207,49 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[t][r] = 0.f;
 
-    const float* b1 = p.b1 + (long)smp * p.sb1;
-    // LDS-DMA bookkeeping (the only vector-memory operations inside the loop besides four bias loads, no stores, so the
-    // counted wait is exact): W1(c+1) is issued in the middle of chunk c (after the GELU, before fc2), W2(c+1) at its end.
-    // At the top of chunk c+1 the queue is [W1(c+1): NC pieces][W2(c+1): NC pieces] - vmcnt(NC) retires exactly W1(c+1).
+    // Everything loaded so far is consumed HERE: hipcc places its own (counted) waits for a plain load at its first use
+    // and knows nothing of the LDS-DMA pieces, so a first use inside the loop would drain the ring every iteration.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < KS1; ++j) asm volatile("" : "+v"(xh[j]), "+v"(xl[j]));
+    __syncthreads();                       // bias table visible; groups 0 and 1 landed in every wave's share
+#pragma unroll
+    for (int q = 2; q < AHEAD; ++q) issue(q);
+
+    // LDS-DMA bookkeeping: the only vector-memory operations inside the loop are the DMA pieces (no plain loads, no
+    // stores), so the counted wait is exact.  At the top of group q the queue holds the groups q .. q + AHEAD - 1 that
+    // have not landed; vmcnt((AHEAD - 1) * PW) retires exactly group q.
+    auto top = [&](int q) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PW) : "memory");
+        __builtin_amdgcn_s_barrier();      // group q landed in every wave's share; every wave is done with group q - 1
+        issue(q + AHEAD);                  // ... whose slot is refilled now
+    };
     for (int c = 0; c < nchunks; ++c) {
-        // ---- fc1 of chunk c
-        if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // both first chunks and the input strip
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NC) : "memory");         // W1(c); W2(c) may still be in flight
-        __syncthreads();                       // W1 chunk c landed in every wave's share
         f32x16 u0, u1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { u0[r] = 0.f; u1[r] = 0.f; }
+        // ---- fc1 of chunk c: two k-halves
 #pragma unroll
-        for (int j = 0; j < KS1; ++j) {
-            const half8 ah = *reinterpret_cast<const half8*>(s1 + j * 2048 + lane * 16);
-            const half8 al = *reinterpret_cast<const half8*>(s1 + j * 2048 + 1024 + lane * 16);
-            u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[j], u0, 0, 0, 0);
-            u1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[j], u1, 0, 0, 0);
-            u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[j], u0, 0, 0, 0);
+        for (int ph = 0; ph < 2; ++ph) {
+            const int q = 4 * c + ph;
+            top(q);
+            const char* sl = smem + (q % NSLOT) * GRP + lane * 16;
+#pragma unroll
+            for (int jj = 0; jj < NC; ++jj) {
+                const int j = ph * NC + jj;
+                const half8 ah = *reinterpret_cast<const half8*>(sl + jj * 2048);
+                const half8 al = *reinterpret_cast<const half8*>(sl + jj * 2048 + 1024);
+                u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[j], u0, 0, 0, 0);
+                u1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[j], u1, 0, 0, 0);
+                u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[j], u0, 0, 0, 0);
+            }
         }
         f32x16 u = u0 + u1;
         // bias of this lane's rows after the swap: rows 8 g + e (e < 8) and 16 + 8 g + e
-        const f32x4 bA = *reinterpret_cast<const f32x4*>(b1 + 32 * c + 8 * g);
-        const f32x4 bB = *reinterpret_cast<const f32x4*>(b1 + 32 * c + 8 * g + 4);
-        const f32x4 bC = *reinterpret_cast<const f32x4*>(b1 + 32 * c + 16 + 8 * g);
-        const f32x4 bD = *reinterpret_cast<const f32x4*>(b1 + 32 * c + 16 + 8 * g + 4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W2(c) (issued a whole fc1 ago) and the bias loads
-        __syncthreads();                       // every wave is done with the W1 slot; W2 chunk c landed
+        const f32x4 bA = *reinterpret_cast<const f32x4*>(b1s + 32 * c + 8 * g);
+        const f32x4 bB = *reinterpret_cast<const f32x4*>(b1s + 32 * c + 8 * g + 4);
+        const f32x4 bC = *reinterpret_cast<const f32x4*>(b1s + 32 * c + 16 + 8 * g);
+        const f32x4 bD = *reinterpret_cast<const f32x4*>(b1s + 32 * c + 16 + 8 * g + 4);
         rows_to_kgroups(u);
         half8 uh[2], ul[2];
 #pragma unroll
@@ -240,27 +262,27 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
             uh[0][e] = h0; ul[0][e] = (_Float16)(y0 - (float)h0);
             uh[1][e] = h1; ul[1][e] = (_Float16)(y1 - (float)h1);
         }
-        // refill the W1 slot now: after the bias has been consumed (hipcc waits vmcnt(0) at the first use of a plain load and
-        // would drain a DMA issued before it), with the whole fc2 of this chunk to land
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nchunks) issue1(c + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- fc2 of chunk c: NT2 output tiles x 2 k-steps
+        // ---- fc2 of chunk c: two halves of NT2 / 2 output tiles x 2 k-steps
+        static_for<0, 2>([&](auto phh) {
+            constexpr int ph = decltype(phh)::value;
+            const int q = 4 * c + 2 + ph;
+            top(q);
+            const char* sl = smem + (q % NSLOT) * GRP + lane * 16;
+            static_for<0, NT2 / 2>([&](auto tt) {
+                constexpr int tl = decltype(tt)::value;
+                constexpr int t = ph * (NT2 / 2) + tl;
 #pragma unroll
-        for (int t = 0; t < NT2; ++t)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const half8 ah = *reinterpret_cast<const half8*>(s2 + (t * 2 + kk) * 2048 + lane * 16);
-                const half8 al = *reinterpret_cast<const half8*>(s2 + (t * 2 + kk) * 2048 + 1024 + lane * 16);
-                out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, uh[kk], out[t], 0, 0, 0);
-                out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ul[kk], out[t], 0, 0, 0);
-                out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, uh[kk], out[t], 0, 0, 0);
-            }
-        if (c + 1 < nchunks) {
-            __syncthreads();                   // every wave is done with the W2 slot
-            issue2(c + 1);
-        }
+                for (int kk = 0; kk < 2; ++kk) {
+                    const half8 ah = *reinterpret_cast<const half8*>(sl + (tl * 2 + kk) * 2048);
+                    const half8 al = *reinterpret_cast<const half8*>(sl + (tl * 2 + kk) * 2048 + 1024);
+                    out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, uh[kk], out[t], 0, 0, 0);
+                    out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ul[kk], out[t], 0, 0, 0);
+                    out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, uh[kk], out[t], 0, 0, 0);
+                }
+            });
+        });
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy refills of the tail
 
     // ---- epilogue: rows of tile t are output channels 32 t + acc_row(r, g); lane column = pixel n
     float cscale = 1.f;
@@ -405,7 +427,7 @@ bool mlp_strip_eligible(int C, int hid, int act) {
     static const bool off = std::getenv("ACE_NO_MLP_STRIP") != nullptr;   // A/B switch for measurements
     if (off) return false;
     if (!(act == ACT_GELU || act == ACT_GELU_FAST)) return false;
-    return (C == 128 || C == 256 || C == 384) && hid % 32 == 0 && hid >= 32;
+    return (C == 128 || C == 256 || C == 384) && hid % 32 == 0 && hid >= 64 && hid <= 4096;
 }
 
 template <int NC>

@@ -9,13 +9,14 @@
 // (DESIGN.md section 3.4); here instead
 //   * a wave owns a 32-column strip of the data operand for the WHOLE contraction: it loads it once (fp32, 128-byte row
 //     segments), splits it into fp16 hi/lo MFMA B fragments in registers (96 VGPRs at K = 192) and never touches it again;
-//   * the table operand arrives as ready-made A fragments (strip_pack.h) by 1-KiB LDS-DMA pieces into a two-slot ring
-//     shared by the four waves of the workgroup, one slot = one 32-row output tile;
+//   * the table operand arrives as ready-made A fragments (strip_pack.h) by 1-KiB LDS-DMA pieces into a three-slot ring
+//     shared by the four waves of the workgroup, one slot = one 32-row output tile, two tiles of lookahead (an LDS-DMA
+//     piece issued under full-chip load lands 2 - 3 us later);
 //   * per tile: one barrier, 3 x 12 MFMAs (f16x3: lo.hi + hi.lo + hi.hi, fp32 accumulate) against the resident strip;
 //   * the epilogue of tile t - 1 (scale, split to fp16 planes or fp32, 8/16-byte row-contiguous stores through a 4 KiB
-//     per-wave LDS transpose) is issued under the MFMAs of tile t, right after the DMA of tile t + 1; everything issued at
-//     the top of an iteration is covered by the single vmcnt(0) at the top of the next one (vmcnt counts stores on
-//     gfx950 and loads / stores may retire out of order with respect to each other, so no counted wait is used);
+//     per-wave LDS transpose) is issued under the MFMAs of tile t, right after the DMA of tile t + 2; vmcnt counts stores
+//     on gfx950 and loads / stores may retire out of order with respect to each other, so the wait at the top of an
+//     iteration is the count that is safe under that rule (see the loop);
 //   * workgroups are dealt to XCDs by m mod 8: the table slice of one m stays in one L2 and every XCD gets the same mix of
 //     heavy (small m) and light (large m) workgroups, heavy ones first.
 #include <hip/hip_runtime.h>
@@ -41,8 +42,9 @@ typedef __attribute__((address_space(3))) char* lds_cptr;
 
 constexpr int KS_MAX = 12;                  // resident k16-steps (K <= 192)
 constexpr int SLOT_BYTES = KS_MAX * 2048;   // one 32-row tile of A fragments (hi + lo)
-constexpr int TS_BYTES = 4096;              // per-wave transpose buffer: 32 rows x 32 dwords
-constexpr int LDS_BYTES = 2 * SLOT_BYTES + 4 * TS_BYTES;
+constexpr int NSLOT = 3;                    // ring depth: tile t + 2 is in flight while tile t is consumed
+constexpr int TS_BYTES = 2048;              // per-wave transpose buffer: 16 rows x 32 dwords (half a tile at a time)
+constexpr int LDS_BYTES = NSLOT * SLOT_BYTES + 4 * TS_BYTES;   // 80 KiB: two workgroups per CU
 
 SDEV unsigned slot_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 SDEV int pow2_exponent_for(float mx) {
@@ -80,22 +82,23 @@ SDEV void strip_body(const LegStripArgs& p, char* smem, const int m, const int g
     const int n = n0 + i;
     const int nc = n < N ? n : N - 1;
     char* ring = smem;
-    char* Ts = smem + 2 * SLOT_BYTES + wave * TS_BYTES;
+    char* Ts = smem + NSLOT * SLOT_BYTES + wave * TS_BYTES;
 
     const unsigned raw_b = p.bmax ? slot_load(p.bmax + lane) : 0u;
 
     // ---- table stream: tile t = nks4 consecutive 2-KiB k-step blocks = 2 nks4 pieces, 2 NG per wave
     const _Float16* Am = p.A + (long)p.tile_off[m] * 1024;
-    auto issue_tile = [&](int t) {
-        const _Float16* src = Am + (long)t * NK * 1024 + lane * 8;
-        const char* dst = ring + (t & 1) * SLOT_BYTES;
+    auto issue_tile = [&](int t) {   // tile t -> slot t % NSLOT; tiles past the end re-fetch the last one (uniform count)
+        const int tt = t < gm.ntiles ? t : gm.ntiles - 1;
+        const _Float16* src = Am + (long)tt * NK * 1024 + lane * 8;
+        const char* dst = ring + (t % NSLOT) * SLOT_BYTES;
 #pragma unroll
         for (int c = 0; c < 2 * NG; ++c) {
             const int pc = wave + 4 * c;
             glds16(src + pc * 512, dst + pc * 1024);
         }
     };
-    if (gm.ntiles > 0) issue_tile(0);
+    if (gm.ntiles > 0) { issue_tile(0); issue_tile(1); }
 
     // ---- resident strip: fp32 rows -> fp16 hi/lo B fragments (lane (i, g) holds k = 16 jj + 8 g .. + 7 of column i)
     const float* Bm = p.B + (long)m * p.b_moff + nc;
@@ -161,48 +164,53 @@ SDEV void strip_body(const LegStripArgs& p, char* smem, const int m, const int g
             }
             return;
         }
-        // park the tile row-major in this wave's transpose buffer: dword (row, column) at row * 32 + column
+        // row-major through this wave's transpose buffer, half a tile (16 rows = 8 accumulator registers) at a time:
+        // dword (row, column) at row * 32 + column, read back as four consecutive columns of one row per lane (8 lanes
+        // cover a row, 8 rows per instruction)
         unsigned* T32 = reinterpret_cast<unsigned*>(Ts);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v = acc[r] * oscale;
-            unsigned w;
-            if (OUT == 1) {
-                const _Float16 h = (_Float16)v;
-                const _Float16 l = (_Float16)(v - (float)h);
-                w = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-            } else {
-                w = __float_as_uint(v);
-            }
-            T32[acc_row(r, g) * 32 + i] = w;
-        }
-        // read back four consecutive columns of one row per lane: 8 lanes cover a row, 8 rows per instruction
         const int c4 = (lane & 7) * 4;
         const int ncol = n0 + c4;
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int rl = ps * 8 + (lane >> 3);
-            const int row = rbase + rl;
-            const u32x4 d = *reinterpret_cast<const u32x4*>(T32 + rl * 32 + c4);
-            const bool ok = NOMASK || (row >= rlo && row < R && ncol < N);
-            if (OUT == 1) {
-                u32x2 hi2, lo2;
-                hi2[0] = (d[0] & 0xffffu) | (d[1] << 16);
-                hi2[1] = (d[2] & 0xffffu) | (d[3] << 16);
-                lo2[0] = (d[0] >> 16) | (d[1] & 0xffff0000u);
-                lo2[1] = (d[2] >> 16) | (d[3] & 0xffff0000u);
-                if (ok) {
-                    const long off = cm + (long)row * p.c_rstride + ncol;
-                    *reinterpret_cast<u32x2*>(p.Chi + off) = hi2;
-                    *reinterpret_cast<u32x2*>(p.Clo + off) = lo2;
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int r = 8 * hf + r8;
+                const float v = acc[r] * oscale;
+                unsigned w;
+                if (OUT == 1) {
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 l = (_Float16)(v - (float)h);
+                    w = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+                } else {
+                    w = __float_as_uint(v);
                 }
-            } else {
-                if (ok) {
-                    f32x4 v;
-                    v[0] = __uint_as_float(d[0]); v[1] = __uint_as_float(d[1]);
-                    v[2] = __uint_as_float(d[2]); v[3] = __uint_as_float(d[3]);
-                    *reinterpret_cast<f32x4*>(p.C + cm + (long)row * p.c_rstride + ncol) = v;
-                    vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                T32[(acc_row(r, g) - 16 * hf) * 32 + i] = w;
+            }
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int rl = ps * 8 + (lane >> 3);           // row within this half
+                const int row = rbase + 16 * hf + rl;
+                const u32x4 d = *reinterpret_cast<const u32x4*>(T32 + rl * 32 + c4);
+                const bool ok = NOMASK || (row >= rlo && row < R && ncol < N);
+                if (OUT == 1) {
+                    u32x2 hi2, lo2;
+                    hi2[0] = (d[0] & 0xffffu) | (d[1] << 16);
+                    hi2[1] = (d[2] & 0xffffu) | (d[3] << 16);
+                    lo2[0] = (d[0] >> 16) | (d[1] & 0xffff0000u);
+                    lo2[1] = (d[2] >> 16) | (d[3] & 0xffff0000u);
+                    if (ok) {
+                        const long off = cm + (long)row * p.c_rstride + ncol;
+                        *reinterpret_cast<u32x2*>(p.Chi + off) = hi2;
+                        *reinterpret_cast<u32x2*>(p.Clo + off) = lo2;
+                    }
+                } else {
+                    if (ok) {
+                        f32x4 v;
+                        v[0] = __uint_as_float(d[0]); v[1] = __uint_as_float(d[1]);
+                        v[2] = __uint_as_float(d[2]); v[3] = __uint_as_float(d[3]);
+                        *reinterpret_cast<f32x4*>(p.C + cm + (long)row * p.c_rstride + ncol) = v;
+                        vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                    }
                 }
             }
         }
@@ -212,12 +220,18 @@ SDEV void strip_body(const LegStripArgs& p, char* smem, const int m, const int g
     f32x16 prev;
 #pragma unroll
     for (int r = 0; r < 16; ++r) prev[r] = 0.f;
+    // vmcnt counts stores too and loads / stores may retire out of order with respect to each other, so the wait is not a
+    // plain count of newer operations.  Queue at the top of iteration t >= 1 (issue order): [pieces of tile t | stores of
+    // tile t - 3] from iteration t - 2, [pieces of tile t + 1 | stores of tile t - 2] from iteration t - 1.  Loads retire in
+    // order, so "a piece of tile t pending" implies "all 2 NG pieces of tile t + 1 pending", i.e. more than 2 NG
+    // operations outstanding: vmcnt(2 NG) therefore guarantees tile t has landed, while tile t + 1 may stay in flight.
     for (int t = 0; t < gm.ntiles; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile t (and the stores of tile t - 2)
+        if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tiles 0 and 1 and the data strip
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NG) : "memory");
         __syncthreads();                                     // every share landed; every wave is done reading tile t - 1
-        if (t + 1 < gm.ntiles) issue_tile(t + 1);
+        issue_tile(t + 2);                                   // ... whose slot is refilled now (a dummy past the end)
         if (t > 0) store_tile(t - 1, prev, std::true_type{});
-        const char* slot = ring + (t & 1) * SLOT_BYTES + lane * 16;
+        const char* slot = ring + (t % NSLOT) * SLOT_BYTES + lane * 16;
         f32x16 a0, a1, a2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; }
