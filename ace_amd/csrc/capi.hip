@@ -278,8 +278,8 @@ extern "C" int ace_sht_forward(ace_sht_plan* p, const float* x, float* coeffs, i
     if (!p || !x || !coeffs || n <= 0) return fail(ACE_ERR_INVALID, "ace_sht_forward: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long N2 = 2L * n;
-    HIP_TRY(p->X.ensure((size_t)p->mmax * p->nlat * N2));
-    HIP_TRY(p->D.ensure((size_t)p->lmax * p->mmax * N2));
+    HIP_TRY(p->X.ensure(((size_t)p->mmax * p->nlat + LEG_STRIP_SLACK_ROWS) * N2));
+    HIP_TRY(p->D.ensure(((size_t)p->lmax + LEG_STRIP_SLACK_ROWS) * p->mmax * N2));
     // coefficients with l < m are never written by the triangular Legendre stage: they are zero
     HIP_TRY(hipMemsetAsync(p->D.p, 0, (size_t)p->lmax * p->mmax * N2 * sizeof(float), s));
     unsigned* xmax = nullptr;
@@ -296,8 +296,8 @@ extern "C" int ace_sht_inverse(ace_sht_plan* p, const float* coeffs, float* x, i
     if (!p || !x || !coeffs || n <= 0) return fail(ACE_ERR_INVALID, "ace_sht_inverse: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long N2 = 2L * n;
-    HIP_TRY(p->X.ensure((size_t)p->mmax * p->nlat * N2));
-    HIP_TRY(p->D.ensure((size_t)p->lmax * p->mmax * N2));
+    HIP_TRY(p->X.ensure(((size_t)p->mmax * p->nlat + LEG_STRIP_SLACK_ROWS) * N2));
+    HIP_TRY(p->D.ensure(((size_t)p->lmax + LEG_STRIP_SLACK_ROWS) * p->mmax * N2));
     HIP_TRY(launch_ref_to_spec(coeffs, p->D.p, 1, n, p->lmax, p->mmax, s));
     unsigned* emax = nullptr;
     if (p->f16 && p->slots.p) {   // f16x3: range of the coefficients (entries with l < m are zero after the conversion)
@@ -687,8 +687,9 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
                             ((long)n->Bmax * 2 * n->C) % 4 == 0) ? 1 : 0;
     }
     const size_t act = (size_t)n->Bmax * C * HW;
-    const size_t spec_x = (size_t)n->Mm * n->H * n->Bmax * 2 * C;
-    const size_t spec_d = (size_t)n->L * n->Mm * n->Bmax * 2 * C;
+    // + slack rows read (never used) by the strip Legendre kernels past the last contraction row
+    const size_t spec_x = ((size_t)n->Mm * n->H + LEG_STRIP_SLACK_ROWS) * n->Bmax * 2 * C;
+    const size_t spec_d = ((size_t)n->L + LEG_STRIP_SLACK_ROWS) * n->Mm * n->Bmax * 2 * C;
     HIP_TRY(n->h0.alloc(act));
     HIP_TRY(n->h1.alloc(act));
     HIP_TRY(n->Y.alloc(act));

@@ -137,6 +137,9 @@ struct LegStripArgs {
     int nbatch = 0;   // mmax
     int mode = 0;     // 0 forward (rows l >= m), 1 inverse (contraction over l >= m)
 };
+// the kernels read up to 15 rows (of b_kstride elements) past the last contraction row of the last batch: buffers they read
+// must carry this many rows of slack
+constexpr int LEG_STRIP_SLACK_ROWS = 16;
 bool legendre_strip_eligible(const LegStripArgs& a);
 hipError_t launch_legendre_strip(const LegStripArgs& a, hipStream_t s);
 

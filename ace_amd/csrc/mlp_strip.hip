@@ -24,6 +24,9 @@ namespace ace {
 namespace {
 
 #define MDEV __device__ __forceinline__
+#ifndef ACE_MLP_FDEPTH
+#define ACE_MLP_FDEPTH 2
+#endif
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -87,6 +90,42 @@ MDEV void rows_to_kgroups(f32x16& v) {
 }
 
 template <int I0, int I1, class F>
+MDEV void static_for(F&& f);
+
+// A-fragment reads with a hand-managed pipeline.  hipcc, left alone at 480 registers per lane, reuses ONE fragment register
+// set and waits lgkmcnt(0) before every MFMA (r02 profile: half of the kernel's time in s_waitcnt); as inline asm the reads
+// are invisible to its bookkeeping, so they are issued DEPTH k-steps ahead and retired by a counted wait that names the
+// destination registers (the data dependence keeps the consuming MFMAs below it).  LDS operations retire in order, so
+// "lgkmcnt <= N" means all but the newest N have landed, whatever scalar loads are in flight.
+struct Frag { half8 h, l; };
+template <int OFF>
+MDEV void frag_issue(Frag& f, unsigned lds_addr) {
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                 : "=&v"(f.h), "=&v"(f.l)
+                 : "v"(lds_addr), "n"(OFF), "n"(OFF + 1024));
+}
+template <int N>
+MDEV void frag_wait(Frag& f) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.h), "+v"(f.l) : "n"(N));
+}
+// NS k-steps of one group: body(step, fragment) with the fragments of the steps s + 1 .. s + DEPTH already requested
+template <int NS, int DEPTH, class F>
+MDEV void pipelined_steps(unsigned lds_addr, F&& body) {
+    Frag fr[DEPTH + 1];
+    static_for<0, (DEPTH < NS ? DEPTH : NS)>([&](auto ss) {
+        constexpr int s0 = decltype(ss)::value;
+        frag_issue<s0 * 2048>(fr[s0 % (DEPTH + 1)], lds_addr);
+    });
+    static_for<0, NS>([&](auto ss) {
+        constexpr int st = decltype(ss)::value;
+        if constexpr (st + DEPTH < NS) frag_issue<(st + DEPTH) * 2048>(fr[(st + DEPTH) % (DEPTH + 1)], lds_addr);
+        constexpr int newer = (NS - 1 - st) < DEPTH ? (NS - 1 - st) : DEPTH;   // requested after step st's fragments
+        frag_wait<2 * newer>(fr[st % (DEPTH + 1)]);
+        body(ss, fr[st % (DEPTH + 1)]);
+    });
+}
+
+template <int I0, int I1, class F>
 MDEV void static_for(F&& f) {
     if constexpr (I0 < I1) {
         f(std::integral_constant<int, I0>{});
@@ -139,6 +178,7 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
     constexpr int PW = NC / 2;              // 1-KiB pieces per wave per group
     constexpr int RING = NSLOT * GRP;
     constexpr int B1MAX = 4096;             // hidden units whose folded bias is kept in LDS
+    constexpr int FDEPTH = ACE_MLP_FDEPTH;  // k-steps of fragment read-ahead
     __shared__ __attribute__((aligned(16))) char smem[RING + B1MAX * 4];
     float* b1s = reinterpret_cast<float*>(smem + RING);
     const int tid = threadIdx.x;
@@ -229,21 +269,18 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { u0[r] = 0.f; u1[r] = 0.f; }
         // ---- fc1 of chunk c: two k-halves
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
+        static_for<0, 2>([&](auto phh) {
+            constexpr int ph = decltype(phh)::value;
             const int q = 4 * c + ph;
             top(q);
-            const char* sl = smem + (q % NSLOT) * GRP + lane * 16;
-#pragma unroll
-            for (int jj = 0; jj < NC; ++jj) {
-                const int j = ph * NC + jj;
-                const half8 ah = *reinterpret_cast<const half8*>(sl + jj * 2048);
-                const half8 al = *reinterpret_cast<const half8*>(sl + jj * 2048 + 1024);
-                u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[j], u0, 0, 0, 0);
-                u1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[j], u1, 0, 0, 0);
-                u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[j], u0, 0, 0, 0);
-            }
-        }
+            const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (q % NSLOT) * GRP) + lane * 16;
+            pipelined_steps<NC, FDEPTH>(sl, [&](auto ss, const Frag& f) {
+                constexpr int j = ph * NC + decltype(ss)::value;
+                u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l, xh[j], u0, 0, 0, 0);
+                u1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, xl[j], u1, 0, 0, 0);
+                u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, xh[j], u0, 0, 0, 0);
+            });
+        });
         f32x16 u = u0 + u1;
         // bias of this lane's rows after the swap: rows 8 g + e (e < 8) and 16 + 8 g + e
         const f32x4 bA = *reinterpret_cast<const f32x4*>(b1s + 32 * c + 8 * g);
@@ -267,18 +304,13 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
             constexpr int ph = decltype(phh)::value;
             const int q = 4 * c + 2 + ph;
             top(q);
-            const char* sl = smem + (q % NSLOT) * GRP + lane * 16;
-            static_for<0, NT2 / 2>([&](auto tt) {
-                constexpr int tl = decltype(tt)::value;
-                constexpr int t = ph * (NT2 / 2) + tl;
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const half8 ah = *reinterpret_cast<const half8*>(sl + (tl * 2 + kk) * 2048);
-                    const half8 al = *reinterpret_cast<const half8*>(sl + (tl * 2 + kk) * 2048 + 1024);
-                    out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, uh[kk], out[t], 0, 0, 0);
-                    out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ul[kk], out[t], 0, 0, 0);
-                    out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, uh[kk], out[t], 0, 0, 0);
-                }
+            const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (q % NSLOT) * GRP) + lane * 16;
+            pipelined_steps<NC, FDEPTH>(sl, [&](auto ss, const Frag& f) {
+                constexpr int st = decltype(ss)::value;
+                constexpr int t = ph * (NT2 / 2) + st / 2, kk = st % 2;
+                out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l, uh[kk], out[t], 0, 0, 0);
+                out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, ul[kk], out[t], 0, 0, 0);
+                out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, uh[kk], out[t], 0, 0, 0);
             });
         });
     }

@@ -110,24 +110,29 @@ SDEV void strip_body(const LegStripArgs& p, char* smem, const int m, const int g
         bscale = ldexpf(1.0f, eb);
         inv_b = ldexpf(1.0f, -eb);
     }
+    // Loads are un-clamped per lane and (almost) un-masked: contraction indices outside [klo, K) meet ZERO table fragments,
+    // so any finite value will do there.  Indices >= K read at most 15 rows past K: the next batch's rows or the 16 rows of
+    // zero slack the library's buffers carry (LEG_STRIP_SLACK_ROWS); padded k-steps re-read the last real one (wave-uniform
+    // clamp).  Indices below klo (inverse: l < m, never written by the producer - possibly stale bits of another layout)
+    // only occur in the first resident k-step and are zeroed there.
     half8 bh[NK], bl[NK];
     {
+        const int klast16 = (K + 15) / 16 - 1;                // last k16-step with real data
+        const float* Bl = Bm + (long)(8 * g) * ks;
         float raw[NK][8];
 #pragma unroll
+        for (int jj = 0; jj < NK; ++jj) {
+            const int kstep = gm.j0 + jj < klast16 ? gm.j0 + jj : klast16;
+            const long rowoff = (long)(16 * kstep) * ks;       // wave-uniform
+#pragma unroll
+            for (int e = 0; e < 8; ++e) raw[jj][e] = Bl[rowoff + (long)e * ks];
+        }
+#pragma unroll
         for (int jj = 0; jj < NK; ++jj)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int k = 16 * (gm.j0 + jj) + 8 * g + e;
-                const int kc = k < K ? k : K - 1;
-                raw[jj][e] = Bm[(long)kc * ks];
-            }
-#pragma unroll
-        for (int jj = 0; jj < NK; ++jj)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = 16 * (gm.j0 + jj) + 8 * g + e;
-                const bool ok = k >= gm.klo && k < K;
-                const float x = ok ? raw[jj][e] * bscale : 0.f;
+                float x = raw[jj][e] * bscale;
+                if (jj == 0) x = (16 * gm.j0 + 8 * g + e) >= gm.klo ? x : 0.f;
                 const _Float16 h = (_Float16)x;
                 bh[jj][e] = h;
                 bl[jj][e] = (_Float16)(x - (float)h);

@@ -29,8 +29,10 @@ static double run_case(int mode, int H, int L, int M, int N, unsigned seed) {
             }
     // data operand in the kernel's addressing: element (m, k, n) at m * b_moff + k * b_kstride + n
     const long b_kstride = mode == 0 ? N : (long)M * N, b_moff = mode == 0 ? (long)H * N : N;
-    std::vector<float> B((size_t)M * K * N);
-    for (auto& v : B) v = U(rng);
+    // + 16 rows of zero slack past the last contraction row (LEG_STRIP_SLACK_ROWS in kernels.h)
+    const size_t bsize = mode == 0 ? ((size_t)M * K + 16) * N : ((size_t)K + 16) * M * N;
+    std::vector<float> B(bsize, 0.f);
+    for (size_t q = 0; q < (size_t)M * K * N; ++q) B[q] = U(rng);
     if (mode == 1)   // entries with l < m are never written by the producer: poison them
         for (int l = 0; l < K; ++l)
             for (int m = l + 1; m < M; ++m)
@@ -51,16 +53,18 @@ static double run_case(int mode, int H, int L, int M, int N, unsigned seed) {
                 const int n0 = grp * 128 + wave * 32;
                 // resident strip
                 std::vector<double> bfrag((size_t)gm.nks4 * 64 * 8);
+                const int klast16 = (K + 15) / 16 - 1;
                 for (int jj = 0; jj < gm.nks4; ++jj)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int i = lane & 31, g = lane >> 5;
                         const int n = n0 + i, nc = n < N ? n : N - 1;
+                        const int kstep = gm.j0 + jj < klast16 ? gm.j0 + jj : klast16;   // padded k-steps re-read the last real one
                         for (int e = 0; e < 8; ++e) {
-                            const int k = 16 * (gm.j0 + jj) + 8 * g + e;
-                            const int kc = k < K ? k : K - 1;
-                            const float raw = B[(size_t)m * b_moff + (size_t)kc * b_kstride + nc];
-                            const bool ok = k >= gm.klo && k < K;
-                            bfrag[((size_t)jj * 64 + lane) * 8 + e] = ok ? raw : 0.0;
+                            const size_t at = (size_t)m * b_moff + (size_t)(16 * kstep + 8 * g + e) * b_kstride + nc;
+                            if (at >= B.size()) { std::printf("B read out of bounds\n"); return 1e9; }
+                            double x = B[at];                                        // un-masked: zero table rows kill k >= K
+                            if (jj == 0 && 16 * gm.j0 + 8 * g + e < gm.klo) x = 0.0;  // ... only l < m needs the explicit zero
+                            bfrag[((size_t)jj * 64 + lane) * 8 + e] = x;
                         }
                     }
                 for (int t = 0; t < gm.ntiles; ++t) {
