@@ -89,6 +89,13 @@ MDEV void rows_to_kgroups(f32x16& v) {
         }
 }
 
+#ifdef ACE_X_TRACE   // measurement build only (tools/trace_mlp.py): s_memtime stamps of wave 0 of one workgroup
+__device__ unsigned long long mlp_trace[512];
+#define MT(ev) do { if (blockIdx.x == ACE_X_TRACE && threadIdx.x == 0 && (ev) < 512) mlp_trace[ev] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MT(ev) do { } while (0)
+#endif
+
 template <int I0, int I1, class F>
 MDEV void static_for(F&& f);
 
@@ -133,38 +140,6 @@ MDEV void static_for(F&& f) {
     }
 }
 
-// Row statistics of an 8-row x 32-column block held as v[0..7] per lane (lane = column, the 32 lanes of one half-wave):
-// butterfly with halving - after the offsets 16, 8, 4 every lane holds ONE partially reduced row (row index = bits 4..2 of
-// the lane, bit-reversed order handled by the caller through the returned row id), offsets 2 and 1 finish it.
-// 9 exchanges per quantity instead of 40.
-template <class Op>
-MDEV float reduce8(const float (&v)[8], int i, Op op, int* row_of_lane) {
-    float a[4];
-    const bool up16 = (i & 16) != 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float mine = up16 ? v[4 + r] : v[r];        // rows this lane keeps
-        const float send = up16 ? v[r] : v[4 + r];        // rows the partner keeps
-        a[r] = op(mine, __shfl_xor(send, 16, 64));
-    }
-    float b[2];
-    const bool up8 = (i & 8) != 0;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const float mine = up8 ? a[2 + r] : a[r];
-        const float send = up8 ? a[r] : a[2 + r];
-        b[r] = op(mine, __shfl_xor(send, 8, 64));
-    }
-    const bool up4 = (i & 4) != 0;
-    const float mine = up4 ? b[1] : b[0];
-    const float send = up4 ? b[0] : b[1];
-    float c = op(mine, __shfl_xor(send, 4, 64));
-    c = op(c, __shfl_xor(c, 2, 64));
-    c = op(c, __shfl_xor(c, 1, 64));
-    *row_of_lane = (up16 ? 4 : 0) + (up8 ? 2 : 0) + (up4 ? 1 : 0);
-    return c;
-}
-
 // NC = C / 32: KS1 = 2 NC k16-steps of fc1, NT2 = NC 32-row output tiles of fc2.  The two weight matrices are one stream
 // of GROUPS of NC k-step blocks (NC * 2 KiB): per hidden chunk c the groups 4c, 4c+1 are the two k-halves of the W1 chunk
 // (32 hidden rows x C) and 4c+2, 4c+3 the two row-halves of the W2 chunk (C rows x 32 hidden).  A ring of six groups in
@@ -193,6 +168,7 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
     const int nchunks = p.hid / 32;
     const int ngroups = 4 * nchunks;
 
+    MT(0);
     const unsigned raw_x = slot_load(p.xslot + lane);
     const unsigned raw_a = slot_load(p.a1slot + lane);
     const unsigned raw_c = slot_load(p.cinb + lane);
@@ -229,7 +205,12 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
     }
     {   // folded fc1 bias of this sample -> LDS (read back per chunk with ds_read: no vector-memory load inside the loop)
         const float* b1 = p.b1 + (long)smp * p.sb1;
-        for (int k = tid; k < p.hid; k += 256) b1s[k] = b1[k];
+        float bv[B1MAX / 256];
+#pragma unroll
+        for (int k = 0; k < B1MAX / 256; ++k) bv[k] = b1[(tid + 256 * k) < p.hid ? tid + 256 * k : 0];   // one batch of loads
+#pragma unroll
+        for (int k = 0; k < B1MAX / 256; ++k)
+            if (tid + 256 * k < p.hid) b1s[tid + 256 * k] = bv[k];
     }
     const float xbound = wave_max_bits(raw_x);
     const float inv_x = ldexpf(1.0f, -pow2_exponent_for(xbound));
@@ -249,10 +230,13 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
 
     // Everything loaded so far is consumed HERE: hipcc places its own (counted) waits for a plain load at its first use
     // and knows nothing of the LDS-DMA pieces, so a first use inside the loop would drain the ring every iteration.
+    MT(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MT(2);
 #pragma unroll
     for (int j = 0; j < KS1; ++j) asm volatile("" : "+v"(xh[j]), "+v"(xl[j]));
     __syncthreads();                       // bias table visible; groups 0 and 1 landed in every wave's share
+    MT(3);
 #pragma unroll
     for (int q = 2; q < AHEAD; ++q) issue(q);
 
@@ -260,9 +244,20 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
     // stores), so the counted wait is exact.  At the top of group q the queue holds the groups q .. q + AHEAD - 1 that
     // have not landed; vmcnt((AHEAD - 1) * PW) retires exactly group q.
     auto top = [&](int q) {
+        MT(8 + 4 * q);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PW) : "memory");
+        MT(9 + 4 * q);
         __builtin_amdgcn_s_barrier();      // group q landed in every wave's share; every wave is done with group q - 1
-        issue(q + AHEAD);                  // ... whose slot is refilled now
+        MT(10 + 4 * q);
+    };
+    // ... whose slot is refilled DURING the steps of group q: one 1-KiB piece every NC / PW steps, between the MFMA triples
+    // (an LDS-DMA issue costs ~90 cycles of the wave's issue slot; six of them at the top of a group stalled the matrix pipe
+    // for 500 cycles per group, 19 % of the loop - r02 in-kernel timeline)
+    auto piece_src = [&](int q) -> const _Float16* {
+        const int qq = q < ngroups ? q : ngroups - 1;
+        const int c = qq >> 2, ph = qq & 3;
+        return (ph < 2 ? A1 + (long)c * (KS1 * 1024) + (long)ph * (NC * 1024)
+                       : A2 + (long)c * (NT2 * 2 * 1024) + (long)(ph - 2) * (NC * 1024)) + lane * 8 + wave * 512;
     };
     for (int c = 0; c < nchunks; ++c) {
         f32x16 u0, u1;
@@ -274,11 +269,15 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
             const int q = 4 * c + ph;
             top(q);
             const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (q % NSLOT) * GRP) + lane * 16;
+            const _Float16* nsrc = piece_src(q + AHEAD);
+            const char* ndst = smem + ((q + AHEAD) % NSLOT) * GRP + wave * 1024;
             pipelined_steps<NC, FDEPTH>(sl, [&](auto ss, const Frag& f) {
-                constexpr int j = ph * NC + decltype(ss)::value;
+                constexpr int st = decltype(ss)::value;
+                constexpr int j = ph * NC + st;
                 u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l, xh[j], u0, 0, 0, 0);
                 u1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, xl[j], u1, 0, 0, 0);
                 u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, xh[j], u0, 0, 0, 0);
+                if constexpr (st % (NC / PW) == 0) glds16(nsrc + (st / (NC / PW)) * 4 * 512, ndst + (st / (NC / PW)) * 4 * 1024);
             });
         });
         f32x16 u = u0 + u1;
@@ -290,31 +289,36 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
         rows_to_kgroups(u);
         half8 uh[2], ul[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float bv0 = e < 4 ? bA[e & 3] : bB[e & 3];
-            const float bv1 = e < 4 ? bC[e & 3] : bD[e & 3];
-            const float y0 = act_fn<ACT>(fmaf(u[e], s_fc1, bv0)) * uscale;
-            const float y1 = act_fn<ACT>(fmaf(u[8 + e], s_fc1, bv1)) * uscale;
-            const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
-            uh[0][e] = h0; ul[0][e] = (_Float16)(y0 - (float)h0);
-            uh[1][e] = h1; ul[1][e] = (_Float16)(y1 - (float)h1);
-        }
-        // ---- fc2 of chunk c: two halves of NT2 / 2 output tiles x 2 k-steps
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float bv = kk == 0 ? (e < 4 ? bA[e & 3] : bB[e & 3]) : (e < 4 ? bC[e & 3] : bD[e & 3]);
+                const float y = act_fn<ACT>(fmaf(u[8 * kk + e], s_fc1, bv)) * uscale;
+                const _Float16 h = (_Float16)y;
+                uh[kk][e] = h;
+                ul[kk][e] = (_Float16)(y - (float)h);
+            }
+        // ---- fc2 of chunk c: k-step 0 of all NT2 output tiles, then k-step 1 (the GELU of the second 16 hidden rows runs
+        //      under the MFMAs of the first; three dependent MFMAs per accumulator and phase instead of six)
         static_for<0, 2>([&](auto phh) {
-            constexpr int ph = decltype(phh)::value;
-            const int q = 4 * c + 2 + ph;
+            constexpr int kk = decltype(phh)::value;
+            const int q = 4 * c + 2 + kk;
             top(q);
             const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (q % NSLOT) * GRP) + lane * 16;
+            const _Float16* nsrc = piece_src(q + AHEAD);
+            const char* ndst = smem + ((q + AHEAD) % NSLOT) * GRP + wave * 1024;
             pipelined_steps<NC, FDEPTH>(sl, [&](auto ss, const Frag& f) {
-                constexpr int st = decltype(ss)::value;
-                constexpr int t = ph * (NT2 / 2) + st / 2, kk = st % 2;
+                constexpr int t = decltype(ss)::value;
                 out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l, uh[kk], out[t], 0, 0, 0);
                 out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, ul[kk], out[t], 0, 0, 0);
                 out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, uh[kk], out[t], 0, 0, 0);
+                if constexpr (t % (NC / PW) == 0) glds16(nsrc + (t / (NC / PW)) * 4 * 512, ndst + (t / (NC / PW)) * 4 * 1024);
             });
         });
     }
+    MT(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy refills of the tail
+    MT(5);
 
     // ---- epilogue: rows of tile t are output channels 32 t + acc_row(r, g); lane column = pixel n
     float cscale = 1.f;
@@ -331,8 +335,106 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
     float vmax = 0.f;
     const bool nok = n < p.HW;
     const long HW = p.HW;
-    static_for<0, NT2>([&](auto tt) {
-        constexpr int t = decltype(tt)::value;
+    // per-wave transpose buffer of the row statistics and the per-row epilogue parameters, in the ring: every wave's tail
+    // refills have landed and every wave is out of the main loop once the barrier below has been passed
+    __syncthreads();
+    float* St = reinterpret_cast<float*>(smem) + wave * (33 * 32);
+    float* Pb = reinterpret_cast<float*>(smem) + 4 * (33 * 32);      // [Cch] b2 + rsh
+    float* Ps = Pb + NC * 32;                                         // [Cch] rsc
+    for (int k = tid; k < NC * 32; k += 256) {
+        Pb[k] = p.b2[k] + (rsh ? rsh[k] : 0.f);
+        Ps[k] = rsc ? rsc[k] : 1.f;
+    }
+    __syncthreads();
+    const int ncols_ok = p.HW - n0 < 32 ? (p.HW - n0 > 0 ? p.HW - n0 : 0) : 32;
+    if (ncols_ok == 32) {
+        // ---- whole strip (all but the last workgroup): no masks, buffer addressing (per-lane offset once, per-row
+        //      offsets wave-uniform in soffset: no address arithmetic per access)
+        const int plane_bytes = NC * 32 * p.HW * 4;
+        const auto rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R + (long)smp * p.sR), 0, plane_bytes, 0x00020000);
+        const auto rsC = __builtin_amdgcn_make_buffer_rsrc(p.C + (long)smp * p.sC, 0, plane_bytes, 0x00020000);
+        const auto rsH = __builtin_amdgcn_make_buffer_rsrc(PK ? p.Chi + (long)smp * p.sCp : nullptr, 0, plane_bytes, 0x00020000);
+        const auto rsL = __builtin_amdgcn_make_buffer_rsrc(PK ? p.Clo + (long)smp * p.sCp : nullptr, 0, plane_bytes, 0x00020000);
+        const int voff = (8 * g * p.HW + n) * 4;          // fp32 element (row 8 g, column n)
+        const int voffp = (g * p.HW + n) * 16;            // P entry (k group g, column n)
+        const int rowb = p.HW * 4;                        // bytes per channel row
+        static_for<0, 2>([&](auto hh) {
+            constexpr int th = decltype(hh)::value;
+            float resv[NT2 / 2][16];
+            static_for<0, NT2 / 2>([&](auto tt) {
+                constexpr int tl = decltype(tt)::value;
+                constexpr int t = th * (NT2 / 2) + tl;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    resv[tl][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsR, voff, (32 * t + 16 * (r >> 3) + (r & 7)) * rowb, 0));
+            });
+            static_for<0, NT2 / 2>([&](auto tt) {
+                constexpr int tl = decltype(tt)::value;
+                constexpr int t = th * (NT2 / 2) + tl;
+                f32x16 v = out[t];
+                rows_to_kgroups(v);
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {
+                    const int row0 = 32 * t + 16 * hq + 8 * g;
+                    const f32x4 ba = *reinterpret_cast<const f32x4*>(Pb + row0), bb = *reinterpret_cast<const f32x4*>(Pb + row0 + 4);
+                    const f32x4 sa = *reinterpret_cast<const f32x4*>(Ps + row0), sb = *reinterpret_cast<const f32x4*>(Ps + row0 + 4);
+                    float val[8];
+                    half8 hh8, ll8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float bq = e < 4 ? ba[e & 3] : bb[e & 3];
+                        const float sq_ = e < 4 ? sa[e & 3] : sb[e & 3];
+                        val[e] = fmaf(resv[tl][8 * hq + e], sq_, fmaf(v[8 * hq + e], s_fc2, bq));
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[e]), rsC, voff, (32 * t + 16 * hq + e) * rowb, 0);
+                        vmax = fmaxf(vmax, fabsf(val[e]));
+                        if (PK) {
+                            const float xs = val[e] * cscale;
+                            const _Float16 a16 = (_Float16)xs;
+                            hh8[e] = a16;
+                            ll8[e] = (_Float16)(xs - (float)a16);
+                        }
+                        if (p.part) St[i * 33 + 16 * hq + 8 * g + e] = val[e];
+                    }
+                    if (PK) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hh8), rsH, voffp, (4 * t + 2 * hq) * p.HW * 16, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ll8), rsL, voffp, (4 * t + 2 * hq) * p.HW * 16, 0);
+                    }
+                }
+                if (p.part) {   // row statistics over this wave's 32 pixels: see the masked path below
+                    float sm = 0.f, sq = 0.f, mn = 3.0e38f, mx = -3.0e38f;
+#pragma unroll
+                    for (int cc = 0; cc < 16; ++cc) {
+                        const float x = St[(16 * g + cc) * 33 + i];
+                        sm += x;
+                        sq = fmaf(x, x, sq);
+                        mn = fminf(mn, x);
+                        mx = fmaxf(mx, x);
+                    }
+                    sm += __shfl_xor(sm, 32, 64);
+                    sq += __shfl_xor(sq, 32, 64);
+                    mn = fminf(mn, __shfl_xor(mn, 32, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    if (g == 0) p.part[((long)smp * p.nstrips32 + (n0 >> 5)) * p.Cch + 32 * t + i] = make_float4(sm, sq, mn, mx);
+                }
+            });
+        });
+    } else {
+    // ---- ragged strip (last workgroup): masked, plain addressing
+    // the input strip is dead: its registers take the residual strip in TWO batches of loads (per-tile loads cost a memory
+    // round trip under full load each: 70 k cycles of epilogue in the r02 timeline)
+    static_for<0, 2>([&](auto hh) {
+    constexpr int th = decltype(hh)::value;
+    float resv[NT2 / 2][16];
+    static_for<0, NT2 / 2>([&](auto tt) {
+        constexpr int t = th * (NT2 / 2) + decltype(tt)::value;
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) resv[t - th * (NT2 / 2)][8 * hq + e] = R[(long)(32 * t + 16 * hq + 8 * g + e) * HW];
+    });
+    static_for<0, NT2 / 2>([&](auto tt) {
+        constexpr int tl = decltype(tt)::value;
+        constexpr int t = th * (NT2 / 2) + tl;
         f32x16 v = out[t];
         rows_to_kgroups(v);      // rows 8 g + e and 16 + 8 g + e: whole P entries, 8 consecutive channel rows
 #pragma unroll
@@ -345,9 +447,6 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
                 sa = *reinterpret_cast<const f32x4*>(rsc + row0); sb = *reinterpret_cast<const f32x4*>(rsc + row0 + 4);
                 ta = *reinterpret_cast<const f32x4*>(rsh + row0); tb = *reinterpret_cast<const f32x4*>(rsh + row0 + 4);
             }
-            float res[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) res[e] = R[(long)(row0 + e) * HW];
             float val[8];
             half8 hh, ll;
 #pragma unroll
@@ -355,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
                 const float bb = e < 4 ? b2a[e & 3] : b2b[e & 3];
                 const float rs = e < 4 ? sa[e & 3] : sb[e & 3];
                 const float rt = e < 4 ? ta[e & 3] : tb[e & 3];
-                val[e] = fmaf(v[8 * hq + e], s_fc2, bb) + fmaf(res[e], rs, rt);
+                val[e] = fmaf(v[8 * hq + e], s_fc2, bb) + fmaf(resv[tl][8 * hq + e], rs, rt);
                 if (nok) Cc[(long)(row0 + e) * HW] = val[e];
                 vmax = fmaxf(vmax, nok ? fabsf(val[e]) : 0.f);
                 if (PK) {
@@ -370,25 +469,36 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
                 *reinterpret_cast<half8*>(p.Chi + (long)smp * p.sCp + eo) = hh;
                 *reinterpret_cast<half8*>(p.Clo + (long)smp * p.sCp + eo) = ll;
             }
-            if (p.part) {   // wave-uniform: row statistics over this wave's 32 pixels (sum, sum of squares, min, max)
-                float q1[8], q2[8], q3[8], q4[8];
+            if (p.part) {   // wave-uniform: park the final values transposed for the row statistics below
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    q1[e] = nok ? val[e] : 0.f;
-                    q2[e] = nok ? val[e] * val[e] : 0.f;
-                    q3[e] = nok ? val[e] : 3.0e38f;
-                    q4[e] = nok ? val[e] : -3.0e38f;
-                }
-                int rl;
-                const float sm = reduce8(q1, i, [](float a, float b) { return a + b; }, &rl);
-                const float sq = reduce8(q2, i, [](float a, float b) { return a + b; }, &rl);
-                const float mn = reduce8(q3, i, [](float a, float b) { return fminf(a, b); }, &rl);
-                const float mx = reduce8(q4, i, [](float a, float b) { return fmaxf(a, b); }, &rl);
-                if ((i & 3) == 0)
-                    p.part[((long)smp * p.nstrips32 + (n0 >> 5)) * p.Cch + row0 + rl] = make_float4(sm, sq, mn, mx);
+                for (int e = 0; e < 8; ++e) St[i * 33 + 16 * hq + 8 * g + e] = val[e];
             }
         }
+        if (p.part) {
+            // Row statistics over this wave's 32 pixels (sum, sum of squares, min, max) through a per-wave LDS transpose:
+            // value (row, column) sits at column * 33 + row, lane (i, g) walks row i over the columns 16 g .. 16 g + 15
+            // (conflict-free both ways), the two half-waves meet in one exchange.  ~110 instructions per tile instead of
+            // ~600 for a shuffle butterfly over 16 registers x 4 quantities.
+            float sm = 0.f, sq = 0.f, mn = 3.0e38f, mx = -3.0e38f;
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) {
+                const float x = St[(16 * g + cc) * 33 + i];
+                const bool ok = 16 * g + cc < ncols_ok;
+                sm += ok ? x : 0.f;
+                sq = ok ? fmaf(x, x, sq) : sq;
+                mn = ok ? fminf(mn, x) : mn;
+                mx = ok ? fmaxf(mx, x) : mx;
+            }
+            sm += __shfl_xor(sm, 32, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            mn = fminf(mn, __shfl_xor(mn, 32, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (g == 0) p.part[((long)smp * p.nstrips32 + (n0 >> 5)) * p.Cch + 32 * t + i] = make_float4(sm, sq, mn, mx);
+        }
     });
+    });
+    }
+    MT(6);
     if (p.omax) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
@@ -402,11 +512,15 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
 
 }  // namespace
 
+#ifdef ACE_X_TRACE
+extern "C" int ace_debug_mlp_trace(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mlp_trace), sizeof(mlp_trace)); }
+#endif
+
 // A-fragment packing of a conv weight W (O x I, row pitch ldw), optionally with a per-input-channel scale folded in
 // (instance-norm affine: W diag(a)), as fp16 hi/lo blocks of 64 lanes x 8 halves (strip_pack.h layout: lane = i + 32 g holds
 // row 32 T + i, columns 16 J + 8 g .. + 7):
 //   order 0 (streamed by output-row chunk, fc1): block (T, J) at T * (I / 16) + J
-//   order 1 (streamed by 32-column chunk, fc2):  block (T, J) at ((J / 2) * (O / 32) + T) * 2 + (J % 2)
+//   order 1 (streamed by 16-column step, fc2):   block (T, J) at J * (O / 32) + T
 // O % 32 == 0, I % 16 == 0.  scale: a power of two, or derived from `bound` = wmax * max|a| (published to wslot).
 __global__ __launch_bounds__(256) void pack_conv_frag_kernel(const float* __restrict__ W, long ldw, int O, int I, int order,
                                                              const float* __restrict__ a, float wmax, float scale_static,
@@ -429,7 +543,7 @@ __global__ __launch_bounds__(256) void pack_conv_frag_kernel(const float* __rest
     const int nJ = I / 16, nT = O / 32;
     const int blk = blockIdx.x;                 // one workgroup = one (T, J) block: 512 elements, two per thread
     const int T = blk / nJ, J = blk % nJ;
-    const long bidx = order == 0 ? (long)T * nJ + J : ((long)(J / 2) * nT + T) * 2 + (J % 2);
+    const long bidx = order == 0 ? (long)T * nJ + J : (long)J * nT + T;
     _Float16* out = dst + (long)smp * sDst + bidx * 1024;
     const float* as = a ? a + (long)smp * I : nullptr;
 #pragma unroll
