@@ -132,6 +132,31 @@ MDEV void pipelined_steps(unsigned lds_addr, F&& body) {
     });
 }
 
+// The same in UNITS of two k-steps, one unit of read-ahead: body(unit, fragment of step 2u, fragment of step 2u + 1).  Two
+// fragments per unit give the MFMA stream two independent accumulators to alternate between: a v_mfma_f32_32x32x16_f16 that
+// accumulates into the result of the MFMA right before it waits for it (64 instead of 32 cycles - r02 in-kernel timeline:
+// three dependent MFMAs per tile made the fc2 phases 1.7x their issue time).
+template <int NS, class F>
+MDEV void pipelined_pairs(unsigned lds_addr, F&& body) {
+    static_assert(NS % 2 == 0, "units of two k-steps");
+    constexpr int NU = NS / 2;
+    Frag fr[2][2];
+    frag_issue<0>(fr[0][0], lds_addr);
+    frag_issue<2048>(fr[0][1], lds_addr);
+    static_for<0, NU>([&](auto uu) {
+        constexpr int u = decltype(uu)::value;
+        if constexpr (u + 1 < NU) {
+            frag_issue<(2 * u + 2) * 2048>(fr[(u + 1) % 2][0], lds_addr);
+            frag_issue<(2 * u + 3) * 2048>(fr[(u + 1) % 2][1], lds_addr);
+        }
+        constexpr int newer = u + 1 < NU ? 4 : 0;
+        asm volatile("s_waitcnt lgkmcnt(%4)"
+                     : "+v"(fr[u % 2][0].h), "+v"(fr[u % 2][0].l), "+v"(fr[u % 2][1].h), "+v"(fr[u % 2][1].l)
+                     : "n"(newer));
+        body(uu, fr[u % 2][0], fr[u % 2][1]);
+    });
+}
+
 template <int I0, int I1, class F>
 MDEV void static_for(F&& f) {
     if constexpr (I0 < I1) {
@@ -271,13 +296,17 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
             const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (q % NSLOT) * GRP) + lane * 16;
             const _Float16* nsrc = piece_src(q + AHEAD);
             const char* ndst = smem + ((q + AHEAD) % NSLOT) * GRP + wave * 1024;
-            pipelined_steps<NC, FDEPTH>(sl, [&](auto ss, const Frag& f) {
-                constexpr int st = decltype(ss)::value;
-                constexpr int j = ph * NC + st;
-                u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l, xh[j], u0, 0, 0, 0);
-                u1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, xl[j], u1, 0, 0, 0);
-                u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, xh[j], u0, 0, 0, 0);
-                if constexpr (st % (NC / PW) == 0) glds16(nsrc + (st / (NC / PW)) * 4 * 512, ndst + (st / (NC / PW)) * 4 * 1024);
+            pipelined_pairs<NC>(sl, [&](auto uu, const Frag& f0, const Frag& f1) {
+                constexpr int un = decltype(uu)::value;
+                constexpr int j0 = ph * NC + 2 * un, j1 = j0 + 1;
+                // six MFMAs, the two accumulators strictly alternating (all six products are summed in the end)
+                u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.l, xh[j0], u0, 0, 0, 0);
+                u1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.h, xl[j0], u1, 0, 0, 0);
+                u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.h, xh[j0], u0, 0, 0, 0);
+                u1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.l, xh[j1], u1, 0, 0, 0);
+                u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.h, xl[j1], u0, 0, 0, 0);
+                u1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.h, xh[j1], u1, 0, 0, 0);
+                glds16(nsrc + un * 4 * 512, ndst + un * 4 * 1024);
             });
         });
         f32x16 u = u0 + u1;
@@ -307,12 +336,16 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
             const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (q % NSLOT) * GRP) + lane * 16;
             const _Float16* nsrc = piece_src(q + AHEAD);
             const char* ndst = smem + ((q + AHEAD) % NSLOT) * GRP + wave * 1024;
-            pipelined_steps<NC, FDEPTH>(sl, [&](auto ss, const Frag& f) {
-                constexpr int t = decltype(ss)::value;
-                out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l, uh[kk], out[t], 0, 0, 0);
-                out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, ul[kk], out[t], 0, 0, 0);
-                out[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, uh[kk], out[t], 0, 0, 0);
-                if constexpr (t % (NC / PW) == 0) glds16(nsrc + (t / (NC / PW)) * 4 * 512, ndst + (t / (NC / PW)) * 4 * 1024);
+            pipelined_pairs<NC>(sl, [&](auto uu, const Frag& f0, const Frag& f1) {
+                constexpr int un = decltype(uu)::value;
+                constexpr int t0 = 2 * un, t1 = t0 + 1;
+                out[t0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.l, uh[kk], out[t0], 0, 0, 0);
+                out[t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.l, uh[kk], out[t1], 0, 0, 0);
+                out[t0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.h, ul[kk], out[t0], 0, 0, 0);
+                out[t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.h, ul[kk], out[t1], 0, 0, 0);
+                out[t0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.h, uh[kk], out[t0], 0, 0, 0);
+                out[t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.h, uh[kk], out[t1], 0, 0, 0);
+                glds16(nsrc + un * 4 * 512, ndst + un * 4 * 1024);
             });
         });
     }
