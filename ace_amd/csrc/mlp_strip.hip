@@ -27,6 +27,9 @@ namespace {
 #ifndef ACE_MLP_FDEPTH
 #define ACE_MLP_FDEPTH 2
 #endif
+#ifndef ACE_MLP_ABL
+#define ACE_MLP_ABL 0   // measurement only (wrong results): bit 0 no DMA in the loop, bit 1 no fragment reads, bit 2 no GELU,
+#endif                  // bit 3 no barrier / DMA wait in the loop
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -141,6 +144,11 @@ MDEV void pipelined_pairs(unsigned lds_addr, F&& body) {
     static_assert(NS % 2 == 0, "units of two k-steps");
     constexpr int NU = NS / 2;
     Frag fr[2][2];
+#if ACE_MLP_ABL & 2
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) { asm volatile("" : "=v"(fr[a][b].h), "=v"(fr[a][b].l)); }
+    static_for<0, NU>([&](auto uu) { constexpr int u = decltype(uu)::value; body(uu, fr[u % 2][0], fr[u % 2][1]); });
+    return;
+#endif
     frag_issue<0>(fr[0][0], lds_addr);
     frag_issue<2048>(fr[0][1], lds_addr);
     static_for<0, NU>([&](auto uu) {
@@ -270,9 +278,9 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
     // have not landed; vmcnt((AHEAD - 1) * PW) retires exactly group q.
     auto top = [&](int q) {
         MT(8 + 4 * q);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PW) : "memory");
+        if (!(ACE_MLP_ABL & 8)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PW) : "memory");
         MT(9 + 4 * q);
-        __builtin_amdgcn_s_barrier();      // group q landed in every wave's share; every wave is done with group q - 1
+        if (!(ACE_MLP_ABL & 8)) __builtin_amdgcn_s_barrier();      // group q landed in every wave's share; every wave is done with group q - 1
         MT(10 + 4 * q);
     };
     // ... whose slot is refilled DURING the steps of group q: one 1-KiB piece every NC / PW steps, between the MFMA triples
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
                 u1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.l, xh[j1], u1, 0, 0, 0);
                 u0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.h, xl[j1], u0, 0, 0, 0);
                 u1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.h, xh[j1], u1, 0, 0, 0);
-                glds16(nsrc + un * 4 * 512, ndst + un * 4 * 1024);
+                if (!(ACE_MLP_ABL & 1)) glds16(nsrc + un * 4 * 512, ndst + un * 4 * 1024);
             });
         });
         f32x16 u = u0 + u1;
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float bv = kk == 0 ? (e < 4 ? bA[e & 3] : bB[e & 3]) : (e < 4 ? bC[e & 3] : bD[e & 3]);
-                const float y = act_fn<ACT>(fmaf(u[8 * kk + e], s_fc1, bv)) * uscale;
+                const float y = ((ACE_MLP_ABL & 4) ? fmaf(u[8 * kk + e], s_fc1, bv) : act_fn<ACT>(fmaf(u[8 * kk + e], s_fc1, bv))) * uscale;
                 const _Float16 h = (_Float16)y;
                 uh[kk][e] = h;
                 ul[kk][e] = (_Float16)(y - (float)h);
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void mlp_strip_kernel(MlpStripArgs p) {
                 out[t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.h, ul[kk], out[t1], 0, 0, 0);
                 out[t0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.h, uh[kk], out[t0], 0, 0, 0);
                 out[t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.h, uh[kk], out[t1], 0, 0, 0);
-                glds16(nsrc + un * 4 * 512, ndst + un * 4 * 1024);
+                if (!(ACE_MLP_ABL & 1)) glds16(nsrc + un * 4 * 512, ndst + un * 4 * 1024);
             });
         });
     }
