@@ -521,7 +521,8 @@ struct Weight {
     DevBuf hi, lo;      // f16x3 mode: fp16 planes of the conv weight scaled by `ascale` (pitch halves)
     float ascale = 1.f;
     DevBuf thi, tlo;    // the same planes in the v4 engine's A-tile order (rows padded to 16)
-    DevBuf frag;        // mlp.fwd.2: packed MFMA A fragments streamed by 32-column chunk (fused MLP, mlp_strip.hip)
+    DevBuf frag;        // mlp.fwd.2: packed MFMA A fragments streamed by 16-column step (fused MLP, mlp_strip.hip)
+    DevBuf frag0;       // inner_skip: packed MFMA A fragments streamed by 32-row tile (conv_strip.hip, un-folded first block)
     float wabs = 0.f;   // conv weights: max |w|
     float winf = 0.f;   // conv weights: max row sum of |w| (bounds |W x| by winf * max|x|)
     float absmax = 0.f; // small parameters (biases): max |value|
@@ -552,7 +553,8 @@ struct ace_sfno {
     DevBuf P2;           // second one: the block input h as written by the previous block's fc2 epilogue
     DevBuf part;         // per-strip row statistics from the GEMM epilogues (fused instance norm), two tensors
     DevBuf Wp0, Wp1;     // folded (norm affine) skip / fc1 weights as tiled fp16 planes, per sample
-    DevBuf Wq1;          // folded fc1 weights as packed MFMA A fragments, per sample (fused MLP)
+    DevBuf Wq1;          // folded fc1 weights as packed MFMA A fragments, per sample (fused MLP / conv_strip)
+    DevBuf Wq0;          // folded inner-skip weights likewise (conv_strip)
     int nstrips = 0;
     DevBuf Wf0, bf0, Wf1, bf1;
     DevBuf amax;  // [8] uint words: bit patterns of max|X|, max|D|, max|E| of the current block (f16x3 dynamic range)  // instance-norm affine folded into inner_skip / mlp.fc1 weights, per sample
@@ -701,8 +703,9 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
         if (c.normalization_layer == 1 && c.use_mlp) {
             HIP_TRY(n->P2.alloc(act, true));
             n->nstrips = (int)((HW + 31) / 32) + 8;     // >= tilesN * WN of either tile shape and the fused MLP's 32-pixel strips
-            if (mlp_strip_eligible((int)C, n->hid, ACT_GELU))
+            if (mlp_strip_eligible((int)C, n->hid, ACT_GELU) || conv_strip_eligible((int)C, n->hid, ACT_GELU))
                 HIP_TRY(n->Wq1.alloc((size_t)n->Bmax * n->hid * C, true));   // hi + lo halves = one float per element
+            if (conv_strip_eligible((int)C, (int)C, ACT_GELU)) HIP_TRY(n->Wq0.alloc((size_t)n->Bmax * C * C, true));
             HIP_TRY(n->part.alloc((size_t)2 * n->Bmax * n->nstrips * C * 4, true));
             const size_t cp = (size_t)((C + 31) & ~31);
             HIP_TRY(n->Wp0.alloc((size_t)n->Bmax * ((C + 15) / 16 * 16) * cp, true));       // 2 planes of halves = 1 float per element
@@ -833,6 +836,12 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
             mlp_strip_eligible(w.rows, w.cols, ACT_GELU)) {
             if (!w.frag.p) HIP_TRY(w.frag.alloc((size_t)w.rows * w.cols, false));
             HIP_TRY(launch_pack_conv_frag(w.buf.p, w.pitch, w.rows, w.cols, 1, nullptr, 0.f, w.ascale, nullptr, w.frag.p,
+                                          0, 1, s));
+        }
+        if (wn.size() > 17 && wn.compare(wn.size() - 17, 17, "inner_skip.weight") == 0 &&
+            conv_strip_eligible(w.cols, w.rows, ACT_GELU)) {
+            if (!w.frag0.p) HIP_TRY(w.frag0.alloc((size_t)w.rows * w.cols, false));
+            HIP_TRY(launch_pack_conv_frag(w.buf.p, w.pitch, w.rows, w.cols, 0, nullptr, 0.f, w.ascale, nullptr, w.frag0.p,
                                           0, 1, s));
         }
         HIP_TRY(hipStreamSynchronize(s));
@@ -1206,10 +1215,33 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 o.bias = bsw.buf.p;
                 o.bhi = PBh; o.blo = PBl; o.in_slot = skip_max;
             }
-            ACE_TRY(conv_pk2(n, o, B, s));
+            const bool strip_ok = c.activation_function == ACT_GELU && conv_strip_eligible(C, C, ACT_GELU) && n->Wq0.p != nullptr &&
+                                  ws.frag0.p != nullptr;
+            int t_nparts = gemm4_strips(C, (int)HW);
+            if (strip_ok) {   // register-resident strip kernel (conv_strip.hip)
+                ConvStripArgs k;
+                k.Xhi = PBh; k.Xlo = PBl; k.ldn = HW; k.sX = (long)C * HW; k.xslot = o.in_slot;
+                if (have_ph) {
+                    _Float16* Q0 = reinterpret_cast<_Float16*>(n->Wq0.p);
+                    HIP_TRY(launch_pack_conv_frag(ws.buf.p, ws.pitch, C, C, 0, ra, ws.wabs, 1.f, slot(sb + 8), Q0, (long)C * C * 2, B, s));
+                    k.A = Q0; k.sA = (long)C * C * 2; k.aslot = slot(sb + 8);
+                } else {
+                    k.A = reinterpret_cast<const _Float16*>(ws.frag0.p); k.sA = 0; k.ascale = ws.ascale;
+                }
+                k.bias = o.bias; k.sbias = o.sbias;
+                k.R = n->Y.p; k.sR = actB;
+                k.cw = ws.winf; k.cb = bsw.absmax; k.cinb = slot(sb + 3); k.rmax = slot(sb + 7);
+                k.Chi = PAh; k.Clo = PAl; k.sCp = (long)C * HW; k.cslot = slot(sb + 4);
+                k.part = reinterpret_cast<float4*>(part_t); k.nstrips32 = (int)((HW + 255) / 256) * 8;
+                k.C = C; k.M = C; k.HW = (int)HW; k.nbatch = B; k.act = ACT_GELU;
+                HIP_TRY(launch_conv_strip(k, s));
+                t_nparts = k.nstrips32;
+            } else {
+                ACE_TRY(conv_pk2(n, o, B, s));
+            }
             MARK(ST_INNER_SKIP);
             // norm1 statistics -> affine -> folded fc1 weights
-            HIP_TRY(launch_instnorm_finalize(reinterpret_cast<const float4*>(part_t), gemm4_strips(C, (int)HW), B, C, HW,
+            HIP_TRY(launch_instnorm_finalize(reinterpret_cast<const float4*>(part_t), t_nparts, B, C, HW,
                                              W(p + "norm1.weight"), W(p + "norm1.bias"), 1e-6f, sc1, sh1, slot(sb + 5), s));
             HIP_TRY(launch_fold_affine_f16(w1.buf.p, w1.pitch, w1.wabs, sc1, sh1, b1w.buf.p, F1h, F1l, n->bf1.p, B, n->hid, C,
                                            cp, f1s, slot(sb + 9), s));
@@ -1247,7 +1279,21 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             f1.bhi = PAh; f1.blo = PAl; f1.cin = C; f1.in_slot = slot(sb + 4);
             f1.cout = n->hid; f1.act = act;
             f1.ohi = Uh; f1.olo = Ul; f1.cb = b1w.absmax; f1.cslot = slot(sb + 6); f1.cinb = slot(sb + 5);
-            ACE_TRY(conv_pk2(n, f1, B, s));
+            if (c.activation_function == ACT_GELU && conv_strip_eligible(C, n->hid, ACT_GELU) && n->Wq1.p != nullptr) {
+                _Float16* Q1 = reinterpret_cast<_Float16*>(n->Wq1.p);
+                const long q1s = (long)n->hid * C * 2;
+                HIP_TRY(launch_pack_conv_frag(w1.buf.p, w1.pitch, n->hid, C, 0, sc1, w1.wabs, 1.f, slot(sb + 9), Q1, q1s, B, s));
+                ConvStripArgs k;
+                k.Xhi = PAh; k.Xlo = PAl; k.ldn = HW; k.sX = (long)C * HW; k.xslot = slot(sb + 4);
+                k.A = Q1; k.sA = q1s; k.aslot = slot(sb + 9);
+                k.bias = n->bf1.p; k.sbias = n->hid;
+                k.cw = w1.winf; k.cb = b1w.absmax; k.cinb = slot(sb + 5);
+                k.Chi = Uh; k.Clo = Ul; k.sCp = (long)n->hid * HW; k.cslot = slot(sb + 6);
+                k.C = C; k.M = n->hid; k.HW = (int)HW; k.nbatch = B; k.act = ACT_GELU;
+                HIP_TRY(launch_conv_strip(k, s));
+            } else {
+                ACE_TRY(conv_pk2(n, f1, B, s));
+            }
             MARK(ST_MLP_FC1);
             PkOpts f2;
             f2.w = &w2; f2.bias = b2w.buf.p;

@@ -166,6 +166,22 @@ bool mlp_strip_eligible(int C, int hid, int act);
 hipError_t launch_pack_conv_frag(const float* W, long ldw, int O, int I, int order, const float* a, float wmax,
                                  float scale_static, unsigned* wslot, void* dst, long sDst, int nsamples, hipStream_t s);
 
+// 1x1 convolution with the input strip resident in registers (conv_strip.hip): P-format planes in, P-format planes out.
+struct ConvStripArgs {
+    const _Float16* Xhi = nullptr; const _Float16* Xlo = nullptr; long ldn = 0; long sX = 0;   // input planes [C/8][ldn][8]
+    const unsigned* xslot = nullptr;                  // bound the producer scaled the input planes with
+    const _Float16* A = nullptr; long sA = 0;         // packed A fragments (launch_pack_conv_frag order 0), per-sample stride
+    const unsigned* aslot = nullptr; float ascale = 1.f;   // dynamic (folded) or static weight scale
+    const float* bias = nullptr; long sbias = 0;
+    const float* R = nullptr; long sR = 0;            // optional fp32 residual (M x HW per sample), added before the activation
+    float cw = 0.f, cb = 0.f; const unsigned* cinb = nullptr; const unsigned* rmax = nullptr;   // output bound (see Gemm4Args)
+    _Float16* Chi = nullptr; _Float16* Clo = nullptr; long sCp = 0; unsigned* cslot = nullptr;  // output planes [M/8][HW][8]
+    float4* part = nullptr; int nstrips32 = 0;        // optional row statistics per (sample, 32-pixel strip, row)
+    int C = 0, M = 0, HW = 0, nbatch = 1, act = ACT_NONE;
+};
+bool conv_strip_eligible(int C, int M, int act);
+hipError_t launch_conv_strip(const ConvStripArgs& a, hipStream_t s);
+
 // Spectral-space layout used between the kernels ("channel-fastest planar"):
 //   X[m][k][b][ri][c]  (after the longitude DFT)     index ((m*H + k)*Bt + b)*2C + ri*C + c
 //   D[l][m][b][ri][c]  (after the Legendre stage)    index ((l*Mm + m)*Bt + b)*2C + ri*C + c
