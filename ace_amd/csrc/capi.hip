@@ -1204,9 +1204,12 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             o.R = n->Y.p; o.r_bs = actB;
             o.ohi = PAh; o.olo = PAl; o.cb = bsw.absmax; o.cslot = slot(sb + 4); o.cinb = slot(sb + 3); o.rmax = slot(sb + 7);
             o.part = part_t;
+            const bool strip_ok = c.activation_function == ACT_GELU && conv_strip_eligible(C, C, ACT_GELU) && n->Wq0.p != nullptr &&
+                                  ws.frag0.p != nullptr;
             if (have_ph) {   // h planes from the previous fc2; the affine goes into the weights
-                HIP_TRY(launch_fold_affine_f16(ws.buf.p, ws.pitch, ws.wabs, ra, rb, bsw.buf.p, F0h, F0l, n->bf0.p, B, C, C, cp,
-                                               f0s, slot(sb + 8), s));
+                if (!strip_ok)
+                    HIP_TRY(launch_fold_affine_f16(ws.buf.p, ws.pitch, ws.wabs, ra, rb, bsw.buf.p, F0h, F0l, n->bf0.p, B, C, C, cp,
+                                                   f0s, slot(sb + 8), s));
                 o.fhi = F0h; o.flo = F0l; o.fslot = slot(sb + 8); o.f_stride = f0s;
                 o.bias = n->bf0.p; o.sbias = C;
                 o.bhi = PBh; o.blo = PBl; o.in_slot = hslot(i);
@@ -1215,15 +1218,14 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 o.bias = bsw.buf.p;
                 o.bhi = PBh; o.blo = PBl; o.in_slot = skip_max;
             }
-            const bool strip_ok = c.activation_function == ACT_GELU && conv_strip_eligible(C, C, ACT_GELU) && n->Wq0.p != nullptr &&
-                                  ws.frag0.p != nullptr;
             int t_nparts = gemm4_strips(C, (int)HW);
             if (strip_ok) {   // register-resident strip kernel (conv_strip.hip)
                 ConvStripArgs k;
                 k.Xhi = PBh; k.Xlo = PBl; k.ldn = HW; k.sX = (long)C * HW; k.xslot = o.in_slot;
                 if (have_ph) {
                     _Float16* Q0 = reinterpret_cast<_Float16*>(n->Wq0.p);
-                    HIP_TRY(launch_pack_conv_frag(ws.buf.p, ws.pitch, C, C, 0, ra, ws.wabs, 1.f, slot(sb + 8), Q0, (long)C * C * 2, B, s));
+                    HIP_TRY(launch_pack_conv_frag(ws.buf.p, ws.pitch, C, C, 0, ra, ws.wabs, 1.f, slot(sb + 8), Q0, (long)C * C * 2, B, s,
+                                                  rb, bsw.buf.p, n->bf0.p));
                     k.A = Q0; k.sA = (long)C * C * 2; k.aslot = slot(sb + 8);
                 } else {
                     k.A = reinterpret_cast<const _Float16*>(ws.frag0.p); k.sA = 0; k.ascale = ws.ascale;
@@ -1243,15 +1245,19 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             // norm1 statistics -> affine -> folded fc1 weights
             HIP_TRY(launch_instnorm_finalize(reinterpret_cast<const float4*>(part_t), t_nparts, B, C, HW,
                                              W(p + "norm1.weight"), W(p + "norm1.bias"), 1e-6f, sc1, sh1, slot(sb + 5), s));
-            HIP_TRY(launch_fold_affine_f16(w1.buf.p, w1.pitch, w1.wabs, sc1, sh1, b1w.buf.p, F1h, F1l, n->bf1.p, B, n->hid, C,
-                                           cp, f1s, slot(sb + 9), s));
             const bool strip_mlp = c.activation_function == ACT_GELU && mlp_strip_eligible(C, n->hid, ACT_GELU) &&
                                    n->Wq1.p != nullptr && w2.frag.p != nullptr;
+            const bool strip_fc1 = !strip_mlp && c.activation_function == ACT_GELU && conv_strip_eligible(C, n->hid, ACT_GELU) &&
+                                   n->Wq1.p != nullptr;
+            if (!strip_mlp && !strip_fc1)
+                HIP_TRY(launch_fold_affine_f16(w1.buf.p, w1.pitch, w1.wabs, sc1, sh1, b1w.buf.p, F1h, F1l, n->bf1.p, B, n->hid, C,
+                                               cp, f1s, slot(sb + 9), s));
             if (strip_mlp) {
                 // fused MLP (mlp_strip.hip): fc1, GELU and fc2 in one launch, the hidden activation stays in registers
                 _Float16* Q1 = reinterpret_cast<_Float16*>(n->Wq1.p);
                 const long q1s = (long)n->hid * C * 2;
-                HIP_TRY(launch_pack_conv_frag(w1.buf.p, w1.pitch, n->hid, C, 0, sc1, w1.wabs, 1.f, slot(sb + 9), Q1, q1s, B, s));
+                HIP_TRY(launch_pack_conv_frag(w1.buf.p, w1.pitch, n->hid, C, 0, sc1, w1.wabs, 1.f, slot(sb + 9), Q1, q1s, B, s,
+                                              sh1, b1w.buf.p, n->bf1.p));
                 MARK(ST_NORM1);
                 MlpStripArgs m;
                 m.Xhi = PAh; m.Xlo = PAl; m.ldn = HW; m.sX = (long)C * HW; m.xslot = slot(sb + 4);
@@ -1279,10 +1285,11 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             f1.bhi = PAh; f1.blo = PAl; f1.cin = C; f1.in_slot = slot(sb + 4);
             f1.cout = n->hid; f1.act = act;
             f1.ohi = Uh; f1.olo = Ul; f1.cb = b1w.absmax; f1.cslot = slot(sb + 6); f1.cinb = slot(sb + 5);
-            if (c.activation_function == ACT_GELU && conv_strip_eligible(C, n->hid, ACT_GELU) && n->Wq1.p != nullptr) {
+            if (strip_fc1) {
                 _Float16* Q1 = reinterpret_cast<_Float16*>(n->Wq1.p);
                 const long q1s = (long)n->hid * C * 2;
-                HIP_TRY(launch_pack_conv_frag(w1.buf.p, w1.pitch, n->hid, C, 0, sc1, w1.wabs, 1.f, slot(sb + 9), Q1, q1s, B, s));
+                HIP_TRY(launch_pack_conv_frag(w1.buf.p, w1.pitch, n->hid, C, 0, sc1, w1.wabs, 1.f, slot(sb + 9), Q1, q1s, B, s,
+                                              sh1, b1w.buf.p, n->bf1.p));
                 ConvStripArgs k;
                 k.Xhi = PAh; k.Xlo = PAl; k.ldn = HW; k.sX = (long)C * HW; k.xslot = slot(sb + 4);
                 k.A = Q1; k.sA = q1s; k.aslot = slot(sb + 9);

@@ -102,46 +102,30 @@ __global__ __launch_bounds__(512, 2) void conv_strip_kernel(ConvStripArgs p) {
 
     const auto rsR = __builtin_amdgcn_make_buffer_rsrc(RES ? const_cast<float*>(p.R + (long)smp * p.sR) : nullptr, 0,
                                                        RES ? p.M * p.HW * 4 : 0, 0x00020000);
-    const int voff = (8 * g * p.HW + nc) * 4;
+    const int voff4 = (4 * g * p.HW + nc) * 4;     // accumulator layout: lane half g starts 4 rows down
     const int rowb = p.HW * 4;
     _Float16* Chi = p.Chi + (long)smp * p.sCp;
     _Float16* Clo = p.Clo + (long)smp * p.sCp;
     const int ncols_ok = p.HW - n0 < 32 ? (p.HW - n0 > 0 ? p.HW - n0 : 0) : 32;
 
-    // Two slots: tile t + 1 is fetched into the slot of tile t - 1 during tile t.  vmcnt counts stores on gfx950 and loads /
-    // stores retire out of order with respect to each other, so with the stores of tile t - 1 in the queue no count short
-    // of zero proves that the pieces of tile t have landed; the partner wave of the SIMD covers the store latency.
-    for (int t = 0; t < ntiles; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();      // tile t landed in every wave's share; every wave is done with tile t - 1
-        const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (t % NSLOT) * SLOT) + lane * 16;
-        f32x16 v;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = 0.f;
-        pipelined_steps<KS, 1>(sl, [&](auto ss, const Frag& f) {
-            constexpr int j = decltype(ss)::value;
-            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l, xh[j], v, 0, 0, 0);
-            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, xl[j], v, 0, 0, 0);
-            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, xh[j], v, 0, 0, 0);
-            // the slot of tile t - 1 is free since the barrier above: refill it with tile t + 1, one piece every four steps
-            if constexpr (j % 4 == 3) piece(t + 1, j / 4);
-        });
+    // Two slots, epilogue one tile late, residual through the accumulator.  Iteration t: barrier - epilogue of tile t - 1 -
+    // residual of tile t loaded INTO the accumulator registers (pre-divided by the accumulator scale, an exact power of two:
+    // acc * s + bias then carries the residual; no second register tile) - the PW pieces of tile t + 1 (into the slot of
+    // tile t - 1, free since the barrier) - MFMAs of tile t.  vmcnt counts stores on gfx950 and loads / stores retire out
+    // of order with respect to each other, so only vmcnt(0) proves that the pieces of a tile have landed; at the top of an
+    // iteration everything it waits for was issued a whole tile of MFMAs earlier.  The residual loads are inline asm so
+    // that THEIR wait can leave the pieces issued after them in flight (hipcc would wait vmcnt(0) at the first use of a
+    // plain load: it does not see the LDS-DMA pieces).  The second wave of the SIMD runs its MFMAs meanwhile.
+    auto epilogue = [&](int t, f32x16& v) {
         rows_to_kgroups(v);                // rows 8 g + e and 16 + 8 g + e: whole P entries
 #pragma unroll
         for (int hq = 0; hq < 2; ++hq) {
             const int row0 = 32 * t + 16 * hq + 8 * g;
             const f32x4 ba = *reinterpret_cast<const f32x4*>(bs + row0), bb = *reinterpret_cast<const f32x4*>(bs + row0 + 4);
-            float res[8];
-            if (RES) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    res[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsR, voff, (32 * t + 16 * hq + e) * rowb, 0));
-            }
             half8 hh, ll;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float val = fmaf(v[8 * hq + e], s_acc, e < 4 ? ba[e & 3] : bb[e & 3]);
-                if (RES) val += res[e];
                 val = act_fn<ACT>(val);
                 if (STATS) St[i * 33 + 16 * hq + 8 * g + e] = val;
                 const float xs = val * cscale;
@@ -174,7 +158,44 @@ __global__ __launch_bounds__(512, 2) void conv_strip_kernel(ConvStripArgs p) {
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             if (g == 0) p.part[((long)smp * p.nstrips32 + (n0 >> 5)) * p.M + 32 * t + i] = make_float4(sm, sq, mn, mx);
         }
+    };
+    const float inv_s = 1.0f / s_acc;
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = 0.f;
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // tile t landed in every wave's share; every wave is done with tile t - 1
+        if (t > 0) epilogue(t - 1, v);
+        if (RES) {   // accumulator register r holds row acc_row(r, g) = (r & 3) + 8 (r >> 2) + 4 g of the tile, column i
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int soff = (32 * t + (r & 3) + 8 * (r >> 2)) * rowb;
+                asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(v[r]) : "v"(voff4), "s"(rsR), "s"(soff));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PW; ++k) piece(t + 1, k);
+        if (RES) {
+            asm volatile("s_waitcnt vmcnt(%16)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                           "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                         : "n"(PW));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] *= inv_s;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = 0.f;
+        }
+        const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (t % NSLOT) * SLOT) + lane * 16;
+        pipelined_steps<KS, 1>(sl, [&](auto ss, const Frag& f) {
+            constexpr int j = decltype(ss)::value;
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l, xh[j], v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, xl[j], v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, xh[j], v, 0, 0, 0);
+        });
     }
+    epilogue(ntiles - 1, v);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy refills of the tail land before the LDS is released
 }
 

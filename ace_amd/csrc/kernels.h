@@ -163,8 +163,10 @@ hipError_t launch_mlp_strip(const MlpStripArgs& a, hipStream_t s);
 bool mlp_strip_eligible(int C, int hid, int act);
 // conv weight (O x I) -> packed MFMA A fragments (fp16 hi/lo), optionally W diag(a) per sample with the scale derived from
 // wmax * max|a| (published to wslot); order 0: streamed by 32-row chunk (fc1), 1: streamed by 32-column chunk (fc2)
+// optional: bf[sample][row] = bias[row] + sum_i W[row][i] b[sample][i] (the folded bias of the same affine)
 hipError_t launch_pack_conv_frag(const float* W, long ldw, int O, int I, int order, const float* a, float wmax,
-                                 float scale_static, unsigned* wslot, void* dst, long sDst, int nsamples, hipStream_t s);
+                                 float scale_static, unsigned* wslot, void* dst, long sDst, int nsamples, hipStream_t s,
+                                 const float* b = nullptr, const float* bias = nullptr, float* bf = nullptr);
 
 // 1x1 convolution with the input strip resident in registers (conv_strip.hip): P-format planes in, P-format planes out.
 struct ConvStripArgs {

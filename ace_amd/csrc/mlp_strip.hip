@@ -415,7 +415,9 @@ extern "C" int ace_debug_mlp_trace(void* dst) { return (int)hipMemcpyFromSymbol(
 // O % 32 == 0, I % 16 == 0.  scale: a power of two, or derived from `bound` = wmax * max|a| (published to wslot).
 __global__ __launch_bounds__(256) void pack_conv_frag_kernel(const float* __restrict__ W, long ldw, int O, int I, int order,
                                                              const float* __restrict__ a, float wmax, float scale_static,
-                                                             unsigned* wslot, _Float16* __restrict__ dst, long sDst) {
+                                                             unsigned* wslot, _Float16* __restrict__ dst, long sDst,
+                                                             const float* __restrict__ b, const float* __restrict__ bias,
+                                                             float* __restrict__ bf) {
     const int smp = blockIdx.y;
     float scale = scale_static;
     if (a) {   // one scale for all samples (as fold_affine_f16_kernel)
@@ -449,14 +451,25 @@ __global__ __launch_bounds__(256) void pack_conv_frag_kernel(const float* __rest
         out[t] = h;
         out[512 + t] = (_Float16)(x - (float)h);
     }
+    if (bf && J == 0) {   // folded bias of the 32 rows of this tile: bias + W b (8 threads per row)
+        const int r = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+        const long row = 32L * T + r;
+        const float* bs = b + (long)smp * I;
+        float acc = 0.f;
+        for (int q = l8; q < I; q += 8) acc = fmaf(W[row * ldw + q], bs[q], acc);
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (l8 == 0) bf[(long)smp * O + row] = (bias ? bias[row] : 0.f) + acc;
+    }
 }
 
 hipError_t launch_pack_conv_frag(const float* W, long ldw, int O, int I, int order, const float* a, float wmax,
-                                 float scale_static, unsigned* wslot, void* dst, long sDst, int nsamples, hipStream_t s) {
-    if (O % 32 != 0 || I % 16 != 0 || (order == 1 && I % 32 != 0) || (a && !wslot)) return hipErrorInvalidValue;
+                                 float scale_static, unsigned* wslot, void* dst, long sDst, int nsamples, hipStream_t s,
+                                 const float* b, const float* bias, float* bf) {
+    if (O % 32 != 0 || I % 16 != 0 || (order == 1 && I % 32 != 0) || (a && !wslot) || (bf && !b)) return hipErrorInvalidValue;
     dim3 grid((unsigned)((O / 32) * (I / 16)), (unsigned)nsamples);
     hipLaunchKernelGGL(pack_conv_frag_kernel, grid, dim3(256), 0, s, W, ldw, O, I, order, a, wmax, scale_static, wslot,
-                       static_cast<_Float16*>(dst), sDst);
+                       static_cast<_Float16*>(dst), sDst, b, bias, bf);
     return hipGetLastError();
 }
 
