@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k16(float* out, const float* in, int iter
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // fp16 32x32x16 (the instruction of the f16x3 engines): NACC independent accumulators, operands from memory (random fp16)
 template <int NACC>
-__global__ __launch_bounds__(256) void kh(float* out, const float* in, int iters, unsigned long long* clk) {
+__global__ __launch_bounds__(512) void kh(float* out, const float* in, int iters, unsigned long long* clk) {
     f32x16 acc[NACC];
     for (int a = 0; a < NACC; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
     half8 av, bv;
@@ -108,6 +108,26 @@ int main() {
             hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
             printf("  cycles/mfma(wave) %.1f\n", (double)c / (iters * 4.0));
         }
+    }
+    // dependent-accumulator latency of v_mfma_f32_32x32x16_f16: NACC independent chains, one wave per SIMD (256 blocks of
+    // 256 threads) and two waves per SIMD (256 blocks of 512 threads)
+    for (auto& v : h) v = 0.f;
+    for (int i = 0; i < 512; ++i) h[i] = (float)((i * 2654435761u) % 1000) / 500.f - 1.f;
+    hipMemcpy(in, h.data(), 512 * 4, hipMemcpyHostToDevice);
+    printf("---- dependent chains (fp16 32x32x16, random operands)\n");
+    for (int threads : {256, 512}) {
+        const int iters = 20000;
+        unsigned long long c = 0;
+        auto rep = [&](const char* nm, int nacc, auto kern) {
+            hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, out, in, iters, clk);
+            hipDeviceSynchronize();
+            hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
+            printf("%s threads/block %d: cycles per MFMA (one wave) %.1f\n", nm, threads, (double)c / (iters * (double)nacc));
+        };
+        rep("1 accumulator ", 1, kh<1>);
+        rep("2 accumulators", 2, kh<2>);
+        rep("3 accumulators", 3, kh<3>);
+        rep("4 accumulators", 4, kh<4>);
     }
     return 0;
 }
