@@ -95,10 +95,10 @@ __global__ __launch_bounds__(512, 2) void conv_strip_kernel(ConvStripArgs p) {
     const float cscale = ldexpf(1.0f, pow2_exponent_for(cbound));
     if (tid == 0) atomicMax(p.cslot + (blockIdx.x & 63), __float_as_uint(cbound));
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0, the input strip, the bias
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tiles 0, 1, the input strip, the bias
 #pragma unroll
     for (int j = 0; j < KS; ++j) asm volatile("" : "+v"(xh[j]), "+v"(xl[j]));
-    __syncthreads();                       // bias table visible
+    __syncthreads();
 
     const auto rsR = __builtin_amdgcn_make_buffer_rsrc(RES ? const_cast<float*>(p.R + (long)smp * p.sR) : nullptr, 0,
                                                        RES ? p.M * p.HW * 4 : 0, 0x00020000);
@@ -108,15 +108,14 @@ __global__ __launch_bounds__(512, 2) void conv_strip_kernel(ConvStripArgs p) {
     _Float16* Clo = p.Clo + (long)smp * p.sCp;
     const int ncols_ok = p.HW - n0 < 32 ? (p.HW - n0 > 0 ? p.HW - n0 : 0) : 32;
 
-    // Two slots, two phases per tile, the two waves of a SIMD half a tile apart.  Waves 0-3 (group A, one per SIMD) run
-    // the MFMAs of tile t in phase 2t and its epilogue in phase 2t + 1; waves 4-7 (group B, their SIMD partners) are one
-    // phase behind, so each SIMD always has one wave on the matrix pipe and one in its epilogue (with the whole workgroup in
-    // lockstep both waves of a SIMD did their epilogues at the same time and the pipe idled: 126 us for fc1 against a 70 us
-    // MFMA floor).  Every phase ends with vmcnt(0) + barrier.  Tile t sits in slot t % 2, read by A in phase 2t and by B in
-    // phase 2t + 1; the slot is refilled with tile t + 2 at the start of phase 2t + 2 and is next read in phase 2t + 4.
-    // The residual of tile t + 1 is loaded INTO the accumulator registers at the end of the epilogue of tile t (pre-divided
-    // by the accumulator scale, an exact power of two: acc * s + bias then carries the residual; no second register tile);
-    // its latency is covered by the phase-ending wait while the partner computes.
+    // Two slots, epilogue one tile late, residual through the accumulator.  Iteration t: barrier - epilogue of tile t - 1 -
+    // residual of tile t loaded INTO the accumulator registers (pre-divided by the accumulator scale, an exact power of two:
+    // acc * s + bias then carries the residual; no second register tile) - the PW pieces of tile t + 1 (into the slot of
+    // tile t - 1, free since the barrier) - MFMAs of tile t.  vmcnt counts stores on gfx950 and loads / stores retire out
+    // of order with respect to each other, so only vmcnt(0) proves that the pieces of a tile have landed; at the top of an
+    // iteration everything it waits for was issued a whole tile of MFMAs earlier.  The residual loads are inline asm so
+    // that THEIR wait can leave the pieces issued after them in flight (hipcc would wait vmcnt(0) at the first use of a
+    // plain load: it does not see the LDS-DMA pieces).  The second wave of the SIMD runs its MFMAs meanwhile.
     auto epilogue = [&](int t, f32x16& v) {
         rows_to_kgroups(v);                // rows 8 g + e and 16 + 8 g + e: whole P entries
 #pragma unroll
@@ -161,40 +160,33 @@ __global__ __launch_bounds__(512, 2) void conv_strip_kernel(ConvStripArgs p) {
         }
     };
     const float inv_s = 1.0f / s_acc;
-    const bool grpB = wave >= 4;
     f32x16 v;
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = 0.f;
-    auto load_res = [&](int t) {   // residual rows of tile t -> accumulator registers (register r = row acc_row(r, g), column i)
-        if (!RES) return;
-        const int tt = t < ntiles ? t : ntiles - 1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int soff = (32 * tt + (r & 3) + 8 * (r >> 2)) * rowb;
-            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(v[r]) : "v"(voff4), "s"(rsR), "s"(soff));
-        }
-    };
-    auto end_phase = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
-                       "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
-                     :
-                     : "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-    load_res(0);
-#pragma unroll
-    for (int k = 0; k < PW; ++k) piece(1, k);
-    end_phase();                            // tiles 0 and 1 landed in every wave's share (+ the residual of tile 0)
-    if (grpB) end_phase();                  // group B starts one phase late
     for (int t = 0; t < ntiles; ++t) {
-        // ---- MFMA phase of tile t
-        if (!grpB && t >= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // tile t landed in every wave's share; every wave is done with tile t - 1
+        if (t > 0) epilogue(t - 1, v);
+        if (RES) {   // accumulator register r holds row acc_row(r, g) = (r & 3) + 8 (r >> 2) + 4 g of the tile, column i
 #pragma unroll
-            for (int k = 0; k < PW; ++k) piece(t + 1, k);
+            for (int r = 0; r < 16; ++r) {
+                const int soff = (32 * t + (r & 3) + 8 * (r >> 2)) * rowb;
+                asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(v[r]) : "v"(voff4), "s"(rsR), "s"(soff));
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = RES ? v[r] * inv_s : 0.f;
+        for (int k = 0; k < PW; ++k) piece(t + 1, k);
+        if (RES) {
+            asm volatile("s_waitcnt vmcnt(%16)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                           "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                         : "n"(PW));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] *= inv_s;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = 0.f;
+        }
         const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (t % NSLOT) * SLOT) + lane * 16;
         pipelined_steps<KS, 1>(sl, [&](auto ss, const Frag& f) {
             constexpr int j = decltype(ss)::value;
@@ -202,17 +194,8 @@ __global__ __launch_bounds__(512, 2) void conv_strip_kernel(ConvStripArgs p) {
             v = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, xl[j], v, 0, 0, 0);
             v = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, xh[j], v, 0, 0, 0);
         });
-        end_phase();
-        // ---- epilogue phase of tile t
-        if (grpB) {
-#pragma unroll
-            for (int k = 0; k < PW; ++k) piece(t + 2, k);
-        }
-        epilogue(t, v);
-        load_res(t + 1);
-        end_phase();
     }
-    if (!grpB) end_phase();
+    epilogue(ntiles - 1, v);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy refills of the tail land before the LDS is released
 }
 
