@@ -703,7 +703,7 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
         if (c.normalization_layer == 1 && c.use_mlp) {
             HIP_TRY(n->P2.alloc(act, true));
             n->nstrips = (int)((HW + 31) / 32) + 8;     // >= tilesN * WN of either tile shape and the fused MLP's 32-pixel strips
-            if (mlp_strip_eligible((int)C, n->hid, ACT_GELU) || conv_strip_eligible((int)C, n->hid, ACT_GELU))
+            if (mlp_strip_shape_ok((int)C, n->hid) || conv_strip_eligible((int)C, n->hid, ACT_GELU))
                 HIP_TRY(n->Wq1.alloc((size_t)n->Bmax * n->hid * C, true));   // hi + lo halves = one float per element
             if (conv_strip_eligible((int)C, (int)C, ACT_GELU)) HIP_TRY(n->Wq0.alloc((size_t)n->Bmax * C * C, true));
             HIP_TRY(n->part.alloc((size_t)2 * n->Bmax * n->nstrips * C * 4, true));
@@ -833,7 +833,7 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
         HIP_TRY(launch_split_f16_tiled(w.buf.p, w.pitch, w.thi.p, w.tlo.p, w.pitch, w.rows, w.cols, w.ascale, s));
         const std::string& wn = w.name;
         if (wn.size() > 16 && wn.compare(wn.size() - 16, 16, "mlp.fwd.2.weight") == 0 &&
-            mlp_strip_eligible(w.rows, w.cols, ACT_GELU)) {
+            mlp_strip_shape_ok(w.rows, w.cols)) {
             if (!w.frag.p) HIP_TRY(w.frag.alloc((size_t)w.rows * w.cols, false));
             HIP_TRY(launch_pack_conv_frag(w.buf.p, w.pitch, w.rows, w.cols, 1, nullptr, 0.f, w.ascale, nullptr, w.frag.p,
                                           0, 1, s));

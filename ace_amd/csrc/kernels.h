@@ -160,7 +160,8 @@ struct MlpStripArgs {
     int Cch = 0, hid = 0, HW = 0, nbatch = 1, act = ACT_NONE;
 };
 hipError_t launch_mlp_strip(const MlpStripArgs& a, hipStream_t s);
-bool mlp_strip_eligible(int C, int hid, int act);
+bool mlp_strip_eligible(int C, int hid, int act);   // shape + the ACE_MLP_FUSED opt-in
+bool mlp_strip_shape_ok(int C, int hid);
 // conv weight (O x I) -> packed MFMA A fragments (fp16 hi/lo), optionally W diag(a) per sample with the scale derived from
 // wmax * max|a| (published to wslot); order 0: streamed by 32-row chunk (fc1), 1: streamed by 32-column chunk (fc2)
 // optional: bf[sample][row] = bias[row] + sum_i W[row][i] b[sample][i] (the folded bias of the same affine)

@@ -473,11 +473,15 @@ hipError_t launch_pack_conv_frag(const float* W, long ldw, int O, int I, int ord
     return hipGetLastError();
 }
 
+bool mlp_strip_shape_ok(int C, int hid) { return (C == 128 || C == 256 || C == 384) && hid % 32 == 0 && hid >= 64 && hid <= 4096; }
+
 bool mlp_strip_eligible(int C, int hid, int act) {
-    static const bool off = std::getenv("ACE_NO_MLP_STRIP") != nullptr;   // A/B switch for measurements
-    if (off) return false;
+    // Opt-in (ACE_MLP_FUSED=1, read per call so that tests can flip it): at the ACE2 shape the fused kernel (one wave per
+    // SIMD, 306 us) is slower than fc1 on the strip convolution + fc2 on the v4 tile engine (126 + 179 us) - r02 measurements
+    const char* e = std::getenv("ACE_MLP_FUSED");
+    if (!(e && e[0] && e[0] != '0')) return false;
     if (!(act == ACT_GELU || act == ACT_GELU_FAST)) return false;
-    return (C == 128 || C == 256 || C == 384) && hid % 32 == 0 && hid >= 64 && hid <= 4096;
+    return mlp_strip_shape_ok(C, hid);
 }
 
 template <int NC>
@@ -490,7 +494,7 @@ static hipError_t launch_mlp_nc(const MlpStripArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_mlp_strip(const MlpStripArgs& a, hipStream_t s) {
-    if (!mlp_strip_eligible(a.Cch, a.hid, a.act) || !a.C || !a.R) return hipErrorInvalidValue;
+    if (!mlp_strip_shape_ok(a.Cch, a.hid) || !(a.act == ACT_GELU || a.act == ACT_GELU_FAST) || !a.C || !a.R) return hipErrorInvalidValue;
     if (a.Chi && (!a.cslot || !a.rmax)) return hipErrorInvalidValue;
     switch (a.Cch / 32) {
         case 4: return launch_mlp_nc<4>(a, s);

@@ -65,11 +65,14 @@ def test_headline_network_vs_reference(dev, headline, precision):
     assert torch.equal(out, y)
 
 
+@pytest.mark.parametrize("fused", ["0", "1"])
 @pytest.mark.parametrize("C,hw", [(384, (45, 90)), (128, (24, 48)), (256, (20, 40))])
-def test_fused_mlp_shapes_vs_fp64(dev, C, hw):
-    """the fused MLP kernel (mlp_strip.hip: C in {128, 256, 384}) inside 3-block nets, batch 3, ragged last workgroup,
-    random norm gains - per-block taps against the fp64 oracle."""
+def test_fused_mlp_shapes_vs_fp64(dev, C, hw, fused, monkeypatch):
+    """the register-resident strip kernels at C in {128, 256, 384} inside 3-block nets, batch 3, ragged last workgroup,
+    random norm gains - per-block taps against the fp64 oracle.  fused=0: inner skip and fc1 on conv_strip.hip, fc2 on the
+    tile engine (default); fused=1: fc1 + GELU + fc2 in mlp_strip.hip."""
     from oracle.sfno import SFNOConfig, SFNOOracle, init_state
+    monkeypatch.setenv("ACE_MLP_FUSED", fused)
     cfg = SFNOConfig(in_chans=6, out_chans=5, img_shape=hw, embed_dim=C, num_layers=3, operator_type="dhconv")
     state = init_state(cfg, seed=17)
     g = torch.Generator().manual_seed(18)
