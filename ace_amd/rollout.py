@@ -32,9 +32,11 @@ class RolloutEngine:
         self._corrector = step._corrector
         self._ocean = step._ocean
         self._corrector_state = None
-        if (self._corrector is not None or self._ocean is not None) and graph == "window":
-            raise NotImplementedError("post-step hooks with graph='window': the dry-air reference of the first window "
-                                      "would be re-seeded on every replay; use graph='step' or None")
+        # graph="window" captures the hooks with the steps.  The one piece of hook state - the dry-air reference mass the
+        # corrector seeds on its first step (fme/core/corrector/state.py) - lives in a static device buffer with a device
+        # flag, selected branch-free inside the captured region, so a replay neither re-seeds nor forgets it.
+        self._ref_mass = None       # (B, 1, 1) fp64, allocated on first use
+        self._have_ref = None       # device bool scalar
         self.stepper = stepper
         self.net = step.module.torch_module
         self._conditioned = hasattr(self.net, "draw_noise")
@@ -141,6 +143,19 @@ class RolloutEngine:
         nxt.update({n: self.target[n][:, s + 1] for n in self.target_names})
         new = gen
         if self._corrector is not None:
+            if self.graph_mode == "window" and "conserve_dry_air" in self._corrector.corrections:
+                from .corrector import CorrectorState, _seed_global_dry_air_mass
+                c = self._corrector
+                seeded = _seed_global_dry_air_mass(inp, None, c._mean, c._vcoord(self.device), torch.float64).global_dry_air_mass
+                if self._ref_mass is None:
+                    self._ref_mass = torch.zeros_like(seeded)
+                    self._have_ref = torch.zeros((), dtype=torch.bool, device=self.device)
+                    if self._corrector_state is not None and self._corrector_state.global_dry_air_mass is not None:
+                        self._ref_mass.copy_(self._corrector_state.global_dry_air_mass)
+                        self._have_ref.fill_(True)
+                self._ref_mass.copy_(torch.where(self._have_ref, self._ref_mass, seeded))
+                self._have_ref.fill_(True)
+                self._corrector_state = CorrectorState(global_dry_air_mass=self._ref_mass)
             new, self._corrector_state = self._corrector(inp, new, nxt, self._corrector_state)
         if self._ocean is not None:
             new = self._ocean(inp, new, nxt)
@@ -156,6 +171,8 @@ class RolloutEngine:
         for n in self.target_names:
             self.target[n].copy_(forcing[n][:, : self.T + 1])
         self._corrector_state = None        # a new initial condition re-seeds the corrector
+        if self._have_ref is not None:
+            self._have_ref.fill_(False)
 
     def run_window(self):
         """Enqueue the T steps of the window on the current stream (no host synchronisation)."""
@@ -165,8 +182,6 @@ class RolloutEngine:
             self._window_graph = None
         step = self.stepper._step_obj   # Stepper.replace_ocean / overrides after construction take effect here
         if step._ocean is not self._ocean or step._corrector is not self._corrector:
-            if self.graph_mode == "window" and (step._ocean is not None or step._corrector is not None):
-                raise NotImplementedError("post-step hooks with graph='window'")
             self._ocean, self._corrector = step._ocean, step._corrector
             self._window_graph = None
         if self.graph_mode == "window":
@@ -197,6 +212,10 @@ class RolloutEngine:
             carried = getattr(initial_condition, "stepper_state", None)
             if carried is not None:
                 self._corrector_state = carried.corrector_state
+                cs = carried.corrector_state
+                if self._have_ref is not None and cs is not None and cs.global_dry_air_mass is not None:
+                    self._ref_mass.copy_(cs.global_dry_air_mass)     # carried reference: the captured region keeps it
+                    self._have_ref.fill_(True)
             self.run_window()
         state = PrognosticState({n: self.out[n][:, -1:] for n in self.prognostic})
         if self._corrector_state is not None:

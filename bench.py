@@ -60,10 +60,51 @@ def stage_model(C=384, H=180, W=360, L=180, M=181, hid=768, cin=44, cout=50):
     }
 
 
-def build_stepper(dev, seed):
+def hook_names():
+    """ACE2-style variable names (8 model levels) with the same 44 / 50 channel counts, so that the post-step physics of a
+    real checkpoint (atmosphere corrector + prescribed-SST ocean) finds its fields: --hooks."""
+    lv = range(8)
+    forcing = ["DSWRFtoa", "HGTsfc", "ocean_fraction", "land_fraction", "sea_ice_fraction", "forcing_5", "forcing_6", "forcing_7"]
+    prog = (["PRESsfc", "surface_temperature"] + [f"specific_total_water_{k}" for k in lv] + [f"air_temperature_{k}" for k in lv]
+            + [f"eastward_wind_{k}" for k in lv] + [f"northward_wind_{k}" for k in lv] + ["TMP2m", "Q2m"])
+    diag = ["PRATEsfc", "LHTFLsfc", "SHTFLsfc", "tendency_of_total_water_path_due_to_advection", "DSWRFsfc", "USWRFsfc",
+            "DLWRFsfc", "ULWRFsfc", "ULWRFtoa", "USWRFtoa", "diag_10", "diag_11", "diag_12", "diag_13"]
+    assert (len(forcing), len(prog), len(diag)) == (N_FORCING, N_PROGNOSTIC, N_DIAGNOSTIC)
+    return forcing, prog, diag
+
+
+def build_stepper(dev, seed, hooks=False):
     import ace_amd
     from ace_amd.step import NormalizationConfig
 
+    if hooks:
+        import numpy as np
+        forcing, prog, diag = hook_names()
+        in_names, out_names = forcing + prog, prog + diag
+        # normalisation that keeps the synthetic state in a physically meaningful range (pressure ~1e5 Pa, water ~1e-3 ...)
+        means = {k: 0.1 for k in in_names + out_names}
+        stds = {k: 1.1 for k in in_names + out_names}
+        means.update({"PRESsfc": 1.0e5, "surface_temperature": 288.0, "HGTsfc": 300.0, "DSWRFtoa": 340.0})
+        stds.update({"PRESsfc": 1.0e3, "surface_temperature": 10.0, "HGTsfc": 100.0, "DSWRFtoa": 100.0})
+        for k in range(8):
+            means[f"specific_total_water_{k}"], stds[f"specific_total_water_{k}"] = 3.0e-3, 1.0e-4
+            means[f"air_temperature_{k}"], stds[f"air_temperature_{k}"] = 250.0, 5.0
+        cfg = ace_amd.SingleModuleStepConfig(
+            builder=ace_amd.ModuleSelector(type="SphericalFourierNeuralOperatorNet", config=ACE2),
+            in_names=in_names, out_names=out_names, normalization=NormalizationConfig(means=means, stds=stds),
+            ocean={"surface_temperature_name": "surface_temperature", "ocean_fraction_name": "ocean_fraction"},
+            corrector={"conserve_dry_air": True, "moisture_budget_correction": "advection_and_precipitation",
+                       "force_positive_names": ["PRATEsfc"] + [f"specific_total_water_{k}" for k in range(8)],
+                       "total_energy_budget_correction": {"method": "constant_temperature", "constant_unaccounted_heating": 0.0}})
+        lat, _ = np.polynomial.legendre.leggauss(IMG[0])
+        lat = torch.tensor(np.degrees(np.arcsin(lat)), dtype=torch.float32)
+        ak = torch.linspace(0.0, 2.0e4, 9).flip(0) * torch.linspace(0.0, 1.0, 9)      # 9 interfaces, ak(surface) = 0
+        bk = torch.linspace(0.0, 1.0, 9)
+        info = ace_amd.DatasetInfo(IMG, lat=lat, lon=torch.arange(IMG[1]) * (360.0 / IMG[1]), ak=ak, bk=bk)
+        torch.manual_seed(seed)
+        stepper = ace_amd.Stepper.from_config(cfg, info, device=dev)
+        stepper.set_eval()
+        return stepper, forcing, prog, diag
     forcing, prog, diag = names()
     in_names = forcing + prog
     out_names = prog + diag
@@ -119,8 +160,12 @@ def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, 
     T = K
     eng = RolloutEngine(stepper, batch=1, n_forward_steps=T, graph=None if graph == "none" else graph)
     g = torch.Generator().manual_seed(1 + rank)                   # member `rank`: its own initial state
-    ic = {n: torch.randn(1, 1, *IMG, generator=g).to(dev) for n in prog}
-    fc = {n: torch.randn(1, T + 1, *IMG, generator=g).to(dev) for n in forcing_names}
+    norm = stepper._step_obj.normalizer
+    phys = lambda n, t: (t * float(norm.stds[n]) + float(norm.means[n])) if n in norm.means else t   # noqa: E731
+    ic = {n: phys(n, torch.randn(1, 1, *IMG, generator=g)).to(dev) for n in prog}
+    fc = {n: phys(n, torch.randn(1, T + 1, *IMG, generator=g)).to(dev) for n in list(forcing_names) + list(eng.target_names)}
+    if "ocean_fraction" in fc:
+        fc["ocean_fraction"] = torch.rand(1, T + 1, *IMG, generator=g).to(dev)
     eng.load(ic, fc)
     ens_mean = torch.zeros(len(eng.out_names), *IMG, device=dev)
 
@@ -209,6 +254,8 @@ def main():
     ap.add_argument("--precision", default="both", choices=["both", "f16x3", "fp32"],
                     help="'both': time the default (f16x3) and the exact-fp32 arithmetic in the same run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hooks", action="store_true",
+                    help="ACE2-style post-step physics (atmosphere corrector + prescribed-SST ocean) inside the timed loop")
     args = ap.parse_args()
 
     from ace_amd.distributed import Distributed
@@ -226,7 +273,7 @@ def main():
     dist = Distributed.get_instance()
 
     K, Wm = args.steps, args.warmup
-    stepper, forcing, prog, diag = build_stepper(dev, seed=0)   # same weights on every rank (one model, N members)
+    stepper, forcing, prog, diag = build_stepper(dev, seed=0, hooks=args.hooks)   # same weights on every rank (one model, N members)
     modes = [DEFAULT_PRECISION] + (["fp32" if DEFAULT_PRECISION != "fp32" else "f16x3"] if args.precision == "both" else [])
     if args.precision in ("f16x3", "fp32"):
         modes = [args.precision]

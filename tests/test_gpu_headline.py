@@ -148,3 +148,26 @@ def test_one_year_graph_rollout(dev):
     last = a[T * nwin]
     assert float(last.std()) > 1e-6, "state collapsed: dynamic-range slots lost the signal"
     assert float(last.abs().max()) < 1e6, "state blew up"
+
+
+def test_window_graph_keeps_corrector_state_across_replays(dev):
+    """graph="window" with the ACE2-style corrector captured inside the graph: three one-step windows REPLAY the same
+    captured graph; the dry-air reference mass seeded by the first must survive the replays (static buffer + device flag),
+    so the three windows reproduce the reference stepper's continuous 3-step rollout (tests/golden/gen_checkpoint.pt)."""
+    import ace_amd
+    from _util import checkpoint_case, conditioning_floor
+    from ace_amd.rollout import RolloutEngine
+    g = checkpoint_case(load_golden("gen_checkpoint.pt"), "ace2_like")
+    stepper = ace_amd.load_stepper(g["state"], device=dev).stepper
+    ic = {k: v.to(dev) for k, v in g["ic"].items()}
+    forcing = {k: v.to(dev) for k, v in g["forcing"].items()}
+    eng = RolloutEngine(stepper, batch=2, n_forward_steps=1, graph="window")
+    floor = conditioning_floor(g)
+    state = ic
+    for s, want_all in enumerate(g["steps"]):
+        out, state = eng.predict(state, {k: v[:, s:s + 2] for k, v in forcing.items()})
+        torch.cuda.synchronize()
+        for k, want in want_all.items():
+            err = float((out[k][:, 0].cpu() - want).abs().max()) / float(want.abs().max())
+            assert err <= max(NET_TOL * (s + 1), 3.0 * floor[s][k]), (s, k, err)
+    assert eng._window_graph is not None

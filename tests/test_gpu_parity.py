@@ -584,7 +584,7 @@ def test_stepper_predict_golden(dev):
     torch.testing.assert_close(nxt["b"].cpu(), g["next_state.b"])
 
 
-@pytest.mark.parametrize("graph", [None, "step"])
+@pytest.mark.parametrize("graph", [None, "step", "window"])
 def test_rollout_engine_with_hooks_matches_stepper(dev, graph):
     """post-step hooks inside the static-buffer engine (force-positive + zero-mean moisture advection corrector with
     area weights, prescribed-SST ocean whose target is a prognostic name) == the dict-of-tensors Stepper; a second
@@ -613,8 +613,6 @@ def test_rollout_engine_with_hooks_matches_stepper(dev, graph):
     forcing = {k: torch.randn(B, T + 1, 12, 24, device=dev) for k in ["f0", "sst"]}
     forcing["frac"] = torch.rand(B, T + 1, 12, 24, device=dev)
     ref, _ = stepper.predict(ic, forcing)
-    with pytest.raises(NotImplementedError):
-        RolloutEngine(stepper, batch=B, n_forward_steps=T, graph="window")
     eng = RolloutEngine(stepper, batch=B, n_forward_steps=T, graph=graph)
     assert eng.target_names == ["sst"]
     out, state = eng.predict(ic, forcing)
@@ -674,6 +672,7 @@ def test_rollout_engine_matches_stepper(dev, graph):
 
 
 @pytest.mark.parametrize("case,engine", [("ace2_like", "stepper"), ("ace2_like", None), ("ace2_like", "step"),
+                                         ("ace2_like", "window"), ("ace2_like_override", "window"),
                                          ("residual_prescribed", "stepper"), ("residual_prescribed", None),
                                          ("residual_prescribed", "step"), ("residual_prescribed", "window"),
                                          ("ace2_like_override", "stepper"), ("ace2_like_override", "step")])
