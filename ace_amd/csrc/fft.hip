@@ -89,9 +89,9 @@ constexpr int FFT_ROWS = ACE_FFT_ROWS;  // channel rows per workgroup: 64-byte r
 
 // ---- forward ----------------------------------------------------------------------------------------------------------
 // grid = (ceil(C / 16), H, Bt); block = 16 * max(N1, N2).  LDS: the rows (pitch W + 1), then - aliased - Z.
-template <int N1, int N2>
-__global__ __launch_bounds__(FFT_ROWS * (N1 > N2 ? N1 : N2)) void dft_forward_fft_kernel(DftArgs p) {
-    constexpr int W = N1 * N2, R = FFT_ROWS, H1 = N1 / 2 + 1, NT = R * (N1 > N2 ? N1 : N2);
+template <int N1, int N2, int R>
+__global__ __launch_bounds__(R * (N1 > N2 ? N1 : N2)) void dft_forward_fft_kernel(DftArgs p) {
+    constexpr int W = N1 * N2, H1 = N1 / 2 + 1, NT = R * (N1 > N2 ? N1 : N2);
     constexpr int PITCH = W + 1;
     constexpr int K2N = N2 / 2 + 1;  // k = k1 + N1 k2 <= W / 2  =>  k2 <= N2 / 2
     static_assert(N1 % 2 == 0, "N1 even");
@@ -210,11 +210,11 @@ __global__ __launch_bounds__(FFT_ROWS * (N1 > N2 ? N1 : N2)) void dft_forward_ff
     }
 }
 
-template <int N1, int N2>
+template <int N1, int N2, int R = FFT_ROWS>
 hipError_t launch_fwd(const DftArgs& a, hipStream_t s) {
-    constexpr int NT = FFT_ROWS * (N1 > N2 ? N1 : N2);
-    dim3 grid((unsigned)((a.C + FFT_ROWS - 1) / FFT_ROWS), (unsigned)a.H, (unsigned)a.Bt), block(NT);
-    hipLaunchKernelGGL((dft_forward_fft_kernel<N1, N2>), grid, block, 0, s, a);
+    constexpr int NT = R * (N1 > N2 ? N1 : N2);
+    dim3 grid((unsigned)((a.C + R - 1) / R), (unsigned)a.H, (unsigned)a.Bt), block(NT);
+    hipLaunchKernelGGL((dft_forward_fft_kernel<N1, N2, R>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 
@@ -230,9 +230,9 @@ hipError_t launch_fwd(const DftArgs& a, hipStream_t s) {
 template <int W>
 __device__ constexpr RootTab<W> kRoots{1.0};
 
-template <int N1, int N2>
-__global__ __launch_bounds__(FFT_ROWS * (N2 > N1 / 2 + 1 ? N2 : N1 / 2 + 1)) void dft_inverse_fft_kernel(DftArgs p) {
-    constexpr int W = N1 * N2, R = FFT_ROWS, H1 = N1 / 2 + 1, M2 = N2 / 2, NT = R * (N2 > H1 ? N2 : H1);
+template <int N1, int N2, int R>
+__global__ __launch_bounds__(R * (N2 > N1 / 2 + 1 ? N2 : N1 / 2 + 1)) void dft_inverse_fft_kernel(DftArgs p) {
+    constexpr int W = N1 * N2, H1 = N1 / 2 + 1, M2 = N2 / 2, NT = R * (N2 > H1 ? N2 : H1);
     constexpr int PITCH = W + 1;
     static_assert(N1 % 2 == 0 && N2 % 2 == 0 && N1 >= 4, "even factors");
     constexpr int YS = R * PITCH, US = 2 * R * H1 * N2;
@@ -361,11 +361,11 @@ __global__ __launch_bounds__(FFT_ROWS * (N2 > N1 / 2 + 1 ? N2 : N1 / 2 + 1)) voi
     }
 }
 
-template <int N1, int N2>
+template <int N1, int N2, int R = FFT_ROWS>
 hipError_t launch_inv(const DftArgs& a, hipStream_t s) {
-    constexpr int H1 = N1 / 2 + 1, NT = FFT_ROWS * (N2 > H1 ? N2 : H1);
-    dim3 grid((unsigned)((a.C + FFT_ROWS - 1) / FFT_ROWS), (unsigned)a.H, (unsigned)a.Bt), block(NT);
-    hipLaunchKernelGGL((dft_inverse_fft_kernel<N1, N2>), grid, block, 0, s, a);
+    constexpr int H1 = N1 / 2 + 1, NT = R * (N2 > H1 ? N2 : H1);
+    dim3 grid((unsigned)((a.C + R - 1) / R), (unsigned)a.H, (unsigned)a.Bt), block(NT);
+    hipLaunchKernelGGL((dft_inverse_fft_kernel<N1, N2, R>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 
@@ -385,6 +385,8 @@ bool launch_dft_forward_fft(const DftArgs& a, hipStream_t s, hipError_t* err) {
         return false;
     switch (a.W) {
         case 360: *err = launch_fwd<20, 18>(a, s); return true;
+        case 1440: *err = launch_fwd<40, 36, 8>(a, s); return true;    // 0.25-degree grid: 8 channel rows per workgroup (46 KiB)
+        case 720: *err = launch_fwd<30, 24, 8>(a, s); return true;
         case 48: *err = launch_fwd<8, 6>(a, s); return true;
         case 24: *err = launch_fwd<6, 4>(a, s); return true;
         case 16: *err = launch_fwd<4, 4>(a, s); return true;
@@ -397,6 +399,8 @@ bool launch_dft_inverse_fft(const DftArgs& a, hipStream_t s, hipError_t* err) {
         return false;
     switch (a.W) {
         case 360: *err = launch_inv<20, 18>(a, s); return true;
+        case 1440: *err = launch_inv<40, 36, 8>(a, s); return true;
+        case 720: *err = launch_inv<30, 24, 8>(a, s); return true;
         case 48: *err = launch_inv<8, 6>(a, s); return true;
         case 24: *err = launch_inv<6, 4>(a, s); return true;
         case 16: *err = launch_inv<4, 4>(a, s); return true;

@@ -6,7 +6,7 @@ themselves are exercised by the GPU SHT / network tests at W = 16, 24, 48 and 36
 import numpy as np
 import pytest
 
-CASES = [(360, 20, 18), (48, 8, 6), (24, 6, 4), (16, 4, 4)]   # the instantiated factorisations W = N1 * N2
+CASES = [(360, 20, 18), (1440, 40, 36), (720, 30, 24), (48, 8, 6), (24, 6, 4), (16, 4, 4)]   # the instantiated factorisations W = N1 * N2
 
 
 def w(j, n):

@@ -171,3 +171,22 @@ def test_window_graph_keeps_corrector_state_across_replays(dev):
             err = float((out[k][:, 0].cpu() - want).abs().max()) / float(want.abs().max())
             assert err <= max(NET_TOL * (s + 1), 3.0 * floor[s][k]), (s, k, err)
     assert eng._window_graph is not None
+
+
+def test_quarter_degree_mid_size_net(dev):
+    """BASELINE configs[3] (0.25 degree, 721 x 1440, L = M = 721) at a mid channel count: C = 32, two blocks, both
+    arithmetic modes against the fp64 oracle - the three-factor-free 40 x 36 longitude FFT, the tile-engine Legendre stages
+    (K = 721 is beyond the register-resident strip kernels) and 1.04 M-pixel convolutions."""
+    from oracle.sfno import SFNOConfig, SFNOOracle, init_state
+    H, W = 721, 1440
+    cfg = SFNOConfig(in_chans=4, out_chans=3, img_shape=(H, W), embed_dim=32, num_layers=2, operator_type="dhconv")
+    st = init_state(cfg, seed=3)
+    xin = torch.randn(1, 4, H, W, generator=torch.Generator().manual_seed(4))
+    ref = SFNOOracle(cfg, st, dtype=torch.float64).forward(xin)
+    for prec in ("f16x3", "fp32"):
+        net = build_native_net(cfg, st, dev, prec)
+        with torch.no_grad():
+            out = net(xin.to(dev))
+        err = rel_max(out, ref)
+        print(f"0.25 degree C=32 x 2 blocks, {prec}: rel err vs fp64 {err:.3e}")
+        assert err <= NET_TOL, prec
