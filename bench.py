@@ -120,13 +120,26 @@ def build_stepper(dev, seed, hooks=False):
     return stepper, forcing, prog, diag
 
 
-def cpu_baseline(stepper, x_cpu):
+def cpu_baseline(stepper, x_cpu, budget_s=40.0):
     """The reference CPU path, restated (oracle 'port': the same torch-CPU op sequence as fme's SFNO forward, pinned on the
-    reference's goldens), timed on ALL host cores of this box: 1 warm-up + 3 timed forward steps, median reported
-    (SURVEY 8(d) / BASELINE.md protocol).  Bounded: a box that needs more than 12 s per step times one step only."""
+    reference's goldens), timed on this box's host cores in the same run: 1 warm-up + up to 3 timed forward steps, median
+    reported (SURVEY 8(d) / BASELINE.md protocol).  All logical cores are offered; a 1x1-convolution probe picks the thread
+    count that is actually fastest on this host (oversubscribed torch intra-op pools can be several times slower) and the
+    result states both.  Bounded: timed steps stop once `budget_s` seconds of CPU work are spent."""
     from oracle.sfno import SFNOConfig, SFNOOracle
 
-    threads = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
+    a = torch.randn(384, 384)
+    bmat = torch.randn(384, IMG[0] * IMG[1])
+    probe = {}
+    for th in sorted({ncpu, max(ncpu // 2, 1), min(ncpu, 64), min(ncpu, 32)}, reverse=True):
+        torch.set_num_threads(th)
+        torch.mm(a, bmat)
+        t0 = time.perf_counter()
+        torch.mm(a, bmat)
+        probe[th] = time.perf_counter() - t0
+    best = min(probe.values())
+    threads = max(th for th, v in probe.items() if v <= 1.15 * best)   # the most threads that are not clearly slower
     torch.set_num_threads(threads)
     cfg = SFNOConfig(in_chans=N_FORCING + N_PROGNOSTIC, out_chans=N_PROGNOSTIC + N_DIAGNOSTIC, img_shape=IMG,
                      embed_dim=384, num_layers=8, operator_type="dhconv")
@@ -135,19 +148,22 @@ def cpu_baseline(stepper, x_cpu):
     times = []
     with torch.no_grad():
         t0 = time.perf_counter()
-        y = net(x_cpu)                                            # warm-up (untimed in the result)
+        y = net(x_cpu)                                            # warm-up (untimed in the result unless it is the only one)
         warm = time.perf_counter() - t0
-        for _ in range(3 if warm < 12.0 else 1):
+        spent = warm
+        while len(times) < 3 and spent + (times[-1] if times else warm) <= budget_s:
             t0 = time.perf_counter()
             y = net(x_cpu)
             times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return dict(value=1.0 / med, unit="steps/s", cores=threads, torch_threads=torch.get_num_threads(), kind="port",
-                seconds_per_step={"median": round(med, 3), "min": round(times[0], 3), "warmup": round(warm, 3),
+            spent += times[-1]
+    timed = sorted(times) if times else [warm]
+    med = timed[len(timed) // 2]
+    return dict(value=1.0 / med, unit="steps/s", cores=threads, host_logical_cores=ncpu, kind="port",
+                thread_probe_seconds={str(k): round(v, 4) for k, v in probe.items()},
+                seconds_per_step={"median": round(med, 3), "min": round(timed[0], 3), "warmup": round(warm, 3),
                                   "timed_steps": len(times)},
-                sample=f"forward steps of the same ACE2-shape network (B=1, fp32, torch-CPU ops) on {threads} host threads: "
-                       f"1 warm-up + {len(times)} timed, median {med:.2f} s/step"), y
+                sample=f"forward steps of the same ACE2-shape network (B=1, fp32, torch-CPU ops) on {threads} of {ncpu} host "
+                       f"threads (fastest in a conv probe): 1 warm-up + {len(times)} timed, median {med:.2f} s/step"), y
 
 
 def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, world, rank):
