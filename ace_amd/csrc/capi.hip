@@ -1138,7 +1138,20 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             g.M = n->Mm * B; g.N = 2 * C; g.K = 2 * C; g.nbatch = n->L; g.a_kpad = 2 * C;
             g.tri = TRI_ROWS_LE_BATCH; g.trimul = B;
             g.omax = emax;
-            if (dplanes) {
+            DhconvStripArgs ds;
+            if (dplanes && n->wx_compact[i]) {
+                ds.Dhi = reinterpret_cast<const _Float16*>(n->D.p);
+                ds.Dlo = ds.Dhi + (size_t)n->L * n->Mm * N2;
+                ds.sD = (long)n->Mm * N2; ds.amax = dmax;
+                ds.Whi = reinterpret_cast<const _Float16*>(n->wx_hi[i].p);
+                ds.Wlo = reinterpret_cast<const _Float16*>(n->wx_lo[i].p);
+                ds.sW = (long)2 * C * C; ds.bscale = n->wx_scale[i];
+                ds.E = n->E.p; ds.sE = (long)n->Mm * N2; ds.omax = emax;
+                ds.C = C; ds.L = n->L; ds.Mrows = n->Mm * B; ds.trimul = B;
+            }
+            if (dplanes && n->wx_compact[i] && dhconv_strip_eligible(ds)) {
+                HIP_TRY(launch_dhconv_strip(ds, s));
+            } else if (dplanes) {
                 Gemm4Args a;
                 a.Ahi = reinterpret_cast<const _Float16*>(n->D.p);
                 a.Alo = a.Ahi + (size_t)n->L * n->Mm * N2;

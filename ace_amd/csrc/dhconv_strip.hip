@@ -1,0 +1,222 @@
+// Spectral filter contraction (fme/ace/models/modulus/contractions.py:183-195, "dhconv") for gfx950 with the weights
+// streamed ONCE, straight from HBM into MFMA B fragments:
+//     E_l[(m, b)][o] = sum_i D_l[(m, b)][i] W_l[i][o]      complex, one (C x C) filter matrix per degree l, rows m <= l
+// The filter is 212 MB at the ACE2 shape and every element is used by at most 181 rows: the stage is bound by streaming
+// the weights.  The 128 x 128 tile engine moves each weight through L2 -> LDS once per 128-row tile and each coefficient
+// once per 128-column tile (1.1 GB of LDS-DMA traffic per launch, 465 MB of HBM reads for 262 MB of operands: r02 PMC).
+// Here a workgroup owns (degree l, 128 output channels): its four waves each hold 64 output columns (real part: waves 0, 1;
+// imaginary part: waves 2, 3) for ALL rows of the degree (up to 192 = 6 strips of 32, 12 accumulator tiles per wave):
+//   * the weights are the MFMA B operand: their stored form (k-packed "P format", compact complex: Wr | Wi per l) IS the
+//     fragment of a lane, so they go global -> registers with coalesced 16-byte loads, two k32-stages ahead, and never
+//     touch LDS; nobody else needs them (the other waves hold other columns);
+//   * the coefficients D_l (fp16 hi/lo planes written by the Legendre stage, row-major) are the A operand shared by the
+//     four waves: 1-KiB LDS-DMA pieces of 16 rows x 32 k, source-side XOR swizzle, four-stage ring, counted waits (all
+//     vector-memory operations of the loop are inline asm, no stores: the count is exact);
+//   * complex structure: real columns contract D_re with Wr and D_im with -Wi (the sign is flipped on the B fragments, once
+//     per loaded fragment), imaginary columns contract D_re with Wi and D_im with Wr;
+//   * row strips beyond l are skipped in pairs (2, 4 or 6 active strips).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
+#include "strip_common.h"
+
+namespace ace {
+namespace {
+
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+MDEV void gload16(half8& dst, const _Float16* p) {   // un-waited 16-byte global load (retired by wait_b below)
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
+}
+MDEV half8 neg8(half8 v) {
+    u32x4v u = __builtin_bit_cast(u32x4v, v);
+    u ^= 0x80008000u;
+    return __builtin_bit_cast(half8, u);
+}
+
+// NS: active 32-row strips (2, 4, 6)
+template <int NS>
+MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const int j, const int rows) {
+    constexpr int NSTG = 4;                       // ring depth (k32-stages)
+    constexpr int STAGE = NS * 4096;              // bytes: NS strips x (2 row pieces x 2 planes) x 1 KiB
+    constexpr int PB = 2;                         // B fragments run PB stages ahead
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, g = lane >> 5;
+    const int C = p.C, K2 = 2 * C;
+    const int nstages = K2 / 32;
+    const int part = wave >> 1;                   // 0: real output columns, 1: imaginary
+    const int oc = 128 * j + 64 * (wave & 1);     // first of this wave's 64 output channels
+
+    const unsigned raw_a = slot_load(p.amax + lane);
+
+    // ---- A pieces: piece q of a stage = (strip s = q / 4, row half rh = (q / 2) % 2, plane pl = q % 2); this wave issues the
+    //      pieces q = wave + 4 k, k < NS.  Lane L fetches the XOR-swizzled 16-byte slot of row L / 4 (gemm4's scheme)
+    const _Float16* Dh = p.Dhi + (long)l * p.sD;
+    const _Float16* Dl = p.Dlo + (long)l * p.sD;
+    const _Float16* asrc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int q = wave + 4 * k;
+        const int s = q >> 2, rh = (q >> 1) & 1, pl = q & 1;
+        int row = 32 * s + 16 * rh + (lane >> 2);
+        const int ls = (lane & 3) ^ ((row >> 2) & 3);
+        row = row < rows ? row : rows - 1;
+        asrc[k] = (pl ? Dl : Dh) + (long)row * K2 + 8 * ls;
+    }
+    auto issue_a = [&](int t) {   // stage t -> ring slot t % NSTG; stages past the end re-fetch the last (uniform count)
+        const int tt = t < nstages ? t : nstages - 1;
+        char* dst = smem + (t % NSTG) * STAGE;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) glds16(asrc[k] + 32 * tt, dst + (wave + 4 * k) * 1024);
+    };
+    // ---- B fragments: stage t = k in [32 t, 32 t + 32); block (Wr | Wi) by (k half, part); entry (k group, column)
+    const _Float16* Wh = p.Whi + (long)l * p.sW;
+    const _Float16* Wl = p.Wlo + (long)l * p.sW;
+    struct BSet { half8 h[2][2], l[2][2]; };      // [k16 step][column tile]
+    auto issue_b = [&](BSet& b, int t) {
+        const int tt = t < nstages ? t : nstages - 1;
+        const int khalf = (32 * tt) >= C;
+        const int blk = khalf != part;            // re: Wr then Wi; im: Wi then Wr
+        const int kg0 = (32 * tt - khalf * C) / 8;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const long off = (long)blk * C * C + ((long)(kg0 + 2 * c + g) * C + oc + 32 * tl + i) * 8;
+                gload16(b.h[c][tl], Wh + off);
+                gload16(b.l[c][tl], Wl + off);
+            }
+    };
+    auto wait_b = [&](BSet& b, auto nn) {         // retire this set: at most nn newer operations stay in flight
+        constexpr int N = decltype(nn)::value;
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(b.h[0][0]), "+v"(b.h[0][1]), "+v"(b.h[1][0]), "+v"(b.h[1][1]), "+v"(b.l[0][0]), "+v"(b.l[0][1]),
+                       "+v"(b.l[1][0]), "+v"(b.l[1][1])
+                     : "n"(N)
+                     : "memory");
+    };
+
+    f32x16 acc[NS][2];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][tl][r] = 0.f;
+
+    // prologue in the steady-state issue order (stage t issues A(t + 3) then B(t + 2)): A0 | A1 B0 | A2 B1
+    BSet bs[4];                                   // ring of fragment sets, indexed with compile-time constants only
+    issue_a(0);
+    issue_a(1); issue_b(bs[0], 0);
+    issue_a(2); issue_b(bs[1], 1);
+
+    const float inv_a = ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_a)));
+    const float oscale = inv_a / p.bscale;
+    const int key = (i >> 2) & 3;                 // swizzle key of this lane's fragment rows (rows i and i + 16 ... share it mod 4)
+
+    // Stage t issues A(t + 3) and B(t + 2).  Issue order: ... A(t+1) B(t) | A(t+2) B(t+1) | A(t+3) B(t+2): after this
+    // stage's issue exactly 2 (NS + 8) operations are newer than B(t), and A(t) is older than B(t-1), which the previous
+    // stage retired.  All of them are loads (in-order retirement), the loop has no stores: vmcnt(2 (NS + 8)) is exact.
+    auto stage = [&](const int t, BSet& b, BSet& bnew) {
+        issue_a(t + 3);
+        issue_b(bnew, t + PB);
+        wait_b(b, std::integral_constant<int, 2 * (NS + 8)>{});
+        __builtin_amdgcn_s_barrier();             // every wave's pieces of stage t landed
+        if (part == 0 && 32 * t >= C) {           // real columns, imaginary k half: -Wi
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) { b.h[c][tl] = neg8(b.h[c][tl]); b.l[c][tl] = neg8(b.l[c][tl]); }
+        }
+        const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (t % NSTG) * STAGE);
+        // A fragment of strip s, k16 step c: rows 32 s + i (piece 2 s + (i >> 4)), logical slot 2 c + g, physical slot ^ key
+        const unsigned la = sl + ((i >> 4) * 2) * 1024 + (i & 15) * 64;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const unsigned slot_off = (unsigned)(((2 * c + g) ^ key) * 16);
+            Frag fr[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024"
+                             : "=&v"(fr[s].h), "=&v"(fr[s].l)
+                             : "v"(la + s * 4096 + slot_off));
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fr[s].h), "+v"(fr[s].l) : "n"(2 * (NS - 1 - s)));
+                acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].l, b.h[c][0], acc[s][0], 0, 0, 0);
+                acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].l, b.h[c][1], acc[s][1], 0, 0, 0);
+                acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].h, b.l[c][0], acc[s][0], 0, 0, 0);
+                acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].h, b.l[c][1], acc[s][1], 0, 0, 0);
+                acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].h, b.h[c][0], acc[s][0], 0, 0, 0);
+                acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].h, b.h[c][1], acc[s][1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_barrier();             // every wave is done reading the slot of stage t (refilled by A(t + 4))
+    };
+    for (int t0 = 0; t0 < nstages; t0 += 4)       // nstages = C / 16 is a multiple of 8
+        static_for<0, 4>([&](auto u) { stage(t0 + u, bs[u], bs[(u + PB) % 4]); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy tail fetches
+
+    // ---- epilogue: lane = column, registers = rows; fp32 E[l][row][part * C + column], 128-byte row segments
+    float* E = p.E + (long)l * p.sE;
+    float vmax = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int col = part * C + oc + 32 * tl + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * s + (r & 3) + 8 * (r >> 2) + 4 * g;
+                const float v = acc[s][tl][r] * oscale;
+                if (row < rows) {
+                    E[(long)row * K2 + col] = v;
+                    vmax = fmaxf(vmax, fabsf(v));
+                }
+            }
+        }
+    if (p.omax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        float* red = reinterpret_cast<float*>(smem);
+        __syncthreads();
+        if (lane == 0) red[wave] = vmax;
+        __syncthreads();
+        if (tid == 0) atomicMax(p.omax + (blockIdx.x & 63), __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void dhconv_strip_kernel(DhconvStripArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 6 * 4096];
+    // heavy degrees first: blocks in dispatch order take l = L - 1, L - 1, L - 1 (its C / 128 column groups), L - 2, ...
+    const int ncg = p.C / 128;
+    const int l = p.L - 1 - (int)(blockIdx.x / ncg);
+    const int j = blockIdx.x % ncg;
+    const int rows = (l + 1) * p.trimul < p.Mrows ? (l + 1) * p.trimul : p.Mrows;
+    if (rows <= 64) dhconv_body<2>(p, smem, l, j, rows);
+    else if (rows <= 128) dhconv_body<4>(p, smem, l, j, rows);
+    else dhconv_body<6>(p, smem, l, j, rows);
+}
+
+}  // namespace
+
+bool dhconv_strip_eligible(const DhconvStripArgs& a) {
+    static const bool off = std::getenv("ACE_NO_DHCONV_STRIP") != nullptr;   // A/B switch for measurements
+    if (off) return false;
+    return a.C % 128 == 0 && a.C >= 128 && a.Mrows <= 192 && a.L >= 1 && a.Dhi && a.Dlo && a.Whi && a.Wlo && a.E && a.amax;
+}
+
+hipError_t launch_dhconv_strip(const DhconvStripArgs& a, hipStream_t s) {
+    if (!dhconv_strip_eligible(a)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)(a.L * (a.C / 128))), block(256);
+    hipLaunchKernelGGL(dhconv_strip_kernel, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace ace

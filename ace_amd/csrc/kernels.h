@@ -185,6 +185,19 @@ struct ConvStripArgs {
 bool conv_strip_eligible(int C, int M, int act);
 hipError_t launch_conv_strip(const ConvStripArgs& a, hipStream_t s);
 
+// dhconv with the filter streamed once into MFMA B fragments (dhconv_strip.hip).  Rows (m, b), m <= l; K = N = 2 C.
+struct DhconvStripArgs {
+    const _Float16* Dhi = nullptr; const _Float16* Dlo = nullptr; long sD = 0;   // coefficient planes [l][row][2C], per-l stride (halves)
+    const unsigned* amax = nullptr;                                               // bound the planes were scaled with
+    const _Float16* Whi = nullptr; const _Float16* Wlo = nullptr; long sW = 0;   // compact filter planes [l][Wr|Wi][C/8][C][8], per-l stride
+    float bscale = 1.f;                                                           // static power-of-two scale of the filter
+    float* E = nullptr; long sE = 0;                                              // fp32 output [l][row][2C]
+    unsigned* omax = nullptr;
+    int C = 0, L = 0, Mrows = 0, trimul = 1;                                      // rows of degree l: min((l + 1) * trimul, Mrows)
+};
+bool dhconv_strip_eligible(const DhconvStripArgs& a);
+hipError_t launch_dhconv_strip(const DhconvStripArgs& a, hipStream_t s);
+
 // Spectral-space layout used between the kernels ("channel-fastest planar"):
 //   X[m][k][b][ri][c]  (after the longitude DFT)     index ((m*H + k)*Bt + b)*2C + ri*C + c
 //   D[l][m][b][ri][c]  (after the Legendre stage)    index ((l*Mm + m)*Bt + b)*2C + ri*C + c
