@@ -181,9 +181,17 @@ struct ConvStripArgs {
     _Float16* Chi = nullptr; _Float16* Clo = nullptr; long sCp = 0; unsigned* cslot = nullptr;  // output planes [M/8][HW][8]
     float4* part = nullptr; int nstrips32 = 0;        // optional row statistics per (sample, 32-pixel strip, row)
     int C = 0, M = 0, HW = 0, nbatch = 1, act = ACT_NONE;
+    // conv_split.hip only (second MLP convolution): fp32 output, per-row affine of the residual, range maximum
+    float* Cf = nullptr; long sCf = 0;
+    const float* rsc = nullptr; const float* rsh = nullptr; long srs = 0;
+    unsigned* omax = nullptr;
 };
 bool conv_strip_eligible(int C, int M, int act);
 hipError_t launch_conv_strip(const ConvStripArgs& a, hipStream_t s);
+// the same contract with the contraction split over wave pairs (conv_split.hip): C in {128, 256, 384, 512, 768}; the mode is
+// derived from the outputs requested (GELU + planes [+ residual + statistics], or residual + fp32 [+ planes + statistics])
+bool conv_split_eligible(int K, int M, long HW);
+hipError_t launch_conv_split(const ConvStripArgs& a, hipStream_t s);
 
 // dhconv with the filter streamed once into MFMA B fragments (dhconv_strip.hip).  Rows (m, b), m <= l; K = N = 2 C.
 struct DhconvStripArgs {
