@@ -841,7 +841,7 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
         const bool is_skip = wn.size() > 17 && wn.compare(wn.size() - 17, 17, "inner_skip.weight") == 0;
         const bool is_fc2 = wn.size() > 16 && wn.compare(wn.size() - 16, 16, "mlp.fwd.2.weight") == 0;
         if ((is_skip && conv_strip_eligible(w.cols, w.rows, ACT_GELU)) ||
-            ((is_skip || is_fc2) && conv_split_eligible(w.cols, w.rows, 1))) {
+            ((is_skip || is_fc2) && conv_split_eligible(w.cols, w.rows, 1, is_skip ? 0 : 2))) {
             if (!w.frag0.p) HIP_TRY(w.frag0.alloc((size_t)w.rows * w.cols, false));
             HIP_TRY(launch_pack_conv_frag(w.buf.p, w.pitch, w.rows, w.cols, 0, nullptr, 0.f, w.ascale, nullptr, w.frag0.p,
                                           0, 1, s));
@@ -1234,7 +1234,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 o.bhi = PBh; o.blo = PBl; o.in_slot = skip_max;
             }
             int t_nparts = gemm4_strips(C, (int)HW);
-            const bool split_ok = strip_ok && conv_split_eligible(C, C, HW);   // contraction split over wave pairs (conv_split.hip)
+            const bool split_ok = strip_ok && conv_split_eligible(C, C, HW, 0);   // contraction split over wave pairs (conv_split.hip)
             const int nsplit32 = (int)((HW + 127) / 128) * 4;
             if (strip_ok) {   // register-resident strip kernels
                 ConvStripArgs k;
@@ -1314,12 +1314,12 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 k.cw = w1.winf; k.cb = b1w.absmax; k.cinb = slot(sb + 5);
                 k.Chi = Uh; k.Clo = Ul; k.sCp = (long)n->hid * HW; k.cslot = slot(sb + 6);
                 k.C = C; k.M = n->hid; k.HW = (int)HW; k.nbatch = B; k.act = ACT_GELU;
-                HIP_TRY(conv_split_eligible(C, n->hid, HW) ? launch_conv_split(k, s) : launch_conv_strip(k, s));
+                HIP_TRY(conv_split_eligible(C, n->hid, HW, 1) ? launch_conv_split(k, s) : launch_conv_strip(k, s));
             } else {
                 ACE_TRY(conv_pk2(n, f1, B, s));
             }
             MARK(ST_MLP_FC1);
-            if (w2.frag0.p && conv_split_eligible(n->hid, C, HW) && C <= 1024) {
+            if (w2.frag0.p && conv_split_eligible(n->hid, C, HW, 2) && C <= 1024) {
                 // fc2 + outer skip on the split-contraction strip kernel: fp32 h' (+ planes and statistics for the next block)
                 ConvStripArgs k;
                 k.Xhi = Uh; k.Xlo = Ul; k.ldn = HW; k.sX = (long)n->hid * HW; k.xslot = slot(sb + 6);
@@ -1458,6 +1458,18 @@ extern "C" int ace_sfno_forward_conditioned(ace_sfno* n, const float* in, const 
     if (!noise && n->cfg.noise_embed_dim > 0) return fail(ACE_ERR_INVALID, "null noise");
     return forward_impl(n, in, out, batch, static_cast<hipStream_t>(stream), nullptr, noise);
 }
+
+#ifdef ACE_DEBUG_WS   // debugging builds only (tools/mkvar.sh dbg -DACE_DEBUG_WS): copy of an internal workspace after a forward
+extern "C" long ace_debug_read_workspace(ace_sfno* n, const char* which, void* dst, long max_bytes) {
+    const std::string w(which);
+    DevBuf* b = w == "U" ? &n->U : w == "P" ? &n->P : w == "P2" ? &n->P2 : w == "part" ? &n->part : w == "Y" ? &n->Y : nullptr;
+    if (!b || !b->p) return -1;
+    const long bytes = std::min<long>((long)(b->n * sizeof(float)), max_bytes);
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (hipMemcpy(dst, b->p, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+    return bytes;
+}
+#endif
 
 extern "C" int ace_sfno_num_stages(void) { return ST_COUNT; }
 extern "C" const char* ace_sfno_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : nullptr; }

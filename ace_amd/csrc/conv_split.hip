@@ -22,12 +22,18 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <string>
 #include <type_traits>
 
 #include "strip_common.h"
 
 namespace ace {
 namespace {
+
+#ifndef ACE_X_TRACE_MODE
+#define ACE_X_TRACE_MODE 1   // measurement builds (-DACE_X_TRACE=<block>): which MODE records its timeline
+#endif
+#define MTQ(ev) do { if (MODE == ACE_X_TRACE_MODE) MT(ev); } while (0)
 
 constexpr int OOBV = 0x7fffff00;   // buffer offset beyond every resource of these kernels: loads return 0, stores are dropped
 
@@ -36,19 +42,29 @@ constexpr int OOBV = 0x7fffff00;   // buffer offset beyond every resource of the
 //      2: fc2, mid    (residual with per-row affine, fp32 output + P-format planes + row statistics)
 //      3: fc2, last   (residual with per-row affine, fp32 output, optional range maximum)
 template <int KSW, int NSTG, int MODE>
-__global__ __launch_bounds__(512) void conv_split_kernel(ConvStripArgs p) {
-    constexpr int KH = KSW * NSTG;          // k16-steps per wave: its half of the contraction
-    constexpr int SLOT = 2 * KSW * 2048;    // one stage of A fragments, both halves
+struct SplitGeom {
+    static constexpr int KH = KSW * NSTG;          // k16-steps per wave: its half of the contraction
+    static constexpr int SLOT = 2 * KSW * 2048;    // one stage of A fragments, both halves
+    static constexpr bool F32 = MODE >= 2, STATS = MODE == 0 || MODE == 2;
+    static constexpr int BMAX = F32 ? 1024 : 2048; // output rows with LDS-resident epilogue parameters
+    static constexpr int TAB = BMAX * 4 * (F32 ? 2 : 1);
+    static constexpr int XCH = 2 * 8 * 2048;       // accumulator exchange: [tile parity][wave][2 planes][64 lanes][16 B]
+    static constexpr int STP = 36;                 // pitch of the statistics transpose (floats)
+    static constexpr int STB = STATS ? 8 * 16 * STP * 4 : 0;
+    static constexpr int LDS = 2 * SLOT + TAB + XCH + STB;
+    static_assert(KSW % 2 == 0 && LDS <= 160 * 1024, "LDS budget");
+};
+
+// H: contraction half of the calling wave (compile time: the accumulator halves kept / handed over are then plain register
+// names; a run-time h made hipcc index the register file through M0 or spill)
+template <int KSW, int NSTG, int MODE, int H>
+MDEV void conv_split_body(const ConvStripArgs& p, char* smem) {
+    using G = SplitGeom<KSW, NSTG, MODE>;
+    constexpr int KH = G::KH, SLOT = G::SLOT, BMAX = G::BMAX, TAB = G::TAB, XCH = G::XCH, STP = G::STP;
     constexpr int PW = KSW / 2;             // 1-KiB pieces per wave per stage
-    constexpr bool GELU = MODE <= 1, RES = MODE != 1, PK = MODE != 3, F32 = MODE >= 2, STATS = MODE == 0 || MODE == 2;
+    constexpr bool GELU = MODE <= 1, RES = MODE != 1, PK = MODE != 3, F32 = MODE >= 2, STATS = G::STATS;
     constexpr bool INTER = MODE <= 1;       // epilogue of tile t - 1 between the MFMAs of tile t
-    constexpr int BMAX = F32 ? 1024 : 2048; // output rows with LDS-resident epilogue parameters
-    constexpr int TAB = BMAX * 4 * (F32 ? 2 : 1);
-    constexpr int XCH = 2 * 8 * 2048;       // accumulator exchange: [tile parity][wave][2 planes][64 lanes][16 B]
-    constexpr int STP = 36;                 // pitch of the statistics transpose (floats)
-    constexpr int STB = STATS ? 8 * 16 * STP * 4 : 0;
-    static_assert(KSW % 2 == 0 && 2 * SLOT + TAB + XCH + STB <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) char smem[2 * SLOT + TAB + XCH + STB];
+    constexpr int h = H;
     float* Pb = reinterpret_cast<float*>(smem + 2 * SLOT);     // bias (+ residual shift)
     float* Ps = Pb + BMAX;                                      // residual scale (F32 modes)
     char* xch = smem + 2 * SLOT + TAB;
@@ -56,7 +72,6 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvStripArgs p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, g = lane >> 5;
-    const int h = wave >> 2;                // contraction half of this wave
     float* St = reinterpret_cast<float*>(smem + 2 * SLOT + TAB + XCH) + wave * (16 * STP);
     const int wgs = (p.HW + 127) / 128;
     const int smp = blockIdx.x / wgs;
@@ -67,6 +82,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvStripArgs p) {
     const int ntiles = p.M / 32;
     const int NU = ntiles * NSTG;
 
+    MTQ(0);
     const unsigned raw_x = slot_load(p.xslot + lane);
     const unsigned raw_a = p.aslot ? slot_load(p.aslot + lane) : 0u;
     const unsigned raw_c = p.cinb ? slot_load(p.cinb + lane) : 0u;
@@ -110,6 +126,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvStripArgs p) {
             }
         }
     }
+    MTQ(1);
     const float xbound = wave_max_bits(raw_x);
     const float inv_x = ldexpf(1.0f, -pow2_exponent_for(xbound));
     const float inv_a = p.aslot ? ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_a))) : 1.0f / p.ascale;
@@ -123,10 +140,13 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvStripArgs p) {
         if (tid == 0) atomicMax(p.cslot + (blockIdx.x & 63), __float_as_uint(cbound));
     }
 
+    MTQ(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage 0, the input strip, the tables' sources
 #pragma unroll
     for (int j = 0; j < KH; ++j) asm volatile("" : "+v"(xh[j]), "+v"(xl[j]));
+    MTQ(3);
     __syncthreads();
+    MTQ(4);
 
     const int fbytes = p.M * p.HW * 4, pbytes = p.M * p.HW * 2;
     const auto rsR = __builtin_amdgcn_make_buffer_rsrc(RES ? const_cast<float*>(p.R + (long)smp * p.sR) : nullptr, 0, RES ? fbytes : 0, 0x00020000);
@@ -145,9 +165,11 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvStripArgs p) {
     float own[8], res[8], resn[8];
     f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
     half8 hh8, ll8;
+    float vals[8];                         // fp32 store data (F32 modes)
+    f32x4 stv = {0.f, 0.f, 0.f, 0.f};      // statistics store data
     float vmax = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { own[e] = 0.f; res[e] = 0.f; resn[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { own[e] = 0.f; res[e] = 0.f; resn[e] = 0.f; vals[e] = 0.f; }
 #pragma unroll
     for (int e = 0; e < 8; ++e) { hh8[e] = (_Float16)0.f; ll8[e] = (_Float16)0.f; }
 
@@ -161,7 +183,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvStripArgs p) {
             if (RES) val = F32 ? fmaf(resn[e], Ps[row], val) : val + res[e];   // light epilogues consume the fetched rows in place
             if (GELU) val = act_fn<ACT_GELU_FAST>(val);
             if (F32) {
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rsC, vo_f, (32 * tp + 16 * h + e) * rowb, 0);
+                vals[e] = val;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[e]), rsC, vo_f, (32 * tp + 16 * h + e) * rowb, 0);
                 vmax = fmaxf(vmax, vo_f != OOBV ? fabsf(val) : 0.f);
             }
             if (STATS) St[(8 * g + e) * STP + i] = val;
@@ -198,8 +221,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvStripArgs p) {
                     mn = fminf(mn, __shfl_xor(mn, off, 64));
                     mx = fmaxf(mx, __shfl_xor(mx, off, 64));
                 }
-                const f32x4 st = {sm, sq, mn, mx};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, st), rsP, vo_s, (32 * tp + 16 * h) * 16, 0);
+                stv = f32x4{sm, sq, mn, mx};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, stv), rsP, vo_s, (32 * tp + 16 * h) * 16, 0);
             }
         }
     };
@@ -208,11 +231,15 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvStripArgs p) {
         for (int e = 0; e < 8; ++e)
             asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(resn[e]) : "v"(vf_ok), "s"(rsR), "s"((32 * t + 16 * h + e) * rowb));
     };
-    auto stage_top = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)"
+    auto stage_top = [&](int u = 0) {
+        MTQ(12 + 6 * u);
+        // lgkmcnt: the accumulator halves written for the partner must be IN the LDS before the barrier releases it (a bare
+        // s_barrier does not wait for them; hipcc only adds that wait to __syncthreads)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
                      : "+v"(resn[0]), "+v"(resn[1]), "+v"(resn[2]), "+v"(resn[3]), "+v"(resn[4]), "+v"(resn[5]), "+v"(resn[6]), "+v"(resn[7])
                      :
                      : "memory");
+        MTQ(13 + 6 * u);
         __builtin_amdgcn_s_barrier();      // the stage landed in every wave's share; every wave is done with the previous one
     };
     auto read_partner = [&](int t) {       // the partner's half of tile t
@@ -224,7 +251,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvStripArgs p) {
     f32x16 v;
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = 0.f;
-    constexpr int FST = KSW / 3;           // first k-step that carries an epilogue item
+    // epilogue items of the previous tile: the eight values over the first VSPAN k-steps, the stores right after - early
+    // enough that the stage-closing vmcnt(0) (gfx950 counts stores) finds them retired
+    constexpr int VSPAN = 2 * KSW / 3;
+    constexpr int FDEPTH = (MODE == 2 && KH == 24) ? 0 : 1;   // fragment read-ahead; 0 where the registers are gone (K = 768 + planes + statistics)
+    // The loop body is one stage FOLLOWED by the wait + barrier that opens the next one (stage 0 was opened by the prologue):
+    // the residual rows are requested, retired and copied inside ONE iteration.  An asm-loaded register that is still in
+    // flight must not be live across the back edge - hipcc believes the value is there and is free to move it (it placed
+    // v_mov copies of in-flight registers in the middle of the stage: r02, nondeterministic results).
     for (int t = 0; t < ntiles; ++t) {
         const bool live = t > 0;
         const int tp = live ? t - 1 : 0;
@@ -232,62 +266,89 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvStripArgs p) {
         static_for<0, NSTG>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             const int u = t * NSTG + q;
-            stage_top();
+            MTQ(8 + 6 * u);
+            // the PW pieces of stage u + 1 (into the slot of stage u - 1, free since the barrier): one per k-step from the first on,
+            // between the MFMAs (an LDS-DMA issue holds the wave's issue slot for ~80 cycles: 470 of 4550 cycles per stage
+            // when all six went out at the top - r02 in-kernel timeline); up front when the stage starts with an epilogue
+            constexpr bool SPREAD = INTER;          // (the K = 768 kernels have no registers for the piece addresses)
+            // K = 768: no registers to hold the store data of the epilogue through the stage either - the stores are retired
+            // before the fragment pipeline starts, the pieces go out after that
+            constexpr bool TIGHT = !INTER && KH == 24;
+            if constexpr (!SPREAD && !(TIGHT && q == 0)) {
 #pragma unroll
-            for (int k = 0; k < PW; ++k) piece(u + 1, k);
+                for (int k = 0; k < PW; ++k) piece(u + 1, k);
+            }
+            MTQ(9 + 6 * u);
             if constexpr (q == 0) {
                 read_partner(tp);
-                if constexpr (INTER) {
-                    if (RES) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) res[e] = resn[e];
-                    }
-                } else {   // light epilogue: all of it before the MFMAs of this tile
+                if constexpr (!INTER)   // light epilogue: all of it before the MFMAs of this tile
                     static_for<0, 9>([&](auto kc) { epi_item(kc, tp, vo_f, vo_p, vo_s); });
+                if constexpr (TIGHT) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    // (the store data stays where it is until here: see the note at the end of the stage)
+                    if constexpr (PK) asm volatile("" ::"v"(hh8), "v"(ll8));
+                    if constexpr (STATS) asm volatile("" ::"v"(stv));
+                    asm volatile("" ::"v"(vals[0]), "v"(vals[1]), "v"(vals[2]), "v"(vals[3]), "v"(vals[4]), "v"(vals[5]), "v"(vals[6]), "v"(vals[7]));
+#pragma unroll
+                    for (int k = 0; k < PW; ++k) piece(u + 1, k);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = 0.f;
             }
             if constexpr (RES && q == NSTG - 1) load_residual(t);
+            MTQ(10 + 6 * u);
             const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (u & 1) * SLOT) + h * (KSW * 2048) + lane * 16;
-            pipelined_steps<KSW, 1>(sl, [&](auto ss, const Frag& f) {
+            pipelined_steps<KSW, FDEPTH>(sl, [&](auto ss, const Frag& f) {
                 constexpr int st = decltype(ss)::value;
                 constexpr int j = q * KSW + st;
                 v = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l, xh[j], v, 0, 0, 0);
                 v = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, xl[j], v, 0, 0, 0);
                 v = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, xh[j], v, 0, 0, 0);
+                if constexpr (SPREAD && st < PW) piece(u + 1, st);
                 if constexpr (INTER && q == 0) {
                     static_for<0, 8>([&](auto kc) {
                         constexpr int e = decltype(kc)::value;
-                        if constexpr (FST + (e * (KSW - FST)) / 8 == st) epi_item(kc, tp, vo_f, vo_p, vo_s);
+                        if constexpr ((e * VSPAN) / 8 == st) epi_item(kc, tp, vo_f, vo_p, vo_s);
                     });
-                    if constexpr (st == KSW - 1) epi_item(std::integral_constant<int, 8>{}, tp, vo_f, vo_p, vo_s);
+                    if constexpr (st == VSPAN) epi_item(std::integral_constant<int, 8>{}, tp, vo_f, vo_p, vo_s);
                 }
             });
+            MTQ(11 + 6 * u);
             if constexpr (q == NSTG - 1) {   // tile complete: keep the rows this wave finishes, hand the others to the partner
                 rows_to_kgroups(v);
                 f32x4 sa, sb;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    sa[e] = h ? v[e] : v[8 + e];
-                    sb[e] = h ? v[4 + e] : v[12 + e];
-                }
+                for (int e = 0; e < 4; ++e) { sa[e] = v[8 * (1 - H) + e]; sb[e] = v[8 * (1 - H) + 4 + e]; }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) own[e] = h ? v[8 + e] : v[e];
+                for (int e = 0; e < 8; ++e) own[e] = v[8 * H + e];
                 char* xw = xch + (((t & 1) * 8) + wave) * 2048 + lane * 16;
                 *reinterpret_cast<f32x4*>(xw) = sa;
                 *reinterpret_cast<f32x4*>(xw + 1024) = sb;
             }
+            stage_top(u);                  // opens stage u + 1 (after the last one: the partner's half and the residual rows are there)
+            // The registers a buffer store takes its data from stay untouched until the store has RETIRED (the vmcnt(0) above).
+            // Measured on gfx950 (r02): with the store data in registers that the fragment pipeline re-used a few
+            // instructions later (an inline-asm ds_read_b128 whose data lands asynchronously), lanes 12 - 15 of each 16 of
+            // the second data dword reached memory with the NEW contents; holding the registers until here removed it.
+            constexpr bool KEEP = q == 0 && !(!INTER && KH == 24);
+            if constexpr (PK && KEEP) asm volatile("" ::"v"(hh8), "v"(ll8));
+            if constexpr (STATS && KEEP) asm volatile("" ::"v"(stv));
+            if constexpr (F32 && KEEP) asm volatile("" ::"v"(vals[0]), "v"(vals[1]), "v"(vals[2]), "v"(vals[3]), "v"(vals[4]), "v"(vals[5]), "v"(vals[6]), "v"(vals[7]));
+            if constexpr (INTER && RES && q == NSTG - 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) res[e] = resn[e];
+            }
         });
     }
     // ---- last tile
-    stage_top();                           // the partner's half is in LDS, the residual rows and the tail's dummy refills have landed
+    MTQ(5);
     read_partner(ntiles - 1);
-    if (INTER) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) res[e] = resn[e];
-    }
     static_for<0, 9>([&](auto kc) { epi_item(kc, ntiles - 1, vf_ok, vp_ok, vs_ok); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and the data registers of these stores are held until they retired
+    if constexpr (PK) asm volatile("" ::"v"(hh8), "v"(ll8));
+    if constexpr (STATS) asm volatile("" ::"v"(stv));
+    if constexpr (F32) asm volatile("" ::"v"(vals[0]), "v"(vals[1]), "v"(vals[2]), "v"(vals[3]), "v"(vals[4]), "v"(vals[5]), "v"(vals[6]), "v"(vals[7]));
+    MTQ(6);
     if (F32 && p.omax) {                   // one atomic per workgroup
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
@@ -301,6 +362,13 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvStripArgs p) {
             atomicMax(p.omax + (blockIdx.x & 63), __float_as_uint(m));
         }
     }
+}
+
+template <int KSW, int NSTG, int MODE>
+__global__ __launch_bounds__(512) void conv_split_kernel(ConvStripArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[SplitGeom<KSW, NSTG, MODE>::LDS];
+    if (threadIdx.x < 256) conv_split_body<KSW, NSTG, MODE, 0>(p, smem);   // waves 0 - 3: first half of the contraction
+    else conv_split_body<KSW, NSTG, MODE, 1>(p, smem);
 }
 
 template <int KSW, int NSTG>
@@ -320,16 +388,31 @@ hipError_t launch_split_k(const ConvStripArgs& a, int mode, hipStream_t s) {
 
 }  // namespace
 
+#ifdef ACE_X_TRACE
+extern "C" int ace_debug_split_trace(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mlp_trace), sizeof(mlp_trace)); }
+#endif
+
 // K: input channels, M: output rows
-bool conv_split_eligible(int K, int M, long HW) {
-    static const bool off = std::getenv("ACE_NO_CONV_SPLIT") != nullptr;   // A/B switch for measurements
-    if (off) return false;
+bool conv_split_eligible(int K, int M, long HW, int role) {
+    // A/B switch for measurements: ACE_NO_CONV_SPLIT=1 (all) or a list of roles, e.g. "skip,fc2"
+    static const int off = [] {
+        const char* e = std::getenv("ACE_NO_CONV_SPLIT");
+        if (!e) return 0;
+        const std::string v(e);
+        int m = 0;
+        if (v.find("skip") != std::string::npos) m |= 1;
+        if (v.find("fc1") != std::string::npos) m |= 2;
+        if (v.find("fc2") != std::string::npos) m |= 4;
+        return m ? m : 7;
+    }();
+    if (role >= 0 && role < 3 && (off >> role & 1)) return false;
+    if (role < 0 && off == 7) return false;
     if (!(K == 128 || K == 256 || K == 384 || K == 512 || K == 768)) return false;
     return M % 32 == 0 && M >= 32 && M <= 2048 && (long)M * HW * 4 < 0x7fffff00L;
 }
 
 hipError_t launch_conv_split(const ConvStripArgs& a, hipStream_t s) {
-    if (!conv_split_eligible(a.C, a.M, a.HW) || !a.bias || !a.xslot || !a.A) return hipErrorInvalidValue;
+    if (!conv_split_eligible(a.C, a.M, a.HW, -2) || !a.bias || !a.xslot || !a.A) return hipErrorInvalidValue;
     const bool f32 = a.Cf != nullptr, pk = a.Chi != nullptr, stats = a.part != nullptr, res = a.R != nullptr;
     const bool gelu = a.act == ACT_GELU || a.act == ACT_GELU_FAST;
     int mode = -1;

@@ -190,7 +190,7 @@ bool conv_strip_eligible(int C, int M, int act);
 hipError_t launch_conv_strip(const ConvStripArgs& a, hipStream_t s);
 // the same contract with the contraction split over wave pairs (conv_split.hip): C in {128, 256, 384, 512, 768}; the mode is
 // derived from the outputs requested (GELU + planes [+ residual + statistics], or residual + fp32 [+ planes + statistics])
-bool conv_split_eligible(int K, int M, long HW);
+bool conv_split_eligible(int K, int M, long HW, int role);   // role 0 inner skip, 1 fc1, 2 fc2 (-1: any)
 hipError_t launch_conv_split(const ConvStripArgs& a, hipStream_t s);
 
 // dhconv with the filter streamed once into MFMA B fragments (dhconv_strip.hip).  Rows (m, b), m <= l; K = N = 2 C.
