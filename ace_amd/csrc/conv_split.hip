@@ -164,17 +164,21 @@ MDEV void conv_split_body(const ConvStripArgs& p, char* smem) {
     // ---- epilogue state of the tile being finished: rows 32 tp + 16 h + 8 g + e of column i
     float own[8], res[8], resn[8];
     f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
-    half8 hh8, ll8;
-    float vals[8];                         // fp32 store data (F32 modes)
-    f32x4 stv = {0.f, 0.f, 0.f, 0.f};      // statistics store data
+    struct EpiOut {                        // data registers of the epilogue's stores (see the note at the end of the stage)
+        half8 hh8, ll8;
+        float vals[8];
+        f32x4 stv;
+    };
+    EpiOut eo;
     float vmax = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { own[e] = 0.f; res[e] = 0.f; resn[e] = 0.f; vals[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { own[e] = 0.f; res[e] = 0.f; resn[e] = 0.f; eo.vals[e] = 0.f; }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { hh8[e] = (_Float16)0.f; ll8[e] = (_Float16)0.f; }
+    for (int e = 0; e < 8; ++e) { eo.hh8[e] = eo.ll8[e] = (_Float16)0.f; }
+    eo.stv = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // item k < 8: value e = k; item 8: the stores of whole P entries and the row statistics
-    auto epi_item = [&](auto kc, const int tp, const int vo_f, const int vo_p, const int vo_s) {
+    auto epi_item = [&](auto kc, const int tp, const int vo_f, const int vo_p, const int vo_s, EpiOut& o) {
         constexpr int k = decltype(kc)::value;
         if constexpr (k < 8) {
             constexpr int e = k;
@@ -183,21 +187,21 @@ MDEV void conv_split_body(const ConvStripArgs& p, char* smem) {
             if (RES) val = F32 ? fmaf(resn[e], Ps[row], val) : val + res[e];   // light epilogues consume the fetched rows in place
             if (GELU) val = act_fn<ACT_GELU_FAST>(val);
             if (F32) {
-                vals[e] = val;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[e]), rsC, vo_f, (32 * tp + 16 * h + e) * rowb, 0);
+                o.vals[e] = val;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o.vals[e]), rsC, vo_f, (32 * tp + 16 * h + e) * rowb, 0);
                 vmax = fmaxf(vmax, vo_f != OOBV ? fabsf(val) : 0.f);
             }
             if (STATS) St[(8 * g + e) * STP + i] = val;
             if (PK) {
                 const float xs = val * cscale;
                 const _Float16 a16 = (_Float16)xs;
-                hh8[e] = a16;
-                ll8[e] = (_Float16)(xs - (float)a16);
+                o.hh8[e] = a16;
+                o.ll8[e] = (_Float16)(xs - (float)a16);
             }
         } else {
             if (PK) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hh8), rsH, vo_p, (4 * tp + 2 * h) * p.HW * 16, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ll8), rsL, vo_p, (4 * tp + 2 * h) * p.HW * 16, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.hh8), rsH, vo_p, (4 * tp + 2 * h) * p.HW * 16, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.ll8), rsL, vo_p, (4 * tp + 2 * h) * p.HW * 16, 0);
             }
             if (STATS) {
                 // lane (r = lane & 15, cq = lane >> 4) reduces columns 8 cq .. 8 cq + 7 of row r; the four quarters meet in two exchanges
@@ -221,8 +225,8 @@ MDEV void conv_split_body(const ConvStripArgs& p, char* smem) {
                     mn = fminf(mn, __shfl_xor(mn, off, 64));
                     mx = fmaxf(mx, __shfl_xor(mx, off, 64));
                 }
-                stv = f32x4{sm, sq, mn, mx};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, stv), rsP, vo_s, (32 * tp + 16 * h) * 16, 0);
+                o.stv = f32x4{sm, sq, mn, mx};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.stv), rsP, vo_s, (32 * tp + 16 * h) * 16, 0);
             }
         }
     };
@@ -282,13 +286,13 @@ MDEV void conv_split_body(const ConvStripArgs& p, char* smem) {
             if constexpr (q == 0) {
                 read_partner(tp);
                 if constexpr (!INTER)   // light epilogue: all of it before the MFMAs of this tile
-                    static_for<0, 9>([&](auto kc) { epi_item(kc, tp, vo_f, vo_p, vo_s); });
+                    static_for<0, 9>([&](auto kc) { epi_item(kc, tp, vo_f, vo_p, vo_s, eo); });
                 if constexpr (TIGHT) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     // (the store data stays where it is until here: see the note at the end of the stage)
-                    if constexpr (PK) asm volatile("" ::"v"(hh8), "v"(ll8));
-                    if constexpr (STATS) asm volatile("" ::"v"(stv));
-                    asm volatile("" ::"v"(vals[0]), "v"(vals[1]), "v"(vals[2]), "v"(vals[3]), "v"(vals[4]), "v"(vals[5]), "v"(vals[6]), "v"(vals[7]));
+                    if constexpr (PK) asm volatile("" ::"v"(eo.hh8), "v"(eo.ll8));
+                    if constexpr (STATS) asm volatile("" ::"v"(eo.stv));
+                    asm volatile("" ::"v"(eo.vals[0]), "v"(eo.vals[1]), "v"(eo.vals[2]), "v"(eo.vals[3]), "v"(eo.vals[4]), "v"(eo.vals[5]), "v"(eo.vals[6]), "v"(eo.vals[7]));
 #pragma unroll
                     for (int k = 0; k < PW; ++k) piece(u + 1, k);
                 }
@@ -308,9 +312,9 @@ MDEV void conv_split_body(const ConvStripArgs& p, char* smem) {
                 if constexpr (INTER && q == 0) {
                     static_for<0, 8>([&](auto kc) {
                         constexpr int e = decltype(kc)::value;
-                        if constexpr ((e * VSPAN) / 8 == st) epi_item(kc, tp, vo_f, vo_p, vo_s);
+                        if constexpr ((e * VSPAN) / 8 == st) epi_item(kc, tp, vo_f, vo_p, vo_s, eo);
                     });
-                    if constexpr (st == VSPAN) epi_item(std::integral_constant<int, 8>{}, tp, vo_f, vo_p, vo_s);
+                    if constexpr (st == VSPAN) epi_item(std::integral_constant<int, 8>{}, tp, vo_f, vo_p, vo_s, eo);
                 }
             });
             MTQ(11 + 6 * u);
@@ -331,23 +335,26 @@ MDEV void conv_split_body(const ConvStripArgs& p, char* smem) {
             // instructions later (an inline-asm ds_read_b128 whose data lands asynchronously), lanes 12 - 15 of each 16 of
             // the second data dword reached memory with the NEW contents; holding the registers until here removed it.
             constexpr bool KEEP = q == 0 && !(!INTER && KH == 24);
-            if constexpr (PK && KEEP) asm volatile("" ::"v"(hh8), "v"(ll8));
-            if constexpr (STATS && KEEP) asm volatile("" ::"v"(stv));
-            if constexpr (F32 && KEEP) asm volatile("" ::"v"(vals[0]), "v"(vals[1]), "v"(vals[2]), "v"(vals[3]), "v"(vals[4]), "v"(vals[5]), "v"(vals[6]), "v"(vals[7]));
+            if constexpr (PK && KEEP) asm volatile("" ::"v"(eo.hh8), "v"(eo.ll8));
+            if constexpr (STATS && KEEP) asm volatile("" ::"v"(eo.stv));
+            if constexpr (F32 && KEEP) asm volatile("" ::"v"(eo.vals[0]), "v"(eo.vals[1]), "v"(eo.vals[2]), "v"(eo.vals[3]), "v"(eo.vals[4]), "v"(eo.vals[5]), "v"(eo.vals[6]), "v"(eo.vals[7]));
             if constexpr (INTER && RES && q == NSTG - 1) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) res[e] = resn[e];
             }
         });
     }
-    // ---- last tile
+    // ---- last tile (its own set of store-data registers, every field written before it is stored: holding THIS set to the end
+    //      of the program does not pin registers inside the loop)
+    EpiOut eo_last;
     MTQ(5);
     read_partner(ntiles - 1);
-    static_for<0, 9>([&](auto kc) { epi_item(kc, ntiles - 1, vf_ok, vp_ok, vs_ok); });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and the data registers of these stores are held until they retired
-    if constexpr (PK) asm volatile("" ::"v"(hh8), "v"(ll8));
-    if constexpr (STATS) asm volatile("" ::"v"(stv));
-    if constexpr (F32) asm volatile("" ::"v"(vals[0]), "v"(vals[1]), "v"(vals[2]), "v"(vals[3]), "v"(vals[4]), "v"(vals[5]), "v"(vals[6]), "v"(vals[7]));
+    static_for<0, 9>([&](auto kc) { epi_item(kc, ntiles - 1, vf_ok, vp_ok, vs_ok, eo_last); });
+    // ... and the data registers of these stores are held to the end of the program (nothing may land in them: the
+    // statistics' LDS reads did, r02); no wait - it would keep the workgroup on the CU for a store round trip
+    if constexpr (PK) asm volatile("" ::"v"(eo_last.hh8), "v"(eo_last.ll8));
+    if constexpr (STATS) asm volatile("" ::"v"(eo_last.stv));
+    if constexpr (F32) asm volatile("" ::"v"(eo_last.vals[0]), "v"(eo_last.vals[1]), "v"(eo_last.vals[2]), "v"(eo_last.vals[3]), "v"(eo_last.vals[4]), "v"(eo_last.vals[5]), "v"(eo_last.vals[6]), "v"(eo_last.vals[7]));
     MTQ(6);
     if (F32 && p.omax) {                   // one atomic per workgroup
 #pragma unroll
@@ -394,19 +401,22 @@ extern "C" int ace_debug_split_trace(void* dst) { return (int)hipMemcpyFromSymbo
 
 // K: input channels, M: output rows
 bool conv_split_eligible(int K, int M, long HW, int role) {
-    // A/B switch for measurements: ACE_NO_CONV_SPLIT=1 (all) or a list of roles, e.g. "skip,fc2"
-    static const int off = [] {
-        const char* e = std::getenv("ACE_NO_CONV_SPLIT");
-        if (!e) return 0;
+    // Which convolutions run here: ACE_CONV_SPLIT = list of roles ("skip,fc1,fc2"), "all" or "none".  Default "fc2": same-box
+    // A/B at the 1-degree shape (r02) has this kernel 1 - 5 % ahead of the 128 x 128 tile engine on fc2 and 7 - 15 % behind
+    // conv_strip.hip on the inner skip and fc1.
+    const int on = [] {   // read per call (host side, a few times per forward): tests switch it per case
+        const char* e = std::getenv("ACE_CONV_SPLIT");
+        if (!e) return 4;
         const std::string v(e);
+        if (v == "all" || v == "1") return 7;
         int m = 0;
         if (v.find("skip") != std::string::npos) m |= 1;
         if (v.find("fc1") != std::string::npos) m |= 2;
         if (v.find("fc2") != std::string::npos) m |= 4;
-        return m ? m : 7;
+        return m;
     }();
-    if (role >= 0 && role < 3 && (off >> role & 1)) return false;
-    if (role < 0 && off == 7) return false;
+    if (role >= 0 && role < 3 && !(on >> role & 1)) return false;
+    if (role == -1 && on == 0) return false;
     if (!(K == 128 || K == 256 || K == 384 || K == 512 || K == 768)) return false;
     return M % 32 == 0 && M >= 32 && M <= 2048 && (long)M * HW * 4 < 0x7fffff00L;
 }
