@@ -163,24 +163,23 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
         static_for<0, 4>([&](auto u) { stage(t0 + u, bs[u], bs[(u + PB) % 4]); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy tail fetches
 
-    // ---- epilogue: lane = column, registers = rows; fp32 E[l][row][part * C + column], 128-byte row segments
+    // ---- epilogue: lane = column, registers = rows; fp32 E[l][row][part * C + column], 128-byte row segments.
+    // Order matters on gfx950: the range maximum (shuffles and an LDS round trip, i.e. loads that LAND in registers) comes
+    // first, the stores last and from the accumulator registers themselves, which nothing writes afterwards.  With the stores
+    // first and their data in temporaries, 7 of 1000 forwards of the 1-degree network came out wrong (r02): a load issued
+    // later returned into a register whose store had not read it yet.
     float* E = p.E + (long)l * p.sE;
     float vmax = 0.f;
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-            const int col = part * C + oc + 32 * tl + i;
+        for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 32 * s + (r & 3) + 8 * (r >> 2) + 4 * g;
-                const float v = acc[s][tl][r] * oscale;
-                if (row < rows) {
-                    E[(long)row * K2 + col] = v;
-                    vmax = fmaxf(vmax, fabsf(v));
-                }
+                acc[s][tl][r] *= oscale;
+                vmax = fmaxf(vmax, row < rows ? fabsf(acc[s][tl][r]) : 0.f);
             }
-        }
     if (p.omax) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
@@ -190,6 +189,19 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
         __syncthreads();
         if (tid == 0) atomicMax(p.omax + (blockIdx.x & 63), __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
     }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int col = part * C + oc + 32 * tl + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * s + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (row < rows) E[(long)row * K2 + col] = acc[s][tl][r];
+            }
+        }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) asm volatile("" ::"v"(acc[s][0]), "v"(acc[s][1]));   // the store data stays put to the end
 }
 
 __global__ __launch_bounds__(256, 1) void dhconv_strip_kernel(DhconvStripArgs p) {
