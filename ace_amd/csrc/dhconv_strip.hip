@@ -4,16 +4,18 @@
 // The filter is 212 MB at the ACE2 shape and every element is used by at most 181 rows: the stage is bound by streaming
 // the weights.  The 128 x 128 tile engine moves each weight through L2 -> LDS once per 128-row tile and each coefficient
 // once per 128-column tile (1.1 GB of LDS-DMA traffic per launch, 465 MB of HBM reads for 262 MB of operands: r02 PMC).
-// Here a workgroup owns (degree l, 128 output channels): its four waves each hold 64 output columns (real part: waves 0, 1;
-// imaginary part: waves 2, 3) for ALL rows of the degree (up to 192 = 6 strips of 32, 12 accumulator tiles per wave):
+// Here a workgroup owns (degree l, 128 output channels): each of its four waves holds 32 output channels, real AND imaginary
+// part, for ALL rows of the degree (up to 192 = 6 strips of 32, 12 accumulator tiles per wave):
 //   * the weights are the MFMA B operand: their stored form (k-packed "P format", compact complex: Wr | Wi per l) IS the
-//     fragment of a lane, so they go global -> registers with coalesced 16-byte loads, two k32-stages ahead, and never
-//     touch LDS; nobody else needs them (the other waves hold other columns);
-//   * the coefficients D_l (fp16 hi/lo planes written by the Legendre stage, row-major) are the A operand shared by the
-//     four waves: 1-KiB LDS-DMA pieces of 16 rows x 32 k, source-side XOR swizzle, four-stage ring, counted waits (all
-//     vector-memory operations of the loop are inline asm, no stores: the count is exact);
-//   * complex structure: real columns contract D_re with Wr and D_im with -Wi (the sign is flipped on the B fragments, once
-//     per loaded fragment), imaginary columns contract D_re with Wi and D_im with Wr;
+//     fragment of a lane, so they go global -> registers with coalesced 16-byte loads, two stages ahead, and never touch LDS;
+//     a stage is 32 rows of Wr and the same 32 rows of Wi, each used for two products (with D_re and with D_im), so every
+//     filter element is fetched exactly once per launch;
+//   * the coefficients D_l (fp16 hi/lo planes written by the Legendre stage, row-major (D_re | D_im)) are the A operand
+//     shared by the four waves: a stage holds the 32-wide k slice of BOTH halves of the row, as 1-KiB LDS-DMA pieces of
+//     16 rows x 32 k with a source-side XOR swizzle, three-stage ring, counted waits (all vector-memory operations of the
+//     loop are inline asm, no stores: the count is exact);
+//   * complex structure: real += D_re Wr - D_im Wi, imaginary += D_re Wi + D_im Wr; the minus sign is put on the D_im
+//     fragment (8 v_xor per strip and k16 step);
 //   * row strips beyond l are skipped in pairs (2, 4 or 6 active strips).
 #include <hip/hip_runtime.h>
 
@@ -40,56 +42,55 @@ MDEV half8 neg8(half8 v) {
 // NS: active 32-row strips (2, 4, 6)
 template <int NS>
 MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const int j, const int rows) {
-    constexpr int NSTG = 4;                       // ring depth (k32-stages)
-    constexpr int STAGE = NS * 4096;              // bytes: NS strips x (2 row pieces x 2 planes) x 1 KiB
-    constexpr int PB = 2;                         // B fragments run PB stages ahead
+    constexpr int NSTG = 3;                       // ring depth (stages)
+    constexpr int STAGE = NS * 8192;              // bytes: NS strips x 2 slices (re, im) x (2 row pieces x 2 planes) x 1 KiB
+    constexpr int NA = 2 * NS;                    // A pieces per wave per stage
+    constexpr int PB = 2;                         // B fragments run PB stages ahead (as the A pieces)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, g = lane >> 5;
     const int C = p.C, K2 = 2 * C;
-    const int nstages = K2 / 32;
-    const int part = wave >> 1;                   // 0: real output columns, 1: imaginary
-    const int oc = 128 * j + 64 * (wave & 1);     // first of this wave's 64 output channels
+    const int nstages = C / 32;                   // stage t = k in [32 t, 32 t + 32) of BOTH halves of the row (D_re | D_im)
+    const int oc = 128 * j + 32 * wave;           // this wave's 32 output channels (real and imaginary part)
 
     const unsigned raw_a = slot_load(p.amax + lane);
 
-    // ---- A pieces: piece q of a stage = (strip s = q / 4, row half rh = (q / 2) % 2, plane pl = q % 2); this wave issues the
-    //      pieces q = wave + 4 k, k < NS.  Lane L fetches the XOR-swizzled 16-byte slot of row L / 4 (gemm4's scheme)
+    // ---- A pieces: piece q of a stage = (strip s, slice sl, row half rh, plane pl) = 8 s + 4 sl + 2 rh + pl; this wave issues
+    //      (rh, pl) = (wave / 2, wave % 2) of every (s, sl).  Lane L fetches the XOR-swizzled 16-byte slot of row L / 4
     const _Float16* Dh = p.Dhi + (long)l * p.sD;
     const _Float16* Dl = p.Dlo + (long)l * p.sD;
-    const _Float16* asrc[NS];
+    const _Float16* asrc[NA];
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        const int q = wave + 4 * k;
-        const int s = q >> 2, rh = (q >> 1) & 1, pl = q & 1;
+    for (int k = 0; k < NA; ++k) {
+        const int s = k >> 1, sl = k & 1, rh = wave >> 1, pl = wave & 1;
         int row = 32 * s + 16 * rh + (lane >> 2);
         const int ls = (lane & 3) ^ ((row >> 2) & 3);
         row = row < rows ? row : rows - 1;
-        asrc[k] = (pl ? Dl : Dh) + (long)row * K2 + 8 * ls;
+        asrc[k] = (pl ? Dl : Dh) + (long)row * K2 + sl * C + 8 * ls;
     }
     auto issue_a = [&](int t) {   // stage t -> ring slot t % NSTG; stages past the end re-fetch the last (uniform count)
         const int tt = t < nstages ? t : nstages - 1;
         char* dst = smem + (t % NSTG) * STAGE;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) glds16(asrc[k] + 32 * tt, dst + (wave + 4 * k) * 1024);
+        for (int k = 0; k < NA; ++k) glds16(asrc[k] + 32 * tt, dst + (wave + 4 * k) * 1024);
     };
-    // ---- B fragments: stage t = k in [32 t, 32 t + 32); block (Wr | Wi) by (k half, part); entry (k group, column)
+    // ---- B fragments of stage t: rows [32 t, 32 t + 32) of Wr and of Wi, this wave's 32 columns.  Each filter element is
+    //      loaded by exactly one wave of one workgroup, once (the first version walked k over (D_re | D_im) with the real
+    //      columns in waves 0 - 1 and the imaginary ones in 2 - 3: Wr and Wi were each fetched twice, half a kernel apart -
+    //      567 MB of HBM reads for 262 MB of operands, r02 PMC)
     const _Float16* Wh = p.Whi + (long)l * p.sW;
     const _Float16* Wl = p.Wlo + (long)l * p.sW;
-    struct BSet { half8 h[2][2], l[2][2]; };      // [k16 step][column tile]
+    struct BSet { half8 h[2][2], l[2][2]; };      // [k16 step][Wr | Wi]
     auto issue_b = [&](BSet& b, int t) {
         const int tt = t < nstages ? t : nstages - 1;
-        const int khalf = (32 * tt) >= C;
-        const int blk = khalf != part;            // re: Wr then Wi; im: Wi then Wr
-        const int kg0 = (32 * tt - khalf * C) / 8;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int tl = 0; tl < 2; ++tl) {
-                const long off = (long)blk * C * C + ((long)(kg0 + 2 * c + g) * C + oc + 32 * tl + i) * 8;
-                gload16(b.h[c][tl], Wh + off);
-                gload16(b.l[c][tl], Wl + off);
+            for (int blk = 0; blk < 2; ++blk) {
+                const long off = (long)blk * C * C + ((long)(4 * tt + 2 * c + g) * C + oc + i) * 8;
+                gload16(b.h[c][blk], Wh + off);
+                gload16(b.l[c][blk], Wl + off);
             }
     };
     auto wait_b = [&](BSet& b, auto nn) {         // retire this set: at most nn newer operations stay in flight
@@ -101,7 +102,7 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
                      : "memory");
     };
 
-    f32x16 acc[NS][2];
+    f32x16 acc[NS][2];                            // [strip][real | imaginary part of the output]
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -109,57 +110,66 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[s][tl][r] = 0.f;
 
-    // prologue in the steady-state issue order (stage t issues A(t + 3) then B(t + 2)): A0 | A1 B0 | A2 B1
+    // prologue in the steady-state issue order (stage t issues A(t + 2) then B(t + 2)): A0 B0 | A1 B1
     BSet bs[4];                                   // ring of fragment sets, indexed with compile-time constants only
-    issue_a(0);
-    issue_a(1); issue_b(bs[0], 0);
-    issue_a(2); issue_b(bs[1], 1);
+    issue_a(0); issue_b(bs[0], 0);
+    issue_a(1); issue_b(bs[1], 1);
 
     const float inv_a = ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_a)));
     const float oscale = inv_a / p.bscale;
     const int key = (i >> 2) & 3;                 // swizzle key of this lane's fragment rows (rows i and i + 16 ... share it mod 4)
 
-    // Stage t issues A(t + 3) and B(t + 2).  Issue order: ... A(t+1) B(t) | A(t+2) B(t+1) | A(t+3) B(t+2): after this
-    // stage's issue exactly 2 (NS + 8) operations are newer than B(t), and A(t) is older than B(t-1), which the previous
-    // stage retired.  All of them are loads (in-order retirement), the loop has no stores: vmcnt(2 (NS + 8)) is exact.
+    // Stage t issues A(t + 2) and B(t + 2).  Issue order: ... A(t) B(t) | A(t+1) B(t+1) | A(t+2) B(t+2): after this stage's
+    // issue exactly 2 (NA + 8) operations are newer than B(t).  All of them are loads (in-order retirement), the loop has
+    // no stores: vmcnt(2 (NA + 8)) is exact.
     auto stage = [&](const int t, BSet& b, BSet& bnew) {
-        issue_a(t + 3);
+        issue_a(t + 2);
         issue_b(bnew, t + PB);
-        wait_b(b, std::integral_constant<int, 2 * (NS + 8)>{});
+        wait_b(b, std::integral_constant<int, 2 * (NA + 8)>{});
         __builtin_amdgcn_s_barrier();             // every wave's pieces of stage t landed
-        if (part == 0 && 32 * t >= C) {           // real columns, imaginary k half: -Wi
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int tl = 0; tl < 2; ++tl) { b.h[c][tl] = neg8(b.h[c][tl]); b.l[c][tl] = neg8(b.l[c][tl]); }
-        }
         const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (t % NSTG) * STAGE);
-        // A fragment of strip s, k16 step c: rows 32 s + i (piece 2 s + (i >> 4)), logical slot 2 c + g, physical slot ^ key
+        // A fragment of (strip s, slice sl), k16 step c: rows 32 s + i (row piece i >> 4), logical slot 2 c + g, physical ^ key
         const unsigned la = sl + ((i >> 4) * 2) * 1024 + (i & 15) * 64;
+        // four phases (c, slice) = (0, re) (0, im) (1, re) (1, im); the fragments of phase ph + 1 are requested strip by strip
+        // while phase ph computes: 2 (NS - 1) LDS reads are in flight behind the fragment being waited for, always
+        Frag fa[NS], fb[NS];
+        auto frag_addr = [&](int ph, int s) { return la + (2 * s + (ph & 1)) * 4096 + (unsigned)(((2 * (ph >> 1) + g) ^ key) * 16); };
+        auto issue_f = [&](Frag& f, unsigned addr) {
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(f.h), "=&v"(f.l) : "v"(addr));
+        };
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const unsigned slot_off = (unsigned)(((2 * c + g) ^ key) * 16);
-            Frag fr[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024"
-                             : "=&v"(fr[s].h), "=&v"(fr[s].l)
-                             : "v"(la + s * 4096 + slot_off));
-            }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fr[s].h), "+v"(fr[s].l) : "n"(2 * (NS - 1 - s)));
-                acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].l, b.h[c][0], acc[s][0], 0, 0, 0);
-                acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].l, b.h[c][1], acc[s][1], 0, 0, 0);
-                acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].h, b.l[c][0], acc[s][0], 0, 0, 0);
-                acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].h, b.l[c][1], acc[s][1], 0, 0, 0);
-                acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].h, b.h[c][0], acc[s][0], 0, 0, 0);
-                acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].h, b.h[c][1], acc[s][1], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_barrier();             // every wave is done reading the slot of stage t (refilled by A(t + 4))
+        for (int s = 0; s < NS; ++s) issue_f(fa[s], frag_addr(0, s));
+        static_for<0, 4>([&](auto phc) {
+            constexpr int ph = decltype(phc)::value;
+            constexpr int c = ph >> 1;
+            constexpr bool im = ph & 1;
+            static_for<0, NS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                Frag& f = (ph & 1) ? fb[s] : fa[s];
+                constexpr int newer = ph < 3 ? 2 * (NS - 1) : 2 * (NS - 1 - s);
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.h), "+v"(f.l) : "n"(newer));
+                if constexpr (!im) {   // D_re: real += D_re Wr, imaginary += D_re Wi
+                    acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l, b.h[c][0], acc[s][0], 0, 0, 0);
+                    acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l, b.h[c][1], acc[s][1], 0, 0, 0);
+                    acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, b.l[c][0], acc[s][0], 0, 0, 0);
+                    acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, b.l[c][1], acc[s][1], 0, 0, 0);
+                    acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, b.h[c][0], acc[s][0], 0, 0, 0);
+                    acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, b.h[c][1], acc[s][1], 0, 0, 0);
+                } else {               // D_im: imaginary += D_im Wr, real -= D_im Wi (sign on the coefficient fragment)
+                    const half8 nh = neg8(f.h), nl = neg8(f.l);
+                    acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l, b.h[c][0], acc[s][1], 0, 0, 0);
+                    acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(nl, b.h[c][1], acc[s][0], 0, 0, 0);
+                    acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, b.l[c][0], acc[s][1], 0, 0, 0);
+                    acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(nh, b.l[c][1], acc[s][0], 0, 0, 0);
+                    acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, b.h[c][0], acc[s][1], 0, 0, 0);
+                    acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(nh, b.h[c][1], acc[s][0], 0, 0, 0);
+                }
+                if constexpr (ph < 3) issue_f((ph & 1) ? fa[s] : fb[s], frag_addr(ph + 1, s));
+            });
+        });
+        __builtin_amdgcn_s_barrier();             // every wave is done reading the slot of stage t (refilled by A(t + 3))
     };
-    for (int t0 = 0; t0 < nstages; t0 += 4)       // nstages = C / 16 is a multiple of 8
+    for (int t0 = 0; t0 < nstages; t0 += 4)       // nstages = C / 32 is a multiple of 4
         static_for<0, 4>([&](auto u) { stage(t0 + u, bs[u], bs[(u + PB) % 4]); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy tail fetches
 
@@ -193,7 +203,7 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
     for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
-            const int col = part * C + oc + 32 * tl + i;
+            const int col = tl * C + oc + i;   // tl: real | imaginary part
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 32 * s + (r & 3) + 8 * (r >> 2) + 4 * g;
@@ -205,7 +215,7 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
 }
 
 __global__ __launch_bounds__(256, 1) void dhconv_strip_kernel(DhconvStripArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * 6 * 4096];
+    __shared__ __attribute__((aligned(16))) char smem[3 * 6 * 8192];
     // heavy degrees first: blocks in dispatch order take l = L - 1, L - 1, L - 1 (its C / 128 column groups), L - 2, ...
     const int ncg = p.C / 128;
     const int l = p.L - 1 - (int)(blockIdx.x / ncg);

@@ -241,21 +241,22 @@ def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, 
     return dict(dt=dt, stages=stages, x_cpu=x_cpu, y_gpu=y_gpu)
 
 
-# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/r01_pmc_*
-# HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, gfx950 correction: wide reads are
-# counted at half size), profiles/r01_pmc_*.json|txt.  Keyed by (mode, stage); None = not measured for this build.
+# HBM bytes per launch from separate rocprofv3 --pmc passes over this build (FETCH_SIZE / WRITE_SIZE in KB; gfx950
+# correction: wide reads are counted at half size), profiles/r02_pmc_traffic.json, written by tools/pmc_to_profile.py.
+# Keyed by "mode|stage"; value {"bytes": per-launch HBM bytes, ...}.  None = not measured for this build.
 MEASURED_TRAFFIC = {}
 try:
     import json as _json
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")) as _f:
-        MEASURED_TRAFFIC = {tuple(k.split("|")): v for k, v in _json.load(_f).items() if not k.startswith("_")}
+        MEASURED_TRAFFIC = {tuple(k.split("|")): (v["bytes"] if isinstance(v, dict) else v)
+                            for k, v in _json.load(_f).items() if not k.startswith("_")}
 except (OSError, ValueError):
     pass
 
 # the kernel that runs each stage in the default (f16x3) mode
 KERNEL_OF_STAGE = {
-    "mlp.fc1": "gemm4_f16x3_kernel", "mlp.fc2+outer_skip": "gemm4_f16x3_kernel", "inner_skip+activation": "gemm4_f16x3_kernel",
-    "dhconv": "gemm4_f16x3_kernel", "forward_transform.legendre": "legendre_strip_kernel",
+    "mlp.fc1": "conv_strip_kernel", "mlp.fc2+outer_skip": "conv_split_kernel", "inner_skip+activation": "conv_strip_kernel",
+    "dhconv": "dhconv_strip_kernel", "forward_transform.legendre": "legendre_strip_kernel",
     "inverse_transform.legendre": "legendre_strip_kernel", "forward_transform.dft": "dft_forward_fft_kernel",
     "inverse_transform.dft": "dft_inverse_fft_kernel", "encoder": "gemm3_f16x3_kernel", "decoder": "gemm3_f16x3_kernel",
 }
@@ -325,7 +326,11 @@ def main():
         sht_bytes = 384 * 180 * 360 * 4 + 181 * 180 * 180 * 4 + 384 * 180 * 181 * 8     # 223.1 MB
         roofline_sht = dict(kernel="forward SHT (dft_forward_fft_kernel + legendre_strip_kernel)", bound="hbm",
                             achieved=round(sht_bytes / (sht_us * 1e-6) / 1e9, 1), peak=PEAK_HBM, unit="GB/s",
-                            frac=round(sht_bytes / (sht_us * 1e-6) / 1e9 / PEAK_HBM, 4), traffic=None)
+                            frac=round(sht_bytes / (sht_us * 1e-6) / 1e9 / PEAK_HBM, 4),
+                            traffic=(MEASURED_TRAFFIC[(main_mode, "forward_transform.dft")] +
+                                     MEASURED_TRAFFIC[(main_mode, "forward_transform.legendre")])
+                            if (main_mode, "forward_transform.dft") in MEASURED_TRAFFIC and
+                               (main_mode, "forward_transform.legendre") in MEASURED_TRAFFIC else None)
         cpu = None
         if not args.no_cpu_baseline:
             cpu, y_cpu = cpu_baseline(stepper, r["x_cpu"])
