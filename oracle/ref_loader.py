@@ -1,9 +1,9 @@
 """Import the REAL reference hot-path modules under stubs (build container only).
 
 Test infrastructure.  ``/root/reference`` exists only in the build container,
-so this module is used exclusively by ``tests/golden/make_golden.py`` (to emit
-golden vectors from the reference itself) and by the CPU-only test
-``tests/test_oracle_vs_reference.py`` (skipped when the reference is absent).
+so this module is used exclusively by the fixture generators
+``tests/golden/make_golden.py`` / ``tests/golden/make_golden_headline.py`` (to emit
+golden vectors from the reference itself); the tests read the committed fixtures.
 Nothing here travels to the GPU box in a usable form and nothing in the
 product path imports it.
 
