@@ -65,6 +65,33 @@ def test_headline_network_vs_reference(dev, headline, precision):
     assert torch.equal(out, y)
 
 
+@pytest.mark.parametrize("B", [1, 2])
+def test_dhconv_at_headline_shape_three_implementations(dev, B, monkeypatch):
+    """The spectral filter contraction at the headline operand shape (rows = 181 B, K = N = 768, 180 degrees, triangular
+    row skipping) on three independent kernels inside a one-block C = 384 network: dhconv_strip.hip (B = 1; B = 2 exceeds its
+    192 spectral rows and runs the tile engine either way), the 128 x 128 f16x3 tile engine (ACE_NO_DHCONV_STRIP=1) and the
+    exact-fp32 engine.  Everything else in the block is the same code in the two f16x3 runs, so their difference is the
+    contraction's; against fp32 arithmetic both sit at the block's f16x3 level."""
+    from oracle.sfno import SFNOConfig, init_state
+    cfg = SFNOConfig(in_chans=8, out_chans=6, img_shape=(180, 360), embed_dim=384, num_layers=1, operator_type="dhconv")
+    state = init_state(cfg, seed=5)
+    x = (torch.randn(B, 8, 180, 360, generator=torch.Generator().manual_seed(6)) * 0.7 + 0.2).to(dev)
+    outs = {}
+    for name, prec, env in (("strip", "f16x3", None), ("tile", "f16x3", "1"), ("fp32", "fp32", None)):
+        if env:
+            monkeypatch.setenv("ACE_NO_DHCONV_STRIP", env)
+        else:
+            monkeypatch.delenv("ACE_NO_DHCONV_STRIP", raising=False)
+        net = build_native_net(cfg, state, dev, prec)
+        with torch.no_grad():
+            outs[name] = net(x).clone()
+        del net
+    assert torch.isfinite(outs["fp32"]).all()
+    assert rel_max(outs["strip"], outs["tile"]) <= 1e-6
+    assert rel_max(outs["strip"], outs["fp32"]) <= 2e-6
+    assert rel_max(outs["tile"], outs["fp32"]) <= 2e-6
+
+
 @pytest.mark.parametrize("split", ["all", "none"])
 def test_headline_bitwise_repeatability(dev, headline, split, monkeypatch):
     """200 forwards of the headline network on the same input must be bitwise identical, and right.  The register-resident
