@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libace_sfno.so")
-SOURCES = ["kernels.hip", "fft.hip", "strip.hip", "mlp_strip.hip", "conv_strip.hip", "conv_split.hip", "dhconv_strip.hip", "capi.hip", "tables.cpp"]
+SOURCES = ["kernels.hip", "fft.hip", "strip.hip", "mlp_strip.hip", "conv_strip.hip", "conv_split.hip", "conv_ws.hip", "dhconv_strip.hip", "capi.hip", "tables.cpp"]
 HEADERS = ["kernels.h", "strip_common.h", "strip_pack.h", "tables.h", os.path.join("..", "..", "include", "ace_sfno.h")]
 
 

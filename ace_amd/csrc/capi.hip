@@ -841,7 +841,8 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
         const bool is_skip = wn.size() > 17 && wn.compare(wn.size() - 17, 17, "inner_skip.weight") == 0;
         const bool is_fc2 = wn.size() > 16 && wn.compare(wn.size() - 16, 16, "mlp.fwd.2.weight") == 0;
         if ((is_skip && conv_strip_eligible(w.cols, w.rows, ACT_GELU)) ||
-            ((is_skip || is_fc2) && conv_split_eligible(w.cols, w.rows, 1, is_skip ? 0 : 2))) {
+            ((is_skip || is_fc2) && conv_split_eligible(w.cols, w.rows, 1, is_skip ? 0 : 2)) ||
+            ((is_skip || is_fc2) && conv_ws_eligible(w.cols, w.rows, 1, is_skip ? 0 : 2))) {
             if (!w.frag0.p) HIP_TRY(w.frag0.alloc((size_t)w.rows * w.cols, false));
             HIP_TRY(launch_pack_conv_frag(w.buf.p, w.pitch, w.rows, w.cols, 0, nullptr, 0.f, w.ascale, nullptr, w.frag0.p,
                                           0, 1, s));
@@ -1234,8 +1235,9 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 o.bhi = PBh; o.blo = PBl; o.in_slot = skip_max;
             }
             int t_nparts = gemm4_strips(C, (int)HW);
-            const bool split_ok = strip_ok && conv_split_eligible(C, C, HW, 0);   // contraction split over wave pairs (conv_split.hip)
-            const int nsplit32 = (int)((HW + 127) / 128) * 4;
+            const bool ws_ok = strip_ok && conv_ws_eligible(C, C, HW, 0);         // weights resident, persistent grid (conv_ws.hip)
+            const bool split_ok = strip_ok && !ws_ok && conv_split_eligible(C, C, HW, 0);   // contraction split over wave pairs (conv_split.hip)
+            const int nsplit32 = ws_ok ? (int)((HW + 31) / 32) : (int)((HW + 127) / 128) * 4;
             if (strip_ok) {   // register-resident strip kernels
                 ConvStripArgs k;
                 k.Xhi = PBh; k.Xlo = PBl; k.ldn = HW; k.sX = (long)C * HW; k.xslot = o.in_slot;
@@ -1251,9 +1253,9 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 k.R = n->Y.p; k.sR = actB;
                 k.cw = ws.winf; k.cb = bsw.absmax; k.cinb = slot(sb + 3); k.rmax = slot(sb + 7);
                 k.Chi = PAh; k.Clo = PAl; k.sCp = (long)C * HW; k.cslot = slot(sb + 4);
-                k.part = reinterpret_cast<float4*>(part_t); k.nstrips32 = split_ok ? nsplit32 : (int)((HW + 255) / 256) * 8;
+                k.part = reinterpret_cast<float4*>(part_t); k.nstrips32 = (split_ok || ws_ok) ? nsplit32 : (int)((HW + 255) / 256) * 8;
                 k.C = C; k.M = C; k.HW = (int)HW; k.nbatch = B; k.act = ACT_GELU;
-                HIP_TRY(split_ok ? launch_conv_split(k, s) : launch_conv_strip(k, s));
+                HIP_TRY(ws_ok ? launch_conv_ws(k, s) : split_ok ? launch_conv_split(k, s) : launch_conv_strip(k, s));
                 t_nparts = k.nstrips32;
             } else {
                 ACE_TRY(conv_pk2(n, o, B, s));
@@ -1314,12 +1316,14 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 k.cw = w1.winf; k.cb = b1w.absmax; k.cinb = slot(sb + 5);
                 k.Chi = Uh; k.Clo = Ul; k.sCp = (long)n->hid * HW; k.cslot = slot(sb + 6);
                 k.C = C; k.M = n->hid; k.HW = (int)HW; k.nbatch = B; k.act = ACT_GELU;
-                HIP_TRY(conv_split_eligible(C, n->hid, HW, 1) ? launch_conv_split(k, s) : launch_conv_strip(k, s));
+                HIP_TRY(conv_ws_eligible(C, n->hid, HW, 1) ? launch_conv_ws(k, s)
+                        : conv_split_eligible(C, n->hid, HW, 1) ? launch_conv_split(k, s) : launch_conv_strip(k, s));
             } else {
                 ACE_TRY(conv_pk2(n, f1, B, s));
             }
             MARK(ST_MLP_FC1);
-            if (w2.frag0.p && conv_split_eligible(n->hid, C, HW, 2) && C <= 1024) {
+            const bool fc2_ws = w2.frag0.p && conv_ws_eligible(n->hid, C, HW, 2);
+            if (w2.frag0.p && (fc2_ws || conv_split_eligible(n->hid, C, HW, 2)) && C <= 1024) {
                 // fc2 + outer skip on the split-contraction strip kernel: fp32 h' (+ planes and statistics for the next block)
                 ConvStripArgs k;
                 k.Xhi = Uh; k.Xlo = Ul; k.ldn = HW; k.sX = (long)n->hid * HW; k.xslot = slot(sb + 6);
@@ -1328,15 +1332,16 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 k.R = res; k.sR = actB; k.rsc = ra; k.rsh = rb; k.srs = C;
                 k.Cf = hn; k.sCf = actB;
                 k.C = n->hid; k.M = C; k.HW = (int)HW; k.nbatch = B; k.act = ACT_NONE;
+                const int nparts = fc2_ws ? (int)((HW + 31) / 32) : (int)((HW + 127) / 128) * 4;
                 if (!last) {
                     k.Chi = PBh; k.Clo = PBl; k.sCp = (long)C * HW; k.cslot = hslot(i + 1);
                     k.cw = w2.winf; k.cb = b2w.absmax; k.rmax = slot(sb + 3);
-                    k.part = reinterpret_cast<float4*>(part_h); k.nstrips32 = (int)((HW + 127) / 128) * 4;
+                    k.part = reinterpret_cast<float4*>(part_h); k.nstrips32 = nparts;
                 } else {
                     k.omax = hslot(i + 1);
                 }
-                HIP_TRY(launch_conv_split(k, s));
-                h_nparts = (int)((HW + 127) / 128) * 4;
+                HIP_TRY(fc2_ws ? launch_conv_ws(k, s) : launch_conv_split(k, s));
+                h_nparts = nparts;
             } else {
             PkOpts f2;
             f2.w = &w2; f2.bias = b2w.buf.p;

@@ -1,0 +1,445 @@
+// Second MLP convolution + outer skip (layers.py:117-124, sfnonet.py:246-250), WEIGHT-stationary, for gfx950:
+//     h' = W2 . P(u) + b2 + (a0 x + b0)        W2: (M x K), u: K x HW hidden activation (P-format fp16 hi/lo planes), K = 256 / 512 / 768
+//
+// conv_split.hip keeps the ACTIVATION strip resident and streams the weights: every workgroup of 128 pixels starts with a
+// phase in which all of them fetch their strips at once while the matrix cores idle (K = 768: 58 k of 213 k cycles per
+// workgroup, two rounds of workgroups per launch - r02 in-kernel timeline), and streams the whole 1.2 MB of W2 through LDS.
+// Here the roles are swapped and the grid is persistent:
+//   * a workgroup owns 128 output channels (four 32-row tiles of W2) and a contiguous range of 32-pixel tiles; wave (tile T,
+//     half h) keeps rows 32 T .. 32 T + 31 of W2 over its half of the contraction as MFMA A fragments for the whole launch
+//     (192 VGPRs at K = 768), loaded once from the packed-fragment form (launch_pack_conv_frag order 0);
+//   * the activation streams: a stage is KSW k16-steps of both contraction halves of ONE pixel tile, fetched by 1-KiB LDS-DMA
+//     pieces straight from the P-format planes (a piece is 2 k-groups x 32 pixels = one MFMA B fragment) into a two-stage
+//     ring; each fragment is read by the four waves that own the four channel tiles;
+//   * accumulator layout, partner exchange (the two halves of the contraction), epilogue and the held store data are those
+//     of conv_split.hip: rows = output channels, columns = pixels; wave h finishes rows 16 h .. 16 h + 15 of its tile;
+//   * the three slices of the channel dimension that need the same pixel tiles run on the same XCD (block -> XCD is
+//     block % 8), so that the activation is fetched from HBM once and twice more from that XCD's L2.
+// No per-workgroup prologue beyond loading 48 KB of weights per wave from L2; 240 of the 256 CUs at M = 384 (three slices
+// do not divide the 32 CUs of an XCD).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <string>
+#include <type_traits>
+
+#include "strip_common.h"
+
+namespace ace {
+namespace {
+
+#ifndef ACE_CONV_WS_DEFAULT
+#define ACE_CONV_WS_DEFAULT 7   // roles on conv_ws.hip by default: bit 0 inner skip, 1 fc1, 2 fc2
+#endif
+constexpr int WS_OOBV = 0x7fffff00;   // buffer offset beyond every resource of these kernels: loads return 0, stores are dropped
+
+template <int KSW, int NSTG, int MODE>
+struct WsGeom {
+    static constexpr int KH = KSW * NSTG;          // k16-steps per wave: its half of the contraction
+    static constexpr int SLOT = 2 * KSW * 2048;    // one stage of activation fragments, both halves
+    static constexpr bool F32 = MODE >= 2, STATS = MODE == 0 || MODE == 2;
+    static constexpr int BMAX = F32 ? 1024 : 2048; // output rows with LDS-resident epilogue parameters
+    static constexpr int TAB = BMAX * 4 * (F32 ? 2 : 1);
+    static constexpr int XCH = 2 * 8 * 2048;       // accumulator exchange: [tile parity][wave][2 planes][64 lanes][16 B]
+    static constexpr int STP = 36;                 // pitch of the statistics transpose (floats)
+    static constexpr int STB = STATS ? 8 * 16 * STP * 4 : 0;
+    static constexpr int LDS = 2 * SLOT + TAB + XCH + STB;
+    static_assert(KSW % 2 == 0 && LDS <= 160 * 1024, "LDS budget");
+};
+
+// MODE 0: inner skip  (fp32 residual, GELU, P-format planes + row statistics)       1: fc1 (GELU, P-format planes)
+//      2: fc2, mid block (residual with per-row affine, fp32 output + P-format planes + row statistics)
+//      3: fc2, last block (fp32 output, optional range maximum)
+// Modes 0 / 1 (K <= 384, registers to spare): the epilogue of pixel tile t - 1 runs between the MFMAs of tile t.
+// H: contraction half of the calling wave (compile time, see conv_split.hip)
+template <int KSW, int NSTG, int MODE, int H>
+MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
+    using G = WsGeom<KSW, NSTG, MODE>;
+    constexpr int KH = G::KH, SLOT = G::SLOT, BMAX = G::BMAX, TAB = G::TAB, XCH = G::XCH, STP = G::STP;
+    constexpr int PW = KSW / 2;             // 1-KiB pieces per wave per stage
+    constexpr bool GELU = MODE <= 1, RES = MODE != 1, PK = MODE != 3, F32 = G::F32, STATS = G::STATS;
+    constexpr bool INTER = MODE <= 1;       // epilogue of tile t - 1 between the MFMAs of tile t
+    constexpr bool HOLD = KH < 24;          // registers to hold the store data through a stage (else: stores retired first)
+    static_assert(!INTER || NSTG == 1, "interleaved epilogue: single-stage tiles");
+    constexpr int h = H;
+    float* Pb = reinterpret_cast<float*>(smem + 2 * SLOT);     // bias (+ residual shift)
+    float* Ps = Pb + BMAX;                                      // residual scale (fc2 modes)
+    char* xch = smem + 2 * SLOT + TAB;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, g = lane >> 5;
+    float* St = reinterpret_cast<float*>(smem + 2 * SLOT + TAB + XCH) + wave * (16 * STP);
+
+    // ---- which sample, channel slice and pixel-tile range (the slices of one group share an XCD: block % 8)
+    const int nslice = p.M / 128;
+    const int per_smp = groups * nslice;
+    const int smp = blockIdx.x / per_smp;
+    const int bb = blockIdx.x % per_smp;
+    const int xcd = bb & 7, rr = bb >> 3;
+    const int slice = rr % nslice, group = (rr / nslice) * 8 + xcd;
+    const int tiles_px = (p.HW + 31) / 32;
+    const int tpg = (tiles_px + groups - 1) / groups;
+    const int tile0 = group * tpg;
+    const int np = tiles_px - tile0 < tpg ? tiles_px - tile0 : tpg;
+    if (np <= 0) return;                    // (whole workgroup: no barrier has been executed yet)
+    const int T = slice * 4 + (wave & 3);   // 32-row tile of the output channels
+    const int NU = np * NSTG;
+
+    const unsigned raw_x = slot_load(p.xslot + lane);
+    const unsigned raw_a = p.aslot ? slot_load(p.aslot + lane) : 0u;
+    const unsigned raw_c = p.cinb ? slot_load(p.cinb + lane) : 0u;
+    const unsigned raw_r = p.rmax ? slot_load(p.rmax + lane) : 0u;
+
+    // ---- streamed activation: piece k (of PW) of this wave for stage u -> slot u % 2; stages past the end re-fetch the last.
+    //      Piece pc = (block pc / 2 of the stage: half hh, k-step jj; plane pc % 2): lane (i, g) fetches k-group 2 J + g, pixel i
+    const _Float16* Xh = p.Xhi + (long)smp * p.sX;
+    const _Float16* Xl = p.Xlo + (long)smp * p.sX;
+    auto piece = [&](int u, int k) {
+        const int uu = u < NU ? u : NU - 1;
+        const int pt = uu / NSTG, q = uu % NSTG;
+        const int pc = wave + 8 * k;
+        const int bl = pc >> 1, hf = pc & 1;
+        const int hh = bl / KSW, jj = bl % KSW;
+        const int J = hh * KH + q * KSW + jj;
+        int n = 32 * (tile0 + pt) + i;
+        n = n < p.HW ? n : p.HW - 1;
+        glds16((hf ? Xl : Xh) + ((long)(2 * J + g) * p.ldn + n) * 8, smem + (u & 1) * SLOT + pc * 1024);
+    };
+#pragma unroll
+    for (int k = 0; k < PW; ++k) piece(0, k);
+
+    // ---- resident weights: rows 32 T .. 32 T + 31, this wave's half of the contraction, as A fragments
+    half8 wh[KH], wl[KH];
+    {
+        const _Float16* A = p.A + (long)smp * p.sA + ((long)T * (2 * KH) + h * KH) * 1024 + lane * 8;
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+            wh[j] = *reinterpret_cast<const half8*>(A + (long)j * 1024);
+            wl[j] = *reinterpret_cast<const half8*>(A + (long)j * 1024 + 512);
+        }
+    }
+    {   // epilogue parameters of this sample -> LDS
+        const float* b = p.bias + (long)smp * p.sbias;
+        const float* rsc = (F32 && p.rsc) ? p.rsc + (long)smp * p.srs : nullptr;
+        const float* rsh = (F32 && p.rsc) ? p.rsh + (long)smp * p.srs : nullptr;
+#pragma unroll
+        for (int k = 0; k < BMAX / 512; ++k) {
+            const int r = tid + 512 * k;
+            if (r < p.M) {
+                Pb[r] = b[r] + (rsh ? rsh[r] : 0.f);
+                if (F32) Ps[r] = rsc ? rsc[r] : 1.f;
+            }
+        }
+    }
+    const float xbound = wave_max_bits(raw_x);
+    const float inv_x = ldexpf(1.0f, -pow2_exponent_for(xbound));
+    const float inv_a = p.aslot ? ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_a))) : 1.0f / p.ascale;
+    const float s_acc = inv_x * inv_a;
+    float cscale = 1.f;
+    if (PK) {   // bound of this launch's output, identical in every workgroup; the consumer reads it from cslot
+        const float inb = p.cinb ? wave_max_bits(raw_c) : xbound;
+        const float resb = p.rmax ? wave_max_bits(raw_r) : 0.f;
+        const float cbound = fmaf(p.cw, inb, p.cb) + resb;
+        cscale = ldexpf(1.0f, pow2_exponent_for(cbound));
+        if (tid == 0) atomicMax(p.cslot + (blockIdx.x & 63), __float_as_uint(cbound));
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage 0, the weights, the tables' sources
+#pragma unroll
+    for (int j = 0; j < KH; ++j) asm volatile("" : "+v"(wh[j]), "+v"(wl[j]));
+    __syncthreads();
+
+    const int fbytes = p.M * p.HW * 4, pbytes = p.M * p.HW * 2;
+    const auto rsR = __builtin_amdgcn_make_buffer_rsrc(RES ? const_cast<float*>(p.R + (long)smp * p.sR) : nullptr, 0, RES ? fbytes : 0, 0x00020000);
+    const auto rsC = __builtin_amdgcn_make_buffer_rsrc(F32 ? p.Cf + (long)smp * p.sCf : nullptr, 0, F32 ? fbytes : 0, 0x00020000);
+    const auto rsH = __builtin_amdgcn_make_buffer_rsrc(PK ? p.Chi + (long)smp * p.sCp : nullptr, 0, PK ? pbytes : 0, 0x00020000);
+    const auto rsL = __builtin_amdgcn_make_buffer_rsrc(PK ? p.Clo + (long)smp * p.sCp : nullptr, 0, PK ? pbytes : 0, 0x00020000);
+    const auto rsP = __builtin_amdgcn_make_buffer_rsrc(STATS ? p.part + (long)smp * p.nstrips32 * p.M : nullptr, 0,
+                                                       STATS ? p.nstrips32 * p.M * 16 : 0, 0x00020000);
+    const int row0 = 32 * T + 16 * h;                            // first of the 16 rows this wave finishes
+    // per-lane buffer offsets, recomputed where they are used from an opaque copy of the lane index: as loop invariants they
+    // (and what hipcc derives from them) would sit in registers this kernel does not have at K = 768
+    auto lane_offsets = [&](int& vf_lane, int& vp_lane, int& vs_lane, int& li, int& lg) {
+        int lz = lane;
+        asm volatile("" : "+v"(lz));
+        li = lz & 31; lg = lz >> 5;
+        vf_lane = ((row0 + 8 * lg) * p.HW + li) * 4;             // fp32 element (row row0 + 8 g, pixel i of tile 0)
+        vp_lane = (((row0 >> 3) + lg) * p.HW + li) * 16;         // P entry (k group row0 / 8 + g, pixel i)
+        vs_lane = lz < 16 ? (row0 + lz) * 16 : WS_OOBV;          // statistics row (lane & 15), lanes of column quarter 0
+    };
+
+    // ---- epilogue state of the tile being finished: rows row0 + 8 g + e, pixel 32 (tile0 + pt) + i
+    float own[8], res[8], resn[8];
+    f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
+    struct EpiOut {                        // data registers of the epilogue's stores (held until the stores retired)
+        half8 hh8, ll8;
+        float vals[8];
+        f32x4 stv;
+    };
+    struct TileCtx { int n0, vo_f, vo_p, vo_s, ncols_ok, i, g; };   // per pixel tile: offsets / validity of this lane
+    EpiOut eo;
+    float vmax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { own[e] = 0.f; res[e] = 0.f; resn[e] = 0.f; eo.vals[e] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { eo.hh8[e] = eo.ll8[e] = (_Float16)0.f; }
+    eo.stv = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto tile_ctx = [&](const int pt, const bool live) {   // live = false: every store of the tile suppressed
+        TileCtx c;
+        c.n0 = 32 * (tile0 + pt);
+        int vf_lane, vp_lane, vs_lane;
+        lane_offsets(vf_lane, vp_lane, vs_lane, c.i, c.g);
+        const bool nok = live && c.n0 + c.i < p.HW;
+        c.vo_f = nok ? vf_lane : WS_OOBV; c.vo_p = nok ? vp_lane : WS_OOBV; c.vo_s = live ? vs_lane : WS_OOBV;
+        c.ncols_ok = p.HW - c.n0 < 32 ? (p.HW - c.n0 > 0 ? p.HW - c.n0 : 0) : 32;
+        return c;
+    };
+    // item k < 8: value e = k; item 8: the stores of whole P entries and the row statistics
+    auto epi_item = [&](auto kc, const TileCtx& c, EpiOut& o) {
+        constexpr int k = decltype(kc)::value;
+        const int i = c.i, g = c.g;
+        if constexpr (k < 8) {
+            constexpr int e = k;
+            const int row = row0 + 8 * g + e;
+            float val = fmaf(own[e] + (e < 4 ? pa[e & 3] : pb[e & 3]), s_acc, Pb[row]);
+            if (RES) val = F32 ? fmaf(resn[e], Ps[row], val) : val + res[e];   // light epilogues consume the fetched rows in place
+            if (GELU) val = act_fn<ACT_GELU_FAST>(val);
+            if (F32) {
+                o.vals[e] = val;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o.vals[e]), rsC, c.vo_f, (e * p.HW + c.n0) * 4, 0);
+                vmax = fmaxf(vmax, c.vo_f != WS_OOBV ? fabsf(val) : 0.f);
+            }
+            if (STATS) St[(8 * g + e) * STP + i] = val;
+            if (PK) {
+                const float xs = val * cscale;
+                const _Float16 a16 = (_Float16)xs;
+                o.hh8[e] = a16;
+                o.ll8[e] = (_Float16)(xs - (float)a16);
+            }
+        } else {
+            if (PK) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.hh8), rsH, c.vo_p, c.n0 * 16, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.ll8), rsL, c.vo_p, c.n0 * 16, 0);
+            }
+            if (STATS) {
+                // lane (r = lane & 15, cq = lane >> 4) reduces columns 8 cq .. 8 cq + 7 of row r; the four quarters meet in two exchanges
+                const int ln = i + 32 * g, r = ln & 15, cq = ln >> 4;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(St + r * STP + 8 * cq);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(St + r * STP + 8 * cq + 4);
+                float sm = 0.f, sq = 0.f, mn = 3.0e38f, mx = -3.0e38f;
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) {
+                    const float x = cc < 4 ? a[cc & 3] : b[cc & 3];
+                    const bool ok = 8 * cq + cc < c.ncols_ok;
+                    sm += ok ? x : 0.f;
+                    sq = ok ? fmaf(x, x, sq) : sq;
+                    mn = ok ? fminf(mn, x) : mn;
+                    mx = ok ? fmaxf(mx, x) : mx;
+                }
+#pragma unroll
+                for (int off = 16; off <= 32; off <<= 1) {
+                    sm += __shfl_xor(sm, off, 64);
+                    sq += __shfl_xor(sq, off, 64);
+                    mn = fminf(mn, __shfl_xor(mn, off, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+                }
+                o.stv = f32x4{sm, sq, mn, mx};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.stv), rsP, c.vo_s, (c.n0 >> 5) * p.M * 16, 0);
+            }
+        }
+    };
+    auto epilogue = [&](const int pt, const bool live, EpiOut& o) {   // all of it at once
+        const TileCtx c = tile_ctx(pt, live);
+        static_for<0, 9>([&](auto kc) { epi_item(kc, c, o); });
+    };
+    auto hold = [&](EpiOut& o) {           // gfx950 store-data rule (profiles/r02_store_data_hazard.txt)
+        if constexpr (PK) asm volatile("" ::"v"(o.hh8), "v"(o.ll8));
+        if constexpr (STATS) asm volatile("" ::"v"(o.stv));
+        if constexpr (F32) asm volatile("" ::"v"(o.vals[0]), "v"(o.vals[1]), "v"(o.vals[2]), "v"(o.vals[3]), "v"(o.vals[4]), "v"(o.vals[5]), "v"(o.vals[6]), "v"(o.vals[7]));
+    };
+    auto load_residual = [&](int pt) {     // rows of pixel tile pt this wave will finish -> resn (retired by the next stage-top wait)
+        const int n0 = 32 * (tile0 + pt);
+        int vf_lane, vp_lane, vs_lane, i, g;
+        lane_offsets(vf_lane, vp_lane, vs_lane, i, g);
+        const int vo = n0 + i < p.HW ? vf_lane : WS_OOBV;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(resn[e]) : "v"(vo), "s"(rsR), "s"((e * p.HW + n0) * 4));
+    };
+    auto stage_top = [&]() {
+        // lgkmcnt: the accumulator halves written for the partner must be IN the LDS before the barrier releases it
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : "+v"(resn[0]), "+v"(resn[1]), "+v"(resn[2]), "+v"(resn[3]), "+v"(resn[4]), "+v"(resn[5]), "+v"(resn[6]), "+v"(resn[7])
+                     :
+                     : "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto read_partner = [&](int pt) {      // the partner's half of pixel tile pt
+        const char* xr = xch + (((pt & 1) * 8) + (wave ^ 4)) * 2048 + lane * 16;
+        pa = *reinterpret_cast<const f32x4*>(xr);
+        pb = *reinterpret_cast<const f32x4*>(xr + 1024);
+    };
+
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = 0.f;
+    constexpr int FDEPTH = (MODE == 2 && KH == 24) ? 0 : 1;   // fragment read-ahead; 0 where the registers are gone (K = 768 + planes + statistics)
+    // Loop body = one stage followed by the wait + barrier that opens the next (stage 0 was opened by the prologue); an
+    // asm-loaded register still in flight is never live across the back edge (conv_split.hip).
+    constexpr int VSPAN = 2 * KSW / 3;     // interleaved epilogue: the eight values over the first VSPAN k-steps, the stores right after
+    for (int pt = 0; pt < np; ++pt) {
+        static_for<0, NSTG>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            const int u = pt * NSTG + q;
+            if constexpr (!INTER && !(q == 0 && !HOLD)) {
+#pragma unroll
+                for (int k = 0; k < PW; ++k) piece(u + 1, k);
+            }
+            TileCtx ctx = {0, WS_OOBV, WS_OOBV, WS_OOBV, 0, 0, 0};
+            if constexpr (q == 0) {
+                read_partner(pt > 0 ? pt - 1 : 0);
+                if constexpr (INTER) {
+                    ctx = tile_ctx(pt > 0 ? pt - 1 : 0, pt > 0);
+                } else {
+                    epilogue(pt > 0 ? pt - 1 : 0, pt > 0, eo);
+                    if constexpr (!HOLD) {   // no registers to hold the store data through the stage: retire the stores first
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        hold(eo);
+#pragma unroll
+                        for (int k = 0; k < PW; ++k) piece(u + 1, k);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = 0.f;
+            }
+            if constexpr (RES && q == NSTG - 1) load_residual(pt);
+            const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (u & 1) * SLOT) + h * (KSW * 2048) + lane * 16;
+            pipelined_steps<KSW, FDEPTH>(sl, [&](auto ss, const Frag& f) {
+                constexpr int st = decltype(ss)::value;
+                constexpr int j = q * KSW + st;
+                v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], f.h, v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], f.l, v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], f.h, v, 0, 0, 0);
+                if constexpr (INTER) {
+                    if constexpr (st < PW) piece(u + 1, st);   // the pieces of the next stage, one per k-step from the first on
+                    static_for<0, 8>([&](auto kc) {
+                        constexpr int e = decltype(kc)::value;
+                        if constexpr ((e * VSPAN) / 8 == st) epi_item(kc, ctx, eo);
+                    });
+                    if constexpr (st == VSPAN) epi_item(std::integral_constant<int, 8>{}, ctx, eo);
+                }
+            });
+            if constexpr (q == NSTG - 1) {   // tile complete: keep the rows this wave finishes, hand the others to the partner
+                rows_to_kgroups(v);
+                f32x4 sa, sb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sa[e] = v[8 * (1 - H) + e]; sb[e] = v[8 * (1 - H) + 4 + e]; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) own[e] = v[8 * H + e];
+                char* xw = xch + (((pt & 1) * 8) + wave) * 2048 + lane * 16;
+                *reinterpret_cast<f32x4*>(xw) = sa;
+                *reinterpret_cast<f32x4*>(xw + 1024) = sb;
+            }
+            stage_top();
+            if constexpr (INTER && RES) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) res[e] = resn[e];
+            }
+            if constexpr (q == 0 && (HOLD || INTER)) hold(eo);
+        });
+    }
+    // ---- last tile (its own set of store-data registers, held to the end of the program)
+    EpiOut eo_last;
+    read_partner(np - 1);
+    epilogue(np - 1, true, eo_last);
+    hold(eo_last);
+    if (F32 && p.omax) {                   // one atomic per workgroup
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        float* red = reinterpret_cast<float*>(smem);   // the ring is dead
+        __syncthreads();
+        if (lane == 0) red[wave] = vmax;
+        __syncthreads();
+        if (tid == 0) {
+            float m = red[0];
+            for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
+            atomicMax(p.omax + (blockIdx.x & 63), __float_as_uint(m));
+        }
+    }
+}
+
+template <int KSW, int NSTG, int MODE>
+__global__ __launch_bounds__(512) void conv_ws_kernel(ConvStripArgs p, int groups) {
+    __shared__ __attribute__((aligned(16))) char smem[WsGeom<KSW, NSTG, MODE>::LDS];
+    if (threadIdx.x < 256) conv_ws_body<KSW, NSTG, MODE, 0>(p, smem, groups);   // waves 0 - 3: first half of the contraction
+    else conv_ws_body<KSW, NSTG, MODE, 1>(p, smem, groups);
+}
+
+template <int KSW, int NSTG>
+hipError_t launch_ws_k(const ConvStripArgs& a, int mode, hipStream_t s) {
+    const int nslice = a.M / 128;
+    int gpx = 32 / nslice;                       // groups per XCD (32 CUs each)
+    if (gpx < 1) gpx = 1;
+    const int tiles_px = (a.HW + 31) / 32;
+    int groups = 8 * gpx;
+    if (groups > tiles_px) groups = ((tiles_px + 7) / 8) * 8;   // small fields: fewer groups (still whole multiples of the XCD count)
+    dim3 grid((unsigned)(groups * nslice * a.nbatch)), block(512);
+    if constexpr (NSTG == 1) {   // the GELU modes exist for the single-stage contractions only (K <= 384)
+        if (mode == 0) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 0>), grid, block, 0, s, a, groups);
+        if (mode == 1) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 1>), grid, block, 0, s, a, groups);
+    } else if (mode <= 1) {
+        return hipErrorInvalidValue;
+    }
+    if (mode == 2) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 2>), grid, block, 0, s, a, groups);
+    if (mode == 3) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 3>), grid, block, 0, s, a, groups);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// K: input channels (contraction), M: output channels; role 0 inner skip, 1 fc1, 2 fc2 (-1: any)
+bool conv_ws_eligible(int K, int M, long HW, int role) {
+    // Which convolutions run here: ACE_CONV_WS = list of roles ("skip,fc1,fc2"), "all" or "none" (read per call).
+    const int on = [] {
+        const char* e = std::getenv("ACE_CONV_WS");
+        if (!e) return ACE_CONV_WS_DEFAULT;
+        const std::string v(e);
+        if (v == "all" || v == "1") return 7;
+        int m = 0;
+        if (v.find("skip") != std::string::npos) m |= 1;
+        if (v.find("fc1") != std::string::npos) m |= 2;
+        if (v.find("fc2") != std::string::npos) m |= 4;
+        return m;
+    }();
+    if (role >= 0 && role < 3 && !(on >> role & 1)) return false;
+    if (role == -1 && on == 0) return false;
+    if (!(K == 128 || K == 256 || K == 384 || K == 512 || K == 768)) return false;
+    if (role >= 0 && role <= 1 && K > 384) return false;
+    return M % 128 == 0 && M >= 128 && M <= 2048 && (long)M * HW * 4 < 0x7fffff00L && ((HW + 31) / 32 + 8) * (long)M * 16 < 0x7fffff00L;
+}
+
+hipError_t launch_conv_ws(const ConvStripArgs& a, hipStream_t s) {
+    if (!conv_ws_eligible(a.C, a.M, a.HW, -2) || !a.bias || !a.xslot || !a.A) return hipErrorInvalidValue;
+    const bool f32 = a.Cf != nullptr, pk = a.Chi != nullptr, stats = a.part != nullptr, res = a.R != nullptr;
+    const bool gelu = a.act == ACT_GELU || a.act == ACT_GELU_FAST;
+    int mode = -1;
+    if (gelu && res && pk && stats && !f32) mode = 0;
+    else if (gelu && !res && pk && !stats && !f32) mode = 1;
+    else if (a.act == ACT_NONE && res && f32 && pk && stats) mode = 2;
+    else if (a.act == ACT_NONE && res && f32 && !pk && !stats) mode = 3;
+    if (mode < 0 || (pk && (!a.Clo || !a.cslot)) || (f32 && a.M > 1024)) return hipErrorInvalidValue;
+    if (mode <= 1 && a.C > 384) return hipErrorInvalidValue;
+    switch (a.C) {
+        case 128: return launch_ws_k<4, 1>(a, mode, s);
+        case 256: return launch_ws_k<8, 1>(a, mode, s);
+        case 384: return launch_ws_k<12, 1>(a, mode, s);
+        case 512: return launch_ws_k<8, 2>(a, mode, s);
+        case 768: return launch_ws_k<12, 2>(a, mode, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ace

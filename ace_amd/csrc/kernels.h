@@ -192,6 +192,10 @@ hipError_t launch_conv_strip(const ConvStripArgs& a, hipStream_t s);
 // derived from the outputs requested (GELU + planes [+ residual + statistics], or residual + fp32 [+ planes + statistics])
 bool conv_split_eligible(int K, int M, long HW, int role);   // role 0 inner skip, 1 fc1, 2 fc2 (-1: any)
 hipError_t launch_conv_split(const ConvStripArgs& a, hipStream_t s);
+// the block's 1x1 convolutions with the WEIGHTS resident and a persistent grid over pixel tiles (conv_ws.hip); same arguments
+// and modes as conv_split.hip, statistics per 32-pixel tile: nstrips32 >= ceil(HW / 32)
+bool conv_ws_eligible(int K, int M, long HW, int role);   // role 0 inner skip, 1 fc1, 2 fc2 (-1: any)
+hipError_t launch_conv_ws(const ConvStripArgs& a, hipStream_t s);
 
 // dhconv with the filter streamed once into MFMA B fragments (dhconv_strip.hip).  Rows (m, b), m <= l; K = N = 2 C.
 struct DhconvStripArgs {

@@ -92,14 +92,15 @@ def test_dhconv_at_headline_shape_three_implementations(dev, B, monkeypatch):
     assert rel_max(outs["tile"], outs["fp32"]) <= 2e-6
 
 
-@pytest.mark.parametrize("split", ["all", "none"])
+@pytest.mark.parametrize("split", ["ws", "all", "none"])
 def test_headline_bitwise_repeatability(dev, headline, split, monkeypatch):
     """200 forwards of the headline network on the same input must be bitwise identical, and right.  The register-resident
     kernels issue stores whose data registers are recycled a few instructions later; on gfx950 a load landing in such a
     register before the store has read it corrupts a few lanes, rarely and not reproducibly (r02: seen with 125 of
-    25 M plane entries wrong) - a sampled accuracy check can miss that, bitwise repeatability cannot.  Both settings of
-    ACE_CONV_SPLIT (every 1x1 convolution on conv_split.hip / none of them, i.e. conv_strip.hip and the tile engine)."""
-    monkeypatch.setenv("ACE_CONV_SPLIT", split)
+    25 M plane entries wrong) - a sampled accuracy check can miss that, bitwise repeatability cannot.  Three routings of the
+    1x1 convolutions: all on conv_ws.hip, all on conv_split.hip, none of either (conv_strip.hip and the tile engine)."""
+    monkeypatch.setenv("ACE_CONV_WS", "all" if split == "ws" else "none")
+    monkeypatch.setenv("ACE_CONV_SPLIT", "none" if split == "ws" else split)
     d, cfg, state, x = headline
     net = build_native_net(cfg, state, dev, "f16x3")
     xd = x[:1].to(dev).contiguous()
@@ -118,7 +119,7 @@ def test_headline_bitwise_repeatability(dev, headline, split, monkeypatch):
     assert err <= NET_TOL, err
 
 
-@pytest.mark.parametrize("fused", ["0", "1", "split"])
+@pytest.mark.parametrize("fused", ["0", "1", "split", "ws", "strip"])
 @pytest.mark.parametrize("C,hw", [(384, (45, 90)), (128, (24, 48)), (256, (20, 40))])
 def test_fused_mlp_shapes_vs_fp64(dev, C, hw, fused, monkeypatch):
     """the register-resident strip kernels at C in {128, 256, 384} inside 3-block nets, batch 3, ragged last workgroup,
@@ -126,8 +127,14 @@ def test_fused_mlp_shapes_vs_fp64(dev, C, hw, fused, monkeypatch):
     tile engine / conv_split.hip (default); fused=1: fc1 + GELU + fc2 in mlp_strip.hip; split: all three on conv_split.hip."""
     from oracle.sfno import SFNOConfig, SFNOOracle, init_state
     monkeypatch.setenv("ACE_MLP_FUSED", "1" if fused == "1" else "0")
-    if fused == "split":   # every 1x1 convolution of the block on conv_split.hip (default: fc2 only)
+    if fused == "split":   # every 1x1 convolution of the block on conv_split.hip
         monkeypatch.setenv("ACE_CONV_SPLIT", "all")
+        monkeypatch.setenv("ACE_CONV_WS", "none")
+    if fused == "ws":      # ... on the weight-stationary conv_ws.hip
+        monkeypatch.setenv("ACE_CONV_WS", "all")
+    if fused == "strip":   # inner skip / fc1 on conv_strip.hip, fc2 on the tile engine
+        monkeypatch.setenv("ACE_CONV_WS", "none")
+        monkeypatch.setenv("ACE_CONV_SPLIT", "none")
     cfg = SFNOConfig(in_chans=6, out_chans=5, img_shape=hw, embed_dim=C, num_layers=3, operator_type="dhconv")
     state = init_state(cfg, seed=17)
     g = torch.Generator().manual_seed(18)
