@@ -153,6 +153,17 @@ SDEV void strip_body(const LegStripArgs& p, char* smem, const int m, const int g
     // `inner`: a tile that is not the last one of its column.  Its rows are all below R, and rows below the triangle
     // (forward, l < m) hold exact zeros at addresses nobody reads, so with whole strips (FULLN) the stores need no mask:
     // the in-loop epilogue is straight-line code that the scheduler can lay under the MFMAs of the next tile.
+    auto tile_max = [&](int t, const f32x16& acc, auto inner_tag) {   // range of the fp32 outputs of tile t (valid entries only)
+        constexpr bool NOMASK = decltype(inner_tag)::value && FULLN;
+        const int rbase = gm.row0 + 32 * t;
+        const int rlo = p.mode == 0 ? m : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + acc_row(r, g);
+            const bool ok = NOMASK || (row >= rlo && row < R && n < N);
+            vmax = fmaxf(vmax, ok ? fabsf(acc[r] * oscale) : 0.f);
+        }
+    };
     auto store_tile = [&](int t, const f32x16& acc, auto inner_tag) {
         constexpr bool NOMASK = decltype(inner_tag)::value && FULLN;
         const int rbase = gm.row0 + 32 * t;
@@ -162,10 +173,7 @@ SDEV void strip_body(const LegStripArgs& p, char* smem, const int m, const int g
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + acc_row(r, g);
                 const float v = acc[r] * oscale;
-                if (row >= rlo && row < R && n < N) {
-                    p.C[cm + (long)row * p.c_rstride + n] = v;
-                    vmax = fmaxf(vmax, fabsf(v));
-                }
+                if (row >= rlo && row < R && n < N) p.C[cm + (long)row * p.c_rstride + n] = v;
             }
             return;
         }
@@ -214,7 +222,6 @@ SDEV void strip_body(const LegStripArgs& p, char* smem, const int m, const int g
                         v[0] = __uint_as_float(d[0]); v[1] = __uint_as_float(d[1]);
                         v[2] = __uint_as_float(d[2]); v[3] = __uint_as_float(d[3]);
                         *reinterpret_cast<f32x4*>(p.C + cm + (long)row * p.c_rstride + ncol) = v;
-                        vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                     }
                 }
             }
@@ -235,7 +242,10 @@ SDEV void strip_body(const LegStripArgs& p, char* smem, const int m, const int g
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NG) : "memory");
         __syncthreads();                                     // every share landed; every wave is done reading tile t - 1
         issue_tile(t + 2);                                   // ... whose slot is refilled now (a dummy past the end)
-        if (t > 0) store_tile(t - 1, prev, std::true_type{});
+        if (t > 0) {
+            if (OUT != 1) tile_max(t - 1, prev, std::true_type{});
+            store_tile(t - 1, prev, std::true_type{});
+        }
         const char* slot = ring + (t % NSLOT) * SLOT_BYTES + lane * 16;
         f32x16 a0, a1, a2;
 #pragma unroll
@@ -254,8 +264,9 @@ SDEV void strip_body(const LegStripArgs& p, char* smem, const int m, const int g
         }
         prev = (a0 + a1) + a2;
     }
-    if (gm.ntiles > 0) store_tile(gm.ntiles - 1, prev, std::false_type{});
-
+    // gfx950 store-data rule (profiles/r02_store_data_hazard.txt): the range reduction (shuffles, an LDS round trip - loads that
+    // LAND in registers) runs before the last tile's stores, which are the last thing the wave does
+    if (OUT != 1 && gm.ntiles > 0) tile_max(gm.ntiles - 1, prev, std::false_type{});
     if (OUT != 1 && p.omax) {   // one atomic per workgroup
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
@@ -264,7 +275,9 @@ SDEV void strip_body(const LegStripArgs& p, char* smem, const int m, const int g
         if (lane == 0) red[wave] = vmax;
         __syncthreads();
         if (tid == 0) atomicMax(p.omax + (blockIdx.x & 63), __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+        __syncthreads();        // ... before the transpose buffer of the last tile re-uses the LDS
     }
+    if (gm.ntiles > 0) store_tile(gm.ntiles - 1, prev, std::false_type{});
 }
 
 template <int OUT, bool FULLN>

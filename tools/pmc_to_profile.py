@@ -12,6 +12,10 @@ RULES = [  # (regex on kernel key, stage, reads are wide (x2 correction applies)
     (r"^legendre_strip_kernel<0", "forward_transform.legendre", True),
     (r"^legendre_strip_kernel<1", "inverse_transform.legendre", True),
     (r"^dhconv_strip_kernel", "dhconv", True),
+    (r"^conv_ws_kernel<12, 1, 0>", "inner_skip+activation", True),
+    (r"^conv_ws_kernel<12, 1, 1>", "mlp.fc1", True),
+    (r"^conv_ws_kernel<12, 2, 2>", "mlp.fc2+outer_skip", True),
+    (r"^conv_ws_kernel<12, 2, 3>", "mlp.fc2+outer_skip(last block)", True),
     (r"^conv_strip_kernel<12, 4, true, true>", "inner_skip+activation", True),
     (r"^conv_strip_kernel<12, 4, false, false>", "mlp.fc1", True),
     (r"^conv_split_kernel<12, 2, 2>", "mlp.fc2+outer_skip", True),
