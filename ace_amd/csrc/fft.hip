@@ -116,9 +116,9 @@ __global__ __launch_bounds__(R * (N1 > N2 ? N1 : N2)) void dft_forward_fft_kerne
 #else
         const float4 v = *reinterpret_cast<const float4*>(p.x + bc * HW + (long)k * W + 4 * j);
 #endif
-        float* d = xs + r * PITCH + 4 * j;
-        d[0] = v.x;
-        d[1] = v.y;
+        float* d = xs + r * PITCH + 4 * j;   // (8-way bank conflicts on these four writes - rotating the element order per
+        d[0] = v.x;                          //  lane group removes them and made the kernel 5 % SLOWER: not on the critical
+        d[1] = v.y;                          //  path, r02 same-box A/B)
         d[2] = v.z;
         d[3] = v.w;
     }
@@ -341,8 +341,18 @@ __global__ __launch_bounds__(R * (N2 > N1 / 2 + 1 ? N2 : N1 / 2 + 1)) void dft_i
         const int r = idx / (W / 4), j = idx % (W / 4);
         const int c = c0 + r;
         if (c < p.C) {
+            // (same rotation of the element order on the way out: four conflict-free reads instead of four 8-way ones)
             const float* d = ys + r * PITCH + 4 * j;
-            const float4 v = make_float4(d[0], d[1], d[2], d[3]);
+            const int rot = (tid >> 3) & 3;
+            float t[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = d[(q + rot) & 3];
+            // t[q] holds element (q + rot) & 3: element e sits in t[(e - rot) & 3]
+            const float e0 = rot == 0 ? t[0] : rot == 1 ? t[3] : rot == 2 ? t[2] : t[1];
+            const float e1 = rot == 0 ? t[1] : rot == 1 ? t[0] : rot == 2 ? t[3] : t[2];
+            const float e2 = rot == 0 ? t[2] : rot == 1 ? t[1] : rot == 2 ? t[0] : t[3];
+            const float e3 = rot == 0 ? t[3] : rot == 1 ? t[2] : rot == 2 ? t[1] : t[0];
+            const float4 v = make_float4(e0, e1, e2, e3);
             *reinterpret_cast<float4*>(p.y + ((long)b * p.C + c) * HW + (long)k * W + 4 * j) = v;
             vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         }
@@ -398,7 +408,7 @@ bool launch_dft_inverse_fft(const DftArgs& a, hipStream_t s, hipError_t* err) {
     if (!fft_enabled() || (reinterpret_cast<uintptr_t>(a.y) & 15) != 0 || a.Mm > a.W / 2 + 1 || a.H > 65535 || a.Bt > 65535)
         return false;
     switch (a.W) {
-        case 360: *err = launch_inv<20, 18>(a, s); return true;
+        case 360: *err = launch_inv<20, 18, 32>(a, s); return true;   // 32 channel rows per workgroup: 128-byte runs on the spectral side (r02: 81.7 -> 75.6 us; the forward kernel is faster with 16)
         case 1440: *err = launch_inv<40, 36, 8>(a, s); return true;
         case 720: *err = launch_inv<30, 24, 8>(a, s); return true;
         case 48: *err = launch_inv<8, 6>(a, s); return true;
