@@ -9,3 +9,4 @@ python tools/repeat_check.py 2000 > gpurun_out/repeat_check_final.txt 2>&1; tail
 ( time timeout 600 python bench.py > gpurun_out/bench_final_default.json 2> gpurun_out/bench_final_default.err ) 2>&1 | grep real
 head -c 1800 gpurun_out/bench_final_default.json
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 600 python tools/bench_csfno.py --no-oracle > gpurun_out/bench_csfno_r02.json 2> gpurun_out/bench_csfno_r02.err; head -c 400 gpurun_out/bench_csfno_r02.json
