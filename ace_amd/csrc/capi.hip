@@ -555,6 +555,8 @@ struct ace_sfno {
     DevBuf Wp0, Wp1;     // folded (norm affine) skip / fc1 weights as tiled fp16 planes, per sample
     DevBuf Wq1;          // folded fc1 weights as packed MFMA A fragments, per sample (fused MLP / conv_strip)
     DevBuf Wq0;          // folded inner-skip weights likewise (conv_strip)
+    DevBuf zero_c;       // C zeros (bias of the bias-free last encoder convolution on conv_ws.hip)
+    DevBuf pe_slot;      // dynamic-range slot (64 words) holding max|pos_embed|: the residual bound of that convolution
     int nstrips = 0;
     DevBuf Wf0, bf0, Wf1, bf1;
     DevBuf amax;  // [8] uint words: bit patterns of max|X|, max|D|, max|E| of the current block (f16x3 dynamic range)  // instance-norm affine folded into inner_skip / mlp.fc1 weights, per sample
@@ -706,6 +708,8 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
             if (mlp_strip_shape_ok((int)C, n->hid) || conv_strip_eligible((int)C, n->hid, ACT_GELU))
                 HIP_TRY(n->Wq1.alloc((size_t)n->Bmax * n->hid * C, true));   // hi + lo halves = one float per element
             if (conv_strip_eligible((int)C, (int)C, ACT_GELU)) HIP_TRY(n->Wq0.alloc((size_t)n->Bmax * C * C, true));
+            HIP_TRY(n->zero_c.alloc((size_t)C, true));
+            HIP_TRY(n->pe_slot.alloc(64, true));
             HIP_TRY(n->part.alloc((size_t)2 * n->Bmax * n->nstrips * C * 4, true));
             const size_t cp = (size_t)((C + 31) & ~31);
             HIP_TRY(n->Wp0.alloc((size_t)n->Bmax * ((C + 15) / 16 * 16) * cp, true));       // 2 planes of halves = 1 float per element
@@ -838,16 +842,25 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
             HIP_TRY(launch_pack_conv_frag(w.buf.p, w.pitch, w.rows, w.cols, 1, nullptr, 0.f, w.ascale, nullptr, w.frag.p,
                                           0, 1, s));
         }
+        const bool is_enc2 = wn == "encoder." + std::to_string(2 * n->cfg.encoder_layers) + ".weight";
         const bool is_skip = wn.size() > 17 && wn.compare(wn.size() - 17, 17, "inner_skip.weight") == 0;
         const bool is_fc2 = wn.size() > 16 && wn.compare(wn.size() - 16, 16, "mlp.fwd.2.weight") == 0;
         if ((is_skip && conv_strip_eligible(w.cols, w.rows, ACT_GELU)) ||
             ((is_skip || is_fc2) && conv_split_eligible(w.cols, w.rows, 1, is_skip ? 0 : 2)) ||
-            ((is_skip || is_fc2) && conv_ws_eligible(w.cols, w.rows, 1, is_skip ? 0 : 2))) {
+            ((is_skip || is_fc2 || is_enc2) && conv_ws_eligible(w.cols, w.rows, 1, is_skip ? 0 : 2))) {
             if (!w.frag0.p) HIP_TRY(w.frag0.alloc((size_t)w.rows * w.cols, false));
             HIP_TRY(launch_pack_conv_frag(w.buf.p, w.pitch, w.rows, w.cols, 0, nullptr, 0.f, w.ascale, nullptr, w.frag0.p,
                                           0, 1, s));
         }
         HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (w.name == "pos_embed" && n->pe_slot.p) {   // its bound, as a dynamic-range slot (the residual of the last encoder convolution)
+        std::vector<float> host((size_t)numel);
+        HIP_TRY(hipMemcpy(host.data(), w.buf.p, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+        float mx = 0.f;
+        for (float v : host) mx = std::max(mx, std::fabs(v));
+        std::vector<float> rep(64, mx);
+        HIP_TRY(hipMemcpy(n->pe_slot.p, rep.data(), rep.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     if (w.pitch == 0 && !w.is_filter && numel <= (1 << 16)) {  // biases: bound used by the P-format producers
         std::vector<float> host((size_t)numel);
@@ -1053,6 +1066,37 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     }
     float* h = n->h0.p;
     float* hn = n->h1.p;
+    // The last encoder convolution (C -> C, no bias, + pos_embed) on the weight-stationary strip kernel when block 0 takes the
+    // packed path: its epilogue then writes h0 as fp32 AND as P-format planes with the row statistics of norm0, so block 0
+    // starts like every other block (no pack pass, no statistics pass over h0).
+    bool enc_planes = false;
+    {
+        const Weight& we = *n->weights[n->index.at("encoder." + std::to_string(2 * c.encoder_layers) + ".weight")];
+        static const bool enc_off = getenv("ACE_NO_ENC_WS") != nullptr;   // A/B switch for measurements
+        const bool block0_fused = f16 && c.normalization_layer == 1 && c.use_mlp && n->P2.p && packed_ok(n, C) && n->hid % 8 == 0 &&
+                                  (n->plan_data == n->plan_lg.get() || c.num_layers == 1);
+        if (!enc_off && block0_fused && c.encoder_layers >= 1 && c.pos_embed && curC == C && we.frag0.p && n->zero_c.p &&
+            n->pe_slot.p && n->part.p && conv_ws_eligible(C, C, HW, 2)) {
+            _Float16* Th = reinterpret_cast<_Float16*>(n->P.p);
+            _Float16* Tl = Th + (size_t)n->Bmax * C * HW;
+            _Float16* Hh = reinterpret_cast<_Float16*>(n->P2.p);
+            _Float16* Hl = Hh + (size_t)n->Bmax * C * HW;
+            ACE_TRY(pack_act(n, cur, cur_bs, C, nullptr, nullptr, slot(c.encoder_layers), Th, Tl, B, s));
+            ConvStripArgs k;
+            k.Xhi = Th; k.Xlo = Tl; k.ldn = HW; k.sX = (long)C * HW; k.xslot = slot(c.encoder_layers);
+            k.A = reinterpret_cast<const _Float16*>(we.frag0.p); k.sA = 0; k.ascale = we.ascale;
+            k.bias = n->zero_c.p; k.sbias = 0;
+            k.R = W("pos_embed"); k.sR = 0;
+            k.Cf = h; k.sCf = actB;
+            k.Chi = Hh; k.Clo = Hl; k.sCp = (long)C * HW; k.cslot = hslot(0);
+            k.cw = we.winf; k.cb = 0.f; k.rmax = reinterpret_cast<const unsigned*>(n->pe_slot.p);
+            k.part = reinterpret_cast<float4*>(n->part.p); k.nstrips32 = (int)((HW + 31) / 32);
+            k.C = C; k.M = C; k.HW = (int)HW; k.nbatch = B; k.act = ACT_NONE;
+            HIP_TRY(launch_conv_ws(k, s));
+            enc_planes = true;
+        }
+    }
+    if (!enc_planes)
     ACE_TRY(conv(n, conv_weight(n, "encoder." + std::to_string(2 * c.encoder_layers) + ".weight", ""), cur, cur_bs, curC,
                  nullptr, 0, -1, h, C, c.pos_embed ? W("pos_embed") : nullptr, 0, nullptr, nullptr, ACT_NONE, B, s,
                  nullptr, nullptr, slot(c.encoder_layers), nullptr, hslot(0)));
@@ -1078,8 +1122,8 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     }
 
     // fused-norm state of the packed-operand path: does P2 hold the block input in P format / `part_h` its statistics?
-    bool have_ph = false, have_hstats = false;
-    int h_nparts = 0;   // statistics partials per row in part_h (depends on which kernel produced them)
+    bool have_ph = enc_planes, have_hstats = enc_planes;
+    int h_nparts = enc_planes ? (int)((HW + 31) / 32) : 0;   // statistics partials per row in part_h (depends on which kernel produced them)
     float* part_h = n->part.p;
     float* part_t = n->part.p ? n->part.p + (size_t)n->Bmax * n->nstrips * C * 4 : nullptr;
     _Float16* PAh = reinterpret_cast<_Float16*>(n->P.p);                  // T planes / pack fallback
