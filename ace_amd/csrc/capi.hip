@@ -1299,6 +1299,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 k.Chi = PAh; k.Clo = PAl; k.sCp = (long)C * HW; k.cslot = slot(sb + 4);
                 k.part = reinterpret_cast<float4*>(part_t); k.nstrips32 = (split_ok || ws_ok) ? nsplit32 : (int)((HW + 255) / 256) * 8;
                 k.C = C; k.M = C; k.HW = (int)HW; k.nbatch = B; k.act = ACT_GELU;
+                if (ws_ok) k.nstrips32 = conv_ws_stat_parts(k);   // one partial per pixel group (statistics accumulated in registers)
                 HIP_TRY(ws_ok ? launch_conv_ws(k, s) : split_ok ? launch_conv_split(k, s) : launch_conv_strip(k, s));
                 t_nparts = k.nstrips32;
             } else {

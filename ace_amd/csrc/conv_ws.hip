@@ -43,7 +43,8 @@ struct WsGeom {
     static constexpr int TAB = BMAX * 4 * (F32 ? 2 : 1);
     static constexpr int XCH = 2 * 8 * 2048;       // accumulator exchange: [tile parity][wave][2 planes][64 lanes][16 B]
     static constexpr int STP = 36;                 // pitch of the statistics transpose (floats)
-    static constexpr int STB = STATS ? 8 * 16 * STP * 4 : 0;
+    static constexpr bool RSTATS = MODE == 0;      // statistics accumulated in registers over the workgroup's pixel range
+    static constexpr int STB = (STATS && !RSTATS) ? 8 * 16 * STP * 4 : 0;
     static constexpr int LDS = 2 * SLOT + TAB + XCH + STB;
     static_assert(KSW % 2 == 0 && LDS <= 160 * 1024, "LDS budget");
 };
@@ -58,7 +59,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
     using G = WsGeom<KSW, NSTG, MODE>;
     constexpr int KH = G::KH, SLOT = G::SLOT, BMAX = G::BMAX, TAB = G::TAB, XCH = G::XCH, STP = G::STP;
     constexpr int PW = KSW / 2;             // 1-KiB pieces per wave per stage
-    constexpr bool GELU = MODE <= 1, RES = MODE != 1, PK = MODE != 3, F32 = G::F32, STATS = G::STATS;
+    constexpr bool GELU = MODE <= 1, RES = MODE != 1, PK = MODE != 3, F32 = G::F32, STATS = G::STATS, RSTATS = G::RSTATS;
     constexpr bool INTER = MODE <= 1;       // epilogue of tile t - 1 between the MFMAs of tile t
     constexpr bool HOLD = KH < 24;          // registers to hold the store data through a stage (else: stores retired first)
     static_assert(!INTER || NSTG == 1, "interleaved epilogue: single-stage tiles");
@@ -83,8 +84,12 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
     const int tpg = (tiles_px + groups - 1) / groups;
     const int tile0 = group * tpg;
     const int np = tiles_px - tile0 < tpg ? tiles_px - tile0 : tpg;
-    if (np <= 0) return;                    // (whole workgroup: no barrier has been executed yet)
     const int T = slice * 4 + (wave & 3);   // 32-row tile of the output channels
+    if (np <= 0) {                          // (whole workgroup: no barrier has been executed yet)
+        if (RSTATS && lane < 16)            // an idle pixel group still owes the finaliser a (neutral) partial
+            p.part[((long)smp * p.nstrips32 + group) * p.M + 32 * T + 16 * h + lane] = make_float4(0.f, 0.f, 3.0e38f, -3.0e38f);
+        return;
+    }
     const int NU = np * NSTG;
 
     const unsigned raw_x = slot_load(p.xslot + lane);
@@ -181,6 +186,12 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
     struct TileCtx { int n0, vo_f, vo_p, vo_s, ncols_ok, i, g; };   // per pixel tile: offsets / validity of this lane
     EpiOut eo;
     float vmax = 0.f;
+    // RSTATS (inner skip: registers to spare): running sum / sum of squares / min / max of this lane's pixel column for the
+    // eight rows it finishes; reduced over the 32 pixel lanes once, at the end: ONE partial per workgroup and row instead of
+    // one per 32-pixel tile (80 instead of 2025 for the norm finaliser at 180 x 360), no LDS transpose, no per-tile store
+    float rsm[8], rsq[8], rmn[8], rmx[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { rsm[e] = 0.f; rsq[e] = 0.f; rmn[e] = 3.0e38f; rmx[e] = -3.0e38f; }
 #pragma unroll
     for (int e = 0; e < 8; ++e) { own[e] = 0.f; res[e] = 0.f; resn[e] = 0.f; eo.vals[e] = 0.f; }
 #pragma unroll
@@ -212,7 +223,14 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o.vals[e]), rsC, c.vo_f, (e * p.HW + c.n0) * 4, 0);
                 vmax = fmaxf(vmax, c.vo_f != WS_OOBV ? fabsf(val) : 0.f);
             }
-            if (STATS) St[(8 * g + e) * STP + i] = val;
+            if (STATS && !RSTATS) St[(8 * g + e) * STP + i] = val;
+            if (RSTATS) {
+                const bool ok = c.vo_p != WS_OOBV;   // a stored pixel of a live tile
+                rsm[e] += ok ? val : 0.f;
+                rsq[e] = ok ? fmaf(val, val, rsq[e]) : rsq[e];
+                rmn[e] = ok ? fminf(rmn[e], val) : rmn[e];
+                rmx[e] = ok ? fmaxf(rmx[e], val) : rmx[e];
+            }
             if (PK) {
                 const float xs = val * cscale;
                 const _Float16 a16 = (_Float16)xs;
@@ -224,7 +242,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.hh8), rsH, c.vo_p, c.n0 * 16, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.ll8), rsL, c.vo_p, c.n0 * 16, 0);
             }
-            if (STATS) {
+            if (STATS && !RSTATS) {
                 // lane (r = lane & 15, cq = lane >> 4) reduces columns 8 cq .. 8 cq + 7 of row r; the four quarters meet in two exchanges
                 const int ln = i + 32 * g, r = ln & 15, cq = ln >> 4;
                 const f32x4 a = *reinterpret_cast<const f32x4*>(St + r * STP + 8 * cq);
@@ -257,7 +275,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
     };
     auto hold = [&](EpiOut& o) {           // gfx950 store-data rule (profiles/r02_store_data_hazard.txt)
         if constexpr (PK) asm volatile("" ::"v"(o.hh8), "v"(o.ll8));
-        if constexpr (STATS) asm volatile("" ::"v"(o.stv));
+        if constexpr (STATS && !RSTATS) asm volatile("" ::"v"(o.stv));
         if constexpr (F32) asm volatile("" ::"v"(o.vals[0]), "v"(o.vals[1]), "v"(o.vals[2]), "v"(o.vals[3]), "v"(o.vals[4]), "v"(o.vals[5]), "v"(o.vals[6]), "v"(o.vals[7]));
     };
     auto load_residual = [&](int pt) {     // rows of pixel tile pt this wave will finish -> resn (retired by the next stage-top wait)
@@ -355,6 +373,29 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
     EpiOut eo_last;
     read_partner(np - 1);
     epilogue(np - 1, true, eo_last);
+    if constexpr (RSTATS) {   // statistics of the whole pixel range: reduce over the 32 pixel lanes (same g), one store per row
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int off = 1; off <= 16; off <<= 1) {
+                rsm[e] += __shfl_xor(rsm[e], off, 64);
+                rsq[e] += __shfl_xor(rsq[e], off, 64);
+                rmn[e] = fminf(rmn[e], __shfl_xor(rmn[e], off, 64));
+                rmx[e] = fmaxf(rmx[e], __shfl_xor(rmx[e], off, 64));
+            }
+        // lanes 0 and 32 hold rows row0 + 8 g + e; part[(sample, group) x M + row], group = the workgroup's pixel group
+        const auto rsG = __builtin_amdgcn_make_buffer_rsrc(p.part + ((long)smp * p.nstrips32 + group) * p.M, 0, p.M * 16, 0x00020000);
+        const int gq = lane >> 5;
+        const int vo = (lane & 31) == 0 ? (row0 + 8 * gq) * 16 : WS_OOBV;
+        f32x4 st8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            st8[e] = f32x4{rsm[e], rsq[e], rmn[e], rmx[e]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, st8[e]), rsG, vo, e * 16, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(st8[e]));   // store data held to the end of the program
+    }
     hold(eo_last);
     if (F32 && p.omax) {                   // one atomic per workgroup
 #pragma unroll
@@ -378,14 +419,20 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvStripArgs p, int group
     else conv_ws_body<KSW, NSTG, MODE, 1>(p, smem, groups);
 }
 
+int ws_groups(int M, long HW) {
+    const int nslice = M / 128;
+    int gpx = 32 / nslice;                       // groups per XCD (32 CUs each)
+    if (gpx < 1) gpx = 1;
+    const int tiles_px = (int)((HW + 31) / 32);
+    int groups = 8 * gpx;
+    if (groups > tiles_px) groups = ((tiles_px + 7) / 8) * 8;   // small fields: fewer groups (still whole multiples of the XCD count)
+    return groups;
+}
+
 template <int KSW, int NSTG>
 hipError_t launch_ws_k(const ConvStripArgs& a, int mode, hipStream_t s) {
     const int nslice = a.M / 128;
-    int gpx = 32 / nslice;                       // groups per XCD (32 CUs each)
-    if (gpx < 1) gpx = 1;
-    const int tiles_px = (a.HW + 31) / 32;
-    int groups = 8 * gpx;
-    if (groups > tiles_px) groups = ((tiles_px + 7) / 8) * 8;   // small fields: fewer groups (still whole multiples of the XCD count)
+    const int groups = ws_groups(a.M, a.HW);
     dim3 grid((unsigned)(groups * nslice * a.nbatch)), block(512);
     if constexpr (NSTG == 1) {   // the GELU modes exist for the single-stage contractions only (K <= 384)
         if (mode == 0) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 0>), grid, block, 0, s, a, groups);
@@ -399,6 +446,12 @@ hipError_t launch_ws_k(const ConvStripArgs& a, int mode, hipStream_t s) {
 }
 
 }  // namespace
+
+// statistics partials per row the launch described by `a` writes (a.nstrips32 must be at least this)
+int conv_ws_stat_parts(const ConvStripArgs& a) {
+    const bool skip_mode = (a.act == ACT_GELU || a.act == ACT_GELU_FAST) && a.R && a.part && !a.Cf;
+    return skip_mode ? ws_groups(a.M, a.HW) : (a.HW + 31) / 32;
+}
 
 // K: input channels (contraction), M: output channels; role 0 inner skip, 1 fc1, 2 fc2 (-1: any)
 bool conv_ws_eligible(int K, int M, long HW, int role) {

@@ -196,6 +196,7 @@ hipError_t launch_conv_split(const ConvStripArgs& a, hipStream_t s);
 // and modes as conv_split.hip, statistics per 32-pixel tile: nstrips32 >= ceil(HW / 32)
 bool conv_ws_eligible(int K, int M, long HW, int role);   // role 0 inner skip, 1 fc1, 2 fc2 (-1: any)
 hipError_t launch_conv_ws(const ConvStripArgs& a, hipStream_t s);
+int conv_ws_stat_parts(const ConvStripArgs& a);   // statistics partials per row that launch writes (nstrips32 >= this)
 
 // dhconv with the filter streamed once into MFMA B fragments (dhconv_strip.hip).  Rows (m, b), m <= l; K = N = 2 C.
 struct DhconvStripArgs {
