@@ -47,6 +47,8 @@ SIGNATURES = {
     "ace_sfno_create": (c_int, [POINTER(AceSfnoConfig), POINTER(c_void_p)]),
     "ace_sfno_destroy": (None, [c_void_p]),
     "ace_sfno_set_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_long, c_void_p]),
+    "ace_sfno_weights_generation": (c_long, [c_void_p]),
+    "ace_sfno_workspace_size": (c_long, [c_void_p, c_int]),
     "ace_sfno_num_weights": (c_int, [c_void_p]),
     "ace_sfno_weight_name": (c_char_p, [c_void_p, c_int]),
     "ace_sfno_weight_numel": (c_long, [c_void_p, c_int]),

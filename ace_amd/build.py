@@ -1,14 +1,20 @@
-"""In-tree build of libace_sfno.so for gfx950 (hipcc cross-compiles without a GPU)."""
+"""In-tree build of libace_sfno.so for gfx950 (hipcc cross-compiles without a GPU).
 
+One object per source file, compiled in parallel and cached by modification time (csrc/build/), then one link:
+an edit of a single kernel file rebuilds in well under a minute."""
+
+import concurrent.futures
 import os
 import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libace_sfno.so")
-SOURCES = ["kernels.hip", "fft.hip", "strip.hip", "mlp_strip.hip", "conv_strip.hip", "conv_split.hip", "conv_ws.hip", "dhconv_strip.hip", "capi.hip", "tables.cpp"]
+SOURCES = ["kernels.hip", "fft.hip", "strip.hip", "conv_ws.hip", "dhconv_strip.hip", "physics.hip", "capi.hip", "tables.cpp"]
 HEADERS = ["kernels.h", "strip_common.h", "strip_pack.h", "tables.h", os.path.join("..", "..", "include", "ace_sfno.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
 def _hipcc() -> str:
@@ -16,6 +22,14 @@ def _hipcc() -> str:
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found (need ROCm >= 7.0 to build libace_sfno.so)")
+
+
+def _mtime(path: str) -> float:
+    return os.path.getmtime(path) if os.path.exists(path) else 0.0
+
+
+def _header_time() -> float:
+    return max(_mtime(os.path.join(CSRC, h)) for h in HEADERS)
 
 
 def needs_build() -> bool:
@@ -26,20 +40,44 @@ def needs_build() -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP library for gfx950; returns the path of the .so."""
-    if not force and not needs_build():
-        return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB + ".tmp"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+def _compile(hipcc: str, src: str, obj: str, extra, verbose: bool) -> None:
+    cmd = [hipcc] + FLAGS + list(extra) + ["-c", src, "-o", obj]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+        raise RuntimeError(f"hipcc failed on {src}:\n" + res.stdout + res.stderr)
+
+
+def build(force: bool = False, verbose: bool = False, out: str = LIB, extra=(), objdir: str = OBJ) -> str:
+    """Compile the HIP library for gfx950; returns the path of the .so.  `extra`: additional compiler flags (-D...) for a
+    variant build, which then needs its own `out` and `objdir`."""
+    if not force and out == LIB and not needs_build():
+        return LIB
+    hipcc = _hipcc()
+    os.makedirs(objdir, exist_ok=True)
+    ht = _header_time()
+    jobs, objs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s + ".o")
+        objs.append(obj)
+        if force or _mtime(obj) < max(_mtime(src), ht):
+            jobs.append((src, obj))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        for f in [ex.submit(_compile, hipcc, src, obj, extra, verbose) for src, obj in jobs]:
+            f.result()
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp"] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -41,6 +42,26 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 extern "C" const char* ace_last_error(void) { return g_err.c_str(); }
+
+namespace ace {
+Switches read_switches() {
+    auto on = [](const char* name) { const char* e = std::getenv(name); return e && e[0] && !(e[0] == '0' && !e[1]); };
+    Switches sw;
+    sw.no_fft = on("ACE_NO_FFT");
+    sw.no_strip = on("ACE_NO_STRIP");
+    sw.no_dhconv_strip = on("ACE_NO_DHCONV_STRIP");
+    sw.no_pk = on("ACE_NO_PK");
+    sw.no_pk_sht = on("ACE_NO_PK_SHT");
+    sw.no_enc_ws = on("ACE_NO_ENC_WS");
+    if (const char* e = std::getenv("ACE_CONV_WS")) {
+        const std::string v(e);
+        if (v == "all" || v == "1") sw.conv_ws_roles = 7;
+        else sw.conv_ws_roles = (v.find("skip") != std::string::npos ? 1 : 0) | (v.find("fc1") != std::string::npos ? 2 : 0) |
+                                (v.find("fc2") != std::string::npos ? 4 : 0);
+    }
+    return sw;
+}
+}  // namespace ace
 extern "C" int ace_version(void) { return 100; }
 
 struct DevBuf {
@@ -94,6 +115,7 @@ struct ace_sht_plan {
     DevBuf wt_frag, pt_frag, wt_off, pt_off;
     bool strip = false;
     DevBuf slots;   // standalone transforms in f16x3 mode: dynamic-range slots (max|X|, max|coefficients|)
+    Switches sw;    // measurement switches, read when the plan was built
 };
 
 static float pow2_scale_for(const std::vector<float>& v) {  // puts max|v| in [2^9, 2^10)
@@ -110,6 +132,7 @@ static int plan_build(int nlat, int nlon, int lmax, int mmax, Grid g, std::uniqu
     std::string err = build_sht_tables(nlat, nlon, lmax, mmax, g, t);
     if (!err.empty()) return fail(ACE_ERR_INVALID, err);
     auto p = std::make_unique<ace_sht_plan>();
+    p->sw = read_switches();
     p->nlat = t.nlat; p->nlon = t.nlon; p->lmax = t.lmax; p->mmax = t.mmax;
     p->Hp = t.Hp; p->Lp = t.Lp; p->Kfp = t.Kfp; p->grid = g;
     HIP_TRY(p->wt.upload(t.wt));
@@ -161,7 +184,7 @@ static int run_dft_forward(const ace_sht_plan& pl, const float* x, const float* 
     DftArgs a;
     a.omax = xmax;
     a.x = x; a.spec_out = X; a.tc = pl.fc.p; a.ts = pl.fs.p; a.ldt = pl.Kfp; a.sc = sc; a.sh = sh;
-    a.Bt = Bt; a.C = C; a.H = pl.nlat; a.W = pl.nlon; a.Mm = pl.mmax;
+    a.Bt = Bt; a.C = C; a.H = pl.nlat; a.W = pl.nlon; a.Mm = pl.mmax; a.no_fft = pl.sw.no_fft;
     HIP_TRY(launch_dft_forward(a, s));
     return ACE_OK;
 }
@@ -170,7 +193,7 @@ static int run_dft_inverse(const ace_sht_plan& pl, const float* X, const float* 
     DftArgs a;
     a.omax = ymax;
     a.spec = X; a.y = y; a.tc = pl.gc.p; a.ts = pl.gs.p; a.ldt = pl.Kfp; a.bias = bias;
-    a.Bt = Bt; a.C = C; a.H = pl.nlat; a.W = pl.nlon; a.Mm = pl.mmax;
+    a.Bt = Bt; a.C = C; a.H = pl.nlat; a.W = pl.nlon; a.Mm = pl.mmax; a.no_fft = pl.sw.no_fft;
     HIP_TRY(launch_dft_inverse(a, s));
     return ACE_OK;
 }
@@ -184,7 +207,7 @@ static int run_legendre_forward(const ace_sht_plan& pl, const float* X, float* D
     g.C = D; g.ldc = (long)pl.mmax * N2; g.sC = N2;
     g.M = pl.lmax; g.N = (int)N2; g.K = pl.nlat; g.nbatch = pl.mmax; g.a_kpad = pl.Hp;
     g.tri = TRI_ROWS_GE_BATCH;
-    if (pl.strip && xmax) {   // register-resident strip kernel (strip.hip)
+    if (pl.strip && !pl.sw.no_strip && xmax) {   // register-resident strip kernel (strip.hip)
         LegStripArgs a;
         a.B = X; a.b_kstride = N2; a.b_moff = (long)pl.nlat * N2;
         a.A = reinterpret_cast<const _Float16*>(pl.wt_frag.p); a.tile_off = reinterpret_cast<const int*>(pl.wt_off.p);
@@ -228,7 +251,7 @@ static int run_legendre_inverse(const ace_sht_plan& pl, const float* E, float* X
     g.C = X; g.ldc = N2; g.sC = (long)pl.nlat * N2;
     g.M = pl.nlat; g.N = (int)N2; g.K = pl.lmax; g.nbatch = pl.mmax; g.a_kpad = pl.Lp;
     g.tri = TRI_K_GE_BATCH;
-    if (pl.strip && emax) {   // register-resident strip kernel (strip.hip)
+    if (pl.strip && !pl.sw.no_strip && emax) {   // register-resident strip kernel (strip.hip)
         LegStripArgs a;
         a.B = E; a.b_kstride = (long)pl.mmax * N2; a.b_moff = N2;
         a.A = reinterpret_cast<const _Float16*>(pl.pt_frag.p); a.tile_off = reinterpret_cast<const int*>(pl.pt_off.p);
@@ -521,8 +544,7 @@ struct Weight {
     DevBuf hi, lo;      // f16x3 mode: fp16 planes of the conv weight scaled by `ascale` (pitch halves)
     float ascale = 1.f;
     DevBuf thi, tlo;    // the same planes in the v4 engine's A-tile order (rows padded to 16)
-    DevBuf frag;        // mlp.fwd.2: packed MFMA A fragments streamed by 16-column step (fused MLP, mlp_strip.hip)
-    DevBuf frag0;       // inner_skip: packed MFMA A fragments streamed by 32-row tile (conv_strip.hip, un-folded first block)
+    DevBuf frag0;       // inner_skip / mlp.fwd.2 / last encoder convolution: packed MFMA A fragments (conv_ws.hip, static weights)
     float wabs = 0.f;   // conv weights: max |w|
     float winf = 0.f;   // conv weights: max row sum of |w| (bounds |W x| by winf * max|x|)
     float absmax = 0.f; // small parameters (biases): max |value|
@@ -553,10 +575,11 @@ struct ace_sfno {
     DevBuf P2;           // second one: the block input h as written by the previous block's fc2 epilogue
     DevBuf part;         // per-strip row statistics from the GEMM epilogues (fused instance norm), two tensors
     DevBuf Wp0, Wp1;     // folded (norm affine) skip / fc1 weights as tiled fp16 planes, per sample
-    DevBuf Wq1;          // folded fc1 weights as packed MFMA A fragments, per sample (fused MLP / conv_strip)
-    DevBuf Wq0;          // folded inner-skip weights likewise (conv_strip)
+    DevBuf Wq1;          // folded (norm affine) fc1 weights as packed MFMA A fragments, per sample (conv_ws.hip)
+    DevBuf Wq0;          // folded inner-skip weights likewise
     DevBuf zero_c;       // C zeros (bias of the bias-free last encoder convolution on conv_ws.hip)
     DevBuf pe_slot;      // dynamic-range slot (64 words) holding max|pos_embed|: the residual bound of that convolution
+    DevBuf phys;         // fused post-step physics (ace_step_physics): fp64 global sums, parameters
     int nstrips = 0;
     DevBuf Wf0, bf0, Wf1, bf1;
     DevBuf amax;  // [8] uint words: bit patterns of max|X|, max|D|, max|E| of the current block (f16x3 dynamic range)  // instance-norm affine folded into inner_skip / mlp.fc1 weights, per sample
@@ -564,6 +587,9 @@ struct ace_sfno {
     std::vector<DevBuf> taps;
     std::map<GraphKey, hipGraphExec_t> graphs;
     hipStream_t capture_stream = nullptr;
+    long weights_generation = 0; // bumped by every ace_sfno_set_weight (ace_sfno_weights_generation)
+    bool graphs_stale = false;   // a parameter was uploaded since the graphs were captured: re-capture lazily
+    Switches sw;                 // measurement switches, read once at ace_sfno_create
 
     const float* w(const std::string& name) const {
         auto it = index.find(name);
@@ -611,6 +637,7 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
 
     auto n = std::make_unique<ace_sfno>();
     n->cfg = c;
+    n->sw = read_switches();
     n->H = c.nlat; n->W = c.nlon; n->C = c.embed_dim; n->HW = (long)c.nlat * c.nlon;
     n->Bmax = c.max_batch > 0 ? c.max_batch : 1;
     // sfnonet.py:471-472
@@ -687,7 +714,7 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
         // blocks whose input/output grid differs from the internal one keep D in fp32 (residual round trip) and use
         // the expanded operand
         const bool mixed = (n->plan_data != n->plan_lg.get()) && (i == 0 || i == c.num_layers - 1);
-        n->wx_compact[i] = (getenv("ACE_NO_PK_SHT") == nullptr && c.precision == 1 && c.operator_type == 1 && n->C % 128 == 0 && !mixed &&
+        n->wx_compact[i] = (!n->sw.no_pk_sht && c.precision == 1 && c.operator_type == 1 && n->C % 128 == 0 && !mixed &&
                             ((long)n->Bmax * 2 * n->C) % 4 == 0) ? 1 : 0;
     }
     const size_t act = (size_t)n->Bmax * C * HW;
@@ -704,10 +731,10 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
         HIP_TRY(n->P.alloc(act, true));
         if (c.normalization_layer == 1 && c.use_mlp) {
             HIP_TRY(n->P2.alloc(act, true));
-            n->nstrips = (int)((HW + 31) / 32) + 8;     // >= tilesN * WN of either tile shape and the fused MLP's 32-pixel strips
-            if (mlp_strip_shape_ok((int)C, n->hid) || conv_strip_eligible((int)C, n->hid, ACT_GELU))
+            n->nstrips = (int)((HW + 31) / 32) + 8;     // >= tilesN * WN of either tile shape and conv_ws's 32-pixel tiles
+            if (conv_ws_eligible((int)C, n->hid, HW, 1, n->sw.conv_ws_roles))
                 HIP_TRY(n->Wq1.alloc((size_t)n->Bmax * n->hid * C, true));   // hi + lo halves = one float per element
-            if (conv_strip_eligible((int)C, (int)C, ACT_GELU)) HIP_TRY(n->Wq0.alloc((size_t)n->Bmax * C * C, true));
+            if (conv_ws_eligible((int)C, (int)C, HW, 0, n->sw.conv_ws_roles)) HIP_TRY(n->Wq0.alloc((size_t)n->Bmax * C * C, true));
             HIP_TRY(n->zero_c.alloc((size_t)C, true));
             HIP_TRY(n->pe_slot.alloc(64, true));
             HIP_TRY(n->part.alloc((size_t)2 * n->Bmax * n->nstrips * C * 4, true));
@@ -743,6 +770,38 @@ extern "C" void ace_sfno_destroy(ace_sfno* n) {
     for (auto& kv : n->graphs) (void)hipGraphExecDestroy(kv.second);
     if (n->capture_stream) (void)hipStreamDestroy(n->capture_stream);
     delete n;
+}
+
+extern "C" long ace_sfno_weights_generation(const ace_sfno* n) { return n ? n->weights_generation : -1; }
+
+// Device bytes the library owns for this handle at batch sizes up to `batch` (workspace + both operand forms of the weights
+// + tables): SURVEY 8(b) workspace_size.  The workspace is sized by ace_sfno_config.max_batch at creation.
+extern "C" long ace_sfno_workspace_size(const ace_sfno* n, int batch) {
+    if (!n) { (void)fail(ACE_ERR_INVALID, "null argument"); return -1; }
+    if (batch <= 0 || batch > n->Bmax) {
+        (void)fail(ACE_ERR_INVALID, "batch " + std::to_string(batch) + " outside [1, max_batch=" + std::to_string(n->Bmax) + "]");
+        return -1;
+    }
+    size_t fl = 0;
+    auto add = [&](const DevBuf& b) { fl += b.n; };
+    for (const DevBuf* b : {&n->h0, &n->h1, &n->Y, &n->T, &n->R, &n->U, &n->X, &n->D, &n->E, &n->stats, &n->P, &n->cln_stats, &n->inN,
+                            &n->P2, &n->part, &n->Wp0, &n->Wp1, &n->Wq1, &n->Wq0, &n->zero_c, &n->pe_slot, &n->Wf0, &n->bf0, &n->Wf1,
+                            &n->bf1, &n->amax, &n->phys})
+        add(*b);
+    for (const auto& t : n->taps) add(t);
+    for (const auto& v : {&n->wx, &n->wx_hi, &n->wx_lo})
+        for (const auto& b : *v) add(b);
+    for (const auto& w : n->weights)
+        for (const DevBuf* b : {&w->buf, &w->hi, &w->lo, &w->thi, &w->tlo, &w->frag0}) add(*b);
+    auto plan_bytes = [&](const ace_sht_plan* p) {
+        if (!p) return;
+        for (const DevBuf* b : {&p->wt, &p->pt, &p->fc, &p->fs, &p->gc, &p->gs, &p->X, &p->D, &p->wt_hi, &p->wt_lo, &p->pt_hi, &p->pt_lo,
+                                &p->wt_frag, &p->pt_frag, &p->wt_off, &p->pt_off, &p->slots})
+            add(*b);
+    };
+    plan_bytes(n->plan_lg.get());
+    plan_bytes(n->plan_data_own.get());
+    return (long)(fl * sizeof(float));
 }
 
 extern "C" int ace_sfno_num_weights(const ace_sfno* n) { return n ? (int)n->weights.size() : 0; }
@@ -836,18 +895,10 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
         if (!w.tlo.p) HIP_TRY(w.tlo.alloc((thalves + 1) / 2, false));
         HIP_TRY(launch_split_f16_tiled(w.buf.p, w.pitch, w.thi.p, w.tlo.p, w.pitch, w.rows, w.cols, w.ascale, s));
         const std::string& wn = w.name;
-        if (wn.size() > 16 && wn.compare(wn.size() - 16, 16, "mlp.fwd.2.weight") == 0 &&
-            mlp_strip_shape_ok(w.rows, w.cols)) {
-            if (!w.frag.p) HIP_TRY(w.frag.alloc((size_t)w.rows * w.cols, false));
-            HIP_TRY(launch_pack_conv_frag(w.buf.p, w.pitch, w.rows, w.cols, 1, nullptr, 0.f, w.ascale, nullptr, w.frag.p,
-                                          0, 1, s));
-        }
         const bool is_enc2 = wn == "encoder." + std::to_string(2 * n->cfg.encoder_layers) + ".weight";
         const bool is_skip = wn.size() > 17 && wn.compare(wn.size() - 17, 17, "inner_skip.weight") == 0;
         const bool is_fc2 = wn.size() > 16 && wn.compare(wn.size() - 16, 16, "mlp.fwd.2.weight") == 0;
-        if ((is_skip && conv_strip_eligible(w.cols, w.rows, ACT_GELU)) ||
-            ((is_skip || is_fc2) && conv_split_eligible(w.cols, w.rows, 1, is_skip ? 0 : 2)) ||
-            ((is_skip || is_fc2 || is_enc2) && conv_ws_eligible(w.cols, w.rows, 1, is_skip ? 0 : 2))) {
+        if ((is_skip || is_fc2 || is_enc2) && conv_ws_eligible(w.cols, w.rows, n->HW, is_skip ? 0 : 2, n->sw.conv_ws_roles)) {
             if (!w.frag0.p) HIP_TRY(w.frag0.alloc((size_t)w.rows * w.cols, false));
             HIP_TRY(launch_pack_conv_frag(w.buf.p, w.pitch, w.rows, w.cols, 0, nullptr, 0.f, w.ascale, nullptr, w.frag0.p,
                                           0, 1, s));
@@ -872,8 +923,9 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
     // Captured graphs keep pointing at the same library buffers, but the host-side scalars derived from the weights
     // (ascale, winf, wabs, bias bounds, filter scale) are baked into their kernel arguments by value: drop the graphs so
     // that the next ace_sfno_forward_graph re-captures with the new scalars.
-    for (auto& kv : n->graphs) (void)hipGraphExecDestroy(kv.second);
-    n->graphs.clear();
+    // Marked stale here, destroyed in ace_sfno_forward_graph after a stream synchronise (an exec may still be in flight).
+    n->graphs_stale = true;
+    n->weights_generation += 1;
     return ACE_OK;
 }
 
@@ -923,8 +975,7 @@ static int fold(const ace_sfno* n, const ConvW& cw, int O, int I, const float* a
 // f16x3 "v4": 1x1 convolution whose input already is in P format (fp16 hi/lo planes [cin/8][HW][8] per sample, scaled
 // from the bound in `in_slot`).  Output: fp32 (+ omax) and/or P-format planes for the next convolution.
 static bool packed_ok(const ace_sfno* n, int cin) {
-    static const bool off = getenv("ACE_NO_PK") != nullptr;   // A/B switch for measurements
-    return !off && n->cfg.precision == 1 && n->P.p && cin % 8 == 0 && n->HW % 4 == 0;
+    return !n->sw.no_pk && n->cfg.precision == 1 && n->P.p && cin % 8 == 0 && n->HW % 4 == 0;
 }
 static int pack_act(const ace_sfno* n, const float* x, long x_bs, int cin, const float* sc, const float* sh,
                     const unsigned* slot, void* hi, void* lo, int batch, hipStream_t s) {
@@ -1072,11 +1123,11 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     bool enc_planes = false;
     {
         const Weight& we = *n->weights[n->index.at("encoder." + std::to_string(2 * c.encoder_layers) + ".weight")];
-        static const bool enc_off = getenv("ACE_NO_ENC_WS") != nullptr;   // A/B switch for measurements
+        const bool enc_off = n->sw.no_enc_ws;
         const bool block0_fused = f16 && c.normalization_layer == 1 && c.use_mlp && n->P2.p && packed_ok(n, C) && n->hid % 8 == 0 &&
                                   (n->plan_data == n->plan_lg.get() || c.num_layers == 1);
         if (!enc_off && block0_fused && c.encoder_layers >= 1 && c.pos_embed && curC == C && we.frag0.p && n->zero_c.p &&
-            n->pe_slot.p && n->part.p && conv_ws_eligible(C, C, HW, 2)) {
+            n->pe_slot.p && n->part.p && conv_ws_eligible(C, C, HW, 2, n->sw.conv_ws_roles)) {
             _Float16* Th = reinterpret_cast<_Float16*>(n->P.p);
             _Float16* Tl = Th + (size_t)n->Bmax * C * HW;
             _Float16* Hh = reinterpret_cast<_Float16*>(n->P2.p);
@@ -1163,8 +1214,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         ACE_TRY(run_dft_forward(fwd, h, a0, b0, n->X.p, B, C, s, xmax));
         MARK(ST_DFT_FWD);
         // packed dhconv: D goes from the Legendre epilogue to the filter GEMM as fp16 planes (never fp32)
-        static const bool no_pk_sht = getenv("ACE_NO_PK_SHT") != nullptr;   // A/B switch for measurements
-        const bool dplanes = f16 && !no_pk_sht && c.operator_type == 1 && n->wx_hi[i].p && !scale_residual && fwd.f16 &&
+        const bool dplanes = f16 && !n->sw.no_pk_sht && c.operator_type == 1 && n->wx_hi[i].p && !scale_residual && fwd.f16 &&
                              N2 % 4 == 0 && (2 * C) % 32 == 0;
         ACE_TRY(run_legendre_forward(fwd, n->X.p, n->D.p, N2, s, xmax, dmax, dplanes));
         MARK(ST_LEGENDRE_FWD);
@@ -1196,7 +1246,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 ds.E = n->E.p; ds.sE = (long)n->Mm * N2; ds.omax = emax;
                 ds.C = C; ds.L = n->L; ds.Mrows = n->Mm * B; ds.trimul = B;
             }
-            if (dplanes && n->wx_compact[i] && dhconv_strip_eligible(ds)) {
+            if (dplanes && n->wx_compact[i] && !n->sw.no_dhconv_strip && dhconv_strip_eligible(ds)) {
                 HIP_TRY(launch_dhconv_strip(ds, s));
             } else if (dplanes) {
                 Gemm4Args a;
@@ -1264,10 +1314,14 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             o.R = n->Y.p; o.r_bs = actB;
             o.ohi = PAh; o.olo = PAl; o.cb = bsw.absmax; o.cslot = slot(sb + 4); o.cinb = slot(sb + 3); o.rmax = slot(sb + 7);
             o.part = part_t;
-            const bool strip_ok = c.activation_function == ACT_GELU && conv_strip_eligible(C, C, ACT_GELU) && n->Wq0.p != nullptr &&
-                                  ws.frag0.p != nullptr;
+            const bool gelu = c.activation_function == ACT_GELU;
+            const int roles = n->sw.conv_ws_roles;
+            // which of the three convolutions run on the weight-stationary kernel (conv_ws.hip); the others on the tile engine
+            const bool ws_skip = gelu && n->Wq0.p && ws.frag0.p && conv_ws_eligible(C, C, HW, 0, roles);
+            const bool ws_fc1 = gelu && n->Wq1.p && conv_ws_eligible(C, n->hid, HW, 1, roles);
+            const bool ws_fc2 = w2.frag0.p && C <= 1024 && conv_ws_eligible(n->hid, C, HW, 2, roles);
             if (have_ph) {   // h planes from the previous fc2; the affine goes into the weights
-                if (!strip_ok)
+                if (!ws_skip)
                     HIP_TRY(launch_fold_affine_f16(ws.buf.p, ws.pitch, ws.wabs, ra, rb, bsw.buf.p, F0h, F0l, n->bf0.p, B, C, C, cp,
                                                    f0s, slot(sb + 8), s));
                 o.fhi = F0h; o.flo = F0l; o.fslot = slot(sb + 8); o.f_stride = f0s;
@@ -1279,10 +1333,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 o.bhi = PBh; o.blo = PBl; o.in_slot = skip_max;
             }
             int t_nparts = gemm4_strips(C, (int)HW);
-            const bool ws_ok = strip_ok && conv_ws_eligible(C, C, HW, 0);         // weights resident, persistent grid (conv_ws.hip)
-            const bool split_ok = strip_ok && !ws_ok && conv_split_eligible(C, C, HW, 0);   // contraction split over wave pairs (conv_split.hip)
-            const int nsplit32 = ws_ok ? (int)((HW + 31) / 32) : (int)((HW + 127) / 128) * 4;
-            if (strip_ok) {   // register-resident strip kernels
+            if (ws_skip) {
                 ConvStripArgs k;
                 k.Xhi = PBh; k.Xlo = PBl; k.ldn = HW; k.sX = (long)C * HW; k.xslot = o.in_slot;
                 if (have_ph) {
@@ -1297,10 +1348,10 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 k.R = n->Y.p; k.sR = actB;
                 k.cw = ws.winf; k.cb = bsw.absmax; k.cinb = slot(sb + 3); k.rmax = slot(sb + 7);
                 k.Chi = PAh; k.Clo = PAl; k.sCp = (long)C * HW; k.cslot = slot(sb + 4);
-                k.part = reinterpret_cast<float4*>(part_t); k.nstrips32 = (split_ok || ws_ok) ? nsplit32 : (int)((HW + 255) / 256) * 8;
+                k.part = reinterpret_cast<float4*>(part_t);
                 k.C = C; k.M = C; k.HW = (int)HW; k.nbatch = B; k.act = ACT_GELU;
-                if (ws_ok) k.nstrips32 = conv_ws_stat_parts(k);   // one partial per pixel group (statistics accumulated in registers)
-                HIP_TRY(ws_ok ? launch_conv_ws(k, s) : split_ok ? launch_conv_split(k, s) : launch_conv_strip(k, s));
+                k.nstrips32 = conv_ws_stat_parts(k);   // one partial per pixel group (statistics accumulated in registers)
+                HIP_TRY(launch_conv_ws(k, s));
                 t_nparts = k.nstrips32;
             } else {
                 ACE_TRY(conv_pk2(n, o, B, s));
@@ -1309,51 +1360,12 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             // norm1 statistics -> affine -> folded fc1 weights
             HIP_TRY(launch_instnorm_finalize(reinterpret_cast<const float4*>(part_t), t_nparts, B, C, HW,
                                              W(p + "norm1.weight"), W(p + "norm1.bias"), 1e-6f, sc1, sh1, slot(sb + 5), s));
-            const bool strip_mlp = c.activation_function == ACT_GELU && mlp_strip_eligible(C, n->hid, ACT_GELU) &&
-                                   n->Wq1.p != nullptr && w2.frag.p != nullptr;
-            const bool strip_fc1 = !strip_mlp && c.activation_function == ACT_GELU && conv_strip_eligible(C, n->hid, ACT_GELU) &&
-                                   n->Wq1.p != nullptr;
-            if (!strip_mlp && !strip_fc1)
-                HIP_TRY(launch_fold_affine_f16(w1.buf.p, w1.pitch, w1.wabs, sc1, sh1, b1w.buf.p, F1h, F1l, n->bf1.p, B, n->hid, C,
-                                               cp, f1s, slot(sb + 9), s));
-            if (strip_mlp) {
-                // fused MLP (mlp_strip.hip): fc1, GELU and fc2 in one launch, the hidden activation stays in registers
+            if (ws_fc1) {
                 _Float16* Q1 = reinterpret_cast<_Float16*>(n->Wq1.p);
                 const long q1s = (long)n->hid * C * 2;
                 HIP_TRY(launch_pack_conv_frag(w1.buf.p, w1.pitch, n->hid, C, 0, sc1, w1.wabs, 1.f, slot(sb + 9), Q1, q1s, B, s,
                                               sh1, b1w.buf.p, n->bf1.p));
                 MARK(ST_NORM1);
-                MlpStripArgs m;
-                m.Xhi = PAh; m.Xlo = PAl; m.ldn = HW; m.sX = (long)C * HW; m.xslot = slot(sb + 4);
-                m.A1 = Q1; m.sA1 = q1s; m.a1slot = slot(sb + 9); m.b1 = n->bf1.p; m.sb1 = n->hid;
-                m.A2 = reinterpret_cast<const _Float16*>(w2.frag.p); m.a2scale = w2.ascale; m.b2 = b2w.buf.p;
-                m.cw1 = w1.winf; m.cb1 = b1w.absmax; m.cinb = slot(sb + 5);
-                m.cw2 = w2.winf; m.cb2 = b2w.absmax; m.rmax = slot(sb + 3);
-                m.R = res; m.sR = actB; m.rsc = ra; m.rsh = rb; m.srs = C;
-                m.C = hn; m.sC = actB;
-                m.Cch = C; m.hid = n->hid; m.HW = (int)HW; m.nbatch = B; m.act = ACT_GELU;
-                if (!last) {
-                    m.Chi = PBh; m.Clo = PBl; m.sCp = (long)C * HW; m.cslot = hslot(i + 1);
-                    m.part = reinterpret_cast<float4*>(part_h); m.nstrips32 = (int)((HW + 127) / 128) * 4;
-                } else {
-                    m.omax = hslot(i + 1);
-                }
-                HIP_TRY(launch_mlp_strip(m, s));
-                MARK(ST_MLP_FC1);
-                h_nparts = (int)((HW + 127) / 128) * 4;
-            } else {
-            MARK(ST_NORM1);
-            PkOpts f1;
-            f1.w = &w1; f1.fhi = F1h; f1.flo = F1l; f1.fslot = slot(sb + 9); f1.f_stride = f1s;
-            f1.bias = n->bf1.p; f1.sbias = n->hid;
-            f1.bhi = PAh; f1.blo = PAl; f1.cin = C; f1.in_slot = slot(sb + 4);
-            f1.cout = n->hid; f1.act = act;
-            f1.ohi = Uh; f1.olo = Ul; f1.cb = b1w.absmax; f1.cslot = slot(sb + 6); f1.cinb = slot(sb + 5);
-            if (strip_fc1) {
-                _Float16* Q1 = reinterpret_cast<_Float16*>(n->Wq1.p);
-                const long q1s = (long)n->hid * C * 2;
-                HIP_TRY(launch_pack_conv_frag(w1.buf.p, w1.pitch, n->hid, C, 0, sc1, w1.wabs, 1.f, slot(sb + 9), Q1, q1s, B, s,
-                                              sh1, b1w.buf.p, n->bf1.p));
                 ConvStripArgs k;
                 k.Xhi = PAh; k.Xlo = PAl; k.ldn = HW; k.sX = (long)C * HW; k.xslot = slot(sb + 4);
                 k.A = Q1; k.sA = q1s; k.aslot = slot(sb + 9);
@@ -1361,15 +1373,22 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 k.cw = w1.winf; k.cb = b1w.absmax; k.cinb = slot(sb + 5);
                 k.Chi = Uh; k.Clo = Ul; k.sCp = (long)n->hid * HW; k.cslot = slot(sb + 6);
                 k.C = C; k.M = n->hid; k.HW = (int)HW; k.nbatch = B; k.act = ACT_GELU;
-                HIP_TRY(conv_ws_eligible(C, n->hid, HW, 1) ? launch_conv_ws(k, s)
-                        : conv_split_eligible(C, n->hid, HW, 1) ? launch_conv_split(k, s) : launch_conv_strip(k, s));
+                HIP_TRY(launch_conv_ws(k, s));
             } else {
+                HIP_TRY(launch_fold_affine_f16(w1.buf.p, w1.pitch, w1.wabs, sc1, sh1, b1w.buf.p, F1h, F1l, n->bf1.p, B, n->hid, C,
+                                               cp, f1s, slot(sb + 9), s));
+                MARK(ST_NORM1);
+                PkOpts f1;
+                f1.w = &w1; f1.fhi = F1h; f1.flo = F1l; f1.fslot = slot(sb + 9); f1.f_stride = f1s;
+                f1.bias = n->bf1.p; f1.sbias = n->hid;
+                f1.bhi = PAh; f1.blo = PAl; f1.cin = C; f1.in_slot = slot(sb + 4);
+                f1.cout = n->hid; f1.act = act;
+                f1.ohi = Uh; f1.olo = Ul; f1.cb = b1w.absmax; f1.cslot = slot(sb + 6); f1.cinb = slot(sb + 5);
                 ACE_TRY(conv_pk2(n, f1, B, s));
             }
             MARK(ST_MLP_FC1);
-            const bool fc2_ws = w2.frag0.p && conv_ws_eligible(n->hid, C, HW, 2);
-            if (w2.frag0.p && (fc2_ws || conv_split_eligible(n->hid, C, HW, 2)) && C <= 1024) {
-                // fc2 + outer skip on the split-contraction strip kernel: fp32 h' (+ planes and statistics for the next block)
+            if (ws_fc2) {
+                // fc2 + outer skip: fp32 h' (+ planes and statistics for the next block)
                 ConvStripArgs k;
                 k.Xhi = Uh; k.Xlo = Ul; k.ldn = HW; k.sX = (long)n->hid * HW; k.xslot = slot(sb + 6);
                 k.A = reinterpret_cast<const _Float16*>(w2.frag0.p); k.sA = 0; k.ascale = w2.ascale;
@@ -1377,7 +1396,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 k.R = res; k.sR = actB; k.rsc = ra; k.rsh = rb; k.srs = C;
                 k.Cf = hn; k.sCf = actB;
                 k.C = n->hid; k.M = C; k.HW = (int)HW; k.nbatch = B; k.act = ACT_NONE;
-                const int nparts = fc2_ws ? (int)((HW + 31) / 32) : (int)((HW + 127) / 128) * 4;
+                const int nparts = (int)((HW + 31) / 32);
                 if (!last) {
                     k.Chi = PBh; k.Clo = PBl; k.sCp = (long)C * HW; k.cslot = hslot(i + 1);
                     k.cw = w2.winf; k.cb = b2w.absmax; k.rmax = slot(sb + 3);
@@ -1385,23 +1404,22 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 } else {
                     k.omax = hslot(i + 1);
                 }
-                HIP_TRY(fc2_ws ? launch_conv_ws(k, s) : launch_conv_split(k, s));
+                HIP_TRY(launch_conv_ws(k, s));
                 h_nparts = nparts;
             } else {
-            PkOpts f2;
-            f2.w = &w2; f2.bias = b2w.buf.p;
-            f2.bhi = Uh; f2.blo = Ul; f2.cin = n->hid; f2.in_slot = slot(sb + 6);
-            f2.out = hn; f2.cout = C; f2.act = ACT_NONE;
-            f2.R = res; f2.r_bs = actB; f2.rsc = ra; f2.rsh = rb;
-            if (!last) {   // next block: h planes + statistics, bound instead of the true max in the h slot
-                f2.ohi = PBh; f2.olo = PBl; f2.cb = b2w.absmax; f2.cslot = hslot(i + 1); f2.rmax = slot(sb + 3);
-                f2.part = part_h;
-            } else {
-                f2.omax = hslot(i + 1);
-            }
-            ACE_TRY(conv_pk2(n, f2, B, s));
-            h_nparts = gemm4_strips(C, (int)HW);
-            }
+                PkOpts f2;
+                f2.w = &w2; f2.bias = b2w.buf.p;
+                f2.bhi = Uh; f2.blo = Ul; f2.cin = n->hid; f2.in_slot = slot(sb + 6);
+                f2.out = hn; f2.cout = C; f2.act = ACT_NONE;
+                f2.R = res; f2.r_bs = actB; f2.rsc = ra; f2.rsh = rb;
+                if (!last) {   // next block: h planes + statistics, bound instead of the true max in the h slot
+                    f2.ohi = PBh; f2.olo = PBl; f2.cb = b2w.absmax; f2.cslot = hslot(i + 1); f2.rmax = slot(sb + 3);
+                    f2.part = part_h;
+                } else {
+                    f2.omax = hslot(i + 1);
+                }
+                ACE_TRY(conv_pk2(n, f2, B, s));
+                h_nparts = gemm4_strips(C, (int)HW);
             }
             have_ph = have_hstats = !last;
         } else if (pk) {
@@ -1570,6 +1588,12 @@ extern "C" int ace_sfno_forward_graph(ace_sfno* n, const float* in, float* out, 
     if (n->cfg.normalization_layer == 2) return fail(ACE_ERR_STATE, "this net is noise conditioned: call ace_sfno_forward_conditioned");
     if (n->taps_on) return fail(ACE_ERR_STATE, "disable taps before using the graph path");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n->graphs_stale) {   // parameters changed since capture: the scalars baked into the kernel arguments are out of date
+        HIP_TRY(hipStreamSynchronize(s));   // no exec of this handle may be in flight when it is destroyed
+        for (auto& kv : n->graphs) (void)hipGraphExecDestroy(kv.second);
+        n->graphs.clear();
+        n->graphs_stale = false;
+    }
     GraphKey key{in, out, batch};
     auto it = n->graphs.find(key);
     if (it == n->graphs.end()) {

@@ -29,9 +29,6 @@
 namespace ace {
 namespace {
 
-#ifndef ACE_CONV_WS_DEFAULT
-#define ACE_CONV_WS_DEFAULT 7   // roles on conv_ws.hip by default: bit 0 inner skip, 1 fc1, 2 fc2
-#endif
 constexpr int WS_OOBV = 0x7fffff00;   // buffer offset beyond every resource of these kernels: loads return 0, stores are dropped
 
 template <int KSW, int NSTG, int MODE>
@@ -447,6 +444,72 @@ hipError_t launch_ws_k(const ConvStripArgs& a, int mode, hipStream_t s) {
 
 }  // namespace
 
+// A-fragment packing of a conv weight W (O x I, row pitch ldw), optionally with a per-input-channel scale folded in
+// (instance-norm affine: W diag(a)), as fp16 hi/lo blocks of 64 lanes x 8 halves (strip_pack.h layout: lane = i + 32 g holds
+// row 32 T + i, columns 16 J + 8 g .. + 7):
+//   order 0 (streamed by output-row chunk, fc1): block (T, J) at T * (I / 16) + J
+//   order 1 (streamed by 16-column step, fc2):   block (T, J) at J * (O / 32) + T
+// O % 32 == 0, I % 16 == 0.  scale: a power of two, or derived from `bound` = wmax * max|a| (published to wslot).
+__global__ __launch_bounds__(256) void pack_conv_frag_kernel(const float* __restrict__ W, long ldw, int O, int I, int order,
+                                                             const float* __restrict__ a, float wmax, float scale_static,
+                                                             unsigned* wslot, _Float16* __restrict__ dst, long sDst,
+                                                             const float* __restrict__ b, const float* __restrict__ bias,
+                                                             float* __restrict__ bf) {
+    const int smp = blockIdx.y;
+    float scale = scale_static;
+    if (a) {   // one scale for all samples (as fold_affine_f16_kernel)
+        __shared__ float red[4];
+        float am = 0.f;
+        for (int q = threadIdx.x; q < I * (int)gridDim.y; q += 256) am = fmaxf(am, fabsf(a[q]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+        __syncthreads();
+        am = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float bound = wmax * am;
+        scale = ldexpf(1.0f, pow2_exponent_for(bound));
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(wslot + (smp & 63), __float_as_uint(bound));
+    }
+    const int nJ = I / 16, nT = O / 32;
+    const int blk = blockIdx.x;                 // one workgroup = one (T, J) block: 512 elements, two per thread
+    const int T = blk / nJ, J = blk % nJ;
+    const long bidx = order == 0 ? (long)T * nJ + J : (long)J * nT + T;
+    _Float16* out = dst + (long)smp * sDst + bidx * 1024;
+    const float* as = a ? a + (long)smp * I : nullptr;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = threadIdx.x + 256 * u;    // = lane * 8 + e
+        const int e = t & 7, lane = t >> 3, i = lane & 31, g = lane >> 5;
+        const int row = 32 * T + i, col = 16 * J + 8 * g + e;
+        float x = W[(long)row * ldw + col] * scale;
+        if (as) x *= as[col];
+        x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+        const _Float16 h = (_Float16)x;
+        out[t] = h;
+        out[512 + t] = (_Float16)(x - (float)h);
+    }
+    if (bf && J == 0) {   // folded bias of the 32 rows of this tile: bias + W b (8 threads per row)
+        const int r = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+        const long row = 32L * T + r;
+        const float* bs = b + (long)smp * I;
+        float acc = 0.f;
+        for (int q = l8; q < I; q += 8) acc = fmaf(W[row * ldw + q], bs[q], acc);
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (l8 == 0) bf[(long)smp * O + row] = (bias ? bias[row] : 0.f) + acc;
+    }
+}
+
+hipError_t launch_pack_conv_frag(const float* W, long ldw, int O, int I, int order, const float* a, float wmax,
+                                 float scale_static, unsigned* wslot, void* dst, long sDst, int nsamples, hipStream_t s,
+                                 const float* b, const float* bias, float* bf) {
+    if (O % 32 != 0 || I % 16 != 0 || (order == 1 && I % 32 != 0) || (a && !wslot) || (bf && !b)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((O / 32) * (I / 16)), (unsigned)nsamples);
+    hipLaunchKernelGGL(pack_conv_frag_kernel, grid, dim3(256), 0, s, W, ldw, O, I, order, a, wmax, scale_static, wslot,
+                       static_cast<_Float16*>(dst), sDst, b, bias, bf);
+    return hipGetLastError();
+}
+
 // statistics partials per row the launch described by `a` writes (a.nstrips32 must be at least this)
 int conv_ws_stat_parts(const ConvStripArgs& a) {
     const bool skip_mode = (a.act == ACT_GELU || a.act == ACT_GELU_FAST) && a.R && a.part && !a.Cf;
@@ -454,21 +517,9 @@ int conv_ws_stat_parts(const ConvStripArgs& a) {
 }
 
 // K: input channels (contraction), M: output channels; role 0 inner skip, 1 fc1, 2 fc2 (-1: any)
-bool conv_ws_eligible(int K, int M, long HW, int role) {
-    // Which convolutions run here: ACE_CONV_WS = list of roles ("skip,fc1,fc2"), "all" or "none" (read per call).
-    const int on = [] {
-        const char* e = std::getenv("ACE_CONV_WS");
-        if (!e) return ACE_CONV_WS_DEFAULT;
-        const std::string v(e);
-        if (v == "all" || v == "1") return 7;
-        int m = 0;
-        if (v.find("skip") != std::string::npos) m |= 1;
-        if (v.find("fc1") != std::string::npos) m |= 2;
-        if (v.find("fc2") != std::string::npos) m |= 4;
-        return m;
-    }();
-    if (role >= 0 && role < 3 && !(on >> role & 1)) return false;
-    if (role == -1 && on == 0) return false;
+bool conv_ws_eligible(int K, int M, long HW, int role, int roles_on) {
+    if (role >= 0 && role < 3 && !(roles_on >> role & 1)) return false;
+    if (role == -1 && roles_on == 0) return false;
     if (!(K == 128 || K == 256 || K == 384 || K == 512 || K == 768)) return false;
     if (role >= 0 && role <= 1 && K > 384) return false;
     return M % 128 == 0 && M >= 128 && M <= 2048 && (long)M * HW * 4 < 0x7fffff00L && ((HW + 31) / 32 + 8) * (long)M * 16 < 0x7fffff00L;

@@ -234,7 +234,6 @@ __global__ __launch_bounds__(256, 1) void dhconv_strip_kernel(DhconvStripArgs p)
 }  // namespace
 
 bool dhconv_strip_eligible(const DhconvStripArgs& a) {
-    if (std::getenv("ACE_NO_DHCONV_STRIP") != nullptr) return false;   // A/B switch (read per call: tests flip it per case)
     return a.C % 128 == 0 && a.C >= 128 && a.Mrows <= 192 && a.L >= 1 && a.Dhi && a.Dlo && a.Whi && a.Wlo && a.E && a.amax;
 }
 

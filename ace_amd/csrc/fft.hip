@@ -379,19 +379,11 @@ hipError_t launch_inv(const DftArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-bool fft_enabled() {
-    static const bool on = [] {
-        const char* e = std::getenv("ACE_NO_FFT");
-        return !(e && e[0] && e[0] != '0');
-    }();
-    return on;
-}
-
 }  // namespace
 
 // true when the FFT form handled the launch (sizes with an instantiated factorisation, 16-byte aligned rows)
 bool launch_dft_forward_fft(const DftArgs& a, hipStream_t s, hipError_t* err) {
-    if (!fft_enabled() || (reinterpret_cast<uintptr_t>(a.x) & 15) != 0 || a.Mm > a.W / 2 + 1 || a.H > 65535 || a.Bt > 65535)
+    if (a.no_fft || (reinterpret_cast<uintptr_t>(a.x) & 15) != 0 || a.Mm > a.W / 2 + 1 || a.H > 65535 || a.Bt > 65535)
         return false;
     switch (a.W) {
         case 360: *err = launch_fwd<20, 18>(a, s); return true;
@@ -405,7 +397,7 @@ bool launch_dft_forward_fft(const DftArgs& a, hipStream_t s, hipError_t* err) {
 }
 
 bool launch_dft_inverse_fft(const DftArgs& a, hipStream_t s, hipError_t* err) {
-    if (!fft_enabled() || (reinterpret_cast<uintptr_t>(a.y) & 15) != 0 || a.Mm > a.W / 2 + 1 || a.H > 65535 || a.Bt > 65535)
+    if (a.no_fft || (reinterpret_cast<uintptr_t>(a.y) & 15) != 0 || a.Mm > a.W / 2 + 1 || a.H > 65535 || a.Bt > 65535)
         return false;
     switch (a.W) {
         case 360: *err = launch_inv<20, 18, 32>(a, s); return true;   // 32 channel rows per workgroup: 128-byte runs on the spectral side (r02: 81.7 -> 75.6 us; the forward kernel is faster with 16)

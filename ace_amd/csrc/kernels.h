@@ -5,6 +5,19 @@
 
 namespace ace {
 
+// Measurement switches (environment variables, A/B timing only - every path is a gfx950 HIP kernel).  Read ONCE per handle, at
+// ace_sfno_create / ace_sht_plan_create, and kept there: which kernels run never changes between weight upload and forward.
+struct Switches {
+    bool no_fft = false;           // ACE_NO_FFT: longitude DFT on the matrix kernels
+    bool no_strip = false;         // ACE_NO_STRIP: Legendre stages on the tile engine
+    bool no_dhconv_strip = false;  // ACE_NO_DHCONV_STRIP: spectral filter contraction on the tile engine
+    bool no_pk = false;            // ACE_NO_PK: 1x1 convolutions on the on-the-fly-split engine (v3)
+    bool no_pk_sht = false;        // ACE_NO_PK_SHT: fp32 D, expanded filter operand
+    bool no_enc_ws = false;        // ACE_NO_ENC_WS: last encoder convolution on the v3 engine
+    int conv_ws_roles = 7;         // ACE_CONV_WS=skip,fc1,fc2|all|none: roles on conv_ws.hip (bit 0 inner skip, 1 fc1, 2 fc2)
+};
+Switches read_switches();
+
 enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SILU = 3, ACT_GELU_FAST = 4 /* erf to 1.1e-7 abs */ };
 enum Tri {
     TRI_NONE = 0,
@@ -143,33 +156,16 @@ constexpr int LEG_STRIP_SLACK_ROWS = 16;
 bool legendre_strip_eligible(const LegStripArgs& a);
 hipError_t launch_legendre_strip(const LegStripArgs& a, hipStream_t s);
 
-// Fused MLP (mlp_strip.hip): h' = W2 act(W1f P(T) + b1f) + b2 + (rsc h + rsh), the hidden activation stays on chip.
-struct MlpStripArgs {
-    const _Float16* Xhi = nullptr; const _Float16* Xlo = nullptr; long ldn = 0; long sX = 0;   // P-format input planes
-    const unsigned* xslot = nullptr;       // bound the producer scaled the input planes with
-    const _Float16* A1 = nullptr; long sA1 = 0; const unsigned* a1slot = nullptr;   // folded fc1 weights, packed fragments
-    const float* b1 = nullptr; long sb1 = 0;                                       // folded fc1 bias, per sample
-    const _Float16* A2 = nullptr; float a2scale = 1.f; const float* b2 = nullptr;   // fc2 weights (packed fragments), bias
-    float cw1 = 0.f, cb1 = 0.f; const unsigned* cinb = nullptr;   // |U| <= cw1 * bound(normalised input) + cb1
-    float cw2 = 0.f, cb2 = 0.f; const unsigned* rmax = nullptr;   // |h'| <= cw2 * bound(U) + cb2 + bound(residual)
-    const float* R = nullptr; long sR = 0; const float* rsc = nullptr; const float* rsh = nullptr; long srs = 0;
-    float* C = nullptr; long sC = 0;
-    _Float16* Chi = nullptr; _Float16* Clo = nullptr; long sCp = 0; unsigned* cslot = nullptr;
-    float4* part = nullptr; int nstrips32 = 0;   // per-(sample, 32-pixel strip, row) statistics
-    unsigned* omax = nullptr;
-    int Cch = 0, hid = 0, HW = 0, nbatch = 1, act = ACT_NONE;
-};
-hipError_t launch_mlp_strip(const MlpStripArgs& a, hipStream_t s);
-bool mlp_strip_eligible(int C, int hid, int act);   // shape + the ACE_MLP_FUSED opt-in
-bool mlp_strip_shape_ok(int C, int hid);
 // conv weight (O x I) -> packed MFMA A fragments (fp16 hi/lo), optionally W diag(a) per sample with the scale derived from
-// wmax * max|a| (published to wslot); order 0: streamed by 32-row chunk (fc1), 1: streamed by 32-column chunk (fc2)
+// wmax * max|a| (published to wslot); order 0: blocks by 32-row tile then k16-step (what conv_ws.hip keeps resident), 1: by k16-step then tile
 // optional: bf[sample][row] = bias[row] + sum_i W[row][i] b[sample][i] (the folded bias of the same affine)
 hipError_t launch_pack_conv_frag(const float* W, long ldw, int O, int I, int order, const float* a, float wmax,
                                  float scale_static, unsigned* wslot, void* dst, long sDst, int nsamples, hipStream_t s,
                                  const float* b = nullptr, const float* bias = nullptr, float* bf = nullptr);
 
-// 1x1 convolution with the input strip resident in registers (conv_strip.hip): P-format planes in, P-format planes out.
+// The block's 1x1 convolutions on the weight-stationary kernel (conv_ws.hip): P-format planes in; P-format planes and / or
+// fp32 out.  The mode is derived from the outputs requested (GELU + planes [+ residual + statistics], or residual + fp32
+// [+ planes + statistics]).
 struct ConvStripArgs {
     const _Float16* Xhi = nullptr; const _Float16* Xlo = nullptr; long ldn = 0; long sX = 0;   // input planes [C/8][ldn][8]
     const unsigned* xslot = nullptr;                  // bound the producer scaled the input planes with
@@ -181,20 +177,14 @@ struct ConvStripArgs {
     _Float16* Chi = nullptr; _Float16* Clo = nullptr; long sCp = 0; unsigned* cslot = nullptr;  // output planes [M/8][HW][8]
     float4* part = nullptr; int nstrips32 = 0;        // optional row statistics per (sample, 32-pixel strip, row)
     int C = 0, M = 0, HW = 0, nbatch = 1, act = ACT_NONE;
-    // conv_split.hip only (second MLP convolution): fp32 output, per-row affine of the residual, range maximum
+    // second MLP convolution: fp32 output, per-row affine of the residual, range maximum
     float* Cf = nullptr; long sCf = 0;
     const float* rsc = nullptr; const float* rsh = nullptr; long srs = 0;
     unsigned* omax = nullptr;
 };
-bool conv_strip_eligible(int C, int M, int act);
-hipError_t launch_conv_strip(const ConvStripArgs& a, hipStream_t s);
-// the same contract with the contraction split over wave pairs (conv_split.hip): C in {128, 256, 384, 512, 768}; the mode is
-// derived from the outputs requested (GELU + planes [+ residual + statistics], or residual + fp32 [+ planes + statistics])
-bool conv_split_eligible(int K, int M, long HW, int role);   // role 0 inner skip, 1 fc1, 2 fc2 (-1: any)
-hipError_t launch_conv_split(const ConvStripArgs& a, hipStream_t s);
-// the block's 1x1 convolutions with the WEIGHTS resident and a persistent grid over pixel tiles (conv_ws.hip); same arguments
-// and modes as conv_split.hip, statistics per 32-pixel tile: nstrips32 >= ceil(HW / 32)
-bool conv_ws_eligible(int K, int M, long HW, int role);   // role 0 inner skip, 1 fc1, 2 fc2 (-1: any)
+// weights resident in registers, persistent grid over pixel tiles; K in {128, 256, 384, 512, 768}, M % 128 == 0;
+// statistics per 32-pixel tile (fc2) or per pixel group (inner skip): nstrips32 >= conv_ws_stat_parts()
+bool conv_ws_eligible(int K, int M, long HW, int role, int roles_on = 7);   // role 0 inner skip, 1 fc1, 2 fc2 (-1: any); roles_on: Switches::conv_ws_roles
 hipError_t launch_conv_ws(const ConvStripArgs& a, hipStream_t s);
 int conv_ws_stat_parts(const ConvStripArgs& a);   // statistics partials per row that launch writes (nstrips32 >= this)
 
@@ -224,6 +214,7 @@ struct DftArgs {
     const float* bias = nullptr;                           // inverse: per-c bias added to the output
     int Bt = 1, C = 0, H = 0, W = 0, Mm = 0;
     unsigned* omax = nullptr;  // atomicMax of bits(max|output|)
+    bool no_fft = false;       // Switches::no_fft of the owning plan
 };
 hipError_t launch_dft_forward(const DftArgs& a, hipStream_t s);
 hipError_t launch_dft_inverse(const DftArgs& a, hipStream_t s);

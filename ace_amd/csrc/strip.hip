@@ -298,18 +298,9 @@ __global__ __launch_bounds__(256, 2) void legendre_strip_kernel(LegStripArgs p, 
     }
 }
 
-bool strip_enabled() {
-    static const bool on = [] {
-        const char* e = std::getenv("ACE_NO_STRIP");
-        return !(e && e[0] && e[0] != '0');
-    }();
-    return on;
-}
-
 }  // namespace
 
 bool legendre_strip_eligible(const LegStripArgs& a) {
-    if (!strip_enabled()) return false;
     if (a.K < 1 || a.R < 1 || a.N < 1 || a.nbatch < 1) return false;
     if ((a.K + 15) / 16 > KS_MAX) return false;
     if (!a.A || !a.tile_off || !a.B || !a.bmax) return false;

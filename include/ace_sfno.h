@@ -140,6 +140,15 @@ void ace_sfno_destroy(ace_sfno* net);
  * Synchronises `stream` before returning. */
 int ace_sfno_set_weight(ace_sfno* net, const char* name, const float* src, long numel, void* stream);
 
+/* Monotonic counter bumped by every ace_sfno_set_weight: anything a caller captured around forwards of this handle (its
+ * own hipGraph of a whole rollout window) is stale once the value differs from the one seen at capture time. */
+long ace_sfno_weights_generation(const ace_sfno* net);
+
+/* SURVEY 8(b) workspace_size(handle, B): device bytes the library owns for this handle when running batches up to
+ * `batch` <= max_batch - activations workspace (sized by max_batch at creation), both operand forms of the weights,
+ * SHT tables.  Everything else (input, output, caller tensors) is caller-owned.  Returns -1 on a bad argument. */
+long ace_sfno_workspace_size(const ace_sfno* net, int batch);
+
 /* Number of parameters / name of parameter i / its numel, in the reference's state_dict order. */
 int ace_sfno_num_weights(const ace_sfno* net);
 const char* ace_sfno_weight_name(const ace_sfno* net, int i);

@@ -92,24 +92,24 @@ def test_dhconv_at_headline_shape_three_implementations(dev, B, monkeypatch):
     assert rel_max(outs["tile"], outs["fp32"]) <= 2e-6
 
 
-@pytest.mark.parametrize("split", ["ws", "all", "none"])
-def test_headline_bitwise_repeatability(dev, headline, split, monkeypatch):
-    """200 forwards of the headline network on the same input must be bitwise identical, and right.  The register-resident
-    kernels issue stores whose data registers are recycled a few instructions later; on gfx950 a load landing in such a
-    register before the store has read it corrupts a few lanes, rarely and not reproducibly (r02: seen with 125 of
-    25 M plane entries wrong) - a sampled accuracy check can miss that, bitwise repeatability cannot.  Three routings of the
-    1x1 convolutions: all on conv_ws.hip, all on conv_split.hip, none of either (conv_strip.hip and the tile engine)."""
-    monkeypatch.setenv("ACE_CONV_WS", "all" if split == "ws" else "none")
-    monkeypatch.setenv("ACE_CONV_SPLIT", "none" if split == "ws" else split)
+@pytest.mark.parametrize("routing,reps", [("ws", 1000), ("tile", 200)])
+def test_headline_bitwise_repeatability(dev, headline, routing, reps, monkeypatch):
+    """1000 forwards of the headline network on the same input (default routing: every 1x1 convolution of the blocks on
+    conv_ws.hip) must be bitwise identical, and right; 200 more with the convolutions on the tile engine.  The
+    register-resident kernels issue stores whose data registers are recycled a few instructions later; on gfx950 a load
+    landing in such a register before the store has read it corrupts a few lanes, rarely and not reproducibly (r02: seen
+    with 125 of 25 M plane entries wrong; tools/store_hazard.hip is the minimal reproducer) - a sampled accuracy check can
+    miss that, bitwise repeatability cannot."""
+    monkeypatch.setenv("ACE_CONV_WS", "all" if routing == "ws" else "none")
     d, cfg, state, x = headline
     net = build_native_net(cfg, state, dev, "f16x3")
     xd = x[:1].to(dev).contiguous()
     with torch.no_grad():
         y0 = net(xd).clone()
         bad = 0
-        for _ in range(200):
+        for _ in range(reps):
             bad += int(not torch.equal(net(xd), y0))
-    assert bad == 0, f"{bad} of 200 forwards differ from the first"
+    assert bad == 0, f"{bad} of {reps} forwards differ from the first"
     ys = y0.reshape(-1)
     assert torch.isfinite(ys).all()
     # batch 1 of the fixture input: compare with the sampled reference values that fall into sample 0
@@ -119,22 +119,15 @@ def test_headline_bitwise_repeatability(dev, headline, split, monkeypatch):
     assert err <= NET_TOL, err
 
 
-@pytest.mark.parametrize("fused", ["0", "1", "split", "ws", "strip"])
+@pytest.mark.parametrize("routing", ["ws", "tile", "mixed"])
 @pytest.mark.parametrize("C,hw", [(384, (45, 90)), (128, (24, 48)), (256, (20, 40))])
-def test_fused_mlp_shapes_vs_fp64(dev, C, hw, fused, monkeypatch):
-    """the register-resident strip kernels at C in {128, 256, 384} inside 3-block nets, batch 3, ragged last workgroup,
-    random norm gains - per-block taps against the fp64 oracle.  fused=0: inner skip and fc1 on conv_strip.hip, fc2 on the
-    tile engine / conv_split.hip (default); fused=1: fc1 + GELU + fc2 in mlp_strip.hip; split: all three on conv_split.hip."""
+def test_fused_mlp_shapes_vs_fp64(dev, C, hw, routing, monkeypatch):
+    """the block's 1x1 convolutions at C in {128, 256, 384} inside 3-block nets, batch 3, ragged last workgroup, random
+    norm gains - per-block taps against the fp64 oracle.  ws: all three on the weight-stationary conv_ws.hip (default);
+    tile: all three on the 128 x 128 tile engine; mixed: inner skip and fc2 on conv_ws.hip, fc1 on the tile engine (the
+    statistics partials and the folded operands of the two engines meet)."""
     from oracle.sfno import SFNOConfig, SFNOOracle, init_state
-    monkeypatch.setenv("ACE_MLP_FUSED", "1" if fused == "1" else "0")
-    if fused == "split":   # every 1x1 convolution of the block on conv_split.hip
-        monkeypatch.setenv("ACE_CONV_SPLIT", "all")
-        monkeypatch.setenv("ACE_CONV_WS", "none")
-    if fused == "ws":      # ... on the weight-stationary conv_ws.hip
-        monkeypatch.setenv("ACE_CONV_WS", "all")
-    if fused == "strip":   # inner skip / fc1 on conv_strip.hip, fc2 on the tile engine
-        monkeypatch.setenv("ACE_CONV_WS", "none")
-        monkeypatch.setenv("ACE_CONV_SPLIT", "none")
+    monkeypatch.setenv("ACE_CONV_WS", {"ws": "all", "tile": "none", "mixed": "skip,fc2"}[routing])
     cfg = SFNOConfig(in_chans=6, out_chans=5, img_shape=hw, embed_dim=C, num_layers=3, operator_type="dhconv")
     state = init_state(cfg, seed=17)
     g = torch.Generator().manual_seed(18)
