@@ -110,11 +110,10 @@ SDEV void strip_body(const LegStripArgs& p, char* smem, const int m, const int g
         bscale = ldexpf(1.0f, eb);
         inv_b = ldexpf(1.0f, -eb);
     }
-    // Loads are un-clamped per lane and (almost) un-masked: contraction indices outside [klo, K) meet ZERO table fragments,
-    // so any finite value will do there.  Indices >= K read at most 15 rows past K: the next batch's rows or the 16 rows of
-    // zero slack the library's buffers carry (LEG_STRIP_SLACK_ROWS); padded k-steps re-read the last real one (wave-uniform
-    // clamp).  Indices below klo (inverse: l < m, never written by the producer - possibly stale bits of another layout)
-    // only occur in the first resident k-step and are zeroed there.
+    // Loads are un-clamped per lane (uniform offsets); the VALUES outside [klo, K) are zeroed after the load.  Indices >= K
+    // read at most 15 rows past K: the next batch's rows or the 16 rows of slack the library's buffers carry
+    // (LEG_STRIP_SLACK_ROWS); padded k-steps re-read the last real one (wave-uniform clamp).  Indices below klo (inverse:
+    // l < m, never written by the producer - possibly stale bits of another layout) only occur in the first resident k-step.
     half8 bh[NK], bl[NK];
     {
         const int klast16 = (K + 15) / 16 - 1;                // last k16-step with real data
@@ -132,7 +131,13 @@ SDEV void strip_body(const LegStripArgs& p, char* smem, const int m, const int g
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float x = raw[jj][e] * bscale;
-                if (jj == 0) x = (16 * gm.j0 + 8 * g + e) >= gm.klo ? x : 0.f;
+                const int kk = 16 * (gm.j0 + jj) + 8 * g + e;   // un-clamped contraction index of this element
+                if (jj == 0) x = kk >= gm.klo ? x : 0.f;
+                // rows at and beyond K (the tail of the last real k-step, every padded k-step) are ZERO here, not "any finite
+                // value against a zero table fragment": with a batch smaller than the one the buffers were sized for they are
+                // stale data of an earlier, larger call at another magnitude, and (stale * bscale) can overflow fp16 to inf
+                // (0 * inf = NaN in the MFMA)
+                x = kk < K ? x : 0.f;
                 const _Float16 h = (_Float16)x;
                 bh[jj][e] = h;
                 bl[jj][e] = (_Float16)(x - (float)h);

@@ -105,6 +105,7 @@ class RolloutEngine:
             self._res_in = torch.tensor([self.in_names.index(n) for n in self.prognostic], **i64)
             self._res_out = torch.tensor([self.out_names.index(n) for n in self.prognostic], **i64)
         self._window_graph = None
+        self._window_graph_key = None   # (native handle, its weights generation) the window graph was captured against
         self.net._ensure_native(dev, B)
         self.net.sync_weights()
 
@@ -178,7 +179,12 @@ class RolloutEngine:
         """Enqueue the T steps of the window on the current stream (no host synchronisation)."""
         # parameters changed since the last window (load_state_dict / stepper.load_state): upload them; the library drops
         # its captured per-step graphs itself, the window graph captured here is dropped too
-        if self.net.sync_weights():
+        self.net.sync_weights()
+        # The captured forwards hold scalars derived from the weights by value (ace_sfno_set_weight): whoever uploaded last -
+        # this call, net.forward, Stepper.predict, another engine on the same net - the library's generation counter tells.
+        key = (int(self.net._native.value or 0) if hasattr(self.net._native, "value") else int(self.net._native),
+               int(_lib.lib().ace_sfno_weights_generation(self.net._native)))
+        if key != self._window_graph_key:
             self._window_graph = None
         step = self.stepper._step_obj   # Stepper.replace_ocean / overrides after construction take effect here
         if step._ocean is not self._ocean or step._corrector is not self._corrector:
@@ -197,7 +203,13 @@ class RolloutEngine:
                     for s in range(self.T):
                         self._enqueue_step(s, False)
                 self._window_graph = g
+                self._window_graph_key = key
             self._window_graph.replay()
+            if self._have_ref is not None:
+                # host-side view of the hook state the captured region keeps in its static buffer (a replay does not run
+                # the Python that set it at capture time); a copy, so that a state handed out survives the next load()
+                from .corrector import CorrectorState
+                self._corrector_state = CorrectorState(global_dry_air_mass=self._ref_mass.clone())
         else:
             for s in range(self.T):
                 self._enqueue_step(s, self.graph_mode == "step")

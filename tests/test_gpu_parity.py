@@ -482,6 +482,37 @@ def test_f16x3_dynamic_range(dev, scale):
     assert rel_max(y, ref) <= NET_TOL
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "fp32"])
+def test_shrinking_batch_after_large_magnitudes(dev, prec):
+    """A handle sized by a batch of 3 at magnitude 1e4, then reused for a batch of 1 at magnitude 1e-3 (lmax = 24 is not a
+    multiple of 16: the strip Legendre kernels read contraction rows past K, which now fall INSIDE stale data of the larger
+    call - round-2 advisor finding: stale * scale could overflow fp16 and poison the MFMA with 0 * inf).  Also the
+    standalone f16x3 transform plan with a smaller n after a larger one."""
+    from oracle.sfno import SFNOConfig, SFNOOracle, init_state
+    cfg = SFNOConfig(in_chans=4, out_chans=3, img_shape=(24, 48), embed_dim=128, num_layers=2, operator_type="dhconv")
+    state = init_state(cfg, seed=8)
+    g = torch.Generator().manual_seed(9)
+    big = torch.randn(3, 4, 24, 48, generator=g) * 1e4
+    small = torch.randn(1, 4, 24, 48, generator=g) * 1e-3
+    net = build_native_net(cfg, state, dev, prec)
+    with torch.no_grad():
+        yb = net(big.to(dev))
+        ys = net(small.to(dev))
+    assert torch.isfinite(yb).all() and torch.isfinite(ys).all()
+    assert rel_max(ys, SFNOOracle(cfg, state, dtype=torch.float64)(small)) <= NET_TOL
+    if prec == "f16x3":
+        import ace_amd
+        f = ace_amd.RealSHT(24, 48, 24, 25, "legendre-gauss", precision="f16x3").to(dev)
+        i = ace_amd.InverseRealSHT(24, 48, 24, 25, "legendre-gauss", precision="f16x3").to(dev)
+        xb = torch.randn(40, 24, 48, generator=g) * 1e4
+        xs = torch.randn(3, 24, 48, generator=g) * 1e-3
+        cb = f(xb.to(dev)); _ = i(cb)
+        cs = f(xs.to(dev)); rs = i(cs)
+        cs1 = f(xs[:1].to(dev))
+        assert torch.isfinite(cs).all() and torch.isfinite(rs).all()
+        assert rel_max(torch.view_as_real(cs[:1]), torch.view_as_real(cs1)) <= 1e-6
+
+
 def test_f16x3_conv_vs_fp64(dev):
     """the f16x3 building block against fp64 (and against the exact-fp32 engine's own error)."""
     from ace_amd import _lib
