@@ -1,22 +1,21 @@
-// Second MLP convolution + outer skip (layers.py:117-124, sfnonet.py:246-250), WEIGHT-stationary, for gfx950:
-//     h' = W2 . P(u) + b2 + (a0 x + b0)        W2: (M x K), u: K x HW hidden activation (P-format fp16 hi/lo planes), K = 256 / 512 / 768
-//
-// conv_split.hip keeps the ACTIVATION strip resident and streams the weights: every workgroup of 128 pixels starts with a
-// phase in which all of them fetch their strips at once while the matrix cores idle (K = 768: 58 k of 213 k cycles per
-// workgroup, two rounds of workgroups per launch - r02 in-kernel timeline), and streams the whole 1.2 MB of W2 through LDS.
-// Here the roles are swapped and the grid is persistent:
-//   * a workgroup owns 128 output channels (four 32-row tiles of W2) and a contiguous range of 32-pixel tiles; wave (tile T,
-//     half h) keeps rows 32 T .. 32 T + 31 of W2 over its half of the contraction as MFMA A fragments for the whole launch
-//     (192 VGPRs at K = 768), loaded once from the packed-fragment form (launch_pack_conv_frag order 0);
+// The 1x1 convolutions of an FNO block (inner skip sfnonet.py:229-232, MLP layers.py:117-124, outer skip sfnonet.py:246-250),
+// WEIGHT-stationary, for gfx950:
+//     C = epilogue( W . P(x) )        W: (M x K), x: K x HW activation as P-format fp16 hi/lo planes, K in {128 .. 768}
+//   * a workgroup owns 128 output channels (four 32-row tiles of W) and a contiguous range of 32-pixel tiles; wave (tile T,
+//     half h) keeps rows 32 T .. 32 T + 31 of W over its half of the contraction as MFMA A fragments for the whole range
+//     (96 VGPRs at K = 384, 192 at K = 768), loaded once from the packed-fragment form (launch_pack_conv_frag order 0);
 //   * the activation streams: a stage is KSW k16-steps of both contraction halves of ONE pixel tile, fetched by 1-KiB LDS-DMA
 //     pieces straight from the P-format planes (a piece is 2 k-groups x 32 pixels = one MFMA B fragment) into a two-stage
 //     ring; each fragment is read by the four waves that own the four channel tiles;
-//   * accumulator layout, partner exchange (the two halves of the contraction), epilogue and the held store data are those
-//     of conv_split.hip: rows = output channels, columns = pixels; wave h finishes rows 16 h .. 16 h + 15 of its tile;
-//   * the three slices of the channel dimension that need the same pixel tiles run on the same XCD (block -> XCD is
-//     block % 8), so that the activation is fetched from HBM once and twice more from that XCD's L2.
-// No per-workgroup prologue beyond loading 48 KB of weights per wave from L2; 240 of the 256 CUs at M = 384 (three slices
-// do not divide the 32 CUs of an XCD).
+//   * accumulators: rows = output channels, columns = pixels; the two waves of a pair (the halves of the contraction, on one
+//     SIMD) swap accumulator halves through LDS and each finishes 16 rows: scale, bias, residual, GELU, hi/lo split, whole
+//     16-byte P entries out (v_permlane32_swap turns accumulator registers into 8-row groups), row statistics;
+//   * store data is HELD: the registers a store reads are not written again before the stage-closing vmcnt(0) (gfx950
+//     store-data rule, tools/store_hazard.hip);
+//   * grid: persistent, 32 workgroups per XCD = every CU.  The channel slices that need the same pixel tiles run on the same
+//     XCD (block -> XCD is block % 8) and walk them together, so the activation comes from HBM once and from that XCD's
+//     L2 otherwise.  When the slice count does not divide 32 (M = 384: 3 slices) the remaining workgroups of the XCD share
+//     one more tile range, each taking a contiguous run of (slice, tile) units - r02 left 16 of the 256 CUs idle.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -30,6 +29,23 @@ namespace ace {
 namespace {
 
 constexpr int WS_OOBV = 0x7fffff00;   // buffer offset beyond every resource of these kernels: loads return 0, stores are dropped
+
+// Work decomposition of one launch (host side: ws_plan).  XCD x owns the pixel tiles [x tpx, (x + 1) tpx); its first `e`
+// tiles are the EXTRA range shared by the R workgroups that are left over when nslice does not divide 32, the rest is cut
+// into F groups of g tiles, each walked by nslice workgroups (one per channel slice).
+struct WsPlan {
+    int nslice, F, R, tpx, g, e;
+};
+struct WsSeg {
+    int slice, tile0, np;
+};
+
+#ifndef ACE_WS_ACC2
+#define ACE_WS_ACC2 0     // modes (bit 0 inner skip, bit 1 fc1) whose MFMAs alternate between two accumulators (no dependent-issue stalls)
+#endif
+#ifndef ACE_WS_VSPAN
+#define ACE_WS_VSPAN 8    // interleaved epilogue: its eight values are spread over the first VSPAN twelfths of the stage
+#endif
 
 template <int KSW, int NSTG, int MODE>
 struct WsGeom {
@@ -52,13 +68,14 @@ struct WsGeom {
 // Modes 0 / 1 (K <= 384, registers to spare): the epilogue of pixel tile t - 1 runs between the MFMAs of tile t.
 // H: contraction half of the calling wave (compile time, see conv_split.hip)
 template <int KSW, int NSTG, int MODE, int H>
-MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
+MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     using G = WsGeom<KSW, NSTG, MODE>;
     constexpr int KH = G::KH, SLOT = G::SLOT, BMAX = G::BMAX, TAB = G::TAB, XCH = G::XCH, STP = G::STP;
     constexpr int PW = KSW / 2;             // 1-KiB pieces per wave per stage
     constexpr bool GELU = MODE <= 1, RES = MODE != 1, PK = MODE != 3, F32 = G::F32, STATS = G::STATS, RSTATS = G::RSTATS;
     constexpr bool INTER = MODE <= 1;       // epilogue of tile t - 1 between the MFMAs of tile t
-    constexpr bool HOLD = KH < 24;          // registers to hold the store data through a stage (else: stores retired first)
+    constexpr bool HOLD = KH < 24;          // registers to hold the store data through a stage (else: stores retired first; holding them at K = 768 spills 22 VGPRs)
+    constexpr bool ACC2 = INTER && ((ACE_WS_ACC2 >> MODE) & 1);
     static_assert(!INTER || NSTG == 1, "interleaved epilogue: single-stage tiles");
     constexpr int h = H;
     float* Pb = reinterpret_cast<float*>(smem + 2 * SLOT);     // bias (+ residual shift)
@@ -70,30 +87,104 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
     const int i = lane & 31, g = lane >> 5;
     float* St = reinterpret_cast<float*>(smem + 2 * SLOT + TAB + XCH) + wave * (16 * STP);
 
-    // ---- which sample, channel slice and pixel-tile range (the slices of one group share an XCD: block % 8)
-    const int nslice = p.M / 128;
-    const int per_smp = groups * nslice;
+    // ---- which sample, XCD and workgroup of the XCD; its segments (runs of pixel tiles of one channel slice)
+    const int wpx = pl.F * pl.nslice + pl.R;
+    const int per_smp = 8 * wpx;
     const int smp = blockIdx.x / per_smp;
     const int bb = blockIdx.x % per_smp;
-    const int xcd = bb & 7, rr = bb >> 3;
-    const int slice = rr % nslice, group = (rr / nslice) * 8 + xcd;
+    const int xcd = bb & 7, w = bb >> 3;
     const int tiles_px = (p.HW + 31) / 32;
-    const int tpg = (tiles_px + groups - 1) / groups;
-    const int tile0 = group * tpg;
-    const int np = tiles_px - tile0 < tpg ? tiles_px - tile0 : tpg;
-    const int T = slice * 4 + (wave & 3);   // 32-row tile of the output channels
-    if (np <= 0) {                          // (whole workgroup: no barrier has been executed yet)
-        if (RSTATS && lane < 16)            // an idle pixel group still owes the finaliser a (neutral) partial
-            p.part[((long)smp * p.nstrips32 + group) * p.M + 32 * T + 16 * h + lane] = make_float4(0.f, 0.f, 3.0e38f, -3.0e38f);
-        return;
+    const int x0 = xcd * pl.tpx;
+    const int nx = tiles_px - x0 < pl.tpx ? (tiles_px - x0 > 0 ? tiles_px - x0 : 0) : pl.tpx;   // tiles of this XCD
+    const int ex = pl.e < nx ? pl.e : nx;                                                       // ... of them in the extra range
+    const bool extra = w >= pl.F * pl.nslice;
+    const int part_q = xcd * (pl.F + pl.R) + (extra ? pl.F + (w - pl.F * pl.nslice) : w / pl.nslice);   // statistics slot
+    int u0 = 0, u1 = 0, nseg = 1;
+    if (extra) {   // a contiguous run [u0, u1) of the units (slice, tile) = (u / ex, u % ex) of the extra range
+        const int r = w - pl.F * pl.nslice, U = pl.nslice * ex;
+        u0 = (int)((long)r * U / pl.R);
+        u1 = (int)((long)(r + 1) * U / pl.R);
+        nseg = u1 > u0 ? (u1 - 1) / ex - u0 / ex + 1 : 0;
     }
-    const int NU = np * NSTG;
+    auto segment = [&](int k) {
+        WsSeg sg;
+        if (!extra) {
+            const int grp = w / pl.nslice;
+            sg.slice = w % pl.nslice;
+            sg.tile0 = x0 + ex + grp * pl.g;
+            const int end = x0 + ex + (grp + 1) * pl.g < x0 + nx ? x0 + ex + (grp + 1) * pl.g : x0 + nx;
+            sg.np = end - sg.tile0;
+        } else {
+            const int r = w - pl.F * pl.nslice;
+            const int kk = (r & 1) ? nseg - 1 - k : k;   // odd workgroups walk their slices backwards: pairs meet on the same tiles
+            sg.slice = u0 / ex + kk;
+            const int lo = u0 > sg.slice * ex ? u0 - sg.slice * ex : 0;
+            const int hi = u1 < (sg.slice + 1) * ex ? u1 - sg.slice * ex : ex;
+            sg.tile0 = x0 + lo;
+            sg.np = hi - lo;
+        }
+        return sg;
+    };
+    if (!extra && segment(0).np <= 0) nseg = 0;
+    if (RSTATS) {
+        // The norm finaliser sums slot part_q over ALL rows.  An extra workgroup owns its slot alone: rows of the slices it
+        // does not reach get a neutral partial; a group's slot is shared by its nslice workgroups, each answers for its slice.
+        float4* pq = p.part + ((long)smp * p.nstrips32 + part_q) * p.M;
+        const int s_lo = nseg > 0 ? (extra ? u0 / ex : w % pl.nslice) : 0;
+        const int s_hi = nseg > 0 ? (extra ? (u1 - 1) / ex : w % pl.nslice) : -1;
+        for (int r = tid; r < p.M; r += 512) {
+            const int sl = r >> 7;
+            const bool mine = extra || sl == w % pl.nslice;
+            if (mine && !(sl >= s_lo && sl <= s_hi)) pq[r] = make_float4(0.f, 0.f, 3.0e38f, -3.0e38f);
+        }
+    }
+    if (nseg <= 0) return;   // (whole workgroup: no barrier has been executed yet)
 
     const unsigned raw_x = slot_load(p.xslot + lane);
     const unsigned raw_a = p.aslot ? slot_load(p.aslot + lane) : 0u;
     const unsigned raw_c = p.cinb ? slot_load(p.cinb + lane) : 0u;
     const unsigned raw_r = p.rmax ? slot_load(p.rmax + lane) : 0u;
 
+    {   // epilogue parameters of this sample -> LDS
+        const float* b = p.bias + (long)smp * p.sbias;
+        const float* rsc = (F32 && p.rsc) ? p.rsc + (long)smp * p.srs : nullptr;
+        const float* rsh = (F32 && p.rsc) ? p.rsh + (long)smp * p.srs : nullptr;
+#pragma unroll
+        for (int k = 0; k < BMAX / 512; ++k) {
+            const int r = tid + 512 * k;
+            if (r < p.M) {
+                Pb[r] = b[r] + (rsh ? rsh[r] : 0.f);
+                if (F32) Ps[r] = rsc ? rsc[r] : 1.f;
+            }
+        }
+    }
+    const float xbound = wave_max_bits(raw_x);
+    const float inv_x = ldexpf(1.0f, -pow2_exponent_for(xbound));
+    const float inv_a = p.aslot ? ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_a))) : 1.0f / p.ascale;
+    const float s_acc = inv_x * inv_a;
+    float cscale = 1.f;
+    if (PK) {   // bound of this launch's output, identical in every workgroup; the consumer reads it from cslot
+        const float inb = p.cinb ? wave_max_bits(raw_c) : xbound;
+        const float resb = p.rmax ? wave_max_bits(raw_r) : 0.f;
+        const float cbound = fmaf(p.cw, inb, p.cb) + resb;
+        cscale = ldexpf(1.0f, pow2_exponent_for(cbound));
+        if (tid == 0) atomicMax(p.cslot + (blockIdx.x & 63), __float_as_uint(cbound));
+    }
+
+    const int fbytes = p.M * p.HW * 4, pbytes = p.M * p.HW * 2;
+    const auto rsR = __builtin_amdgcn_make_buffer_rsrc(RES ? const_cast<float*>(p.R + (long)smp * p.sR) : nullptr, 0, RES ? fbytes : 0, 0x00020000);
+    const auto rsC = __builtin_amdgcn_make_buffer_rsrc(F32 ? p.Cf + (long)smp * p.sCf : nullptr, 0, F32 ? fbytes : 0, 0x00020000);
+    const auto rsH = __builtin_amdgcn_make_buffer_rsrc(PK ? p.Chi + (long)smp * p.sCp : nullptr, 0, PK ? pbytes : 0, 0x00020000);
+    const auto rsL = __builtin_amdgcn_make_buffer_rsrc(PK ? p.Clo + (long)smp * p.sCp : nullptr, 0, PK ? pbytes : 0, 0x00020000);
+    const auto rsP = __builtin_amdgcn_make_buffer_rsrc(STATS ? p.part + (long)smp * p.nstrips32 * p.M : nullptr, 0,
+                                                       STATS ? p.nstrips32 * p.M * 16 : 0, 0x00020000);
+    float vmax = 0.f;
+    // ---- one segment: np pixel tiles from tile0 on, channel slice `slice` (weights loaded once per segment)
+    auto run_segment = [&](const WsSeg sg, const bool first) {
+    const int tile0 = sg.tile0, np = sg.np;
+    const int T = sg.slice * 4 + (wave & 3);   // 32-row tile of the output channels
+    const int NU = np * NSTG;
+    if (!first) __syncthreads();               // the ring and the exchange buffers of the previous segment are free
     // ---- streamed activation: piece k (of PW) of this wave for stage u -> slot u % 2; stages past the end re-fetch the last.
     //      Piece pc = (block pc / 2 of the stage: half hh, k-step jj; plane pc % 2): lane (i, g) fetches k-group 2 J + g, pixel i
     const _Float16* Xh = p.Xhi + (long)smp * p.sX;
@@ -122,44 +213,11 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
             wl[j] = *reinterpret_cast<const half8*>(A + (long)j * 1024 + 512);
         }
     }
-    {   // epilogue parameters of this sample -> LDS
-        const float* b = p.bias + (long)smp * p.sbias;
-        const float* rsc = (F32 && p.rsc) ? p.rsc + (long)smp * p.srs : nullptr;
-        const float* rsh = (F32 && p.rsc) ? p.rsh + (long)smp * p.srs : nullptr;
-#pragma unroll
-        for (int k = 0; k < BMAX / 512; ++k) {
-            const int r = tid + 512 * k;
-            if (r < p.M) {
-                Pb[r] = b[r] + (rsh ? rsh[r] : 0.f);
-                if (F32) Ps[r] = rsc ? rsc[r] : 1.f;
-            }
-        }
-    }
-    const float xbound = wave_max_bits(raw_x);
-    const float inv_x = ldexpf(1.0f, -pow2_exponent_for(xbound));
-    const float inv_a = p.aslot ? ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_a))) : 1.0f / p.ascale;
-    const float s_acc = inv_x * inv_a;
-    float cscale = 1.f;
-    if (PK) {   // bound of this launch's output, identical in every workgroup; the consumer reads it from cslot
-        const float inb = p.cinb ? wave_max_bits(raw_c) : xbound;
-        const float resb = p.rmax ? wave_max_bits(raw_r) : 0.f;
-        const float cbound = fmaf(p.cw, inb, p.cb) + resb;
-        cscale = ldexpf(1.0f, pow2_exponent_for(cbound));
-        if (tid == 0) atomicMax(p.cslot + (blockIdx.x & 63), __float_as_uint(cbound));
-    }
-
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage 0, the weights, the tables' sources
 #pragma unroll
     for (int j = 0; j < KH; ++j) asm volatile("" : "+v"(wh[j]), "+v"(wl[j]));
     __syncthreads();
 
-    const int fbytes = p.M * p.HW * 4, pbytes = p.M * p.HW * 2;
-    const auto rsR = __builtin_amdgcn_make_buffer_rsrc(RES ? const_cast<float*>(p.R + (long)smp * p.sR) : nullptr, 0, RES ? fbytes : 0, 0x00020000);
-    const auto rsC = __builtin_amdgcn_make_buffer_rsrc(F32 ? p.Cf + (long)smp * p.sCf : nullptr, 0, F32 ? fbytes : 0, 0x00020000);
-    const auto rsH = __builtin_amdgcn_make_buffer_rsrc(PK ? p.Chi + (long)smp * p.sCp : nullptr, 0, PK ? pbytes : 0, 0x00020000);
-    const auto rsL = __builtin_amdgcn_make_buffer_rsrc(PK ? p.Clo + (long)smp * p.sCp : nullptr, 0, PK ? pbytes : 0, 0x00020000);
-    const auto rsP = __builtin_amdgcn_make_buffer_rsrc(STATS ? p.part + (long)smp * p.nstrips32 * p.M : nullptr, 0,
-                                                       STATS ? p.nstrips32 * p.M * 16 : 0, 0x00020000);
     const int row0 = 32 * T + 16 * h;                            // first of the 16 rows this wave finishes
     // per-lane buffer offsets, recomputed where they are used from an opaque copy of the lane index: as loop invariants they
     // (and what hipcc derives from them) would sit in registers this kernel does not have at K = 768
@@ -182,7 +240,6 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
     };
     struct TileCtx { int n0, vo_f, vo_p, vo_s, ncols_ok, i, g; };   // per pixel tile: offsets / validity of this lane
     EpiOut eo;
-    float vmax = 0.f;
     // RSTATS (inner skip: registers to spare): running sum / sum of squares / min / max of this lane's pixel column for the
     // eight rows it finishes; reduced over the 32 pixel lanes once, at the end: ONE partial per workgroup and row instead of
     // one per 32-pixel tile (80 instead of 2025 for the norm finaliser at 180 x 360), no LDS transpose, no per-tile store
@@ -298,13 +355,13 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
         pb = *reinterpret_cast<const f32x4*>(xr + 1024);
     };
 
-    f32x16 v;
+    f32x16 v, v2;   // v2: second accumulator of the ACC2 form (the MFMA stream alternates v, v2, v, v2, ...)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { v[r] = 0.f; v2[r] = 0.f; }
     constexpr int FDEPTH = (MODE == 2 && KH == 24) ? 0 : 1;   // fragment read-ahead; 0 where the registers are gone (K = 768 + planes + statistics)
     // Loop body = one stage followed by the wait + barrier that opens the next (stage 0 was opened by the prologue); an
-    // asm-loaded register still in flight is never live across the back edge (conv_split.hip).
-    constexpr int VSPAN = 2 * KSW / 3;     // interleaved epilogue: the eight values over the first VSPAN k-steps, the stores right after
+    // asm-loaded register still in flight is never live across the back edge (hipcc believes the value is there and may copy it).
+    constexpr int VSPAN = ACE_WS_VSPAN * KSW / 12 > 0 ? ACE_WS_VSPAN * KSW / 12 : 1;   // interleaved epilogue: the eight values over the first VSPAN k-steps, the stores right after
     for (int pt = 0; pt < np; ++pt) {
         static_for<0, NSTG>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
@@ -328,16 +385,26 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = 0.f;
+                for (int r = 0; r < 16; ++r) { v[r] = 0.f; if (ACC2) v2[r] = 0.f; }
             }
             if constexpr (RES && q == NSTG - 1) load_residual(pt);
             const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (u & 1) * SLOT) + h * (KSW * 2048) + lane * 16;
             pipelined_steps<KSW, FDEPTH>(sl, [&](auto ss, const Frag& f) {
                 constexpr int st = decltype(ss)::value;
                 constexpr int j = q * KSW + st;
-                v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], f.h, v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], f.l, v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], f.h, v, 0, 0, 0);
+                if constexpr (!ACC2) {
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], f.h, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], f.l, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], f.h, v, 0, 0, 0);
+                } else if constexpr ((st & 1) == 0) {   // a dependent MFMA on ONE accumulator issues every 44 cycles, not 32
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], f.h, v, 0, 0, 0);
+                    v2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], f.l, v2, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], f.h, v, 0, 0, 0);
+                } else {
+                    v2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], f.h, v2, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], f.l, v, 0, 0, 0);
+                    v2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], f.h, v2, 0, 0, 0);
+                }
                 if constexpr (INTER) {
                     if constexpr (st < PW) piece(u + 1, st);   // the pieces of the next stage, one per k-step from the first on
                     static_for<0, 8>([&](auto kc) {
@@ -348,6 +415,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
                 }
             });
             if constexpr (q == NSTG - 1) {   // tile complete: keep the rows this wave finishes, hand the others to the partner
+                if constexpr (ACC2) v += v2;
                 rows_to_kgroups(v);
                 f32x4 sa, sb;
 #pragma unroll
@@ -366,8 +434,9 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
             if constexpr (q == 0 && (HOLD || INTER)) hold(eo);
         });
     }
-    // ---- last tile (its own set of store-data registers, held to the end of the program)
+    // ---- last tile (its own set of store-data registers, held until every store of the segment has retired)
     EpiOut eo_last;
+    f32x4 st8[8];
     read_partner(np - 1);
     epilogue(np - 1, true, eo_last);
     if constexpr (RSTATS) {   // statistics of the whole pixel range: reduce over the 32 pixel lanes (same g), one store per row
@@ -380,20 +449,31 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
                 rmn[e] = fminf(rmn[e], __shfl_xor(rmn[e], off, 64));
                 rmx[e] = fmaxf(rmx[e], __shfl_xor(rmx[e], off, 64));
             }
-        // lanes 0 and 32 hold rows row0 + 8 g + e; part[(sample, group) x M + row], group = the workgroup's pixel group
-        const auto rsG = __builtin_amdgcn_make_buffer_rsrc(p.part + ((long)smp * p.nstrips32 + group) * p.M, 0, p.M * 16, 0x00020000);
+        // lanes 0 and 32 hold rows row0 + 8 g + e; part[(sample, slot) x M + row], slot = part_q of this workgroup
+        const auto rsG = __builtin_amdgcn_make_buffer_rsrc(p.part + ((long)smp * p.nstrips32 + part_q) * p.M, 0, p.M * 16, 0x00020000);
         const int gq = lane >> 5;
         const int vo = (lane & 31) == 0 ? (row0 + 8 * gq) * 16 : WS_OOBV;
-        f32x4 st8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             st8[e] = f32x4{rsm[e], rsq[e], rmn[e], rmx[e]};
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, st8[e]), rsG, vo, e * 16, 0);
         }
+    }
+    // the next segment loads weights into registers (and the range reduction below shuffles): every store of this segment
+    // has read its data by then
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (RSTATS) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(st8[e]));   // store data held to the end of the program
+        for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(st8[e]));
     }
     hold(eo_last);
+    };
+    if constexpr (NSTG == 1) {
+#pragma unroll 1
+        for (int sgi = 0; sgi < nseg; ++sgi) run_segment(segment(sgi), sgi == 0);
+    } else {   // K >= 512: no registers for a segment loop (ws_plan gives these launches no extra workgroups)
+        run_segment(segment(0), true);
+    }
     if (F32 && p.omax) {                   // one atomic per workgroup
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
@@ -410,35 +490,42 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const int groups) {
 }
 
 template <int KSW, int NSTG, int MODE>
-__global__ __launch_bounds__(512) void conv_ws_kernel(ConvStripArgs p, int groups) {
+__global__ __launch_bounds__(512) void conv_ws_kernel(ConvStripArgs p, WsPlan pl) {
     __shared__ __attribute__((aligned(16))) char smem[WsGeom<KSW, NSTG, MODE>::LDS];
-    if (threadIdx.x < 256) conv_ws_body<KSW, NSTG, MODE, 0>(p, smem, groups);   // waves 0 - 3: first half of the contraction
-    else conv_ws_body<KSW, NSTG, MODE, 1>(p, smem, groups);
+    if (threadIdx.x < 256) conv_ws_body<KSW, NSTG, MODE, 0>(p, smem, pl);   // waves 0 - 3: first half of the contraction
+    else conv_ws_body<KSW, NSTG, MODE, 1>(p, smem, pl);
 }
 
-int ws_groups(int M, long HW) {
-    const int nslice = M / 128;
-    int gpx = 32 / nslice;                       // groups per XCD (32 CUs each)
-    if (gpx < 1) gpx = 1;
+WsPlan ws_plan(int M, long HW, bool allow_extra) {
+    WsPlan pl;
+    pl.nslice = M / 128;
     const int tiles_px = (int)((HW + 31) / 32);
-    int groups = 8 * gpx;
-    if (groups > tiles_px) groups = ((tiles_px + 7) / 8) * 8;   // small fields: fewer groups (still whole multiples of the XCD count)
-    return groups;
+    pl.tpx = (tiles_px + 7) / 8;
+    const int F0 = 32 / pl.nslice > 0 ? 32 / pl.nslice : 1;   // groups per XCD (32 CUs each)
+    if (pl.tpx <= F0) {            // small fields: one tile per group, no leftovers worth sharing
+        pl.F = pl.tpx; pl.R = 0; pl.g = 1; pl.e = 0;
+        return pl;
+    }
+    pl.F = F0;
+    pl.R = (allow_extra && 32 - F0 * pl.nslice > 0) ? 32 - F0 * pl.nslice : 0;
+    pl.e = pl.R > 0 ? (pl.tpx * pl.R + 16) / 32 : 0;           // the extra workgroups take their share of the XCD's tiles
+    if (pl.e * pl.nslice < pl.R) { pl.R = 0; pl.e = 0; }
+    pl.g = (pl.tpx - pl.e + pl.F - 1) / pl.F;
+    return pl;
 }
 
 template <int KSW, int NSTG>
 hipError_t launch_ws_k(const ConvStripArgs& a, int mode, hipStream_t s) {
-    const int nslice = a.M / 128;
-    const int groups = ws_groups(a.M, a.HW);
-    dim3 grid((unsigned)(groups * nslice * a.nbatch)), block(512);
+    const WsPlan pl = ws_plan(a.M, a.HW, NSTG == 1);
+    dim3 grid((unsigned)(8 * (pl.F * pl.nslice + pl.R) * a.nbatch)), block(512);
     if constexpr (NSTG == 1) {   // the GELU modes exist for the single-stage contractions only (K <= 384)
-        if (mode == 0) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 0>), grid, block, 0, s, a, groups);
-        if (mode == 1) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 1>), grid, block, 0, s, a, groups);
+        if (mode == 0) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 0>), grid, block, 0, s, a, pl);
+        if (mode == 1) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 1>), grid, block, 0, s, a, pl);
     } else if (mode <= 1) {
         return hipErrorInvalidValue;
     }
-    if (mode == 2) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 2>), grid, block, 0, s, a, groups);
-    if (mode == 3) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 3>), grid, block, 0, s, a, groups);
+    if (mode == 2) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 2>), grid, block, 0, s, a, pl);
+    if (mode == 3) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 3>), grid, block, 0, s, a, pl);
     return hipGetLastError();
 }
 
@@ -513,7 +600,9 @@ hipError_t launch_pack_conv_frag(const float* W, long ldw, int O, int I, int ord
 // statistics partials per row the launch described by `a` writes (a.nstrips32 must be at least this)
 int conv_ws_stat_parts(const ConvStripArgs& a) {
     const bool skip_mode = (a.act == ACT_GELU || a.act == ACT_GELU_FAST) && a.R && a.part && !a.Cf;
-    return skip_mode ? ws_groups(a.M, a.HW) : (a.HW + 31) / 32;
+    if (!skip_mode) return (a.HW + 31) / 32;
+    const WsPlan pl = ws_plan(a.M, a.HW, a.C <= 384);
+    return 8 * (pl.F + pl.R);
 }
 
 // K: input channels (contraction), M: output channels; role 0 inner skip, 1 fc1, 2 fc2 (-1: any)

@@ -87,114 +87,211 @@ __device__ constexpr RootTab<W> kScaledRoots{2.0 * kPi / (double)W};   // (2 pi 
 #endif
 constexpr int FFT_ROWS = ACE_FFT_ROWS;  // channel rows per workgroup: 64-byte runs of the spectral output
 
+// entries (complex values) per first-level index k1 of the intermediate Z / U: N2 * R, padded to R modulo 32
+template <int N2, int R>
+struct ZPitch {
+    static constexpr int raw = N2 * R;
+    static constexpr int value = R >= 32 ? raw : raw + ((R - raw) % 32 + 32) % 32;
+};
+
 // ---- forward ----------------------------------------------------------------------------------------------------------
-// grid = (ceil(C / 16), H, Bt); block = 16 * max(N1, N2).  LDS: the rows (pitch W + 1), then - aliased - Z.
-template <int N1, int N2, int R>
-__global__ __launch_bounds__(R * (N1 > N2 ? N1 : N2)) void dft_forward_fft_kernel(DftArgs p) {
+// grid = (ceil(C / R), ceil(H / NLAT), Bt); block = R * max(N1, N2).  LDS: the rows, then - aliased - Z.
+// NLAT > 1: a workgroup transforms NLAT consecutive latitudes and fetches the rows of the next one into registers while the
+// two DFT levels of the current one run (the r02 ablation showed load, level 1, level 2 and store phases adding up).
+// XT: the rows are staged transposed, xs[n][r] (r fastest): the strided reads of level 1 become contiguous runs.
+#ifndef ACE_FFT_NLAT
+#define ACE_FFT_NLAT 1
+#endif
+#ifndef ACE_FFT_XT
+#define ACE_FFT_XT 0
+#endif
+#ifndef ACE_FFT_PFU
+#define ACE_FFT_PFU 1
+#endif
+#ifndef ACE_FFT_MINWG
+#define ACE_FFT_MINWG 0
+#endif
+// workgroups per CU the register allocation must allow (0: the compiler's choice); only applied to the 16-row shapes
+template <int N1, int N2, int R, int NLAT, bool XT>
+__global__ __launch_bounds__(R * (N1 > N2 ? N1 : N2), (R == 16 && N1 * N2 <= 360) ? ACE_FFT_MINWG : 0) void dft_forward_fft_kernel(DftArgs p) {
     constexpr int W = N1 * N2, H1 = N1 / 2 + 1, NT = R * (N1 > N2 ? N1 : N2);
     constexpr int PITCH = W + 1;
     constexpr int K2N = N2 / 2 + 1;  // k = k1 + N1 k2 <= W / 2  =>  k2 <= N2 / 2
     static_assert(N1 % 2 == 0, "N1 even");
-    constexpr int XS = R * PITCH, ZS = 2 * R * H1 * N2;
+    // Z[k1][b][r], r fastest: step 1 (thread (b, r), fixed k1) writes and step 2 (thread (k1, r), fixed b) reads whole
+    // contiguous runs of R entries.  ZP = entries per k1, padded so that the 32 lanes of one ds_read_b64 group (32 / R
+    // consecutive k1 x R rows) fall on 64 distinct banks: ZP = R (mod 32).  (r02: the [r][k1][b] order cost 53 % of the
+    // kernel's LDS cycles in bank conflicts.)
+    constexpr int ZP = ZPitch<N2, R>::value;
+    constexpr int XS = XT ? W * R : R * PITCH, ZS = 2 * H1 * ZP;
     __shared__ __attribute__((aligned(16))) float smem[XS > ZS ? XS : ZS];
     float* xs = smem;
     v2f* Zs = reinterpret_cast<v2f*>(smem);
 
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.x * R, k = blockIdx.y, b = blockIdx.z;
-    const int kb = k * p.Bt + b;
+    const int c0 = blockIdx.x * R, klat0 = blockIdx.y * NLAT, b = blockIdx.z;
     const long HW = (long)p.H * W;
+    constexpr int NPF = (R * (W / 4) + NT - 1) / NT;   // 16-byte row pieces per thread
 
-    // ---- rows -> LDS (16 B per lane), fused instance-norm affine
-    for (int idx = tid; idx < R * (W / 4); idx += NT) {
-        const int r = idx / (W / 4), j = idx % (W / 4);
+    // piece idx of the workgroup: (row r, 16-byte column j).  XT: rows fastest, so that the four LDS writes of a lane pair up
+    // at most two lanes per bank; otherwise columns fastest (128-byte runs of one row per 8 lanes)
+    auto piece_rj = [&](int idx, int& r, int& j) {
+        if (XT) { r = idx % R; j = idx / R; }
+        else { r = idx / (W / 4); j = idx % (W / 4); }
+    };
+    float4 pf[NPF];
+    auto fetch = [&](int k) {
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int idx = tid + q * NT;
+            if (idx < R * (W / 4)) {
+                int r, j;
+                piece_rj(idx, r, j);
+                int c = c0 + r;
+                c = c < p.C ? c : p.C - 1;
+                const long bc = (long)b * p.C + c;
+#if ACE_FFT_ABL == 3
+                pf[q] = make_float4(1.f + idx, 2.f, 3.f, 4.f);
+#else
+                pf[q] = *reinterpret_cast<const float4*>(p.x + bc * HW + (long)k * W + 4 * j);
+#endif
+            }
+        }
+    };
+    auto stage_rows = [&]() {   // registers -> LDS
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int idx = tid + q * NT;
+            if (idx < R * (W / 4)) {
+                int r, j;
+                piece_rj(idx, r, j);
+                const float4 v = pf[q];
+                if (XT) {
+                    float* d = xs + (4 * j) * R + r;
+                    d[0] = v.x; d[R] = v.y; d[2 * R] = v.z; d[3 * R] = v.w;
+                } else {
+                    float* d = xs + r * PITCH + 4 * j;   // (8-way bank conflicts on these four writes - rotating the element
+                    d[0] = v.x;                          //  order per lane group removes them and made the kernel 5 % SLOWER:
+                    d[1] = v.y;                          //  not on the critical path, r02 same-box A/B)
+                    d[2] = v.z;
+                    d[3] = v.w;
+                }
+            }
+        }
+    };
+    // fused instance-norm affine of this thread's row in step 1 (one load pair per thread, applied in registers)
+    const int r1 = tid % R, b1 = tid / R;
+    const int cr = c0 + r1 < p.C ? c0 + r1 : p.C - 1;
+    const float sc = p.sc ? p.sc[(long)b * p.C + cr] : 1.f, sh = p.sc ? p.sh[(long)b * p.C + cr] : 0.f;
+
+#if ACE_FFT_PFU
+    fetch(klat0);        // all row pieces of this thread in flight at once
+    stage_rows();
+#else
+    for (int idx = tid; idx < R * (W / 4); idx += NT) {   // r02 form: one piece at a time (fewest registers)
+        int r, j;
+        piece_rj(idx, r, j);
         int c = c0 + r;
         c = c < p.C ? c : p.C - 1;
-        const long bc = (long)b * p.C + c;
-#if ACE_FFT_ABL == 3
-        const float4 v = make_float4(1.f + idx, 2.f, 3.f, 4.f);
-#else
-        const float4 v = *reinterpret_cast<const float4*>(p.x + bc * HW + (long)k * W + 4 * j);
-#endif
-        float* d = xs + r * PITCH + 4 * j;   // (8-way bank conflicts on these four writes - rotating the element order per
-        d[0] = v.x;                          //  lane group removes them and made the kernel 5 % SLOWER: not on the critical
-        d[1] = v.y;                          //  path, r02 same-box A/B)
-        d[2] = v.z;
-        d[3] = v.w;
-    }
-    __syncthreads();
-
-    // ---- step 1: thread (b1, r): N1-point DFT of x[N2 a + b1], outputs k1 = 0 .. N1/2, times w_W^(b1 k1) (2 pi / W folded in)
-    {
-        const int r = tid % R, b1 = tid / R;
-        const bool act = b1 < N2;
-        // fused instance-norm affine of this thread's row (one load pair per thread, applied in registers)
-        const int cr = c0 + r < p.C ? c0 + r : p.C - 1;
-        const float sc = p.sc ? p.sc[(long)b * p.C + cr] : 1.f, sh = p.sc ? p.sh[(long)b * p.C + cr] : 0.f;
-        float xv[N1];
-#pragma unroll
-        for (int a = 0; a < N1; ++a) xv[a] = act ? fmaf(xs[r * PITCH + N2 * a + b1], sc, sh) : 0.f;
-        __syncthreads();   // Z aliases the rows: every row value is in registers before any Z is written
-        if (act) {
-            constexpr RootTab<N1> T1{};
-#pragma unroll
-            for (int k1 = 0; k1 < H1; ++k1) {
-                v2f acc = {0.f, 0.f};
-#pragma unroll
-                for (int a = 0; a < (ACE_FFT_ABL == 4 ? 2 : N1); ++a) {
-                    const int j = (a * k1) % N1;
-                    const v2f w = {T1.re[j], T1.im[j]};
-                    acc += v2f{xv[a], xv[a]} * w;
-                }
-                const int jw = b1 * k1;   // < N2 * (N1 / 2 + 1) <= W for N1 >= 2
-                const float wr = kScaledRoots<W>.re[jw], wi = kScaledRoots<W>.im[jw];
-                Zs[(r * H1 + k1) * N2 + b1] = v2f{acc.x * wr - acc.y * wi, acc.x * wi + acc.y * wr};
-            }
+        const float4 v = *reinterpret_cast<const float4*>(p.x + ((long)b * p.C + c) * HW + (long)klat0 * W + 4 * j);
+        if (XT) {
+            float* d = xs + (4 * j) * R + r;
+            d[0] = v.x; d[R] = v.y; d[2 * R] = v.z; d[3 * R] = v.w;
+        } else {
+            float* d = xs + r * PITCH + 4 * j;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
     }
+#endif
     __syncthreads();
 
-    // ---- step 2: thread (k1, r): N2-point DFT over b of Z[b][k1]; k1 > N1/2 from the Hermitian symmetry of Y:
-    //      Z[b][k1] = conj(Z[b][N1 - k1]) w_N2^b
     float vmax = 0.f;
-    {
-        const int r = tid % R, k1 = tid / R;
-        if (k1 < N1) {
-            constexpr RootTab<N2> T2{};
-            const bool cj = k1 > N1 / 2;
-            const int k1p = cj ? N1 - k1 : k1;
-            v2f z[N2];
+    auto one_latitude = [&](const int it) {
+        const int k = klat0 + it;
+        const bool more = NLAT > 1 && it + 1 < NLAT && k + 1 < p.H;
+        if (more) fetch(k + 1);                    // in flight under both DFT levels
+        const int kb = k * p.Bt + b;
+
+        // ---- step 1: thread (b1, r): N1-point DFT of x[N2 a + b1], outputs k1 = 0 .. N1/2, times w_W^(b1 k1) (2 pi / W folded in)
+        {
+            const int r = r1;
+            const bool act = b1 < N2;
+            float xv[N1];
 #pragma unroll
-            for (int bb = 0; bb < N2; ++bb) {
-                const v2f t = Zs[(r * H1 + k1p) * N2 + bb];
-                const v2f tc = {t.x * T2.re[bb] + t.y * T2.im[bb], t.x * T2.im[bb] - t.y * T2.re[bb]};   // conj(t) * w
-                z[bb] = cj ? tc : t;
-            }
-            const int c = c0 + r;
-            const long N2c = (long)p.Bt * 2 * p.C;
-            float* ob = p.spec_out + (long)kb * 2 * p.C + c;
+            for (int a = 0; a < N1; ++a)
+                xv[a] = act ? fmaf(XT ? xs[(N2 * a + b1) * R + r] : xs[r * PITCH + N2 * a + b1], sc, sh) : 0.f;
+            __syncthreads();   // Z aliases the rows: every row value is in registers before any Z is written
+            if (act) {
+                constexpr RootTab<N1> T1{};
 #pragma unroll
-            for (int k2 = 0; k2 < K2N; ++k2) {
-                const int m = k1 + N1 * k2;
-                if (m < p.Mm) {
+                for (int k1 = 0; k1 < H1; ++k1) {
                     v2f acc = {0.f, 0.f};
 #pragma unroll
-                    for (int bb = 0; bb < (ACE_FFT_ABL == 2 ? 2 : N2); ++bb) {
-                        const int j = (bb * k2) % N2;
-                        const v2f w = {T2.re[j], T2.im[j]};
-                        const v2f wp = {-T2.im[j], T2.re[j]};
-                        acc += v2f{z[bb].x, z[bb].x} * w;
-                        acc += v2f{z[bb].y, z[bb].y} * wp;
+                    for (int a = 0; a < (ACE_FFT_ABL == 4 ? 2 : N1); ++a) {
+                        const int j = (a * k1) % N1;
+                        const v2f w = {T1.re[j], T1.im[j]};
+                        acc += v2f{xv[a], xv[a]} * w;
                     }
-                    if (c < p.C && (ACE_FFT_ABL != 1 || acc.x == 1.2345e-30f)) {
-                        float* o = ob + (long)m * p.H * N2c;
-                        o[0] = acc.x;
-                        o[p.C] = acc.y;
-                        vmax = fmaxf(vmax, fmaxf(fabsf(acc.x), fabsf(acc.y)));
+                    const int jw = b1 * k1;   // < N2 * (N1 / 2 + 1) <= W for N1 >= 2
+                    const float wr = kScaledRoots<W>.re[jw], wi = kScaledRoots<W>.im[jw];
+                    Zs[k1 * ZP + b1 * R + r] = v2f{acc.x * wr - acc.y * wi, acc.x * wi + acc.y * wr};
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- step 2: thread (k1, r): N2-point DFT over b of Z[b][k1]; k1 > N1/2 from the Hermitian symmetry of Y:
+        //      Z[b][k1] = conj(Z[b][N1 - k1]) w_N2^b
+        {
+            const int r = tid % R, k1 = tid / R;
+            if (k1 < N1) {
+                constexpr RootTab<N2> T2{};
+                const bool cj = k1 > N1 / 2;
+                const int k1p = cj ? N1 - k1 : k1;
+                v2f z[N2];
+#pragma unroll
+                for (int bb = 0; bb < N2; ++bb) {
+                    const v2f t = Zs[k1p * ZP + bb * R + r];
+                    const v2f tc = {t.x * T2.re[bb] + t.y * T2.im[bb], t.x * T2.im[bb] - t.y * T2.re[bb]};   // conj(t) * w
+                    z[bb] = cj ? tc : t;
+                }
+                const int c = c0 + r;
+                const long N2c = (long)p.Bt * 2 * p.C;
+                float* ob = p.spec_out + (long)kb * 2 * p.C + c;
+#pragma unroll
+                for (int k2 = 0; k2 < K2N; ++k2) {
+                    const int m = k1 + N1 * k2;
+                    if (m < p.Mm) {
+                        v2f acc = {0.f, 0.f};
+#pragma unroll
+                        for (int bb = 0; bb < (ACE_FFT_ABL == 2 ? 2 : N2); ++bb) {
+                            const int j = (bb * k2) % N2;
+                            const v2f w = {T2.re[j], T2.im[j]};
+                            const v2f wp = {-T2.im[j], T2.re[j]};
+                            acc += v2f{z[bb].x, z[bb].x} * w;
+                            acc += v2f{z[bb].y, z[bb].y} * wp;
+                        }
+                        if (c < p.C && (ACE_FFT_ABL != 1 || acc.x == 1.2345e-30f)) {
+                            float* o = ob + (long)m * p.H * N2c;
+                            o[0] = acc.x;
+                            o[p.C] = acc.y;
+                            vmax = fmaxf(vmax, fmaxf(fabsf(acc.x), fabsf(acc.y)));
+                        }
                     }
                 }
             }
         }
+        if (more) {
+            __syncthreads();   // Z is dead
+            stage_rows();
+            __syncthreads();
+        }
+    };
+    if constexpr (NLAT == 1) {
+        one_latitude(0);
+    } else {
+#pragma unroll 1
+        for (int it = 0; it < NLAT && klat0 + it < p.H; ++it) one_latitude(it);
     }
     if (p.omax) {   // one atomic per workgroup (Z is dead: reduce the wave maxima through LDS)
 #pragma unroll
@@ -210,11 +307,11 @@ __global__ __launch_bounds__(R * (N1 > N2 ? N1 : N2)) void dft_forward_fft_kerne
     }
 }
 
-template <int N1, int N2, int R = FFT_ROWS>
+template <int N1, int N2, int R = FFT_ROWS, int NLAT = 1, bool XT = false>
 hipError_t launch_fwd(const DftArgs& a, hipStream_t s) {
     constexpr int NT = R * (N1 > N2 ? N1 : N2);
-    dim3 grid((unsigned)((a.C + R - 1) / R), (unsigned)a.H, (unsigned)a.Bt), block(NT);
-    hipLaunchKernelGGL((dft_forward_fft_kernel<N1, N2, R>), grid, block, 0, s, a);
+    dim3 grid((unsigned)((a.C + R - 1) / R), (unsigned)((a.H + NLAT - 1) / NLAT), (unsigned)a.Bt), block(NT);
+    hipLaunchKernelGGL((dft_forward_fft_kernel<N1, N2, R, NLAT, XT>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 
@@ -235,7 +332,8 @@ __global__ __launch_bounds__(R * (N2 > N1 / 2 + 1 ? N2 : N1 / 2 + 1)) void dft_i
     constexpr int W = N1 * N2, H1 = N1 / 2 + 1, M2 = N2 / 2, NT = R * (N2 > H1 ? N2 : H1);
     constexpr int PITCH = W + 1;
     static_assert(N1 % 2 == 0 && N2 % 2 == 0 && N1 >= 4, "even factors");
-    constexpr int YS = R * PITCH, US = 2 * R * H1 * N2;
+    constexpr int ZP = ZPitch<N2, R>::value;   // U[k1][b][r], as Z of the forward kernel
+    constexpr int YS = R * PITCH, US = 2 * H1 * ZP;
     __shared__ __attribute__((aligned(16))) float smem[YS > US ? YS : US];
     float* ys = smem;
     v2f* Us = reinterpret_cast<v2f*>(smem);
@@ -291,8 +389,8 @@ __global__ __launch_bounds__(R * (N2 > N1 / 2 + 1 ? N2 : N1 / 2 + 1)) void dft_i
                 const int j0 = k1 * j, j1 = k1 * (j + M2);
                 const float a0 = kRoots<W>.re[j0], b0 = -kRoots<W>.im[j0];
                 const float a1 = kRoots<W>.re[j1], b1 = -kRoots<W>.im[j1];
-                Us[(r * H1 + k1) * N2 + j] = v2f{t0.x * a0 - t0.y * b0, t0.x * b0 + t0.y * a0};
-                Us[(r * H1 + k1) * N2 + j + M2] = v2f{t1.x * a1 - t1.y * b1, t1.x * b1 + t1.y * a1};
+                Us[k1 * ZP + j * R + r] = v2f{t0.x * a0 - t0.y * b0, t0.x * b0 + t0.y * a0};
+                Us[k1 * ZP + (j + M2) * R + r] = v2f{t1.x * a1 - t1.y * b1, t1.x * b1 + t1.y * a1};
             }
         }
     }
@@ -304,7 +402,7 @@ __global__ __launch_bounds__(R * (N2 > N1 / 2 + 1 ? N2 : N1 / 2 + 1)) void dft_i
         const bool act = b1 < N2;
         v2f u[H1];
 #pragma unroll
-        for (int k1 = 0; k1 < H1; ++k1) u[k1] = act ? Us[(r * H1 + k1) * N2 + b1] : v2f{0.f, 0.f};
+        for (int k1 = 0; k1 < H1; ++k1) u[k1] = act ? Us[k1 * ZP + b1 * R + r] : v2f{0.f, 0.f};
         __syncthreads();   // the output rows alias U
         if (act) {
             constexpr RootTab<N1> T1{};
@@ -386,7 +484,7 @@ bool launch_dft_forward_fft(const DftArgs& a, hipStream_t s, hipError_t* err) {
     if (a.no_fft || (reinterpret_cast<uintptr_t>(a.x) & 15) != 0 || a.Mm > a.W / 2 + 1 || a.H > 65535 || a.Bt > 65535)
         return false;
     switch (a.W) {
-        case 360: *err = launch_fwd<20, 18>(a, s); return true;
+        case 360: *err = launch_fwd<20, 18, FFT_ROWS, ACE_FFT_NLAT, ACE_FFT_XT != 0>(a, s); return true;
         case 1440: *err = launch_fwd<40, 36, 8>(a, s); return true;    // 0.25-degree grid: 8 channel rows per workgroup (46 KiB)
         case 720: *err = launch_fwd<30, 24, 8>(a, s); return true;
         case 48: *err = launch_fwd<8, 6>(a, s); return true;

@@ -40,6 +40,8 @@ def names():
 def stage_model(C=384, H=180, W=360, L=180, M=181, hid=768, cin=44, cout=50):
     """Algorithmic flops / bytes per launch of each stage (DESIGN.md section 'Kernels'), B = 1."""
     act = C * H * W * 4
+    tiles = (H * W + 31) // 32                      # fc2 emits one statistics partial (16 B) per 32-pixel tile and channel
+    groups = 8 * (32 // (C // 128) + (32 - (32 // (C // 128)) * (C // 128))) if C % 128 == 0 else tiles   # inner skip: one per pixel group
     coef = C * L * M * 8
     tab = M * L * H * 4
     fft_flops = 2 * 21_000 * C * H      # two-level 20 x 18 FFT on the vector ALUs: ~21 k fp32 FMAs per row (csrc/fft.hip)
@@ -53,8 +55,10 @@ def stage_model(C=384, H=180, W=360, L=180, M=181, hid=768, cin=44, cout=50):
         "inner_skip+activation": (2 * C * C * H * W, 3 * act),
         "mlp.fc1": (2 * hid * C * H * W, act + hid * H * W * 4),
         "mlp.fc2+outer_skip": (2 * hid * C * H * W, 2 * act + hid * H * W * 4),
-        "norm0_stats": (3 * C * H * W, act),
-        "norm1_stats": (3 * C * H * W, act),
+        # f16x3 mode: the instance norms are a finaliser over the statistics partials of the producing convolution (+ the
+        # re-packing of the norm-folded fc1 weight for norm1); no pass over an activation (fp32 mode: one pass, 99.5 MB)
+        "norm0_stats": (8 * tiles * C, tiles * C * 16 + 4 * C * 4),
+        "norm1_stats": (8 * groups * C + 2 * hid * C, groups * C * 16 + 2 * hid * C * 4 + 4 * C * 4),
         "encoder": (2 * (cin * C + C * C) * H * W, cin * H * W * 4 + 4 * act),
         "decoder": (2 * ((C + cin) * C + C * cout) * H * W, 3 * act + (cin + cout) * H * W * 4),
     }
@@ -120,50 +124,48 @@ def build_stepper(dev, seed, hooks=False):
     return stepper, forcing, prog, diag
 
 
-def cpu_baseline(stepper, x_cpu, budget_s=40.0):
+def cpu_baseline(stepper, x_cpu, budget_s=45.0):
     """The reference CPU path, restated (oracle 'port': the same torch-CPU op sequence as fme's SFNO forward, pinned on the
-    reference's goldens), timed on this box's host cores in the same run: 1 warm-up + up to 3 timed forward steps, median
-    reported (SURVEY 8(d) / BASELINE.md protocol).  All logical cores are offered; a 1x1-convolution probe picks the thread
-    count that is actually fastest on this host (oversubscribed torch intra-op pools can be several times slower) and the
-    result states both.  Bounded: timed steps stop once `budget_s` seconds of CPU work are spent."""
+    reference's goldens), timed on this box's host cores in the same run (SURVEY 8(d) / BASELINE.md protocol).  It is a stated
+    baseline and should be the fastest this host can do: one WHOLE forward step is timed at each of 32 / 64 / 128 threads
+    (those the host has; a matrix-multiply probe does not predict the forward's best thread count - round 2 picked 64 and got
+    13 s where 32 threads take 7 s), after one untimed warm-up, while the budget lasts; the fastest is reported with its
+    thread count.  Bounded: no forward starts once `budget_s` seconds of CPU work would be exceeded."""
     from oracle.sfno import SFNOConfig, SFNOOracle
 
     ncpu = os.cpu_count() or 1
-    a = torch.randn(384, 384)
-    bmat = torch.randn(384, IMG[0] * IMG[1])
-    probe = {}
-    for th in sorted({ncpu, max(ncpu // 2, 1), min(ncpu, 64), min(ncpu, 32)}, reverse=True):
-        torch.set_num_threads(th)
-        torch.mm(a, bmat)
-        t0 = time.perf_counter()
-        torch.mm(a, bmat)
-        probe[th] = time.perf_counter() - t0
-    best = min(probe.values())
-    threads = max(th for th, v in probe.items() if v <= 1.15 * best)   # the most threads that are not clearly slower
-    torch.set_num_threads(threads)
+    cands = [t for t in (32, 64, 128) if t <= ncpu] or [ncpu]
     cfg = SFNOConfig(in_chans=N_FORCING + N_PROGNOSTIC, out_chans=N_PROGNOSTIC + N_DIAGNOSTIC, img_shape=IMG,
                      embed_dim=384, num_layers=8, operator_type="dhconv")
     state = {k: v.detach().cpu() for k, v in stepper.modules[0].state_dict().items()}
     net = SFNOOracle(cfg, state)
-    times = []
+    per_threads = {}
     with torch.no_grad():
+        torch.set_num_threads(cands[0])
         t0 = time.perf_counter()
-        y = net(x_cpu)                                            # warm-up (untimed in the result unless it is the only one)
+        y = net(x_cpu)                                            # warm-up (first-touch allocations, table construction)
         warm = time.perf_counter() - t0
-        spent = warm
-        while len(times) < 3 and spent + (times[-1] if times else warm) <= budget_s:
+        spent, last = warm, warm
+        order = cands + cands                                     # a second round if the budget allows
+        for th in order:
+            if spent + min(last, min(per_threads.values(), default=last)) > budget_s:
+                break
+            torch.set_num_threads(th)
             t0 = time.perf_counter()
             y = net(x_cpu)
-            times.append(time.perf_counter() - t0)
-            spent += times[-1]
-    timed = sorted(times) if times else [warm]
-    med = timed[len(timed) // 2]
-    return dict(value=1.0 / med, unit="steps/s", cores=threads, host_logical_cores=ncpu, kind="port",
-                thread_probe_seconds={str(k): round(v, 4) for k, v in probe.items()},
-                seconds_per_step={"median": round(med, 3), "min": round(timed[0], 3), "warmup": round(warm, 3),
-                                  "timed_steps": len(times)},
-                sample=f"forward steps of the same ACE2-shape network (B=1, fp32, torch-CPU ops) on {threads} of {ncpu} host "
-                       f"threads (fastest in a conv probe): 1 warm-up + {len(times)} timed, median {med:.2f} s/step"), y
+            last = time.perf_counter() - t0
+            spent += last
+            per_threads[th] = min(last, per_threads.get(th, last))
+    if not per_threads:
+        per_threads[cands[0]] = warm
+    threads = min(per_threads, key=per_threads.get)
+    best = per_threads[threads]
+    return dict(value=1.0 / best, unit="steps/s", cores=threads, host_logical_cores=ncpu, kind="port",
+                seconds_per_step_by_threads={str(k): round(v, 3) for k, v in sorted(per_threads.items())},
+                seconds_per_step={"best": round(best, 3), "warmup": round(warm, 3), "cpu_seconds_spent": round(spent, 1)},
+                sample=f"whole forward steps of the same ACE2-shape network (B=1, fp32, torch-CPU ops): 1 warm-up, then one "
+                       f"timed step at each of {sorted(per_threads)} threads within a {budget_s:.0f} s budget; fastest "
+                       f"{best:.2f} s/step on {threads} of {ncpu} host threads"), y
 
 
 def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, world, rank):
@@ -227,6 +229,9 @@ def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, 
             for i in range(ns):
                 acc[i] += ms[i] / reps
         model = stage_model()
+        if precision == "fp32":   # exact-fp32 mode: the norm statistics are a stand-alone pass over the activation
+            act_b = 384 * IMG[0] * IMG[1] * 4
+            model["norm0_stats"] = model["norm1_stats"] = (3 * 384 * IMG[0] * IMG[1], act_b)
         stages = {}
         for i in range(ns):
             nm = L.ace_sfno_stage_name(i).decode()
@@ -241,17 +246,31 @@ def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, 
     return dict(dt=dt, stages=stages, x_cpu=x_cpu, y_gpu=y_gpu)
 
 
-# HBM bytes per launch from separate rocprofv3 --pmc passes over this build (FETCH_SIZE / WRITE_SIZE in KB; gfx950
-# correction: wide reads are counted at half size), profiles/r02_pmc_traffic.json, written by tools/pmc_to_profile.py.
-# Keyed by "mode|stage"; value {"bytes": per-launch HBM bytes, ...}.  None = not measured for this build.
-MEASURED_TRAFFIC = {}
-try:
-    import json as _json
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")) as _f:
-        MEASURED_TRAFFIC = {tuple(k.split("|")): (v["bytes"] if isinstance(v, dict) else v)
-                            for k, v in _json.load(_f).items() if not k.startswith("_")}
-except (OSError, ValueError):
-    pass
+# HBM bytes per launch and MFMA-busy from separate rocprofv3 --pmc passes (tools/pmc_collect.sh -> tools/pmc_to_profile.py ->
+# profiles/r03_pmc_traffic.json).  FETCH_SIZE / WRITE_SIZE in KB; gfx950 correction: 16-byte-per-lane streaming reads are
+# counted at half size (MI355X_MICROARCH.md "HBM").  The file carries the sha256 of the library the counters were taken on:
+# figures are attached to the bench line ONLY when that is the library being timed now (otherwise null + the reason).
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+
+
+def lib_sha256():
+    import hashlib
+    from ace_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def measured_counters():
+    """{(mode, stage): entry} from PMC_FILE if it was taken on the library loaded now, else ({}, reason)."""
+    try:
+        with open(PMC_FILE) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return {}, "no counter file (profiles/r03_pmc_traffic.json)"
+    if d.get("_lib_sha256") != lib_sha256():
+        return {}, f"counter file is of another build (sha256 {str(d.get('_lib_sha256'))[:12]} != timed {lib_sha256()[:12]})"
+    return {tuple(k.split("|")): v for k, v in d.items() if not k.startswith("_") and isinstance(v, dict)}, None
+
 
 # the kernel that runs each stage in the default (f16x3) mode
 KERNEL_OF_STAGE = {
@@ -313,24 +332,30 @@ def main():
             dom = max((st for st in stages if KERNEL_OF_STAGE.get(st, st) == kdom), key=lambda k: stages[k]["ms_per_step"])
         fl, by = model[dom]
         t_launch = stages[dom]["us_per_launch"] * 1e-6
+        pmc, pmc_note = measured_counters()
+        ent = pmc.get((main_mode, dom), {})
         if main_mode == "fp32":   # exact-fp32 MFMA: the contraction kernels are bound by the fp32 matrix pipe
             roofline = dict(kernel=f"gemm_f32 engine ({dom})", bound="mfma", achieved=round(fl / t_launch / 1e12, 2),
                             peak=PEAK_MFMA_F32, unit="TFLOP/s", frac=round(fl / t_launch / 1e12 / PEAK_MFMA_F32, 4),
-                            traffic=MEASURED_TRAFFIC.get((main_mode, dom)))
+                            traffic=ent.get("bytes"), traffic_note=pmc_note)
         else:                     # compensated-fp16 MFMA (3 x 1/16 of the fp32 cost): HBM is the bounding roofline
             roofline = dict(kernel=f"{KERNEL_OF_STAGE.get(dom, dom)} ({dom})", bound="hbm", achieved=round(by / t_launch / 1e9, 1),
                             peak=PEAK_HBM, unit="GB/s", frac=round(by / t_launch / 1e9 / PEAK_HBM, 4),
-                            traffic=MEASURED_TRAFFIC.get((main_mode, dom)),
-                            mfma_f16_tflops=round(3 * fl / t_launch / 1e12, 1), mfma_f16_peak=2500.0)
+                            traffic=ent.get("bytes"), traffic_note=pmc_note,
+                            # north_star: MFMA-busy against the chip's peak.  Issue rate from the flop count (3 fp16 MFMAs per
+                            # product) and, when the counters are of this build, SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x
+                            # active cycles of one XCD)
+                            mfma_f16_tflops=round(3 * fl / t_launch / 1e12, 1), mfma_f16_peak=2500.0,
+                            mfma_busy_frac=round(3 * fl / t_launch / 1e12 / 2500.0, 4), mfma_busy_pmc=ent.get("mfma_busy"))
         sht_us = stages["forward_transform.dft"]["us_per_launch"] + stages["forward_transform.legendre"]["us_per_launch"]
         sht_bytes = 384 * 180 * 360 * 4 + 181 * 180 * 180 * 4 + 384 * 180 * 181 * 8     # 223.1 MB
         roofline_sht = dict(kernel="forward SHT (dft_forward_fft_kernel + legendre_strip_kernel)", bound="hbm",
                             achieved=round(sht_bytes / (sht_us * 1e-6) / 1e9, 1), peak=PEAK_HBM, unit="GB/s",
                             frac=round(sht_bytes / (sht_us * 1e-6) / 1e9 / PEAK_HBM, 4),
-                            traffic=(MEASURED_TRAFFIC[(main_mode, "forward_transform.dft")] +
-                                     MEASURED_TRAFFIC[(main_mode, "forward_transform.legendre")])
-                            if (main_mode, "forward_transform.dft") in MEASURED_TRAFFIC and
-                               (main_mode, "forward_transform.legendre") in MEASURED_TRAFFIC else None)
+                            traffic=(pmc[(main_mode, "forward_transform.dft")]["bytes"] +
+                                     pmc[(main_mode, "forward_transform.legendre")]["bytes"])
+                            if (main_mode, "forward_transform.dft") in pmc and
+                               (main_mode, "forward_transform.legendre") in pmc else None, traffic_note=pmc_note)
         cpu = None
         if not args.no_cpu_baseline:
             cpu, y_cpu = cpu_baseline(stepper, r["x_cpu"])
@@ -350,6 +375,7 @@ def main():
                        "members": world, "members_per_gpu": 1, "graph": args.graph, "precision": main_mode,
                        "collective": "RCCL all-reduce mean of the (50,180,360) output state once per window" if world > 1 else "none"},
             "roofline": roofline, "roofline_sht": roofline_sht, "stages": stages, "cpu_baseline": cpu,
+            "lib_sha256": lib_sha256(),
         }
         for m in modes[1:]:
             result[f"mode_{m}"] = {"value": round(world * K / runs[m]["dt"], 3), "unit": "steps/s",

@@ -22,3 +22,4 @@ with torch.no_grad():
         y = net(x)
 torch.cuda.synchronize()
 print("pmc_run done", tuple(y.shape), float(y.abs().max()))
+print("lib_sha256", bench.lib_sha256(), _lib.LIB_PATH)

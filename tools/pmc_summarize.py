@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-kernel means of rocprofv3 counter_collection.csv (one pass), or --merge DIR: merge the per-pass summaries and derive
 HBM bytes per launch (gfx950: FETCH_SIZE counts wide coalesced reads at half size -> bytes = 2 * FETCH_SIZE KB + WRITE_SIZE KB,
-MI355X_MICROARCH.md 'HBM'), L2 hit rate and MFMA-busy share."""
+MI355X_MICROARCH.md 'HBM'), L2 hit rate and MFMA-busy (fraction of the chip's SIMD-cycles with the matrix pipe busy)."""
 import collections
 import csv
 import json
@@ -45,8 +45,10 @@ def merge(d):
         if "TCC_HIT_sum" in v and v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0) > 0:
             v["l2_hit_rate"] = round(v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 4)
         if "SQ_VALU_MFMA_BUSY_CYCLES" in v and v.get("GRBM_GUI_ACTIVE", 0) > 0:
-            # busy cycles are summed over the SIMDs that report (256 CUs x 4 SIMDs); share of the kernel's active cycles
-            v["mfma_busy_share"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] * 1024), 4)
+            # SQ_VALU_MFMA_BUSY_CYCLES: cycles (32 per v_mfma_f32_32x32x16_f16) summed over the 1024 SIMDs of the chip;
+            # GRBM_GUI_ACTIVE: active cycles summed over the 8 XCDs (round 2 divided by the sum and published an 8x too
+            # small share).  mfma_busy = fraction of SIMD-cycles with the matrix pipe busy = fraction of the fp16 MFMA peak.
+            v["mfma_busy"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024), 4)
     return dict(sorted(tot.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)))
 
 

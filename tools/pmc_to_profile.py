@@ -1,10 +1,11 @@
 #!/usr/bin/env python
-"""gpurun_out/pmc_<tag>.json (tools/pmc_collect.sh) -> profiles/r02_pmc_traffic.json keyed "mode|stage" for bench.py's
+"""gpurun_out/pmc_<tag>.json (tools/pmc_collect.sh) -> profiles/r03_pmc_traffic.json keyed "mode|stage" for bench.py's
 roofline.traffic, plus a readable table.  HBM bytes per launch = 2 x FETCH_SIZE KB (gfx950: 16-byte-per-lane reads are counted
 at half size, MI355X_MICROARCH.md) + WRITE_SIZE KB; kernels whose reads are 4-byte-per-lane get the uncorrected figure too."""
 import json, re, sys
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_r02f.json"
-dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_pmc_traffic.json"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_r03.json"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03_pmc_traffic.json"
+sha = sys.argv[3] if len(sys.argv) > 3 else None   # sha256 of the library the passes ran on (bench.py compares it)
 d = json.load(open(src))
 RULES = [  # (regex on kernel key, stage, reads are wide (x2 correction applies))
     (r"^dft_forward_fft_kernel", "forward_transform.dft", True),
@@ -16,14 +17,10 @@ RULES = [  # (regex on kernel key, stage, reads are wide (x2 correction applies)
     (r"^conv_ws_kernel<12, 1, 1>", "mlp.fc1", True),
     (r"^conv_ws_kernel<12, 2, 2>", "mlp.fc2+outer_skip", True),
     (r"^conv_ws_kernel<12, 2, 3>", "mlp.fc2+outer_skip(last block)", True),
-    (r"^conv_strip_kernel<12, 4, true, true>", "inner_skip+activation", True),
-    (r"^conv_strip_kernel<12, 4, false, false>", "mlp.fc1", True),
-    (r"^conv_split_kernel<12, 2, 2>", "mlp.fc2+outer_skip", True),
-    (r"^conv_split_kernel<12, 2, 3>", "mlp.fc2+outer_skip(last block)", True),
     (r"^gemm3_f16x3_kernel<2, 2, false, true, false>", "decoder", True),
     (r"^gemm3_f16x3_kernel<2, 2, false, false, false>", "encoder", True),
 ]
-out = {"_source": src, "_note": "per-launch means over the dispatches of 2 eager forwards; separate rocprofv3 --pmc passes "
+out = {"_source": src, "_lib_sha256": sha, "_note": "per-launch means over the dispatches of 2 eager forwards; separate rocprofv3 --pmc passes "
        "(FETCH_SIZE | WRITE_SIZE TCC_HIT TCC_MISS | SQ busy | SQ insts), never combined with API traces"}
 rows = []
 for k, v in d.items():
@@ -34,11 +31,11 @@ for k, v in d.items():
             wr = v.get("WRITE_SIZE", 0.0) * 1024
             e = {"kernel": k, "bytes": int(rd + wr), "read_MB": round(rd / 1e6, 1), "write_MB": round(wr / 1e6, 1),
                  "read_MB_uncorrected": round(rd_raw / 1e6, 1), "wide_read_correction": wide,
-                 "l2_hit_rate": v.get("l2_hit_rate"), "mfma_busy_share": v.get("mfma_busy_share"),
+                 "l2_hit_rate": v.get("l2_hit_rate"), "mfma_busy": v.get("mfma_busy"),
                  "lds_bank_conflict_cycles": v.get("SQ_LDS_BANK_CONFLICT"), "lds_active_cycles": v.get("SQ_LDS_IDX_ACTIVE"),
                  "dispatches": v.get("_dispatches")}
             out["f16x3|" + stage] = e
             rows.append((stage, e))
 json.dump(out, open(dst, "w"), indent=1)
 for stage, e in rows:
-    print(f"{stage:34s} {e['kernel'][:44]:44s} read {e['read_MB']:7.1f} MB  write {e['write_MB']:7.1f} MB  L2 hit {e['l2_hit_rate']}  MFMA busy {e['mfma_busy_share']}")
+    print(f"{stage:34s} {e['kernel'][:44]:44s} read {e['read_MB']:7.1f} MB  write {e['write_MB']:7.1f} MB  L2 hit {e['l2_hit_rate']}  MFMA busy {e['mfma_busy']}")
