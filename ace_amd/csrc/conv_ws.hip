@@ -24,21 +24,12 @@
 #include <type_traits>
 
 #include "strip_common.h"
+#include "ws_plan.h"
 
 namespace ace {
 namespace {
 
 constexpr int WS_OOBV = 0x7fffff00;   // buffer offset beyond every resource of these kernels: loads return 0, stores are dropped
-
-// Work decomposition of one launch (host side: ws_plan).  XCD x owns the pixel tiles [x tpx, (x + 1) tpx); its first `e`
-// tiles are the EXTRA range shared by the R workgroups that are left over when nslice does not divide 32, the rest is cut
-// into F groups of g tiles, each walked by nslice workgroups (one per channel slice).
-struct WsPlan {
-    int nslice, F, R, tpx, g, e;
-};
-struct WsSeg {
-    int slice, tile0, np;
-};
 
 #ifndef ACE_WS_ACC2
 #define ACE_WS_ACC2 0     // modes (bit 0 inner skip, bit 1 fc1) whose MFMAs alternate between two accumulators (no dependent-issue stalls)
@@ -87,56 +78,20 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     const int i = lane & 31, g = lane >> 5;
     float* St = reinterpret_cast<float*>(smem + 2 * SLOT + TAB + XCH) + wave * (16 * STP);
 
-    // ---- which sample, XCD and workgroup of the XCD; its segments (runs of pixel tiles of one channel slice)
-    const int wpx = pl.F * pl.nslice + pl.R;
-    const int per_smp = 8 * wpx;
+    // ---- which sample, XCD and workgroup of the XCD; its segments (runs of pixel tiles of one channel slice): ws_plan.h
+    const int per_smp = 8 * ws_workgroups_per_xcd(pl);
     const int smp = blockIdx.x / per_smp;
     const int bb = blockIdx.x % per_smp;
     const int xcd = bb & 7, w = bb >> 3;
-    const int tiles_px = (p.HW + 31) / 32;
-    const int x0 = xcd * pl.tpx;
-    const int nx = tiles_px - x0 < pl.tpx ? (tiles_px - x0 > 0 ? tiles_px - x0 : 0) : pl.tpx;   // tiles of this XCD
-    const int ex = pl.e < nx ? pl.e : nx;                                                       // ... of them in the extra range
-    const bool extra = w >= pl.F * pl.nslice;
-    const int part_q = xcd * (pl.F + pl.R) + (extra ? pl.F + (w - pl.F * pl.nslice) : w / pl.nslice);   // statistics slot
-    int u0 = 0, u1 = 0, nseg = 1;
-    if (extra) {   // a contiguous run [u0, u1) of the units (slice, tile) = (u / ex, u % ex) of the extra range
-        const int r = w - pl.F * pl.nslice, U = pl.nslice * ex;
-        u0 = (int)((long)r * U / pl.R);
-        u1 = (int)((long)(r + 1) * U / pl.R);
-        nseg = u1 > u0 ? (u1 - 1) / ex - u0 / ex + 1 : 0;
-    }
-    auto segment = [&](int k) {
-        WsSeg sg;
-        if (!extra) {
-            const int grp = w / pl.nslice;
-            sg.slice = w % pl.nslice;
-            sg.tile0 = x0 + ex + grp * pl.g;
-            const int end = x0 + ex + (grp + 1) * pl.g < x0 + nx ? x0 + ex + (grp + 1) * pl.g : x0 + nx;
-            sg.np = end - sg.tile0;
-        } else {
-            const int r = w - pl.F * pl.nslice;
-            const int kk = (r & 1) ? nseg - 1 - k : k;   // odd workgroups walk their slices backwards: pairs meet on the same tiles
-            sg.slice = u0 / ex + kk;
-            const int lo = u0 > sg.slice * ex ? u0 - sg.slice * ex : 0;
-            const int hi = u1 < (sg.slice + 1) * ex ? u1 - sg.slice * ex : ex;
-            sg.tile0 = x0 + lo;
-            sg.np = hi - lo;
-        }
-        return sg;
-    };
-    if (!extra && segment(0).np <= 0) nseg = 0;
+    const WsWork wk = ws_work(pl, (p.HW + 31) / 32, xcd, w);
+    const int part_q = wk.part_q, nseg = wk.nseg;
+    auto segment = [&](int k) { return ws_segment(pl, wk, w, k); };
     if (RSTATS) {
         // The norm finaliser sums slot part_q over ALL rows.  An extra workgroup owns its slot alone: rows of the slices it
         // does not reach get a neutral partial; a group's slot is shared by its nslice workgroups, each answers for its slice.
         float4* pq = p.part + ((long)smp * p.nstrips32 + part_q) * p.M;
-        const int s_lo = nseg > 0 ? (extra ? u0 / ex : w % pl.nslice) : 0;
-        const int s_hi = nseg > 0 ? (extra ? (u1 - 1) / ex : w % pl.nslice) : -1;
-        for (int r = tid; r < p.M; r += 512) {
-            const int sl = r >> 7;
-            const bool mine = extra || sl == w % pl.nslice;
-            if (mine && !(sl >= s_lo && sl <= s_hi)) pq[r] = make_float4(0.f, 0.f, 3.0e38f, -3.0e38f);
-        }
+        for (int r = tid; r < p.M; r += 512)
+            if (ws_answers_for(pl, wk, w, r >> 7) && !ws_reaches(pl, wk, w, r >> 7)) pq[r] = make_float4(0.f, 0.f, 3.0e38f, -3.0e38f);
     }
     if (nseg <= 0) return;   // (whole workgroup: no barrier has been executed yet)
 
@@ -496,28 +451,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvStripArgs p, WsPlan pl
     else conv_ws_body<KSW, NSTG, MODE, 1>(p, smem, pl);
 }
 
-WsPlan ws_plan(int M, long HW, bool allow_extra) {
-    WsPlan pl;
-    pl.nslice = M / 128;
-    const int tiles_px = (int)((HW + 31) / 32);
-    pl.tpx = (tiles_px + 7) / 8;
-    const int F0 = 32 / pl.nslice > 0 ? 32 / pl.nslice : 1;   // groups per XCD (32 CUs each)
-    if (pl.tpx <= F0) {            // small fields: one tile per group, no leftovers worth sharing
-        pl.F = pl.tpx; pl.R = 0; pl.g = 1; pl.e = 0;
-        return pl;
-    }
-    pl.F = F0;
-    pl.R = (allow_extra && 32 - F0 * pl.nslice > 0) ? 32 - F0 * pl.nslice : 0;
-    pl.e = pl.R > 0 ? (pl.tpx * pl.R + 16) / 32 : 0;           // the extra workgroups take their share of the XCD's tiles
-    if (pl.e * pl.nslice < pl.R) { pl.R = 0; pl.e = 0; }
-    pl.g = (pl.tpx - pl.e + pl.F - 1) / pl.F;
-    return pl;
-}
-
 template <int KSW, int NSTG>
 hipError_t launch_ws_k(const ConvStripArgs& a, int mode, hipStream_t s) {
     const WsPlan pl = ws_plan(a.M, a.HW, NSTG == 1);
-    dim3 grid((unsigned)(8 * (pl.F * pl.nslice + pl.R) * a.nbatch)), block(512);
+    dim3 grid((unsigned)(8 * ws_workgroups_per_xcd(pl) * a.nbatch)), block(512);
     if constexpr (NSTG == 1) {   // the GELU modes exist for the single-stage contractions only (K <= 384)
         if (mode == 0) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 0>), grid, block, 0, s, a, pl);
         if (mode == 1) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 1>), grid, block, 0, s, a, pl);
@@ -602,7 +539,7 @@ int conv_ws_stat_parts(const ConvStripArgs& a) {
     const bool skip_mode = (a.act == ACT_GELU || a.act == ACT_GELU_FAST) && a.R && a.part && !a.Cf;
     if (!skip_mode) return (a.HW + 31) / 32;
     const WsPlan pl = ws_plan(a.M, a.HW, a.C <= 384);
-    return 8 * (pl.F + pl.R);
+    return ws_stat_slots(pl);
 }
 
 // K: input channels (contraction), M: output channels; role 0 inner skip, 1 fc1, 2 fc2 (-1: any)

@@ -17,3 +17,14 @@ def test_strip_kernel_index_algebra(tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "worst" in res.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_conv_ws_work_decomposition(tmp_path):
+    """ace_amd/csrc/ws_plan.h (shared by the kernel and its launcher): every (channel slice, pixel tile) unit exactly once,
+    every (statistics slot, row) exactly one partial, over a sweep of channel counts and field sizes."""
+    exe = str(tmp_path / "ws_plan_emul")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "emul", "ws_plan_emul.cpp")], check=True)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "shapes ok" in res.stdout
