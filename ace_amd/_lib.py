@@ -5,7 +5,7 @@ missing this module raises, loudly, at first use."""
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_long, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ACE_SFNO_LIB") or os.path.join(HERE, "libace_sfno.so")   # ACE_SFNO_LIB: A/B a variant build
@@ -25,6 +25,35 @@ class AceSfnoConfig(ctypes.Structure):
         ("data_grid", c_int), ("max_batch", c_int), ("precision", c_int),
         ("noise_embed_dim", c_int), ("affine_norms", c_int), ("normalize_big_skip", c_int), ("filter_num_groups", c_int),
     ]
+
+
+# ---- post-step physics (ace_physics_*): struct ace_phys_plane / ace_phys_config / ace_phys_fields
+MAX_LEVELS, MAX_POSITIVE, MAX_PRESCRIBED = 16, 32, 8
+
+
+class Plane(ctypes.Structure):
+    _fields_ = [("p", c_void_p), ("stride", c_long)]
+
+
+class PhysConfig(ctypes.Structure):
+    """struct ace_phys_config"""
+    _fields_ = [("nlat", c_int), ("nlon", c_int), ("nlev", c_int), ("timestep_seconds", c_double),
+                ("conserve_dry_air", c_int), ("zero_global_mean_moisture_advection", c_int), ("moisture_budget", c_int),
+                ("clip_frozen_precipitation", c_int), ("energy_budget", c_int), ("unaccounted_heating", c_double),
+                ("ocean", c_int), ("max_batch", c_int)]
+
+
+class PhysFields(ctypes.Structure):
+    """struct ace_phys_fields"""
+    _fields_ = [("ps", Plane), ("wat", Plane * MAX_LEVELS), ("T", Plane * MAX_LEVELS), ("adv", Plane), ("precip", Plane),
+                ("lhf", Plane), ("shf", Plane), ("dswsfc", Plane), ("uswsfc", Plane), ("dlwsfc", Plane), ("ulwsfc", Plane),
+                ("ulwtoa", Plane), ("uswtoa", Plane), ("frozen", Plane), ("frozen_parts", Plane * 3),
+                ("positive", Plane * MAX_POSITIVE), ("npositive", c_int),
+                ("ps_in", Plane), ("wat_in", Plane * MAX_LEVELS), ("T_in", Plane * MAX_LEVELS), ("hgt_in", Plane),
+                ("hgt_next", Plane), ("dswtoa_next", Plane), ("hgt_in_scale", c_float), ("hgt_next_scale", c_float),
+                ("sst", Plane), ("sst_target", Plane), ("ocean_fraction", Plane),
+                ("prescribed_dst", Plane * MAX_PRESCRIBED), ("prescribed_src", Plane * MAX_PRESCRIBED), ("nprescribed", c_int)]
+
 
 
 # every symbol include/ace_sfno.h declares: name -> (restype, argtypes)
@@ -63,6 +92,13 @@ SIGNATURES = {
     "ace_sfno_forward_graph": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ace_pack_normalize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p]),
     "ace_unpack_denormalize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p]),
+    "ace_physics_last_error": (c_char_p, []),
+    "ace_physics_create": (c_int, [POINTER(PhysConfig), c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "ace_physics_destroy": (None, [c_void_p]),
+    "ace_physics_reset": (c_int, [c_void_p, c_void_p]),
+    "ace_physics_set_reference": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "ace_physics_get_reference": (c_int, [c_void_p, c_void_p, POINTER(c_int), c_int, c_void_p]),
+    "ace_physics_apply": (c_int, [c_void_p, POINTER(PhysFields), c_int, c_void_p]),
 }
 
 _lib = None

@@ -171,7 +171,20 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
     };
     for (int t0 = 0; t0 < nstages; t0 += 4)       // nstages = C / 32 is a multiple of 4
         static_for<0, 4>([&](auto u) { stage(t0 + u, bs[u], bs[(u + PB) % 4]); });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy tail fetches
+    // The dummy tail fetches are still in flight into fragment sets that are dead as far as hipcc knows: the wait that retires
+    // them NAMES their registers, or the allocator may hand those registers to the epilogue's values above the wait and the
+    // returning loads would land on them (tools/store_hazard.hip, variant 3: the mechanism behind round 2's "store data"
+    // corruption).  Two statements: an asm takes at most 30 operands.
+    auto name_set = [](BSet& b) {
+        asm volatile("" : "+v"(b.h[0][0]), "+v"(b.h[0][1]), "+v"(b.h[1][0]), "+v"(b.h[1][1]), "+v"(b.l[0][0]), "+v"(b.l[0][1]),
+                          "+v"(b.l[1][0]), "+v"(b.l[1][1]));
+    };
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(bs[0].h[0][0]), "+v"(bs[0].h[0][1]), "+v"(bs[0].h[1][0]), "+v"(bs[0].h[1][1]), "+v"(bs[0].l[0][0]),
+                   "+v"(bs[0].l[0][1]), "+v"(bs[0].l[1][0]), "+v"(bs[0].l[1][1])
+                 :
+                 : "memory");
+    name_set(bs[1]); name_set(bs[2]); name_set(bs[3]);
 
     // ---- epilogue: lane = column, registers = rows; fp32 E[l][row][part * C + column], 128-byte row segments.
     // Order matters on gfx950: the range maximum (shuffles and an LDS round trip, i.e. loads that LAND in registers) comes

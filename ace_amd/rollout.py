@@ -12,6 +12,7 @@ Per step s the engine enqueues
 so the numbers are bit-identical to `Stepper.predict` (same kernels, same (x-mean)/std and y*std+mean roundings).
 Nothing is allocated and the host never synchronises inside the window."""
 
+import os
 from typing import Dict, Mapping, Optional, Tuple
 
 import torch
@@ -104,10 +105,41 @@ class RolloutEngine:
         if cfg.residual_prediction:
             self._res_in = torch.tensor([self.in_names.index(n) for n in self.prognostic], **i64)
             self._res_out = torch.tensor([self.out_names.index(n) for n in self.prognostic], **i64)
+        # Post-step physics as four HIP kernels per step (ace_amd/physics.py, csrc/physics.hip) instead of captured torch ops
+        # (round 2: +29 % step time).  ACE_NO_FUSED_PHYSICS=1 keeps the torch ops (A/B).
+        self._physics = None
+        if (self._corrector is not None or self._ocean is not None or self.prescribed) and not os.environ.get("ACE_NO_FUSED_PHYSICS"):
+            self._physics = self._build_physics()
         self._window_graph = None
         self._window_graph_key = None   # (native handle, its weights generation) the window graph was captured against
         self.net._ensure_native(dev, B)
         self.net.sync_weights()
+
+    def _build_physics(self):
+        from .physics import FusedPhysics
+        T, HW = self.T, self.HW
+
+        def locate_gen(name, s):
+            return (self.out[name].data_ptr() + 4 * s * HW, T * HW) if name in self.out else None
+
+        def locate_in(name, s):
+            if name in self.ic:
+                return (self.ic[name].data_ptr(), HW) if s == 0 else (self.out[name].data_ptr() + 4 * (s - 1) * HW, T * HW)
+            if name in self.forcing:
+                t = s + 1 if name in self.next_step_forcing else s
+                return (self.forcing[name].data_ptr() + 4 * t * HW, (T + 1) * HW)
+            return None
+
+        def locate_next(name, s):
+            for src in (self.forcing, self.target):
+                if name in src:
+                    return (src[name].data_ptr() + 4 * (s + 1) * HW, (T + 1) * HW)
+            return None
+
+        return FusedPhysics(self._corrector, self._ocean, self.prescribed, self.B, (self.H, self.W), T,
+                            gen_names=self.out_names, in_names=self.in_names,
+                            next_names=self.forcing_names + self.target_names,
+                            locate_gen=locate_gen, locate_in=locate_in, locate_next=locate_next, device=self.device)
 
     # -- one step, enqueued on the current stream
     def _enqueue_step(self, s: int, use_library_graph: bool):
@@ -129,6 +161,9 @@ class RolloutEngine:
         _lib.check(L.ace_unpack_denormalize(self.y.data_ptr(), self.out_mean.data_ptr(), self.out_std.data_ptr(),
                                             self._dst_ptr_addr[s], self._dst_strides.data_ptr(),
                                             self.B, nout, self.HW, stream))
+        if self._physics is not None:   # corrector -> ocean -> prescribed prognostics (single_module.py:669-716), four launches
+            self._physics.apply(s, stream)
+            return
         if self._corrector is not None or self._ocean is not None:
             self._apply_hooks(s)
         for n in self.prescribed:     # after the ocean (single_module.py:700-716): overwritten from the data of step s + 1
@@ -174,6 +209,8 @@ class RolloutEngine:
         self._corrector_state = None        # a new initial condition re-seeds the corrector
         if self._have_ref is not None:
             self._have_ref.fill_(False)
+        if self._physics is not None and self._physics.tracks_dry_air:
+            self._physics.reset(_lib.current_stream())
 
     def run_window(self):
         """Enqueue the T steps of the window on the current stream (no host synchronisation)."""
@@ -190,6 +227,8 @@ class RolloutEngine:
         if step._ocean is not self._ocean or step._corrector is not self._corrector:
             self._ocean, self._corrector = step._ocean, step._corrector
             self._window_graph = None
+            if self._physics is not None:
+                self._physics = self._build_physics()
         if self.graph_mode == "window":
             if self._window_graph is None:
                 # warm up outside capture (first-touch allocations inside torch), then capture once
@@ -205,7 +244,7 @@ class RolloutEngine:
                 self._window_graph = g
                 self._window_graph_key = key
             self._window_graph.replay()
-            if self._have_ref is not None:
+            if self._have_ref is not None and self._physics is None:
                 # host-side view of the hook state the captured region keeps in its static buffer (a replay does not run
                 # the Python that set it at capture time); a copy, so that a state handed out survives the next load()
                 from .corrector import CorrectorState
@@ -228,7 +267,14 @@ class RolloutEngine:
                 if self._have_ref is not None and cs is not None and cs.global_dry_air_mass is not None:
                     self._ref_mass.copy_(cs.global_dry_air_mass)     # carried reference: the captured region keeps it
                     self._have_ref.fill_(True)
+                if (self._physics is not None and self._physics.tracks_dry_air and cs is not None
+                        and cs.global_dry_air_mass is not None):
+                    self._physics.set_reference(cs.global_dry_air_mass, _lib.current_stream())
             self.run_window()
+            if self._physics is not None and self._physics.tracks_dry_air:
+                from .corrector import CorrectorState
+                mass = self._physics.get_reference(_lib.current_stream())   # (synchronises: once per window, with the result)
+                self._corrector_state = CorrectorState(global_dry_air_mass=mass) if mass is not None else None
         state = PrognosticState({n: self.out[n][:, -1:] for n in self.prognostic})
         if self._corrector_state is not None:
             state.stepper_state = StepperState(corrector_state=self._corrector_state)

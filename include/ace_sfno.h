@@ -198,6 +198,78 @@ int ace_pack_normalize(const float* const* srcs, const long* strides, const floa
 int ace_unpack_denormalize(const float* src, const float* mean, const float* std_, float* const* dsts,
                            const long* strides, int batch, int nch, long hw, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Post-step physics (fme/core/step/single_module.py:669-716): the AtmosphereCorrector
+ * (fme/core/corrector/atmosphere.py:349-398 order, 404-700 corrections), the prescribed-SST Ocean
+ * (fme/core/ocean.py:167-222, fme/core/prescriber.py:54-117) and the prescribed prognostics, applied in place on the
+ * denormalised output planes of one step, in the reference's order.  Four kernel launches per step (the corrections are
+ * a chain of area-weighted global means), deterministic fp64 reductions, no allocation, no host synchronisation:
+ * capture-safe.  A plane is a (batch, nlat, nlon) fp32 field: device pointer + per-sample stride in floats; p = NULL
+ * means "absent".
+ * ------------------------------------------------------------------------------------------ */
+#define ACE_PHYS_MAX_LEVELS 16
+#define ACE_PHYS_MAX_POSITIVE 32
+#define ACE_PHYS_MAX_PRESCRIBED 8
+
+typedef struct ace_phys_config {
+    int nlat, nlon;
+    int nlev;                          /* vertical layers (ak / bk have nlev + 1 entries) */
+    double timestep_seconds;
+    int conserve_dry_air;              /* AtmosphereCorrectorConfig.conserve_dry_air */
+    int zero_global_mean_moisture_advection;
+    int moisture_budget;               /* 0 none, 1 "precipitation", 2 "evaporation", 3 "advection_and_precipitation",
+                                          4 "advection_and_evaporation" */
+    int clip_frozen_precipitation;
+    int energy_budget;                 /* 0 none, 1 "constant_temperature" */
+    double unaccounted_heating;        /* EnergyBudgetConfig.constant_unaccounted_heating */
+    int ocean;                         /* 0 none, 1 prescribed SST where round(ocean fraction) == 1, 2 interpolate */
+    int max_batch;
+} ace_phys_config;
+
+typedef struct ace_phys_plane { float* p; long stride; } ace_phys_plane;
+
+typedef struct ace_phys_fields {
+    /* output of the step (denormalised), corrected in place; names: fme/core/atmosphere_data.py:18-43 */
+    ace_phys_plane ps;                             /* surface_pressure */
+    ace_phys_plane wat[ACE_PHYS_MAX_LEVELS];       /* specific_total_water_k */
+    ace_phys_plane T[ACE_PHYS_MAX_LEVELS];         /* air_temperature_k */
+    ace_phys_plane adv;                            /* tendency_of_total_water_path_due_to_advection */
+    ace_phys_plane precip, lhf, shf;               /* precipitation_rate, latent / sensible heat flux */
+    ace_phys_plane dswsfc, uswsfc, dlwsfc, ulwsfc, ulwtoa, uswtoa;
+    ace_phys_plane frozen;                         /* total_frozen_precipitation_rate, or ... */
+    ace_phys_plane frozen_parts[3];                /* ... ICEsfc, GRAUPELsfc, SNOWsfc (summed); all absent: zero */
+    ace_phys_plane positive[ACE_PHYS_MAX_POSITIVE];   /* force_positive_names */
+    int npositive;
+    /* input of the step */
+    ace_phys_plane ps_in;
+    ace_phys_plane wat_in[ACE_PHYS_MAX_LEVELS];
+    ace_phys_plane T_in[ACE_PHYS_MAX_LEVELS];
+    ace_phys_plane hgt_in;                         /* surface height (or geopotential) of the input */
+    /* next step's forcing / target data */
+    ace_phys_plane hgt_next, dswtoa_next;
+    float hgt_in_scale, hgt_next_scale;   /* 1, or 1 / 9.80616 when the field is the surface geopotential (PHIS) */
+    ace_phys_plane sst, sst_target, ocean_fraction;   /* output SST, next-step SST, next-step ocean fraction */
+    ace_phys_plane prescribed_dst[ACE_PHYS_MAX_PRESCRIBED], prescribed_src[ACE_PHYS_MAX_PRESCRIBED];
+    int nprescribed;
+} ace_phys_fields;
+
+typedef struct ace_physics ace_physics;
+const char* ace_physics_last_error(void);
+/* area_weights_lat_host: nlat fp32 weights of one grid column (fme/core/metrics.py:14-32, longitudinally uniform);
+ * ak_host / bk_host: nlev + 1 fp32 hybrid-sigma interface coefficients (fme/core/coordinates.py:150-280).  Either may be
+ * NULL when no configured correction needs it. */
+int ace_physics_create(const ace_phys_config* cfg, const float* area_weights_lat_host, const float* ak_host,
+                       const float* bk_host, ace_physics** out);
+void ace_physics_destroy(ace_physics* phys);
+/* A new initial condition: the next ace_physics_apply seeds the dry-air reference mass from its input again
+ * (CorrectorState, fme/core/corrector/state.py).  Stream ordered. */
+int ace_physics_reset(ace_physics* phys, void* stream);
+/* Carry the reference mass across windows: (batch) fp64 on the device.  Both synchronise `stream`. */
+int ace_physics_set_reference(ace_physics* phys, const double* ref_dev, int batch, void* stream);
+int ace_physics_get_reference(ace_physics* phys, double* ref_dev, int* have_host, int batch, void* stream);
+/* One step.  `fields` is a HOST struct of device planes (copied into the kernel arguments). */
+int ace_physics_apply(ace_physics* phys, const ace_phys_fields* fields, int batch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,10 @@
 //   variant 0: store, then ds_read_b128 into the same registers straight away
 //   variant 1: store, NOPS wait states, then the read      (distance, what strip.hip relied on in round 2)
 //   variant 2: store, s_waitcnt vmcnt(0), then the read    (the "held" form every kernel uses now)
+//   variant 3: the SOFTWARE mechanism, by construction: an LDS read is in flight into registers that the store data is then
+//              written to (what the register allocator may do around an inline-asm load it believes has completed: a dead
+//              destination, a destination not named by the wait that retires it); the LDS return lands before the store is
+//              issued and the store carries the read's contents.  Expected: every entry wrong
 // Every workgroup keeps the vector-memory pipeline busy (all waves store 16 B per lane per iteration, whole chip).
 // build: hipcc --offload-arch=gfx950 -O3 -o store_hazard tools/store_hazard.hip      run: ./store_hazard [iters] [nops]
 #include <hip/hip_runtime.h>
@@ -38,6 +42,20 @@ __global__ __launch_bounds__(256) void hazard_kernel(u32x4* out, int iters) {
             asm volatile("global_store_dwordx4 %1, %0, off\n\ts_nop " STR(NOPS) "\n\tds_read_b128 %0, %2\n\ts_waitcnt lgkmcnt(0)" : "+v"(r) : "v"(p), "v"(la) : "memory");
         if (VARIANT == 2)
             asm volatile("global_store_dwordx4 %1, %0, off\n\ts_waitcnt vmcnt(0)\n\tds_read_b128 %0, %2\n\ts_waitcnt lgkmcnt(0)" : "+v"(r) : "v"(p), "v"(la) : "memory");
+        if (VARIANT == 3) {
+            // what the register allocator may legally produce around an inline-asm load whose result it believes is already
+            // there (dead, or copied early): the read is issued into v, the store data is then built IN v, the LDS return lands,
+            // the store goes out.  One asm block so that the interleaving is by construction.
+            *p = r;                                       // dwords 1 - 3 (and 0, re-written below)
+            unsigned q = 0;
+            asm volatile("ds_read_b32 %0, %2\n\t"
+                         "v_mov_b32 %0, %3\n\t"          // "new value" written over the in-flight destination
+                         "s_sleep 4\n\t"                  // ... some hundred cycles of other work
+                         "global_store_dword %1, %0, off\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "+v"(q) : "v"(p), "v"(la), "v"(0xA0000000u + (unsigned)it) : "memory");
+            continue;
+        }
         if (r[1] != 0xB1111111u) asm volatile("s_trap 2");   // the read itself must have landed
     }
 }
@@ -71,9 +89,12 @@ int main(int argc, char** argv) {
     if (hipMalloc(reinterpret_cast<void**>(&dev), n * sizeof(u32x4)) != hipSuccess) { printf("hipMalloc failed\n"); return 2; }
     std::vector<u32x4> host(n);
     printf("store-data hazard probe: %d workgroups x 256 lanes x %d stores of 16 B, NOPS=%d\n", blocks, iters, NOPS);
-    long tot[3] = {0, 0, 0};
-    for (int rep = 0; rep < 3; ++rep) { tot[0] += run<0>(iters, blocks, dev, host); tot[1] += run<1>(iters, blocks, dev, host); tot[2] += run<2>(iters, blocks, dev, host); }
-    printf("SUMMARY immediate=%ld distance=%ld held=%ld (wrong entries over 3 runs)\n", tot[0], tot[1], tot[2]);
+    long tot[4] = {0, 0, 0, 0};
+    for (int rep = 0; rep < 3; ++rep) {
+        tot[0] += run<0>(iters, blocks, dev, host); tot[1] += run<1>(iters, blocks, dev, host);
+        tot[2] += run<2>(iters, blocks, dev, host); tot[3] += run<3>(iters, blocks, dev, host);
+    }
+    printf("SUMMARY immediate=%ld distance=%ld held=%ld dead-asm-destination=%ld (wrong entries over 3 runs)\n", tot[0], tot[1], tot[2], tot[3]);
     (void)hipFree(dev);
     return 0;
 }
