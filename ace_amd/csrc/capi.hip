@@ -53,6 +53,7 @@ Switches read_switches() {
     sw.no_pk = on("ACE_NO_PK");
     sw.no_pk_sht = on("ACE_NO_PK_SHT");
     sw.no_enc_ws = on("ACE_NO_ENC_WS");
+    sw.conv_wl = on("ACE_CONV_WL");
     if (const char* e = std::getenv("ACE_CONV_WS")) {
         const std::string v(e);
         if (v == "all" || v == "1") sw.conv_ws_roles = 7;
@@ -732,7 +733,7 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
         if (c.normalization_layer == 1 && c.use_mlp) {
             HIP_TRY(n->P2.alloc(act, true));
             n->nstrips = (int)((HW + 31) / 32) + 8;     // >= tilesN * WN of either tile shape and conv_ws's 32-pixel tiles
-            if (conv_ws_eligible((int)C, n->hid, HW, 1, n->sw.conv_ws_roles))
+            if (conv_ws_eligible((int)C, n->hid, HW, 1, n->sw.conv_ws_roles) || (n->sw.conv_wl && conv_wl_eligible((int)C, n->hid, HW)))
                 HIP_TRY(n->Wq1.alloc((size_t)n->Bmax * n->hid * C, true));   // hi + lo halves = one float per element
             if (conv_ws_eligible((int)C, (int)C, HW, 0, n->sw.conv_ws_roles)) HIP_TRY(n->Wq0.alloc((size_t)n->Bmax * C * C, true));
             HIP_TRY(n->zero_c.alloc((size_t)C, true));
@@ -1318,7 +1319,8 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             const int roles = n->sw.conv_ws_roles;
             // which of the three convolutions run on the weight-stationary kernel (conv_ws.hip); the others on the tile engine
             const bool ws_skip = gelu && n->Wq0.p && ws.frag0.p && conv_ws_eligible(C, C, HW, 0, roles);
-            const bool ws_fc1 = gelu && n->Wq1.p && conv_ws_eligible(C, n->hid, HW, 1, roles);
+            const bool wl_fc1 = gelu && n->Wq1.p && n->sw.conv_wl && conv_wl_eligible(C, n->hid, HW);
+            const bool ws_fc1 = wl_fc1 || (gelu && n->Wq1.p && conv_ws_eligible(C, n->hid, HW, 1, roles));
             const bool ws_fc2 = w2.frag0.p && C <= 1024 && conv_ws_eligible(n->hid, C, HW, 2, roles);
             if (have_ph) {   // h planes from the previous fc2; the affine goes into the weights
                 if (!ws_skip)
@@ -1373,7 +1375,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 k.cw = w1.winf; k.cb = b1w.absmax; k.cinb = slot(sb + 5);
                 k.Chi = Uh; k.Clo = Ul; k.sCp = (long)n->hid * HW; k.cslot = slot(sb + 6);
                 k.C = C; k.M = n->hid; k.HW = (int)HW; k.nbatch = B; k.act = ACT_GELU;
-                HIP_TRY(launch_conv_ws(k, s));
+                HIP_TRY(wl_fc1 ? launch_conv_wl(k, s) : launch_conv_ws(k, s));
             } else {
                 HIP_TRY(launch_fold_affine_f16(w1.buf.p, w1.pitch, w1.wabs, sc1, sh1, b1w.buf.p, F1h, F1l, n->bf1.p, B, n->hid, C,
                                                cp, f1s, slot(sb + 9), s));

@@ -1,0 +1,193 @@
+// First MLP convolution (layers.py:117-124: GELU(W1 . x + b1), the widest of the block's 1x1 convolutions: M = 768 rows) with
+// the WEIGHTS in LDS and NO synchronisation in the main loop, for gfx950:
+//     U = GELU( W1f . P(t) + b1f )        W1f: (M x K) norm-folded weight, t: K x HW as P-format fp16 hi/lo planes, U likewise
+// conv_ws.hip keeps the weights in registers and streams the activation through an LDS ring shared by eight waves: a barrier,
+// an accumulator exchange between the two contraction halves and 6 LDS-DMA issues per wave and 36-MFMA stage, all in lock
+// step - r03 same-box variants (two accumulators, earlier stores, all 256 CUs) moved its time by < 2 %, the PMC view is one
+// third issuing / one third issue-stalled / one third waiting at the barrier, matrix pipe 40 % busy.  Here the roles are
+// swapped:
+//   * a workgroup owns 32 RT output rows; their A fragments (strip_pack.h order 0: one contiguous 2 KiB x RT x K/16 chunk of
+//     the packed weight) are copied to LDS once (144 KiB at K = 384, RT = 3) and only READ afterwards;
+//   * every wave works alone: for its pixel tile it loads the B fragments straight from the P-format planes (a lane's 16
+//     bytes ARE its fragment: coalesced global_load_dwordx4, no LDS, no DMA), a few k-steps ahead, and feeds each to 3 RT
+//     MFMAs on RT independent accumulators; then the GELU / split epilogue of its tile and 16-byte P-entry stores;
+//   * 12 waves per workgroup (3 per SIMD, <= 168 registers each): while one wave is in its epilogue (VALU) the others keep
+//     the matrix pipe busy - there is no barrier to align them;
+//   * the 8 row slices (M = 768) that need the same pixel tiles sit on one XCD and walk that XCD's tile range in the same
+//     order, so the activation comes from HBM once and from L2 otherwise; 8 slices x 4 pixel groups = the XCD's 32 CUs.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "strip_common.h"
+
+namespace ace {
+namespace {
+
+constexpr int WL_WAVES = 12;
+constexpr int WL_OOBV = 0x7fffff00;
+
+// KS: k16-steps (K / 16), RT: 32-row tiles per workgroup, D: k-steps of B-fragment read-ahead
+template <int KS, int RT, int D>
+__global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p, int nslice, int groups_per_xcd, int tpx) {
+    __shared__ __attribute__((aligned(16))) char smem[RT * KS * 2048 + 32 * RT * 4];   // the slice's fragments, then its bias
+    float* Pb = reinterpret_cast<float*>(smem + RT * KS * 2048);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, g = lane >> 5;
+
+    // ---- workgroup -> (sample, XCD, pixel group of the XCD, row slice); block b runs on XCD b % 8
+    const int per_xcd = nslice * groups_per_xcd;
+    const int per_smp = 8 * per_xcd;
+    const int smp = blockIdx.x / per_smp;
+    const int bb = blockIdx.x % per_smp;
+    const int xcd = bb & 7, w = bb >> 3;
+    const int slice = w % nslice, grp = w / nslice;
+    const int tiles_px = (p.HW + 31) / 32;
+    const int x0 = xcd * tpx;
+    const int x1 = x0 + tpx < tiles_px ? x0 + tpx : tiles_px;
+
+    const unsigned raw_x = slot_load(p.xslot + lane);
+    const unsigned raw_a = p.aslot ? slot_load(p.aslot + lane) : 0u;
+    const unsigned raw_c = p.cinb ? slot_load(p.cinb + lane) : 0u;
+
+    // ---- weights of this slice -> LDS (the slice's fragments are one contiguous chunk of the packed operand)
+    {
+        const char* A = reinterpret_cast<const char*>(p.A + (long)smp * p.sA) + (long)slice * RT * KS * 2048;
+        for (int o = tid * 16; o < RT * KS * 2048; o += 64 * WL_WAVES * 16)
+            *reinterpret_cast<u32x4*>(smem + o) = *reinterpret_cast<const u32x4*>(A + o);
+        const float* b = p.bias + (long)smp * p.sbias + slice * 32 * RT;
+        if (tid < 32 * RT) Pb[tid] = b[tid];
+    }
+    const float xbound = wave_max_bits(raw_x);
+    const float inv_x = ldexpf(1.0f, -pow2_exponent_for(xbound));
+    const float inv_a = p.aslot ? ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_a))) : 1.0f / p.ascale;
+    const float s_acc = inv_x * inv_a;
+    // bound of this launch's output, identical in every workgroup; the consumer reads it from cslot
+    const float inb = p.cinb ? wave_max_bits(raw_c) : xbound;
+    const float cbound = fmaf(p.cw, inb, p.cb);
+    const float cscale = ldexpf(1.0f, pow2_exponent_for(cbound));
+    if (tid == 0) atomicMax(p.cslot + (blockIdx.x & 63), __float_as_uint(cbound));
+    __syncthreads();
+
+    const _Float16* Xh = p.Xhi + (long)smp * p.sX;
+    const _Float16* Xl = p.Xlo + (long)smp * p.sX;
+    const int pbytes = p.M * p.HW * 2;
+    const auto rsH = __builtin_amdgcn_make_buffer_rsrc(p.Chi + (long)smp * p.sCp, 0, pbytes, 0x00020000);
+    const auto rsL = __builtin_amdgcn_make_buffer_rsrc(p.Clo + (long)smp * p.sCp, 0, pbytes, 0x00020000);
+    const char* aw = smem + lane * 16;
+
+    // ---- this wave's pixel tiles: x0 + (grp * 12 + wave) + 12 groups_per_xcd * n
+    const int stride = WL_WAVES * groups_per_xcd;
+    for (int tile = x0 + grp * WL_WAVES + wave; tile < x1; tile += stride) {
+        int n = 32 * tile + i;
+        const bool nok = n < p.HW;
+        n = nok ? n : p.HW - 1;
+        const _Float16* bh0 = Xh + ((long)g * p.ldn + n) * 8;     // k-group 2 j + g of k-step j: + 2 j ldn entries
+        const _Float16* bl0 = Xl + ((long)g * p.ldn + n) * 8;
+        const long kstep = (long)2 * p.ldn * 8;
+        f32x16 acc[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        half8 bh[D], bl[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            bh[d] = *reinterpret_cast<const half8*>(bh0 + d * kstep);
+            bl[d] = *reinterpret_cast<const half8*>(bl0 + d * kstep);
+        }
+        // A fragments double-buffered by hand and a scheduling barrier per k-step: left alone, hipcc hoists all 144 LDS reads of
+        // the unrolled loop to the top (554 VGPRs spilled)
+        half8 ah[2][RT], al[2][RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            ah[0][t] = *reinterpret_cast<const half8*>(aw + (t * KS) * 2048);
+            al[0][t] = *reinterpret_cast<const half8*>(aw + (t * KS) * 2048 + 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const half8 ch = bh[j % D], cl = bl[j % D];
+            if (j + 1 < KS) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    ah[(j + 1) & 1][t] = *reinterpret_cast<const half8*>(aw + (t * KS + j + 1) * 2048);
+                    al[(j + 1) & 1][t] = *reinterpret_cast<const half8*>(aw + (t * KS + j + 1) * 2048 + 1024);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the next step's fragment reads go out BEFORE this step's MFMAs, which cover them
+#pragma unroll
+            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j & 1][t], ch, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][t], cl, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][t], ch, acc[t], 0, 0, 0);
+            if (j + D < KS) {
+                bh[j % D] = *reinterpret_cast<const half8*>(bh0 + (j + D) * kstep);
+                bl[j % D] = *reinterpret_cast<const half8*>(bl0 + (j + D) * kstep);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue: after the swaps lane (i, g) holds rows 8 g + e (r0..r7) and 16 + 8 g + e (r8..r15) of its pixel column:
+        //      two whole P entries (k-groups 4 T + g and 4 T + 2 + g) per row tile
+        const int vo_lane = nok ? ((g * p.HW + 32 * tile + i) * 16) : WL_OOBV;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            rows_to_kgroups(acc[t]);
+            const int T = slice * RT + t;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                half8 hh, ll;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float val = fmaf(acc[t][8 * q + e], s_acc, Pb[32 * t + 16 * q + 8 * g + e]);
+                    val = act_fn<ACT_GELU_FAST>(val);
+                    const float xs = val * cscale;
+                    const _Float16 a16 = (_Float16)xs;
+                    hh[e] = a16;
+                    ll[e] = (_Float16)(xs - (float)a16);
+                }
+                const int soff = (4 * T + 2 * q) * p.HW * 16;      // k-group 4 T + 2 q (+ g in the lane part)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hh), rsH, vo_lane, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ll), rsL, vo_lane, soff, 0);
+            }
+        }
+    }
+}
+
+template <int KS, int RT, int D>
+hipError_t launch_wl(const ConvStripArgs& a, hipStream_t s) {
+    const int nslice = a.M / (32 * RT);
+    int gpx = 32 / nslice;                      // pixel groups per XCD (32 CUs each)
+    if (gpx < 1) gpx = 1;
+    const int tiles_px = (int)((a.HW + 31) / 32);
+    const int tpx = (tiles_px + 7) / 8;
+    if (gpx * WL_WAVES > tpx) gpx = (tpx + WL_WAVES - 1) / WL_WAVES;   // small fields: no idle workgroups
+    dim3 grid((unsigned)(8 * nslice * gpx * a.nbatch)), block(64 * WL_WAVES);
+    hipLaunchKernelGGL((conv_wl_kernel<KS, RT, D>), grid, block, 0, s, a, nslice, gpx, tpx);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// K: input channels, M: output channels.  GELU + P-format output, no residual, no statistics (the first MLP convolution)
+bool conv_wl_eligible(int K, int M, long HW) {
+    if (K == 384) return M % 96 == 0 && M / 96 <= 32 && (long)M * HW * 2 < 0x7fffff00L;
+    if (K == 256 || K == 128) return M % 64 == 0 && M / 64 <= 32 && (long)M * HW * 2 < 0x7fffff00L;   // two row tiles per workgroup
+    return false;
+}
+
+hipError_t launch_conv_wl(const ConvStripArgs& a, hipStream_t s) {
+    if (!conv_wl_eligible(a.C, a.M, a.HW) || !a.bias || !a.xslot || !a.A || !a.Chi || !a.Clo || !a.cslot || a.R || a.part || a.Cf ||
+        !(a.act == ACT_GELU || a.act == ACT_GELU_FAST))
+        return hipErrorInvalidValue;
+    switch (a.C) {
+        case 384: return launch_wl<24, 3, 4>(a, s);
+        case 256: return launch_wl<16, 2, 4>(a, s);
+        case 128: return launch_wl<8, 2, 4>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ace

@@ -15,6 +15,7 @@ struct Switches {
     bool no_pk_sht = false;        // ACE_NO_PK_SHT: fp32 D, expanded filter operand
     bool no_enc_ws = false;        // ACE_NO_ENC_WS: last encoder convolution on the v3 engine
     int conv_ws_roles = 7;         // ACE_CONV_WS=skip,fc1,fc2|all|none: roles on conv_ws.hip (bit 0 inner skip, 1 fc1, 2 fc2)
+    bool conv_wl = false;          // ACE_CONV_WL=1: fc1 on conv_wl.hip (weights in LDS, unsynchronised waves) instead of conv_ws.hip
 };
 Switches read_switches();
 
@@ -186,7 +187,11 @@ struct ConvStripArgs {
 // statistics per 32-pixel tile (fc2) or per pixel group (inner skip): nstrips32 >= conv_ws_stat_parts()
 bool conv_ws_eligible(int K, int M, long HW, int role, int roles_on = 7);   // role 0 inner skip, 1 fc1, 2 fc2 (-1: any); roles_on: Switches::conv_ws_roles
 hipError_t launch_conv_ws(const ConvStripArgs& a, hipStream_t s);
-int conv_ws_stat_parts(const ConvStripArgs& a);   // statistics partials per row that launch writes (nstrips32 >= this)
+int conv_ws_stat_parts(const ConvStripArgs& a);
+// the first MLP convolution (GELU, planes in / planes out, no residual, no statistics) with the weights in LDS and unsynchronised
+// waves (conv_wl.hip); K in {128, 256, 384}
+bool conv_wl_eligible(int K, int M, long HW);
+hipError_t launch_conv_wl(const ConvStripArgs& a, hipStream_t s);   // statistics partials per row that launch writes (nstrips32 >= this)
 
 // dhconv with the filter streamed once into MFMA B fragments (dhconv_strip.hip).  Rows (m, b), m <= l; K = N = 2 C.
 struct DhconvStripArgs {

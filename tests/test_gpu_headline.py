@@ -92,7 +92,7 @@ def test_dhconv_at_headline_shape_three_implementations(dev, B, monkeypatch):
     assert rel_max(outs["tile"], outs["fp32"]) <= 2e-6
 
 
-@pytest.mark.parametrize("routing,reps", [("ws", 1000), ("tile", 200)])
+@pytest.mark.parametrize("routing,reps", [("ws", 1000), ("tile", 200), ("wl", 200)])
 def test_headline_bitwise_repeatability(dev, headline, routing, reps, monkeypatch):
     """1000 forwards of the headline network on the same input (default routing: every 1x1 convolution of the blocks on
     conv_ws.hip) must be bitwise identical, and right; 200 more with the convolutions on the tile engine.  The
@@ -100,7 +100,8 @@ def test_headline_bitwise_repeatability(dev, headline, routing, reps, monkeypatc
     landing in such a register before the store has read it corrupts a few lanes, rarely and not reproducibly (r02: seen
     with 125 of 25 M plane entries wrong; tools/store_hazard.hip is the minimal reproducer) - a sampled accuracy check can
     miss that, bitwise repeatability cannot."""
-    monkeypatch.setenv("ACE_CONV_WS", "all" if routing == "ws" else "none")
+    monkeypatch.setenv("ACE_CONV_WS", "none" if routing == "tile" else "all")
+    monkeypatch.setenv("ACE_CONV_WL", "1" if routing == "wl" else "0")
     d, cfg, state, x = headline
     net = build_native_net(cfg, state, dev, "f16x3")
     xd = x[:1].to(dev).contiguous()
@@ -119,15 +120,17 @@ def test_headline_bitwise_repeatability(dev, headline, routing, reps, monkeypatc
     assert err <= NET_TOL, err
 
 
-@pytest.mark.parametrize("routing", ["ws", "tile", "mixed"])
+@pytest.mark.parametrize("routing", ["ws", "tile", "mixed", "wl"])
 @pytest.mark.parametrize("C,hw", [(384, (45, 90)), (128, (24, 48)), (256, (20, 40))])
 def test_fused_mlp_shapes_vs_fp64(dev, C, hw, routing, monkeypatch):
     """the block's 1x1 convolutions at C in {128, 256, 384} inside 3-block nets, batch 3, ragged last workgroup, random
     norm gains - per-block taps against the fp64 oracle.  ws: all three on the weight-stationary conv_ws.hip (default);
     tile: all three on the 128 x 128 tile engine; mixed: inner skip and fc2 on conv_ws.hip, fc1 on the tile engine (the
-    statistics partials and the folded operands of the two engines meet)."""
+    statistics partials and the folded operands of the two engines meet); wl: fc1 on conv_wl.hip (weights in LDS), the others
+    on conv_ws.hip."""
     from oracle.sfno import SFNOConfig, SFNOOracle, init_state
-    monkeypatch.setenv("ACE_CONV_WS", {"ws": "all", "tile": "none", "mixed": "skip,fc2"}[routing])
+    monkeypatch.setenv("ACE_CONV_WS", {"ws": "all", "tile": "none", "mixed": "skip,fc2", "wl": "all"}[routing])
+    monkeypatch.setenv("ACE_CONV_WL", "1" if routing == "wl" else "0")
     cfg = SFNOConfig(in_chans=6, out_chans=5, img_shape=hw, embed_dim=C, num_layers=3, operator_type="dhconv")
     state = init_state(cfg, seed=17)
     g = torch.Generator().manual_seed(18)

@@ -785,3 +785,104 @@ def test_windowed_inference_matches_reference_continuous_rollout(dev, how, tmp_p
     assert cs is not None and cs.global_dry_air_mass is not None
     first = run_inference(predict, InferenceData(ic, ForcingWindows(g["forcing"], 1, 1, device=dev)))
     assert torch.equal(cs.global_dry_air_mass, first.stepper_state.corrector_state.global_dry_air_mass)
+
+
+# ---- fused post-step physics (csrc/physics.hip) against the reference corrector's own vectors ----------------------------
+def _physics_case(dev, g, corr_cfg, ocean=None, prescribed=()):
+    """Static buffers laid out as the RolloutEngine lays them out (two steps) + a FusedPhysics over them."""
+    import datetime
+
+    import ace_amd
+    from ace_amd.corrector import AtmosphereCorrectorConfig
+    from ace_amd.physics import FusedPhysics
+    info = ace_amd.DatasetInfo((8, 16), timestep=datetime.timedelta(seconds=g["timestep_seconds"]), lat=g["lat"], lon=g["lon"],
+                               ak=g["ak"], bk=g["bk"])
+    corrector = AtmosphereCorrectorConfig.from_state(corr_cfg).get_corrector(info) if corr_cfg is not None else None
+    prog = sorted(g["gen0"])
+    B, T, H, W = 2, 2, 8, 16
+    HW = H * W
+    out = {n: torch.zeros(B, T, H, W, device=dev) for n in prog}
+    ic = {n: g["input0"][n].reshape(B, 1, H, W).to(dev).contiguous() for n in prog}
+    forcing = {n: torch.stack([g["forcing"][n]] * (T + 1), dim=1).to(dev).contiguous() for n in g["forcing"]}
+
+    def locate_gen(name, s):
+        return (out[name].data_ptr() + 4 * s * HW, T * HW) if name in out else None
+
+    def locate_in(name, s):
+        if name in ic:
+            return (ic[name].data_ptr(), HW) if s == 0 else (out[name].data_ptr() + 4 * (s - 1) * HW, T * HW)
+        return (forcing[name].data_ptr() + 4 * s * HW, (T + 1) * HW) if name in forcing else None
+
+    def locate_next(name, s):
+        return (forcing[name].data_ptr() + 4 * (s + 1) * HW, (T + 1) * HW) if name in forcing else None
+
+    phys = FusedPhysics(corrector, ocean, list(prescribed), B, (H, W), T, gen_names=prog, in_names=prog + list(forcing),
+                        next_names=list(forcing), locate_gen=locate_gen, locate_in=locate_in, locate_next=locate_next, device=dev)
+    return phys, out, (ic, forcing)
+
+
+@pytest.mark.parametrize("name", ["force_positive", "dry_air", "zero_advection", "moisture_precipitation", "moisture_evaporation",
+                                  "moisture_advection_and_precipitation", "moisture_advection_and_evaporation", "energy", "ace2_like"])
+def test_fused_physics_vs_reference_corrector(dev, name):
+    """The four physics kernels on the golden vectors the REFERENCE corrector emitted (tests/golden/make_golden_corrector.py):
+    every option of AtmosphereCorrectorConfig (fme/core/corrector/atmosphere.py:223-398), two consecutive steps (the dry-air
+    reference mass is seeded on the first, carried to the second).  fp32 per-column arithmetic in the reference's operation
+    order, fp64 global sums: each field within 2e-6 of its maximum (the torch restatement is held to 1e-6 on the CPU)."""
+    from ace_amd import _lib
+    from test_corrector_cpu import CONFIGS
+    g = load_golden("gen_corrector.pt")
+    phys, out, keep = _physics_case(dev, g, CONFIGS[name])
+    exp = g["expected"][name]
+    st = _lib.current_stream()
+    phys.reset(st)
+    for s, gen in enumerate((g["gen0"], g["gen1"])):
+        for n, v in gen.items():
+            out[n][:, s].copy_(v.to(dev))
+        phys.apply(s, st)
+        torch.cuda.synchronize()
+        for k, want in exp[f"step{s}"].items():
+            got = out[k][:, s].cpu()
+            scale = float(want.abs().max()) or 1.0
+            assert float((got - want).abs().max()) / scale <= 2e-6, (name, s, k, float((got - want).abs().max()) / scale)
+        for k, v in gen.items():          # fields the reference leaves alone are untouched, bit for bit
+            if k not in exp[f"step{s}"]:
+                assert torch.equal(out[k][:, s].cpu(), v), (name, s, k)
+    mass = phys.get_reference(st)
+    if exp["global_dry_air_mass"] is None:
+        assert mass is None
+    else:
+        torch.testing.assert_close(mass.cpu().reshape(-1), exp["global_dry_air_mass"].reshape(-1), rtol=1e-6, atol=0.0)
+    # determinism: the same two steps again give the same bits
+    first = {k: v.clone() for k, v in out.items()}
+    phys.reset(st)
+    for s, gen in enumerate((g["gen0"], g["gen1"])):
+        for n, v in gen.items():
+            out[n][:, s].copy_(v.to(dev))
+        phys.apply(s, st)
+    torch.cuda.synchronize()
+    assert all(torch.equal(out[k], first[k]) for k in out)
+
+
+@pytest.mark.parametrize("interpolate", [False, True])
+def test_fused_physics_ocean_and_prescribed(dev, interpolate):
+    """prescribed SST (fme/core/ocean.py:167-215; half-to-even rounding of the mask) and prescribed prognostics
+    (single_module.py:700-716) in the fused kernel: bitwise against the reference's vectors."""
+    from ace_amd import _lib
+    from ace_amd.ocean import OceanConfig
+    from ace_amd.physics import FusedPhysics
+    o = load_golden("gen_corrector.pt")["ocean"]
+    ocean = OceanConfig(surface_temperature_name="sst", ocean_fraction_name="frac", interpolate=interpolate).build(
+        ["sst", "frac", "q"], ["sst", "q"])
+    B, H, W = o["gen"]["sst"].shape
+    HW = H * W
+    out = {k: v.reshape(B, 1, H, W).to(dev).contiguous().clone() for k, v in o["gen"].items()}
+    nxt = {k: torch.stack([v, v], dim=1).to(dev).contiguous() for k, v in o["target"].items()}
+    nxt["q"] = torch.stack([o["gen"]["q"] - 2.0, o["gen"]["q"] + 1.0], dim=1).to(dev).contiguous()   # a prescribed prognostic: step s + 1's data
+    phys = FusedPhysics(None, ocean, ["q"], B, (H, W), 1, gen_names=list(out), in_names=list(out),
+                        next_names=list(nxt), locate_gen=lambda n, s: (out[n].data_ptr(), HW) if n in out else None,
+                        locate_in=lambda n, s: None,
+                        locate_next=lambda n, s: (nxt[n].data_ptr() + 4 * HW, 2 * HW) if n in nxt else None, device=dev)
+    phys.apply(0, _lib.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out["sst"][:, 0].cpu(), o["expected"][interpolate]["sst"])
+    assert torch.equal(out["q"][:, 0].cpu(), o["gen"]["q"] + 1.0)
