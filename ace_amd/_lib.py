@@ -70,6 +70,7 @@ SIGNATURES = {
     "ace_conv1x1": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p]),
     "ace_conv1x1_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p]),
     "ace_mlp_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_long, c_int, c_void_p]),
+    "ace_dhconv_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ace_instance_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_long, c_void_p]),
     "ace_conditional_layer_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                                            c_int, c_int, c_int, c_long, c_void_p]),

@@ -488,6 +488,54 @@ extern "C" int ace_mlp_f16x3(const float* x, const float* w1, const float* b1, c
     return ACE_OK;
 }
 
+// _contract_dhconv (fme/ace/models/modulus/contractions.py:183-195): einsum("bixy,iox->boxy") on complex coefficients, on the
+// kernel the network uses (dhconv_strip.hip: compensated fp16, filter streamed once).  Operator-level entry for tests and
+// micro-benchmarks: converts to the internal layouts, prepares the filter planes on every call and synchronises.
+extern "C" int ace_dhconv_f16x3(const float* coeffs, const float* weight, float* out, int n, int c, int L, int Mm, void* stream) {
+    if (!coeffs || !weight || !out || n <= 0 || c <= 0 || L <= 0 || Mm <= 0) return fail(ACE_ERR_INVALID, "ace_dhconv_f16x3: bad argument");
+    if (c % 128 != 0) return fail(ACE_ERR_INVALID, "ace_dhconv_f16x3: needs channels % 128 == 0");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long N2 = 2L * n * c;
+    const size_t spec = (size_t)L * Mm * N2;
+    DevBuf D, Dp, E, Wh, Wl, slots;
+    HIP_TRY(D.alloc(spec, true));
+    HIP_TRY(Dp.alloc(spec, true));          // hi | lo planes: two halves per element = one float
+    HIP_TRY(E.alloc(spec, true));           // rows m > l are never written: they stay zero
+    HIP_TRY(slots.alloc(2 * AMAX_SHARDS, true));
+    const size_t wh = (size_t)L * 2 * c * c;
+    HIP_TRY(Wh.alloc((wh + 1) / 2, false));
+    HIP_TRY(Wl.alloc((wh + 1) / 2, false));
+    unsigned* dslot = reinterpret_cast<unsigned*>(slots.p);
+    unsigned* wslot = dslot + AMAX_SHARDS;
+    HIP_TRY(launch_ref_to_spec(coeffs, D.p, n, c, L, Mm, s));
+    HIP_TRY(launch_absmax(D.p, (long)spec, dslot, s));
+    HIP_TRY(launch_absmax(weight, (long)c * c * L * 2, wslot, s));
+    unsigned bits[2 * AMAX_SHARDS];
+    HIP_TRY(hipMemcpyAsync(bits, slots.p, sizeof(bits), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    float dmx = 0.f, wmx = 0.f;
+    for (int k = 0; k < AMAX_SHARDS; ++k) {
+        float f; std::memcpy(&f, &bits[k], 4); dmx = std::max(dmx, f);
+        std::memcpy(&f, &bits[AMAX_SHARDS + k], 4); wmx = std::max(wmx, f);
+    }
+    auto pow2 = [](float mx, int top) { int e = 0; if (mx > 0.f && std::isfinite(mx)) { (void)std::frexp(mx, &e); e = top - e; } return std::ldexp(1.0f, e); };
+    const float dscale = pow2(dmx, 12), wscale = pow2(wmx, 10);   // the kernel derives 2^(12 - exponent) from the slot itself
+    HIP_TRY(launch_split_f16(D.p, N2, Dp.p, reinterpret_cast<_Float16*>(Dp.p) + spec, N2, (long)L * Mm, (int)N2, dscale, s));
+    HIP_TRY(launch_pack_dhconv_f16c(weight, Wh.p, Wl.p, c, c, L, wscale, s));
+    DhconvStripArgs ds;
+    ds.Dhi = reinterpret_cast<const _Float16*>(Dp.p); ds.Dlo = ds.Dhi + spec;
+    ds.sD = (long)Mm * N2; ds.amax = dslot;
+    ds.Whi = reinterpret_cast<const _Float16*>(Wh.p); ds.Wlo = reinterpret_cast<const _Float16*>(Wl.p);
+    ds.sW = (long)2 * c * c; ds.bscale = wscale;
+    ds.E = E.p; ds.sE = (long)Mm * N2;
+    ds.C = c; ds.L = L; ds.Mrows = Mm * n; ds.trimul = n;
+    if (!dhconv_strip_eligible(ds)) return fail(ACE_ERR_INVALID, "ace_dhconv_f16x3: shape not covered by dhconv_strip.hip");
+    HIP_TRY(launch_dhconv_strip(ds, s));
+    HIP_TRY(launch_spec_to_ref(E.p, out, n, c, L, Mm, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return ACE_OK;
+}
+
 extern "C" int ace_instance_norm(const float* x, const float* gamma, const float* beta, float eps, float* y, int n,
                                  int c, long hw, void* stream) {
     if (!x || !y || n <= 0 || c <= 0 || hw <= 0) return fail(ACE_ERR_INVALID, "ace_instance_norm: bad argument");

@@ -5,7 +5,8 @@
 // the weights.  The 128 x 128 tile engine moves each weight through L2 -> LDS once per 128-row tile and each coefficient
 // once per 128-column tile (1.1 GB of LDS-DMA traffic per launch, 465 MB of HBM reads for 262 MB of operands: r02 PMC).
 // Here a workgroup owns (degree l, 128 output channels): each of its four waves holds 32 output channels, real AND imaginary
-// part, for ALL rows of the degree (up to 192 = 6 strips of 32, 12 accumulator tiles per wave):
+// part, for ALL rows of the degree (up to 192 = 6 strips of 32, 12 accumulator tiles per wave; degrees with more rows - batch
+// > 1, the 0.25-degree grid - are cut into 192-row chunks, one workgroup each):
 //   * the weights are the MFMA B operand: their stored form (k-packed "P format", compact complex: Wr | Wi per l) IS the
 //     fragment of a lane, so they go global -> registers with coalesced 16-byte loads, two stages ahead, and never touch LDS;
 //     a stage is 32 rows of Wr and the same 32 rows of Wi, each used for two products (with D_re and with D_im), so every
@@ -39,9 +40,9 @@ MDEV half8 neg8(half8 v) {
     return __builtin_bit_cast(half8, u);
 }
 
-// NS: active 32-row strips (1 .. 6)
+// NS: active 32-row strips (1 .. 6) of this workgroup's row chunk [row0, row0 + rows) of degree l
 template <int NS>
-MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const int j, const int rows) {
+MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const int j, const int row0, const int rows) {
     constexpr int NSTG = 3;                       // ring depth (stages)
     constexpr int STAGE = NS * 8192;              // bytes: NS strips x 2 slices (re, im) x (2 row pieces x 2 planes) x 1 KiB
     constexpr int NA = 2 * NS;                    // A pieces per wave per stage
@@ -58,8 +59,8 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
 
     // ---- A pieces: piece q of a stage = (strip s, slice sl, row half rh, plane pl) = 8 s + 4 sl + 2 rh + pl; this wave issues
     //      (rh, pl) = (wave / 2, wave % 2) of every (s, sl).  Lane L fetches the XOR-swizzled 16-byte slot of row L / 4
-    const _Float16* Dh = p.Dhi + (long)l * p.sD;
-    const _Float16* Dl = p.Dlo + (long)l * p.sD;
+    const _Float16* Dh = p.Dhi + (long)l * p.sD + (long)row0 * K2;
+    const _Float16* Dl = p.Dlo + (long)l * p.sD + (long)row0 * K2;
     const _Float16* asrc[NA];
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
@@ -191,7 +192,7 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
     // first, the stores last and from the accumulator registers themselves, which nothing writes afterwards.  With the stores
     // first and their data in temporaries, 7 of 1000 forwards of the 1-degree network came out wrong (r02): a load issued
     // later returned into a register whose store had not read it yet.
-    float* E = p.E + (long)l * p.sE;
+    float* E = p.E + (long)l * p.sE + (long)row0 * K2;
     float vmax = 0.f;
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -233,26 +234,32 @@ __global__ __launch_bounds__(256, 1) void dhconv_strip_kernel(DhconvStripArgs p)
     const int ncg = p.C / 128;
     const int l = p.L - 1 - (int)(blockIdx.x / ncg);
     const int j = blockIdx.x % ncg;
-    const int rows = (l + 1) * p.trimul < p.Mrows ? (l + 1) * p.trimul : p.Mrows;
+    const int rows_l = (l + 1) * p.trimul < p.Mrows ? (l + 1) * p.trimul : p.Mrows;
+    // degrees with more than 192 rows (a batch of 2 at the 1-degree grid: 362; the 0.25-degree grid: 721) are cut into chunks
+    // of 192 rows, one workgroup each (blockIdx.y); the filter slice of a (degree, column group) is then streamed once per
+    // chunk - the later ones from L2 / MALL (393 KB per slice)
+    const int row0 = (int)blockIdx.y * 192;
+    if (row0 >= rows_l) return;
+    const int rows = rows_l - row0 < 192 ? rows_l - row0 : 192;
     // active 32-row strips: 1 .. 6 (row granularity 32: 14 % fewer MFMAs than strip pairs at the 1-degree shape, and the
     // workgroups' sizes - there are only 2.1 per CU - balance better)
-    if (rows <= 32) dhconv_body<1>(p, smem, l, j, rows);
-    else if (rows <= 64) dhconv_body<2>(p, smem, l, j, rows);
-    else if (rows <= 96) dhconv_body<3>(p, smem, l, j, rows);
-    else if (rows <= 128) dhconv_body<4>(p, smem, l, j, rows);
-    else if (rows <= 160) dhconv_body<5>(p, smem, l, j, rows);
-    else dhconv_body<6>(p, smem, l, j, rows);
+    if (rows <= 32) dhconv_body<1>(p, smem, l, j, row0, rows);
+    else if (rows <= 64) dhconv_body<2>(p, smem, l, j, row0, rows);
+    else if (rows <= 96) dhconv_body<3>(p, smem, l, j, row0, rows);
+    else if (rows <= 128) dhconv_body<4>(p, smem, l, j, row0, rows);
+    else if (rows <= 160) dhconv_body<5>(p, smem, l, j, row0, rows);
+    else dhconv_body<6>(p, smem, l, j, row0, rows);
 }
 
 }  // namespace
 
 bool dhconv_strip_eligible(const DhconvStripArgs& a) {
-    return a.C % 128 == 0 && a.C >= 128 && a.Mrows <= 192 && a.L >= 1 && a.Dhi && a.Dlo && a.Whi && a.Wlo && a.E && a.amax;
+    return a.C % 128 == 0 && a.C >= 128 && a.Mrows >= 1 && (a.Mrows + 191) / 192 <= 65535 && a.L >= 1 && a.Dhi && a.Dlo && a.Whi && a.Wlo && a.E && a.amax;
 }
 
 hipError_t launch_dhconv_strip(const DhconvStripArgs& a, hipStream_t s) {
     if (!dhconv_strip_eligible(a)) return hipErrorInvalidValue;
-    dim3 grid((unsigned)(a.L * (a.C / 128))), block(256);
+    dim3 grid((unsigned)(a.L * (a.C / 128)), (unsigned)((a.Mrows + 191) / 192)), block(256);
     hipLaunchKernelGGL(dhconv_strip_kernel, grid, block, 0, s, a);
     return hipGetLastError();
 }

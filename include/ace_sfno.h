@@ -85,6 +85,13 @@ int ace_conv1x1_f16x3(const float* x, const float* weight, const float* bias, fl
 int ace_mlp_f16x3(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, int n,
                   int cin, int hid, int cout, long hw, int act, void* stream);
 
+/* _contract_dhconv (fme/ace/models/modulus/contractions.py:183-195): out[b,o,l,m] = sum_i coeffs[b,i,l,m] * weight[i,o,l]
+ * on complex values; coeffs / out (n, c, L, Mm) complex64 interleaved, weight (c, c, L, 2).  Runs the network's own kernel
+ * (compensated fp16 MFMA, filter streamed once; entries with m > l are not contracted and come out zero, as they are zero
+ * in every SHT output).  Needs c % 128 == 0.  Test / micro-benchmark entry: prepares the filter planes on every call and
+ * synchronises. */
+int ace_dhconv_f16x3(const float* coeffs, const float* weight, float* out, int n, int c, int L, int Mm, void* stream);
+
 /* nn.InstanceNorm2d(C, eps, affine) (sfnonet.py:593-601) on (n, C, hw); gamma/beta may be NULL. */
 int ace_instance_norm(const float* x, const float* gamma, const float* beta, float eps, float* y, int n, int c,
                       long hw, void* stream);

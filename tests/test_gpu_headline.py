@@ -248,3 +248,24 @@ def test_quarter_degree_mid_size_net(dev):
         err = rel_max(out, ref)
         print(f"0.25 degree C=32 x 2 blocks, {prec}: rel err vs fp64 {err:.3e}")
         assert err <= NET_TOL, prec
+
+
+@pytest.mark.parametrize("n,c,L,Mm", [(1, 384, 180, 181), (2, 384, 180, 181), (3, 128, 24, 25), (5, 256, 40, 41)])
+def test_dhconv_op_vs_fp64_einsum(dev, n, c, L, Mm):
+    """The spectral filter contraction at the operator level through the C ABI (ace_dhconv_f16x3 -> dhconv_strip.hip) against
+    the reference's einsum (fme/ace/models/modulus/contractions.py:183-195: "bixy,iox->boxy", complex) in fp64 - the headline
+    operand shape (rows = 181 n, K = N = 768, 180 degrees) with one and with two samples (two 192-row chunks per degree), and
+    two small ragged shapes.  Coefficients with m > l are zero, as every SHT output has them."""
+    from ace_amd import _lib
+    g = torch.Generator().manual_seed(100 + n + c)
+    x = torch.randn(n, c, L, Mm, 2, generator=g)
+    tri = (torch.arange(Mm)[None, :] <= torch.arange(L)[:, None]).float()           # (L, Mm): m <= l
+    x = x * tri[None, None, :, :, None]
+    w = torch.randn(c, c, L, 2, generator=g) * (1.0 / c)
+    ref = torch.einsum("bixy,iox->boxy", torch.view_as_complex(x.double()), torch.view_as_complex(w.double()))
+    xd, wd = x.to(dev).contiguous(), w.to(dev).contiguous()
+    out = torch.empty_like(xd)
+    _lib.check(_lib.lib().ace_dhconv_f16x3(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(out), n, c, L, Mm, _lib.current_stream()))
+    got = torch.view_as_complex(out.cpu().double())
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err <= 2e-6, err
