@@ -1,5 +1,5 @@
 // First MLP convolution (layers.py:117-124: GELU(W1 . x + b1), the widest of the block's 1x1 convolutions: M = 768 rows) with
-// the WEIGHTS in LDS and NO synchronisation in the main loop, for gfx950:
+// the WEIGHTS in LDS, NO synchronisation in the main loop and the epilogue riding in the MFMA stream, for gfx950:
 //     U = GELU( W1f . P(t) + b1f )        W1f: (M x K) norm-folded weight, t: K x HW as P-format fp16 hi/lo planes, U likewise
 // conv_ws.hip keeps the weights in registers and streams the activation through an LDS ring shared by eight waves: a barrier,
 // an accumulator exchange between the two contraction halves and 6 LDS-DMA issues per wave and 36-MFMA stage, all in lock
@@ -11,8 +11,11 @@
 //   * every wave works alone: for its pixel tile it loads the B fragments straight from the P-format planes (a lane's 16
 //     bytes ARE its fragment: coalesced global_load_dwordx4, no LDS, no DMA), a few k-steps ahead, and feeds each to 3 RT
 //     MFMAs on RT independent accumulators; then the GELU / split epilogue of its tile and 16-byte P-entry stores;
-//   * 12 waves per workgroup (3 per SIMD, <= 168 registers each): while one wave is in its epilogue (VALU) the others keep
-//     the matrix pipe busy - there is no barrier to align them;
+//   * the GELU / split epilogue of tile n - 1 is cut into quarters of a value (~7 VALU each) and one quarter follows each MFMA
+//     of tile n: on gfx950 vector-ALU work hides behind matrix work only inside ONE wave's instruction stream (a second wave's
+//     VALU instructions do not issue while the first keeps the matrix pipe fed: profiles/r03_mfma_valu_overlap_probe.txt);
+//     the first version of this kernel (12 waves, epilogue after the MFMAs) ran at conv_ws.hip's 134 us;
+//   * 8 waves per workgroup (2 per SIMD, <= 256 registers: two sets of accumulators), no barrier to align them;
 //   * the 8 row slices (M = 768) that need the same pixel tiles sit on one XCD and walk that XCD's tile range in the same
 //     order, so the activation comes from HBM once and from L2 otherwise; 8 slices x 4 pixel groups = the XCD's 32 CUs.
 #include <hip/hip_runtime.h>
@@ -24,7 +27,7 @@
 namespace ace {
 namespace {
 
-constexpr int WL_WAVES = 12;
+constexpr int WL_WAVES = 8;            // two per SIMD, <= 256 registers each
 constexpr int WL_OOBV = 0x7fffff00;
 
 // KS: k16-steps (K / 16), RT: 32-row tiles per workgroup, D: k-steps of B-fragment read-ahead
@@ -48,6 +51,7 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
     const int x0 = xcd * tpx;
     const int x1 = x0 + tpx < tiles_px ? x0 + tpx : tiles_px;
 
+    MT(0);
     const unsigned raw_x = slot_load(p.xslot + lane);
     const unsigned raw_a = p.aslot ? slot_load(p.aslot + lane) : 0u;
     const unsigned raw_c = p.cinb ? slot_load(p.cinb + lane) : 0u;
@@ -70,6 +74,8 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
     const float cscale = ldexpf(1.0f, pow2_exponent_for(cbound));
     if (tid == 0) atomicMax(p.cslot + (blockIdx.x & 63), __float_as_uint(cbound));
     __syncthreads();
+    MT(1);
+    int tev = 2;   // (measurement builds: timeline stamps of wave 0 - tile start, k-loop done)
 
     const _Float16* Xh = p.Xhi + (long)smp * p.sX;
     const _Float16* Xl = p.Xlo + (long)smp * p.sX;
@@ -78,9 +84,65 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
     const auto rsL = __builtin_amdgcn_make_buffer_rsrc(p.Clo + (long)smp * p.sCp, 0, pbytes, 0x00020000);
     const char* aw = smem + lane * 16;
 
-    // ---- this wave's pixel tiles: x0 + (grp * 12 + wave) + 12 groups_per_xcd * n
+    // ---- the finished tile whose epilogue rides in the current tile's MFMA stream: rows in k-group order (rows_to_kgroups),
+    //      lane (i, g) holds rows 8 g + e (r0..r7) and 16 + 8 g + e (r8..r15) of its pixel column: two whole P entries
+    //      (k-groups 4 T + g and 4 T + 2 + g) per row tile.  The first tile carries a dummy (stores suppressed).
+    f32x16 prev[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prev[t][r] = 0.f;
+    int prev_vo = WL_OOBV;
+    GeluStage gst = {0.f, 0.f, 0.f, 0.f};
+    half8 hh, ll;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { hh[e] = (_Float16)0.f; ll[e] = (_Float16)0.f; }
+    float bias_next = Pb[8 * g];
+    // quarter `ch` of value v = 16 t + 8 q + e of the finished tile (gfx950 hides vector-ALU work behind matrix work only when
+    // the two alternate in ONE wave's instruction stream, ~6 VALU per MFMA: profiles/r03_mfma_valu_overlap_probe.txt)
+    auto chunk = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int v = k / 4, ch = k % 4, t = v / 16, q = (v % 16) / 8, e = v % 8;
+        if constexpr (ch == 0) {
+            gelu_stage0(gst, fmaf(prev[t][8 * q + e], s_acc, bias_next));
+            asm volatile("" : "+v"(gst.val), "+v"(gst.u), "+v"(gst.t));     // pinned to this slot (pure arithmetic would
+        } else if constexpr (ch == 1) {                                    //  otherwise sink to its last use)
+            gelu_stage1(gst);
+            constexpr int vn = (v + 1) % (16 * RT);                          // bias of the next value, one value ahead
+            bias_next = Pb[32 * (vn / 16) + 16 * ((vn % 16) / 8) + 8 * g + vn % 8];
+            asm volatile("" : "+v"(gst.q));
+        } else if constexpr (ch == 2) {
+            gst.val = gelu_stage2(gst);
+            asm volatile("" : "+v"(gst.val));
+        } else {
+            const float xs = gst.val * cscale;
+            const _Float16 a16 = (_Float16)xs;
+            hh[e] = a16;
+            ll[e] = (_Float16)(xs - (float)a16);
+            if constexpr (e == 7) {   // the entry is complete: k-group 4 T + 2 q (+ g in the lane part of the offset)
+                const int soff = (4 * (slice * RT + t) + 2 * q) * p.HW * 16;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hh), rsH, prev_vo, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ll), rsL, prev_vo, soff, 0);
+            }
+            asm volatile("" : "+v"(hh), "+v"(ll));
+        }
+    };
+    constexpr int NCH = 4 * 16 * RT;     // chunks per tile
+    constexpr int NM = 9 * KS;           // MFMA slots per tile (9 = 3 products x RT at RT = 3; see below)
+    static_assert(RT == 3 || RT == 2, "slot arithmetic below");
+    constexpr int MPS = 3 * RT;          // MFMAs per k-step
+    auto slot = [&](auto mc) {           // what rides behind MFMA m of the tile
+        constexpr int m = decltype(mc)::value;
+        constexpr int NMT = MPS * KS;
+        static_for<(m * NCH) / NMT, ((m + 1) * NCH) / NMT>([&](auto kc) { chunk(kc); });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    (void)NM;
+
+    // ---- this wave's pixel tiles: x0 + (grp * 8 + wave) + 8 groups_per_xcd * n
     const int stride = WL_WAVES * groups_per_xcd;
     for (int tile = x0 + grp * WL_WAVES + wave; tile < x1; tile += stride) {
+        MT(tev);
         int n = 32 * tile + i;
         const bool nok = n < p.HW;
         n = nok ? n : p.HW - 1;
@@ -98,18 +160,18 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
             bh[d] = *reinterpret_cast<const half8*>(bh0 + d * kstep);
             bl[d] = *reinterpret_cast<const half8*>(bl0 + d * kstep);
         }
-        // A fragments double-buffered by hand and a scheduling barrier per k-step: left alone, hipcc hoists all 144 LDS reads of
-        // the unrolled loop to the top (554 VGPRs spilled)
+        // A fragments double-buffered by hand and scheduling barriers: left alone, hipcc hoists all the LDS reads of the
+        // unrolled loop to the top (554 VGPRs spilled in the first version)
         half8 ah[2][RT], al[2][RT];
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             ah[0][t] = *reinterpret_cast<const half8*>(aw + (t * KS) * 2048);
             al[0][t] = *reinterpret_cast<const half8*>(aw + (t * KS) * 2048 + 1024);
         }
-#pragma unroll
-        for (int j = 0; j < KS; ++j) {
+        static_for<0, KS>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
             const half8 ch = bh[j % D], cl = bl[j % D];
-            if (j + 1 < KS) {
+            if constexpr (j + 1 < KS) {
 #pragma unroll
                 for (int t = 0; t < RT; ++t) {
                     ah[(j + 1) & 1][t] = *reinterpret_cast<const half8*>(aw + (t * KS + j + 1) * 2048);
@@ -117,43 +179,39 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
                 }
             }
             __builtin_amdgcn_sched_barrier(0);   // the next step's fragment reads go out BEFORE this step's MFMAs, which cover them
-#pragma unroll
-            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j & 1][t], ch, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][t], cl, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][t], ch, acc[t], 0, 0, 0);
-            if (j + D < KS) {
-                bh[j % D] = *reinterpret_cast<const half8*>(bh0 + (j + D) * kstep);
-                bl[j % D] = *reinterpret_cast<const half8*>(bl0 + (j + D) * kstep);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- epilogue: after the swaps lane (i, g) holds rows 8 g + e (r0..r7) and 16 + 8 g + e (r8..r15) of its pixel column:
-        //      two whole P entries (k-groups 4 T + g and 4 T + 2 + g) per row tile
-        const int vo_lane = nok ? ((g * p.HW + 32 * tile + i) * 16) : WL_OOBV;
+            static_for<0, RT>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j & 1][t], ch, acc[t], 0, 0, 0);
+                slot(std::integral_constant<int, MPS * j + t>{});
+            });
+            static_for<0, RT>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][t], cl, acc[t], 0, 0, 0);
+                slot(std::integral_constant<int, MPS * j + RT + t>{});
+            });
+            static_for<0, RT>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][t], ch, acc[t], 0, 0, 0);
+                if constexpr (t == RT - 1 && j + D < KS) {   // this k-step's B registers are free: the fragment of step j + D
+                    bh[j % D] = *reinterpret_cast<const half8*>(bh0 + (j + D) * kstep);
+                    bl[j % D] = *reinterpret_cast<const half8*>(bl0 + (j + D) * kstep);
+                }
+                slot(std::integral_constant<int, MPS * j + 2 * RT + t>{});
+            });
+        });
+        MT(tev + 1);
+        tev += 2;
+        // ---- this tile becomes the finished one
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             rows_to_kgroups(acc[t]);
-            const int T = slice * RT + t;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                half8 hh, ll;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float val = fmaf(acc[t][8 * q + e], s_acc, Pb[32 * t + 16 * q + 8 * g + e]);
-                    val = act_fn<ACT_GELU_FAST>(val);
-                    const float xs = val * cscale;
-                    const _Float16 a16 = (_Float16)xs;
-                    hh[e] = a16;
-                    ll[e] = (_Float16)(xs - (float)a16);
-                }
-                const int soff = (4 * T + 2 * q) * p.HW * 16;      // k-group 4 T + 2 q (+ g in the lane part)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hh), rsH, vo_lane, soff, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ll), rsL, vo_lane, soff, 0);
-            }
+            prev[t] = acc[t];
         }
+        prev_vo = nok ? ((g * p.HW + 32 * tile + i) * 16) : WL_OOBV;
     }
+    // ---- the last tile's epilogue, on its own
+    static_for<0, NCH>([&](auto kc) { chunk(kc); });
+    MT(tev);
 }
 
 template <int KS, int RT, int D>
@@ -170,6 +228,10 @@ hipError_t launch_wl(const ConvStripArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef ACE_X_TRACE   // measurement builds only (tools/trace_wl.py): the s_memtime stamps of wave 0 of workgroup ACE_X_TRACE
+extern "C" int ace_debug_trace(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mlp_trace), sizeof(mlp_trace)); }
+#endif
 
 // K: input channels, M: output channels.  GELU + P-format output, no residual, no statistics (the first MLP convolution)
 bool conv_wl_eligible(int K, int M, long HW) {

@@ -34,6 +34,9 @@ constexpr int WS_OOBV = 0x7fffff00;   // buffer offset beyond every resource of 
 #ifndef ACE_WS_ACC2
 #define ACE_WS_ACC2 0     // modes (bit 0 inner skip, bit 1 fc1) whose MFMAs alternate between two accumulators (no dependent-issue stalls)
 #endif
+#ifndef ACE_WS_FINE
+#define ACE_WS_FINE 1     // GELU modes: the epilogue of the previous tile goes into the MFMA stream a quarter of a value (~7 VALU) per
+#endif                    // MFMA instead of a whole value (~30 VALU) per k-step
 #ifndef ACE_WS_VSPAN
 #define ACE_WS_VSPAN 8    // interleaved epilogue: its eight values are spread over the first VSPAN twelfths of the stage
 #endif
@@ -278,6 +281,43 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
             }
         }
     };
+    // quarter `ch` of value e (GELU modes): 0 scale / bias / residual + first GELU stage, 1 second stage, 2 last stage +
+    // statistics, 3 hi / lo split
+    GeluStage gst = {0.f, 0.f, 0.f, 0.f};
+    // bias of the value about to be finished: read from the LDS table one value ahead (in the previous value's polynomial
+    // quarter), so that no LDS latency sits in front of an MFMA
+    float bias_next = INTER ? Pb[row0 + 8 * g] : 0.f;
+    auto epi_chunk = [&](auto ec, auto cc, const TileCtx& c, EpiOut& o) {
+        constexpr int e = decltype(ec)::value, ch = decltype(cc)::value;
+        if constexpr (ch == 0) {
+            float val = fmaf(own[e] + (e < 4 ? pa[e & 3] : pb[e & 3]), s_acc, bias_next);
+            if (RES) val = val + res[e];
+            gelu_stage0(gst, val);
+            asm volatile("" : "+v"(gst.val), "+v"(gst.u), "+v"(gst.t));   // pinned to this slot (pure arithmetic would otherwise
+        } else if constexpr (ch == 1) {                                  //  sink to its last use)
+            gelu_stage1(gst);
+            bias_next = Pb[row0 + 8 * c.g + ((e + 1) & 7)];
+            asm volatile("" : "+v"(gst.q));
+        } else if constexpr (ch == 2) {
+            const float val = gelu_stage2(gst);
+            gst.val = val;
+            if (RSTATS) {
+                const bool ok = c.vo_p != WS_OOBV;   // a stored pixel of a live tile
+                rsm[e] += ok ? val : 0.f;
+                rsq[e] = ok ? fmaf(val, val, rsq[e]) : rsq[e];
+                rmn[e] = ok ? fminf(rmn[e], val) : rmn[e];
+                rmx[e] = ok ? fmaxf(rmx[e], val) : rmx[e];
+                asm volatile("" : "+v"(rsm[e]), "+v"(rsq[e]), "+v"(rmn[e]), "+v"(rmx[e]));
+            }
+            asm volatile("" : "+v"(gst.val));
+        } else {
+            const float xs = gst.val * cscale;
+            const _Float16 a16 = (_Float16)xs;
+            o.hh8[e] = a16;
+            o.ll8[e] = (_Float16)(xs - (float)a16);
+            asm volatile("" : "+v"(o.hh8), "+v"(o.ll8));
+        }
+    };
     auto epilogue = [&](const int pt, const bool live, EpiOut& o) {   // all of it at once
         const TileCtx c = tile_ctx(pt, live);
         static_for<0, 9>([&](auto kc) { epi_item(kc, c, o); });
@@ -347,7 +387,28 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
             pipelined_steps<KSW, FDEPTH>(sl, [&](auto ss, const Frag& f) {
                 constexpr int st = decltype(ss)::value;
                 constexpr int j = q * KSW + st;
-                if constexpr (!ACC2) {
+                constexpr bool FINE = INTER && ACE_WS_FINE && GELU && !F32 && !(STATS && !RSTATS);
+                if constexpr (FINE) {
+                    // 33 epilogue chunks (8 values x 4 quarters, then the stores) over the 3 KSW MFMA slots of the stage, a
+                    // scheduling barrier per slot: MFMA, ~7 VALU, MFMA, ~7 VALU, ...
+                    constexpr int NSL = 3 * KSW;
+                    auto slot = [&](auto sc) {
+                        constexpr int sl_ = decltype(sc)::value;
+                        static_for<(sl_ * 33) / NSL, ((sl_ + 1) * 33) / NSL>([&](auto kc) {
+                            constexpr int k = decltype(kc)::value;
+                            if constexpr (k < 32) epi_chunk(std::integral_constant<int, k / 4>{}, std::integral_constant<int, k % 4>{}, ctx, eo);
+                            else epi_item(std::integral_constant<int, 8>{}, ctx, eo);
+                        });
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], f.h, v, 0, 0, 0);
+                    slot(std::integral_constant<int, 3 * st>{});
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], f.l, v, 0, 0, 0);
+                    slot(std::integral_constant<int, 3 * st + 1>{});
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], f.h, v, 0, 0, 0);
+                    if constexpr (st < PW) piece(u + 1, st);   // the pieces of the next stage, one per k-step from the first on
+                    slot(std::integral_constant<int, 3 * st + 2>{});
+                } else if constexpr (!ACC2) {
                     v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], f.h, v, 0, 0, 0);
                     v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], f.l, v, 0, 0, 0);
                     v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], f.h, v, 0, 0, 0);
@@ -360,7 +421,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
                     v = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], f.l, v, 0, 0, 0);
                     v2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], f.h, v2, 0, 0, 0);
                 }
-                if constexpr (INTER) {
+                if constexpr (INTER && !(ACE_WS_FINE && GELU && !F32 && !(STATS && !RSTATS))) {
                     if constexpr (st < PW) piece(u + 1, st);   // the pieces of the next stage, one per k-step from the first on
                     static_for<0, 8>([&](auto kc) {
                         constexpr int e = decltype(kc)::value;

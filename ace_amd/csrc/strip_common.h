@@ -58,6 +58,33 @@ MDEV float fast_erf(float x) {   // kernels.hip: max abs error 1.1e-7
     q = q * t;
     return copysignf(1.0f - __builtin_amdgcn_exp2f(-q), x);
 }
+// The same GELU in three stages (identical operations in identical order), for epilogues that are spread over an MFMA stream
+// a few instructions at a time: gfx950 hides vector-ALU work behind matrix work only when the two alternate in ONE wave's
+// instruction stream, about 6 VALU per MFMA (profiles/r03_mfma_valu_overlap_probe.txt)
+struct GeluStage { float val, u, t, q; };
+MDEV void gelu_stage0(GeluStage& g, float val) {
+    g.val = val;
+    g.u = val * 0.70710678118654752440f;
+    g.t = fminf(fabsf(g.u), 4.0f);
+}
+MDEV void gelu_stage1(GeluStage& g) {
+    float q = -1.150086973e-05f;
+    q = fmaf(q, g.t, 1.518900972e-04f);
+    q = fmaf(q, g.t, -8.436889620e-04f);
+    q = fmaf(q, g.t, 2.264559502e-03f);
+    q = fmaf(q, g.t, -7.151089812e-05f);
+    q = fmaf(q, g.t, -2.773463540e-02f);
+    q = fmaf(q, g.t, 1.483123451e-01f);
+    q = fmaf(q, g.t, 9.184418917e-01f);
+    q = fmaf(q, g.t, 1.627907395e+00f);
+    g.q = q;
+}
+MDEV float gelu_stage2(const GeluStage& g) {
+    const float q = g.q * g.t;
+    const float erf = copysignf(1.0f - __builtin_amdgcn_exp2f(-q), g.u);
+    return 0.5f * g.val * (1.0f + erf);
+}
+
 template <int ACT>
 MDEV float act_fn(float v) {
     if (ACT == ACT_GELU_FAST || ACT == ACT_GELU) return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
@@ -79,7 +106,7 @@ MDEV void rows_to_kgroups(f32x16& v) {
         }
 }
 
-#ifdef ACE_X_TRACE   // measurement build only (tools/trace_mlp.py): s_memtime stamps of wave 0 of one workgroup
+#ifdef ACE_X_TRACE   // measurement build only (tools/trace_wl.py): s_memtime stamps of wave 0 of one workgroup
 __device__ unsigned long long mlp_trace[512];
 #define MT(ev) do { if (blockIdx.x == ACE_X_TRACE && threadIdx.x == 0 && (ev) < 512) mlp_trace[ev] = __builtin_amdgcn_s_memtime(); } while (0)
 #else

@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""In-kernel timeline of conv_wl.hip (s_memtime stamps of wave 0 of one workgroup).  Needs a library built with
+-DACE_X_TRACE=<workgroup>: tools/mkvar.sh wltrace -DACE_X_TRACE=0; ACE_SFNO_LIB=exp/libexp_wltrace.so ACE_CONV_WL=1 python tools/trace_wl.py"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from ace_amd import _lib  # noqa: E402
+
+dev = torch.device("cuda", 0)
+stepper, forcing, prog, diag = bench.build_stepper(dev, seed=0)
+net = stepper.modules[0]
+net.set_precision("f16x3")
+x = torch.randn(1, len(forcing) + len(prog), *bench.IMG, device=dev)
+with torch.no_grad():
+    for _ in range(3):
+        y = net(x)
+torch.cuda.synchronize()
+L = _lib.lib()
+buf = (ctypes.c_ulonglong * 512)()
+fn = L.ace_debug_trace
+fn.restype = ctypes.c_int
+fn.argtypes = [ctypes.c_void_p]
+assert fn(buf) == 0
+t = list(buf)
+print(f"prologue (slots, weights -> LDS, barrier): {t[1] - t[0]} cycles")
+k = 2
+n = 0
+while k + 2 < 512 and t[k + 1] > t[k] > 0:
+    nxt = t[k + 2] if t[k + 2] > 0 else t[k + 1]
+    print(f"tile {n}: MFMA stream with the previous tile's epilogue (216 MFMAs = 6912 cycles of matrix pipe) {t[k + 1] - t[k]:7d}   to the next stamp {nxt - t[k + 1]:6d}")
+    k += 2
+    n += 1
+if n:
+    print(f"{n} tiles, {max(t) - t[0]} cycles from kernel start to the end of the last epilogue")
