@@ -53,7 +53,7 @@ Switches read_switches() {
     sw.no_pk = on("ACE_NO_PK");
     sw.no_pk_sht = on("ACE_NO_PK_SHT");
     sw.no_enc_ws = on("ACE_NO_ENC_WS");
-    sw.conv_wl = on("ACE_CONV_WL");
+    if (const char* e = std::getenv("ACE_CONV_WL")) sw.conv_wl = !(e[0] == '0' && !e[1]);
     if (const char* e = std::getenv("ACE_CONV_WS")) {
         const std::string v(e);
         if (v == "all" || v == "1") sw.conv_ws_roles = 7;

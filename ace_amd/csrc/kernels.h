@@ -15,7 +15,7 @@ struct Switches {
     bool no_pk_sht = false;        // ACE_NO_PK_SHT: fp32 D, expanded filter operand
     bool no_enc_ws = false;        // ACE_NO_ENC_WS: last encoder convolution on the v3 engine
     int conv_ws_roles = 7;         // ACE_CONV_WS=skip,fc1,fc2|all|none: roles on conv_ws.hip (bit 0 inner skip, 1 fc1, 2 fc2)
-    bool conv_wl = false;          // ACE_CONV_WL=1: fc1 on conv_wl.hip (weights in LDS, unsynchronised waves) instead of conv_ws.hip
+    bool conv_wl = true;           // ACE_CONV_WL=0: fc1 on conv_ws.hip instead of conv_wl.hip (weights in LDS, unsynchronised waves)
 };
 Switches read_switches();
 

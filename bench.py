@@ -274,7 +274,7 @@ def measured_counters():
 
 # the kernel that runs each stage in the default (f16x3) mode
 KERNEL_OF_STAGE = {
-    "mlp.fc1": "conv_ws_kernel", "mlp.fc2+outer_skip": "conv_ws_kernel", "inner_skip+activation": "conv_ws_kernel",
+    "mlp.fc1": "conv_wl_kernel", "mlp.fc2+outer_skip": "conv_ws_kernel", "inner_skip+activation": "conv_ws_kernel",
     "dhconv": "dhconv_strip_kernel", "forward_transform.legendre": "legendre_strip_kernel",
     "inverse_transform.legendre": "legendre_strip_kernel", "forward_transform.dft": "dft_forward_fft_kernel",
     "inverse_transform.dft": "dft_inverse_fft_kernel", "encoder": "gemm3_f16x3_kernel", "decoder": "gemm3_f16x3_kernel",

@@ -24,8 +24,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // MODE 0: M, 1: V, 2: MV, 3: interleaved with KV VALU per MFMA
 template <int MODE, int KV>
-__global__ __launch_bounds__(512) void probe(float* out, const float* in, int nm, int nv) {
+__global__ __launch_bounds__(512) void probe(float* out, const float* in, int nm, int nv, unsigned long long* ticks) {
     const int wave = threadIdx.x >> 6;
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     f32x16 acc[4];
     for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
     half8 av, bv;
@@ -60,15 +61,18 @@ __global__ __launch_bounds__(512) void probe(float* out, const float* in, int nm
     for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
     for (int e = 0; e < 8; ++e) s += x[e];
     out[blockIdx.x * 512 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = __builtin_amdgcn_s_memtime() - t_start;   // s_memtime ticks of wave 0
 }
 
+static unsigned long long* g_ticks = nullptr;
+static unsigned long long last_ticks() { unsigned long long t = 0; (void)hipMemcpy(&t, g_ticks, 8, hipMemcpyDeviceToHost); return t; }
 template <int MODE, int KV>
 static double run(float* out, const float* in, int nm, int nv) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((probe<MODE, KV>), dim3(256), dim3(512), 0, 0, out, in, nm, nv);
+    hipLaunchKernelGGL((probe<MODE, KV>), dim3(256), dim3(512), 0, 0, out, in, nm, nv, g_ticks);
     (void)hipEventRecord(e0, 0);
-    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((probe<MODE, KV>), dim3(256), dim3(512), 0, 0, out, in, nm, nv);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((probe<MODE, KV>), dim3(256), dim3(512), 0, 0, out, in, nm, nv, g_ticks);
     (void)hipEventRecord(e1, 0);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
@@ -83,7 +87,14 @@ int main() {
     std::vector<float> h(512);
     for (int i = 0; i < 512; ++i) h[i] = 0.25f + 0.001f * (float)((i * 37) % 101);
     (void)hipMemcpy(in, h.data(), 512 * 4, hipMemcpyHostToDevice);
+    (void)hipMalloc(reinterpret_cast<void**>(&g_ticks), 8);
     const int nm = 40000;              // MFMAs per wave
+    {   // what does one s_memtime tick measure?  8 waves x nm MFMAs = 2 nm x 32 matrix-pipe cycles per SIMD at least
+        const double us = run<0, 0>(out, in, nm, 0);
+        const unsigned long long tk = last_ticks();
+        printf("clock check: M run %.1f us, wave 0 spans %llu s_memtime ticks = %.3f ticks/ns; the matrix pipe needs %d cycles "
+               "=> >= %.2f GHz if a tick is a shader cycle\n", us, tk, (double)tk / (us * 1e3), 2 * nm * 32, 2.0 * nm * 32 / (us * 1e3));
+    }
     for (int ratio : {4, 7, 8}) {      // VALU per MFMA (fc1's epilogue: 6.7)
         const int nv = nm * ratio;
         const double tm = run<0, 0>(out, in, nm, nv), tv = run<1, 0>(out, in, nm, nv), tmv = run<2, 0>(out, in, nm, nv);

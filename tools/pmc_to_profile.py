@@ -15,6 +15,7 @@ RULES = [  # (regex on kernel key, stage, reads are wide (x2 correction applies)
     (r"^dhconv_strip_kernel", "dhconv", True),
     (r"^conv_ws_kernel<12, 1, 0>", "inner_skip+activation", True),
     (r"^conv_ws_kernel<12, 1, 1>", "mlp.fc1", True),
+    (r"^conv_wl_kernel<24, 3", "mlp.fc1", True),
     (r"^conv_ws_kernel<12, 2, 2>", "mlp.fc2+outer_skip", True),
     (r"^conv_ws_kernel<12, 2, 3>", "mlp.fc2+outer_skip(last block)", True),
     (r"^gemm3_f16x3_kernel<2, 2, false, true, false>", "decoder", True),
