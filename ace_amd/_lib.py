@@ -93,6 +93,14 @@ SIGNATURES = {
     "ace_sfno_forward_graph": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ace_pack_normalize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p]),
     "ace_unpack_denormalize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p]),
+    "ace_hpx_last_error": (c_char_p, []),
+    "ace_hpx_pad_table_host": (c_int, [c_int, c_int, c_void_p, c_void_p]),
+    "ace_hpx_pad": (c_int, [c_void_p, c_long, c_long, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ace_hpx_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                             c_int, c_int, c_int, c_float, c_void_p]),
+    "ace_hpx_pool2": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_void_p]),
+    "ace_hpx_tconv2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_long,
+                               c_int, c_float, c_void_p]),
     "ace_physics_last_error": (c_char_p, []),
     "ace_physics_create": (c_int, [POINTER(PhysConfig), c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "ace_physics_destroy": (None, [c_void_p]),

@@ -304,8 +304,8 @@ extern "C" int ace_sht_forward(ace_sht_plan* p, const float* x, float* coeffs, i
     const long N2 = 2L * n;
     HIP_TRY(p->X.ensure(((size_t)p->mmax * p->nlat + LEG_STRIP_SLACK_ROWS) * N2));
     HIP_TRY(p->D.ensure(((size_t)p->lmax + LEG_STRIP_SLACK_ROWS) * p->mmax * N2));
-    // coefficients with l < m are never written by the triangular Legendre stage: they are zero
-    HIP_TRY(hipMemsetAsync(p->D.p, 0, (size_t)p->lmax * p->mmax * N2 * sizeof(float), s));
+    // coefficients with l < m are never written by the triangular Legendre stage: the layout converter writes their zeros
+    // without reading the scratch (no memset)
     unsigned* xmax = nullptr;
     if (p->f16 && p->slots.p) {
         xmax = reinterpret_cast<unsigned*>(p->slots.p);

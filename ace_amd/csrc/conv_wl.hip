@@ -28,6 +28,12 @@ namespace ace {
 namespace {
 
 constexpr int WL_WAVES = 8;            // two per SIMD, <= 256 registers each
+#ifdef ACE_X_TRACE   // measurement builds: first / last s_memtime of every workgroup's wave 0, its XCC id
+__device__ unsigned long long wl_wg_span[4096][3];
+#define WG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) wl_wg_span[blockIdx.x][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WG_STAMP(k) do { } while (0)
+#endif
 constexpr int WL_OOBV = 0x7fffff00;
 
 // KS: k16-steps (K / 16), RT: 32-row tiles per workgroup, D: k-steps of B-fragment read-ahead
@@ -52,6 +58,7 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
     const int x1 = x0 + tpx < tiles_px ? x0 + tpx : tiles_px;
 
     MT(0);
+    WG_STAMP(0);
     const unsigned raw_x = slot_load(p.xslot + lane);
     const unsigned raw_a = p.aslot ? slot_load(p.aslot + lane) : 0u;
     const unsigned raw_c = p.cinb ? slot_load(p.cinb + lane) : 0u;
@@ -212,6 +219,14 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
     // ---- the last tile's epilogue, on its own
     static_for<0, NCH>([&](auto kc) { chunk(kc); });
     MT(tev);
+    WG_STAMP(1);
+#ifdef ACE_X_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        wl_wg_span[blockIdx.x][2] = xcc & 0xf;
+    }
+#endif
 }
 
 template <int KS, int RT, int D>
@@ -231,6 +246,7 @@ hipError_t launch_wl(const ConvStripArgs& a, hipStream_t s) {
 
 #ifdef ACE_X_TRACE   // measurement builds only (tools/trace_wl.py): the s_memtime stamps of wave 0 of workgroup ACE_X_TRACE
 extern "C" int ace_debug_trace(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mlp_trace), sizeof(mlp_trace)); }
+extern "C" int ace_debug_wg_spans(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wl_wg_span), sizeof(wl_wg_span)); }
 #endif
 
 // K: input channels, M: output channels.  GELU + P-format output, no residual, no statistics (the first MLP convolution)

@@ -49,6 +49,7 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0, nbatch = 1;
     int tri = TRI_NONE; int trimul = 1;
     int act = ACT_NONE;
+    float cap = __builtin_inff();   // the activated value is clamped from above (HEALPix CappedGELU, healpix_activations.py:41-85)
     // optional: atomicMax of the bit pattern of max|C| over the launch (dynamic range of the f16x3 consumers);
     // must be zeroed before the launch; AMAX_SHARDS words
     unsigned* omax = nullptr;

@@ -382,8 +382,8 @@ __global__ __launch_bounds__(64 * WM * WN, ACE_LB) void gemm_f32_kernel(GemmArgs
                     v0 += fmaf(rv0[e], rs[e], rt[e]);
                     v1 += fmaf(rv1[e], rs[e], rt[e]);
                 }
-                v0 = act_apply(v0, actk);
-                v1 = act_apply(v1, actk);
+                v0 = fminf(act_apply(v0, actk), p.cap);
+                v1 = fminf(act_apply(v1, actk), p.cap);
                 v0 = fmaf(v0, os[e], ot[e]);
                 v1 = fmaf(v1, os[e], ot[e]);
                 float* crow = C + (long)rr[e] * ldc;
@@ -639,8 +639,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm2_f32_kernel(GemmArgs p, int
                     v0 += fmaf(rv0[e], rs[e], rt[e]);
                     v1 += fmaf(rv1[e], rs[e], rt[e]);
                 }
-                v0 = act_apply(v0, actk);
-                v1 = act_apply(v1, actk);
+                v0 = fminf(act_apply(v0, actk), p.cap);
+                v1 = fminf(act_apply(v1, actk), p.cap);
                 v0 = fmaf(v0, os[e], ot[e]);
                 v1 = fmaf(v1, os[e], ot[e]);
                 float* crow = C + (long)rr[e] * ldc;
@@ -1175,8 +1175,8 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
                     v0 += fmaf(rv0[e], rs[e], rt[e]);
                     v1 += fmaf(rv1[e], rs[e], rt[e]);
                 }
-                v0 = act_apply(v0, actk);
-                v1 = act_apply(v1, actk);
+                v0 = fminf(act_apply(v0, actk), p.cap);
+                v1 = fminf(act_apply(v1, actk), p.cap);
                 v0 = fmaf(v0, os[e], ot[e]);
                 v1 = fmaf(v1, os[e], ot[e]);
                 float* crow = C + (long)rr[e] * ldc;
@@ -2782,32 +2782,61 @@ hipError_t launch_instnorm_stats(const float* x, const float* gamma, const float
 // ---------------------------------------------------------------------------------------------
 // layout converters (API boundary only; the network path never leaves the internal layout)
 // ---------------------------------------------------------------------------------------------
-__global__ void spec_to_ref_kernel(const float* __restrict__ D, float* __restrict__ out, int Bt, int C, int L, int Mm) {
-    const long total = (long)Bt * C * L * Mm;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int m = t % Mm;
-        long q = t / Mm;
-        const int l = q % L;
-        q /= L;
-        const int c = q % C;
-        const int b = q / C;
-        const long src = (((long)l * Mm + m) * Bt + b) * 2 * C + c;
-        out[2 * t] = D[src];
-        out[2 * t + 1] = D[src + C];
-    }
-}
-__global__ void ref_to_spec_kernel(const float* __restrict__ in, float* __restrict__ E, int Bt, int C, int L, int Mm) {
-    const long total = (long)Bt * C * L * Mm;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int m = t % Mm;
-        long q = t / Mm;
-        const int l = q % L;
-        q /= L;
-        const int c = q % C;
-        const int b = q / C;
-        const long dst = (((long)l * Mm + m) * Bt + b) * 2 * C + c;
-        E[dst] = in[2 * t];
-        E[dst + C] = in[2 * t + 1];
+// Both directions are a tiled transpose through LDS between the internal matrix [r = (l, m)][b][ri][c] (c fastest) and the
+// reference's [b][c][r][ri] (complex64, r fastest): a 32 x 32 (r, c) tile is read and written in 128 / 256-byte runs (the
+// first version walked one side with a stride of 2 C Bt floats per lane: the reference's own `sht` benchmark, 1024 fields,
+// spent 1.1 of its 1.5 ms here).  TO_REF: entries with m > l are written as zeros without reading the internal buffer (the
+// triangular Legendre stage never writes them), so the standalone transform needs no memset of its scratch.
+template <bool TO_REF>
+__global__ __launch_bounds__(256) void spec_layout_kernel(const float* __restrict__ src, float* __restrict__ dst, int Bt, int C, int L, int Mm) {
+    __shared__ float tile[2][32][33];
+    const long R = (long)L * Mm;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    const long r0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32, b = blockIdx.z;
+    if (TO_REF) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {          // rows r0 + ty + 8 k, channel c0 + tx: 128-byte runs over c
+            const long r = r0 + ty + 8 * k;
+            const int c = c0 + tx;
+            float re = 0.f, im = 0.f;
+            if (r < R && c < C && (int)(r % Mm) <= (int)(r / Mm)) {
+                const float* p = src + (r * Bt + b) * 2 * C + c;
+                re = p[0];
+                im = p[C];
+            }
+            tile[0][ty + 8 * k][tx] = re;
+            tile[1][ty + 8 * k][tx] = im;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {          // channel c0 + ty + 8 k, row r0 + tx: (re, im) pairs, 256-byte runs over r
+            const int c = c0 + ty + 8 * k;
+            const long r = r0 + tx;
+            if (r < R && c < C)
+                *reinterpret_cast<float2*>(dst + (((long)b * C + c) * R + r) * 2) = make_float2(tile[0][tx][ty + 8 * k], tile[1][tx][ty + 8 * k]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 8 * k;
+            const long r = r0 + tx;
+            float2 v = make_float2(0.f, 0.f);
+            if (r < R && c < C) v = *reinterpret_cast<const float2*>(src + (((long)b * C + c) * R + r) * 2);
+            tile[0][tx][ty + 8 * k] = v.x;
+            tile[1][tx][ty + 8 * k] = v.y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long r = r0 + ty + 8 * k;
+            const int c = c0 + tx;
+            if (r < R && c < C) {
+                float* p = dst + (r * Bt + b) * 2 * C + c;
+                p[0] = tile[0][ty + 8 * k][tx];
+                p[C] = tile[1][ty + 8 * k][tx];
+            }
+        }
     }
 }
 static inline unsigned grid_for(long total, int block) {
@@ -2817,13 +2846,15 @@ static inline unsigned grid_for(long total, int block) {
     return (unsigned)g;
 }
 hipError_t launch_spec_to_ref(const float* D, float* out, int Bt, int C, int L, int Mm, hipStream_t s) {
-    const long total = (long)Bt * C * L * Mm;
-    hipLaunchKernelGGL(spec_to_ref_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, D, out, Bt, C, L, Mm);
+    const long R = (long)L * Mm;
+    if ((R + 31) / 32 > 0x7fffffffL || (C + 31) / 32 > 65535 || Bt > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(spec_layout_kernel<true>, dim3((unsigned)((R + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)Bt), dim3(256), 0, s, D, out, Bt, C, L, Mm);
     return hipGetLastError();
 }
 hipError_t launch_ref_to_spec(const float* in, float* E, int Bt, int C, int L, int Mm, hipStream_t s) {
-    const long total = (long)Bt * C * L * Mm;
-    hipLaunchKernelGGL(ref_to_spec_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, E, Bt, C, L, Mm);
+    const long R = (long)L * Mm;
+    if ((R + 31) / 32 > 0x7fffffffL || (C + 31) / 32 > 65535 || Bt > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(spec_layout_kernel<false>, dim3((unsigned)((R + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)Bt), dim3(256), 0, s, in, E, Bt, C, L, Mm);
     return hipGetLastError();
 }
 

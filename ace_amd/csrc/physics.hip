@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NT) void phys_p2(PhysParams P, ace_phys_fields F, i
     const bool need = P.moisture != 0 || P.zero_adv;
     double acc[NQ] = {0, 0, 0, 0, 0, 0};
     for (long px = (long)blockIdx.x * NT + threadIdx.x; px < HW; px += (long)nblk * NT) {
-        float ps = ld(F.ps, b, px);
+        float ps = (P.conserve_dry_air || P.moisture) ? ld(F.ps, b, px) : 0.f;   // (absent when only the advection mean is removed)
         if (P.conserve_dry_air) {   // atmosphere.py:431-467
             const double dry = (double)(ps - GRAVITY * total_water_path(P, F.wat, b, px, ps)) - error;
             double sa = 0.0, sb = 0.0;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(NT) void phys_p3(PhysParams P, ace_phys_fields F, i
     const float escale = (mb == 2 || mb == 4) ? (tend_gm + precip_gm) / evap_gm : 1.0f;
     double acc[NQ] = {0, 0, 0, 0, 0, 0};
     for (long px = (long)blockIdx.x * NT + threadIdx.x; px < HW; px += (long)nblk * NT) {
-        const float ps = ld(F.ps, b, px);
+        const float ps = (mb >= 3 || P.energy) ? ld(F.ps, b, px) : 0.f;
         float precip = 0.f, lhf = 0.f;
         if (P.zero_adv) st(F.adv, b, px, ld(F.adv, b, px) - adv_gm);          // atmosphere.py:470-487
         if (mb) {

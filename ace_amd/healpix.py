@@ -1,0 +1,700 @@
+"""HEALPix variant (BASELINE configs[4]): the reference's HEALPixUNet behind the same registry / stepper
+API - ``ModuleSelector(type="HEALPixUNet", config=...)`` (fme/ace/registry/hpx.py:14-111) - on the native operators of
+``csrc/healpix.hip`` (include/ace_sfno.h: ace_hpx_*): neighbourhood convolutions on the 12-face mesh in place of the
+spherical harmonic transform.
+
+Host side mirrored here, name for name, so that reference configurations and checkpoints load (strict ``load_state_dict``;
+seeded construction consumes the RNG in the reference's order): the configuration dataclasses and block classes of
+fme/ace/models/healpix/{healpix_blocks.py, healpix_encoder.py, healpix_decoder.py, healpix_layers.py, healpix_activations.py,
+healpix_unet.py} that the reference's own test configuration uses - ConvNeXtBlock, BasicConvBlock, AvgPool / MaxPool,
+TransposedConvUpsample, CappedGELU, face padding modes "karlbauer" and "earth2grid" (which the reference documents as giving
+the same result; one gather table serves both).  Not built (raise at construction): isolatitude padding, the dealiased /
+smoothed-interpolate resamplers, the symmetric ConvNeXt variants.
+
+Runtime layout: an activation of one UNet level is ``[image = item * 12 + face][channel][row][pitch]`` fp32 with the row pitch
+of that level's padded faces (``Hpx``), so every k x k convolution is k^2 accumulated fp32-MFMA GEMMs on shifted views of the
+padded tensor.  There is no CPU path: tensors must live on an MI355X."""
+import ctypes
+import dataclasses
+from typing import Any, Callable, Dict, List, Mapping, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .registry import ModuleConfig, ModuleSelector
+
+ACT_NONE, ACT_GELU = 0, 1
+_INF = float("inf")
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        msg = _lib.lib().ace_hpx_last_error().decode()
+        raise (ValueError if rc == _lib.ACE_ERR_INVALID else RuntimeError)(msg)
+
+
+@dataclasses.dataclass
+class Hpx:
+    """An activation in the runtime layout: data [images, channels, rows, pitch] (contiguous), valid columns [0, width)."""
+    data: torch.Tensor
+    width: int
+
+    @property
+    def pitch(self) -> int:
+        return self.data.shape[-1]
+
+    @property
+    def rows(self) -> int:
+        return self.data.shape[-2]
+
+
+class _Runtime:
+    """Per-forward context: row pitch per face width (a level's tensors share the pitch of that level's padded faces) and the
+    padding gather tables (device copies), cached per (nside, padding)."""
+
+    def __init__(self):
+        self.pitch: Dict[int, int] = {}
+        self._tables: Dict[Tuple[int, int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
+
+    def pitch_for(self, width: int) -> int:
+        return self.pitch.get(width, width)
+
+    def table(self, nside: int, p: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+        key = (nside, p, str(device))
+        if key not in self._tables:
+            m = nside + 2 * p
+            ia = np.zeros(12 * m * m, dtype=np.int32)
+            ib = np.zeros_like(ia)
+            _check(_lib.lib().ace_hpx_pad_table_host(nside, p, ia.ctypes.data, ib.ctypes.data))
+            self._tables[key] = (torch.from_numpy(ia).to(device), torch.from_numpy(ib).to(device))
+        return self._tables[key]
+
+
+_RT = _Runtime()
+
+
+def _repitch(x: Hpx, pitch: int) -> Hpx:
+    if x.pitch == pitch:
+        return x
+    out = torch.empty(*x.data.shape[:-1], pitch, dtype=torch.float32, device=x.data.device)
+    out[..., : x.width] = x.data[..., : x.width]
+    return Hpx(out, x.width)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# activations (healpix_activations.py)
+@dataclasses.dataclass
+class CappedGELUConfig:
+    cap_value: int = 10
+
+    def build(self) -> nn.Module:
+        return CappedGELU(cap_value=self.cap_value)
+
+
+class CappedGELU(nn.Module):
+    """GELU clamped from above (healpix_activations.py:41-85); applied inside the producing convolution's epilogue."""
+
+    def __init__(self, cap_value=1.0, **kwargs):
+        super().__init__()
+        self.add_module("gelu", torch.nn.GELU(**kwargs))
+        self.register_buffer("cap", torch.tensor(cap_value, dtype=torch.float32))
+
+    def code(self) -> Tuple[int, float]:
+        return ACT_GELU, float(self.cap.item())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# layers (healpix_layers.py:48-125, healpix_paddings.py)
+class HEALPixPadding(nn.Module):
+    """Face padding as a gather (no parameters; keeps the reference's ``layers.0`` slot)."""
+
+    def __init__(self, padding: int):
+        super().__init__()
+        if not isinstance(padding, int) or padding < 1:
+            raise ValueError(f"invalid value for 'padding', expected int > 0 but got {padding}")
+        self.p = padding
+
+
+def make_hpx_padding_layer(padding: int, hpx_padding_mode: str, nside: Optional[int] = None) -> nn.Module:
+    if hpx_padding_mode in ("earth2grid", "karlbauer"):
+        return HEALPixPadding(padding)
+    if hpx_padding_mode == "isolatitude":
+        raise NotImplementedError("hpx_padding_mode='isolatitude' is outside the accelerated path (karlbauer / earth2grid are built)")
+    raise ValueError(f"Unknown hpx_padding_mode: {hpx_padding_mode!r}")
+
+
+class HEALPixLayer(nn.Module):
+    """healpix_layers.py:48-125: [padding,] base layer on folded faces.  The base layers are torch modules used as PARAMETER
+    HOLDERS (their initialisation is the reference's); the arithmetic runs in csrc/healpix.hip."""
+
+    def __init__(self, layer, hpx_padding_mode: str = "earth2grid", nside: Optional[int] = None, **kwargs):
+        super().__init__()
+        layers: List[nn.Module] = []
+        if "nside" in kwargs:
+            ns = kwargs.pop("nside")
+            nside = int(ns) if ns is not None else None
+        kernel_size = 3 if "kernel_size" not in kwargs else kwargs["kernel_size"]
+        dilation = 1 if "dilation" not in kwargs else kwargs["dilation"]
+        padding = ((kernel_size - 1) // 2) * dilation
+        if padding > 0:
+            if issubclass(layer, torch.nn.modules.conv._ConvNd):
+                kwargs["padding"] = 0
+            layers.append(make_hpx_padding_layer(padding=padding, hpx_padding_mode=hpx_padding_mode, nside=nside))
+        layers.append(layer(**kwargs))
+        self.layers = torch.nn.Sequential(*layers)
+        self._pad = padding
+        self._k, self._dil = kernel_size, dilation
+        self._prep: Optional[Tuple[Tuple[int, int], torch.Tensor]] = None
+
+    # -- native execution
+    @property
+    def base(self) -> nn.Module:
+        return self.layers[-1]
+
+    def _taps(self) -> torch.Tensor:
+        """Weight in tap-major order [ky][kx][cout][cin] (ConvTranspose2d: [dy][dx][cout][cin]); re-made when it changes."""
+        w = self.base.weight
+        stamp = (w.data_ptr(), w._version)
+        if self._prep is None or self._prep[0] != stamp:
+            if isinstance(self.base, nn.ConvTranspose2d):
+                t = w.detach().permute(2, 3, 1, 0).contiguous().float()
+            else:
+                t = w.detach().permute(2, 3, 0, 1).contiguous().float()
+            self._prep = (stamp, t)
+        return self._prep[1]
+
+    def conv(self, x: Hpx, x2: Optional[Hpx] = None, residual: Optional[Hpx] = None, act: Tuple[int, float] = (ACT_NONE, _INF)) -> Hpx:
+        base = self.base
+        if not isinstance(base, nn.Conv2d):
+            raise TypeError("conv() on a non-convolution HEALPixLayer")
+        L = _lib.lib()
+        st = _lib.current_stream()
+        imgs, H, W = x.data.shape[0], x.rows, x.width
+        cin = x.data.shape[1]
+        cin2 = x2.data.shape[1] if x2 is not None else 0
+        cout = base.out_channels
+        bias = base.bias
+        wt = self._taps()
+        if self._pad > 0:
+            p, m = self._pad, W + 2 * self._pad
+            ia, ib = _RT.table(W, p, x.data.device)
+            xp = torch.empty(imgs, cin + cin2, m, m, dtype=torch.float32, device=x.data.device)
+            for src, c0 in ((x, 0), (x2, cin)):
+                if src is None:
+                    continue
+                d = src.data
+                _check(L.ace_hpx_pad(d.data_ptr(), d.stride(0), d.stride(1), src.pitch, xp.data_ptr(), cin + cin2, c0, d.shape[1],
+                                     ia.data_ptr(), ib.data_ptr(), imgs // 12, W, p, st))
+            y = torch.empty(imgs, cout, H, m, dtype=torch.float32, device=x.data.device)
+            _check(L.ace_hpx_conv(xp.data_ptr(), None, cin + cin2, 0, wt.data_ptr(), _lib.ptr(bias) if bias is not None else None, None,
+                                  y.data_ptr(), imgs, cout, H, W, m, self._k, self._dil, act[0], act[1], st))
+            return Hpx(y, W)
+        pitch = x.pitch
+        if x2 is not None and x2.pitch != pitch:
+            x2 = _repitch(x2, pitch)
+        if residual is not None and residual.pitch != pitch:
+            residual = _repitch(residual, pitch)
+        y = torch.empty(imgs, cout, H, pitch, dtype=torch.float32, device=x.data.device)
+        _check(L.ace_hpx_conv(x.data.data_ptr(), x2.data.data_ptr() if x2 is not None else None, cin, cin2, wt.data_ptr(),
+                              _lib.ptr(bias) if bias is not None else None, residual.data.data_ptr() if residual is not None else None,
+                              y.data_ptr(), imgs, cout, H, W, pitch, 1, 1, act[0], act[1], st))
+        return Hpx(y, W)
+
+    def pool(self, x: Hpx) -> Hpx:
+        base = self.base
+        k = base.kernel_size if isinstance(base.kernel_size, int) else base.kernel_size[0]
+        if k != 2:
+            raise NotImplementedError("only 2 x 2 pooling (the reference's configurations) is built")
+        imgs, C, H, W = x.data.shape[0], x.data.shape[1], x.rows, x.width
+        po = _RT.pitch_for(W // 2)
+        y = torch.empty(imgs, C, H // 2, po, dtype=torch.float32, device=x.data.device)
+        _check(_lib.lib().ace_hpx_pool2(x.data.data_ptr(), y.data_ptr(), imgs * C, H, W, x.pitch, H * x.pitch, po, (H // 2) * po,
+                                        1 if isinstance(base, nn.MaxPool2d) else 0, _lib.current_stream()))
+        return Hpx(y, W // 2)
+
+    def tconv(self, x: Hpx, act: Tuple[int, float]) -> Hpx:
+        base = self.base
+        if not (isinstance(base, nn.ConvTranspose2d) and base.kernel_size == (2, 2) and base.stride == (2, 2)):
+            raise NotImplementedError("only the 2 x 2 stride-2 transposed convolution (the reference's configurations) is built")
+        imgs, cin, H, W = x.data.shape[0], x.data.shape[1], x.rows, x.width
+        cout = base.out_channels
+        po = _RT.pitch_for(2 * W)
+        tmp = torch.empty(4 * imgs * cout * H * x.pitch, dtype=torch.float32, device=x.data.device)
+        y = torch.empty(imgs, cout, 2 * H, po, dtype=torch.float32, device=x.data.device)
+        _check(_lib.lib().ace_hpx_tconv2(x.data.data_ptr(), self._taps().data_ptr(), _lib.ptr(base.bias) if base.bias is not None else None,
+                                         tmp.data_ptr(), y.data_ptr(), imgs, cin, cout, H, W, x.pitch, po, 2 * H * po, act[0], act[1],
+                                         _lib.current_stream()))
+        return Hpx(y, 2 * W)
+
+
+def _act_code(m: Optional[nn.Module]) -> Tuple[int, float]:
+    if m is None:
+        return ACT_NONE, _INF
+    if isinstance(m, CappedGELU):
+        return m.code()
+    raise NotImplementedError(f"activation {type(m).__name__} is not built")
+
+
+def _run_convblock(convblock: nn.Sequential, x: Hpx, x2: Optional[Hpx] = None, residual: Optional[Hpx] = None) -> Hpx:
+    """A Sequential of HEALPixLayer(conv) [+ activation] pairs: each activation is fused into its convolution; `residual` is
+    added by the last convolution (k = 1)."""
+    mods = list(convblock)
+    i = 0
+    while i < len(mods):
+        layer = mods[i]
+        nxt = mods[i + 1] if i + 1 < len(mods) and not isinstance(mods[i + 1], HEALPixLayer) else None
+        last = (i + (2 if nxt is not None else 1)) >= len(mods)
+        x = layer.conv(x, x2=x2, residual=residual if last else None, act=_act_code(nxt))
+        x2 = None
+        i += 2 if nxt is not None else 1
+    return x
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# blocks (healpix_blocks.py)
+@dataclasses.dataclass(frozen=True)
+class HEALPixLayerBuildContext:
+    hpx_padding_mode: str = "earth2grid"
+    nside: Optional[int] = None
+    nside_after: Optional[int] = None
+
+
+@dataclasses.dataclass(frozen=True)
+class HEALPixBuildContext:
+    hpx_padding_mode: str = "earth2grid"
+    nside_levels: Optional[Tuple[int, ...]] = None
+
+    def layer(self, level: int, *, nside_after: Optional[int] = None) -> HEALPixLayerBuildContext:
+        nside = None if self.nside_levels is None else self.nside_levels[level]
+        return HEALPixLayerBuildContext(hpx_padding_mode=self.hpx_padding_mode, nside=nside, nside_after=nside_after)
+
+
+def _kw(ctx: HEALPixLayerBuildContext) -> dict:
+    out: dict = {"hpx_padding_mode": ctx.hpx_padding_mode}
+    if ctx.nside is not None:
+        out["nside"] = ctx.nside
+    return out
+
+
+class MaxPool(nn.Module):
+    def __init__(self, pooling: int = 2, hpx_padding_mode: str = "earth2grid", nside: Optional[int] = None):
+        super().__init__()
+        self.maxpool = HEALPixLayer(layer=nn.MaxPool2d, kernel_size=pooling, **_kw(HEALPixLayerBuildContext(hpx_padding_mode, nside)))
+
+    def forward(self, x: Hpx) -> Hpx:
+        return self.maxpool.pool(x)
+
+
+class AvgPool(nn.Module):
+    def __init__(self, pooling: int = 2, hpx_padding_mode: str = "earth2grid", nside: Optional[int] = None):
+        super().__init__()
+        self.avgpool = HEALPixLayer(layer=nn.AvgPool2d, kernel_size=pooling, **_kw(HEALPixLayerBuildContext(hpx_padding_mode, nside)))
+
+    def forward(self, x: Hpx) -> Hpx:
+        return self.avgpool.pool(x)
+
+
+class TransposedConvUpsample(nn.Module):
+    """healpix_blocks.py:636-697."""
+
+    def __init__(self, in_channels: int = 3, out_channels: int = 1, upsampling: int = 2,
+                 activation_factory: Optional[Callable[[], nn.Module]] = None, hpx_padding_mode: str = "earth2grid",
+                 nside: Optional[int] = None):
+        super().__init__()
+        upsampler: List[nn.Module] = [HEALPixLayer(layer=nn.ConvTranspose2d, in_channels=in_channels, out_channels=out_channels,
+                                                   kernel_size=upsampling, stride=upsampling, padding=0,
+                                                   **_kw(HEALPixLayerBuildContext(hpx_padding_mode, nside)))]
+        if activation_factory is not None:
+            upsampler.append(activation_factory())
+        self.upsampler = nn.Sequential(*upsampler)
+
+    def forward(self, x: Hpx) -> Hpx:
+        act = self.upsampler[1] if len(self.upsampler) > 1 else None
+        return self.upsampler[0].tconv(x, _act_code(act))
+
+
+class BasicConvBlock(nn.Module):
+    """healpix_blocks.py:868-930."""
+
+    def __init__(self, in_channels=3, out_channels=1, kernel_size=3, dilation=1, n_layers=1, latent_channels=None,
+                 activation_factory: Optional[Callable[[], nn.Module]] = None, hpx_padding_mode="earth2grid", nside=None):
+        super().__init__()
+        if latent_channels is None:
+            latent_channels = max(in_channels, out_channels)
+        convblock: List[nn.Module] = []
+        for n in range(n_layers):
+            convblock.append(HEALPixLayer(layer=torch.nn.Conv2d, in_channels=in_channels if n == 0 else latent_channels,
+                                          out_channels=out_channels if n == n_layers - 1 else latent_channels,
+                                          kernel_size=kernel_size, dilation=dilation,
+                                          **_kw(HEALPixLayerBuildContext(hpx_padding_mode, nside))))
+            if activation_factory is not None:
+                convblock.append(activation_factory())
+        self.convblock = nn.Sequential(*convblock)
+
+    def forward(self, x: Hpx, x2: Optional[Hpx] = None) -> Hpx:
+        return _run_convblock(self.convblock, x, x2=x2)
+
+
+class ConvNeXtBlock(nn.Module):
+    """healpix_blocks.py:932-1043: skip(x) + [k x k conv, act, k x k conv, act, 1 x 1 conv](x)."""
+
+    def __init__(self, in_channels: int = 3, latent_channels: int = 1, out_channels: int = 1, kernel_size: int = 3,
+                 dilation: int = 1, upscale_factor: int = 4, activation_factory: Optional[Callable[[], nn.Module]] = None,
+                 hpx_padding_mode: str = "earth2grid", nside: Optional[int] = None):
+        super().__init__()
+        kw = _kw(HEALPixLayerBuildContext(hpx_padding_mode, nside))
+        if in_channels == out_channels:
+            self.skip_module = None
+        else:
+            self.skip_module = HEALPixLayer(layer=torch.nn.Conv2d, in_channels=in_channels, out_channels=out_channels, kernel_size=1, **kw)
+        lat = int(latent_channels * upscale_factor)
+        convblock: List[nn.Module] = [HEALPixLayer(layer=torch.nn.Conv2d, in_channels=in_channels, out_channels=lat,
+                                                   kernel_size=kernel_size, dilation=dilation, **kw)]
+        if activation_factory is not None:
+            convblock.append(activation_factory())
+        convblock.append(HEALPixLayer(layer=torch.nn.Conv2d, in_channels=lat, out_channels=lat, kernel_size=kernel_size,
+                                      dilation=dilation, **kw))
+        if activation_factory is not None:
+            convblock.append(activation_factory())
+        convblock.append(HEALPixLayer(layer=torch.nn.Conv2d, in_channels=lat, out_channels=out_channels, kernel_size=1, **kw))
+        self.convblock = nn.Sequential(*convblock)
+
+    def forward(self, x: Hpx, x2: Optional[Hpx] = None) -> Hpx:
+        # the convolutions' outputs carry the pitch of this level's padded faces; the skip branch is brought to it
+        first = self.convblock[0]
+        target = x.width + 2 * first._pad if first._pad > 0 else x.pitch
+        if self.skip_module is None:
+            if x2 is not None:
+                raise ValueError("identity skip with a concatenated input")
+            skip = _repitch(x, target)
+        else:
+            skip = self.skip_module.conv(_repitch(x, target), x2=_repitch(x2, target) if x2 is not None else None)
+        return _run_convblock(self.convblock, x, x2=x2, residual=skip)
+
+
+def _not_built(name: str):
+    def build(*a, **k):
+        raise NotImplementedError(f"{name} is outside the accelerated path (ConvNeXtBlock, BasicConvBlock, AvgPool, MaxPool and "
+                                  "TransposedConvUpsample are built)")
+    return build
+
+
+@dataclasses.dataclass
+class MaxPoolDownsamplingBlockConfig:
+    block_type: str = "MaxPool"
+    pooling: int = 2
+
+    def downsample_spatial_factor(self) -> int:
+        return self.pooling
+
+    def build(self, *, in_channels: Optional[int] = None, ctx: Optional[HEALPixLayerBuildContext] = None) -> nn.Module:
+        c = ctx or HEALPixLayerBuildContext()
+        return MaxPool(pooling=self.pooling, hpx_padding_mode=c.hpx_padding_mode, nside=c.nside)
+
+
+@dataclasses.dataclass
+class AvgPoolDownsamplingBlockConfig:
+    block_type: str = "AvgPool"
+    pooling: int = 2
+
+    def downsample_spatial_factor(self) -> int:
+        return self.pooling
+
+    def build(self, *, in_channels: Optional[int] = None, ctx: Optional[HEALPixLayerBuildContext] = None) -> nn.Module:
+        c = ctx or HEALPixLayerBuildContext()
+        return AvgPool(pooling=self.pooling, hpx_padding_mode=c.hpx_padding_mode, nside=c.nside)
+
+
+@dataclasses.dataclass
+class TransposedConvUpsampleBlockConfig:
+    block_type: str = "TransposedConvUpsample"
+    stride: int = 2
+    activation: Optional[CappedGELUConfig] = None
+
+    def build(self, in_channels: int, out_channels: int, *, ctx: Optional[HEALPixLayerBuildContext] = None) -> nn.Module:
+        c = ctx or HEALPixLayerBuildContext()
+        return TransposedConvUpsample(in_channels=in_channels, out_channels=out_channels, upsampling=self.stride,
+                                      activation_factory=self.activation.build if self.activation else None,
+                                      hpx_padding_mode=c.hpx_padding_mode, nside=c.nside)
+
+
+@dataclasses.dataclass
+class BasicConvBlockConfig:
+    block_type: str = "BasicConvBlock"
+    kernel_size: int = 3
+    n_layers: int = 1
+    activation: Optional[CappedGELUConfig] = None
+
+    def build(self, in_channels: int, out_channels: int, *, latent_channels: Optional[int] = None, dilation: int = 1,
+              n_layers: Optional[int] = None, ctx: Optional[HEALPixLayerBuildContext] = None) -> nn.Module:
+        c = ctx or HEALPixLayerBuildContext()
+        return BasicConvBlock(in_channels=in_channels, out_channels=out_channels, kernel_size=self.kernel_size, dilation=dilation,
+                              n_layers=self.n_layers if n_layers is None else n_layers, latent_channels=latent_channels,
+                              activation_factory=self.activation.build if self.activation else None,
+                              hpx_padding_mode=c.hpx_padding_mode, nside=c.nside)
+
+
+@dataclasses.dataclass
+class ConvNeXtBlockConfig:
+    block_type: str = "ConvNeXtBlock"
+    kernel_size: int = 3
+    upscale_factor: int = 4
+    activation: Optional[CappedGELUConfig] = None
+
+    def build(self, in_channels: int, out_channels: int, *, latent_channels: Optional[int] = None, dilation: int = 1,
+              n_layers: Optional[int] = None, ctx: Optional[HEALPixLayerBuildContext] = None) -> nn.Module:
+        c = ctx or HEALPixLayerBuildContext()
+        return ConvNeXtBlock(in_channels=in_channels, latent_channels=1 if latent_channels is None else latent_channels,
+                             out_channels=out_channels, kernel_size=self.kernel_size, dilation=dilation,
+                             upscale_factor=self.upscale_factor,
+                             activation_factory=self.activation.build if self.activation else None,
+                             hpx_padding_mode=c.hpx_padding_mode, nside=c.nside)
+
+
+_BLOCK_CONFIGS = {"MaxPool": MaxPoolDownsamplingBlockConfig, "AvgPool": AvgPoolDownsamplingBlockConfig,
+                  "TransposedConvUpsample": TransposedConvUpsampleBlockConfig, "BasicConvBlock": BasicConvBlockConfig,
+                  "ConvNeXtBlock": ConvNeXtBlockConfig}
+_KNOWN_UNBUILT = {"DealiasedDownsample", "SmoothedInterpolateConv", "Interpolate", "SymmetricConvNeXtBlock",
+                  "MultiSymmetricConvNeXtBlock"}
+
+
+def _block_from_state(state: Any, default: Optional[type] = None):
+    """A block configuration from its serialised form (the reference's dacite Union dispatch on ``block_type``)."""
+    if state is None or dataclasses.is_dataclass(state):
+        return state
+    state = dict(state)
+    bt = state.get("block_type", None)
+    if bt is None and default is not None:
+        bt = default().block_type
+    if bt in _KNOWN_UNBUILT:
+        raise NotImplementedError(f"block_type '{bt}' is outside the accelerated path")
+    if bt not in _BLOCK_CONFIGS:
+        raise ValueError(f"unknown block_type {bt!r}")
+    cls = _BLOCK_CONFIGS[bt]
+    names = {f.name for f in dataclasses.fields(cls)}
+    extra = set(state) - names
+    if extra:
+        raise ValueError(f'can not match {sorted(extra)} to any data class field of "{cls.__name__}"')
+    if isinstance(state.get("activation"), Mapping):
+        state["activation"] = CappedGELUConfig(**state["activation"])
+    return cls(**state)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# encoder / decoder (healpix_encoder.py, healpix_decoder.py)
+@dataclasses.dataclass
+class UNetEncoderConfig:
+    conv_block: Any
+    down_sampling_block: Any
+    n_channels: List[int] = dataclasses.field(default_factory=lambda: [136, 68, 34])
+    n_layers: List[int] = dataclasses.field(default_factory=lambda: [2, 2, 1])
+    dilations: Optional[list] = None
+
+    def __post_init__(self):
+        self.conv_block = _block_from_state(self.conv_block)
+        self.down_sampling_block = _block_from_state(self.down_sampling_block)
+
+    def build(self, input_channels: int, *, ctx: HEALPixBuildContext) -> nn.Module:
+        if ctx.nside_levels is not None and len(ctx.nside_levels) != len(self.n_channels):
+            raise ValueError(f"nside length must match encoder levels; got {len(ctx.nside_levels)} vs {len(self.n_channels)}")
+        dilations = self.dilations if self.dilations is not None else [1 for _ in self.n_channels]
+        down_factor = self.down_sampling_block.downsample_spatial_factor()
+        old = input_channels
+        levels: List[nn.Sequential] = []
+        for n, cur in enumerate(self.n_channels):
+            modules: List[nn.Module] = []
+            if n > 0:
+                if ctx.nside_levels is not None and ctx.nside_levels[n - 1] != ctx.nside_levels[n] * down_factor:
+                    raise ValueError(f"encoder nside[{n - 1}]={ctx.nside_levels[n - 1]} must equal nside[{n}] * downsample factor "
+                                     f"({down_factor}), but nside[{n}]={ctx.nside_levels[n]}")
+                modules.append(self.down_sampling_block.build(in_channels=old, ctx=ctx.layer(n - 1)))
+            modules.append(self.conv_block.build(in_channels=old, out_channels=cur, latent_channels=cur, dilation=dilations[n],
+                                                 n_layers=self.n_layers[n], ctx=ctx.layer(n)))
+            old = cur
+            levels.append(nn.Sequential(*modules))
+        return UNetEncoder(encoder=levels)
+
+
+class UNetEncoder(nn.Module):
+    def __init__(self, encoder: List[nn.Sequential]):
+        super().__init__()
+        self.encoder = nn.ModuleList(encoder)
+
+    def forward(self, x: Hpx) -> Sequence[Hpx]:
+        outs = []
+        for level in self.encoder:
+            for mod in level:
+                x = mod(x)
+            outs.append(x)
+        return outs
+
+
+@dataclasses.dataclass
+class UNetDecoderConfig:
+    conv_block: Any
+    up_sampling_block: Any
+    output_layer: Any
+    n_channels: List[int] = dataclasses.field(default_factory=lambda: [34, 68, 136])
+    n_layers: List[int] = dataclasses.field(default_factory=lambda: [1, 2, 2])
+    dilations: Optional[list] = None
+
+    def __post_init__(self):
+        self.conv_block = _block_from_state(self.conv_block)
+        self.up_sampling_block = _block_from_state(self.up_sampling_block)
+        self.output_layer = _block_from_state(self.output_layer)
+
+    def build(self, output_channels: int, *, ctx: HEALPixBuildContext) -> nn.Module:
+        if ctx.nside_levels is not None and len(ctx.nside_levels) != len(self.n_channels):
+            raise ValueError(f"nside length must match decoder levels; got {len(ctx.nside_levels)} vs {len(self.n_channels)}")
+        dilations = self.dilations if self.dilations is not None else [1 for _ in self.n_channels]
+        nside_levels = ctx.nside_levels
+        up_factor = self.up_sampling_block.stride
+        nlev = len(self.n_channels)
+        decoder: List[DecoderLevel] = []
+        cur = self.n_channels[0]
+        for n, cur in enumerate(self.n_channels):
+            up = None
+            level_nside = None if nside_levels is None else nside_levels[nlev - 1 - n]
+            if n != 0:
+                if nside_levels is not None and nside_levels[nlev - n] * up_factor != level_nside:
+                    raise ValueError(f"decoder nside upsample: nside[{nlev - 1 - n}]={level_nside} must equal nside[{nlev - n}] * "
+                                     f"upsample factor ({up_factor}), but nside[{nlev - n}]={nside_levels[nlev - n]}")
+                up = self.up_sampling_block.build(in_channels=cur, out_channels=cur, ctx=ctx.layer(nlev - n, nside_after=level_nside))
+            nxt = self.n_channels[n + 1] if n < nlev - 1 else self.n_channels[-1]
+            conv = self.conv_block.build(in_channels=cur * 2 if n > 0 else cur, out_channels=nxt, latent_channels=cur,
+                                         dilation=dilations[n], n_layers=self.n_layers[n], ctx=ctx.layer(nlev - 1 - n))
+            decoder.append(DecoderLevel(upsamp=up, conv=conv))
+        output_layer = self.output_layer.build(in_channels=cur, out_channels=output_channels, dilation=dilations[-1], ctx=ctx.layer(0))
+        return UNetDecoder(decoder=decoder, output_layer=output_layer)
+
+
+class DecoderLevel(nn.Module):
+    """healpix_decoder.py: upsample, concatenate the encoder skip along the channels, convolve.  The concatenation is never
+    materialised: the two sources are written into one padded tensor / read as two row sources of one GEMM."""
+
+    def __init__(self, upsamp: Optional[nn.Module], conv: nn.Module):
+        super().__init__()
+        self.upsamp = upsamp
+        self.conv = conv
+        self.channel_dim = 1
+
+    def forward(self, x: Hpx, skip: Hpx) -> Hpx:
+        if self.upsamp is not None:
+            return self.conv(self.upsamp(x), skip)
+        return self.conv(x)
+
+
+class UNetDecoder(nn.Module):
+    def __init__(self, decoder: List[DecoderLevel], output_layer: nn.Module):
+        super().__init__()
+        self.decoder = nn.ModuleList(decoder)
+        self.output_layer = output_layer
+
+    def forward(self, inputs: Sequence[Hpx]) -> Hpx:
+        x = inputs[-1]
+        for n, level in enumerate(self.decoder):
+            x = level(x, inputs[-1 - n])
+        return self.output_layer(x)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class HEALPixUNet(nn.Module):
+    """healpix_unet.py:14-94: [B, 12, C, H, W] -> [B, 12, C_out, H, W]."""
+
+    CHANNEL_DIM = 2
+
+    def __init__(self, encoder: nn.Module, decoder: nn.Module, input_channels: int, output_channels: int,
+                 nside: Optional[Tuple[int, ...]] = None):
+        super().__init__()
+        self.input_channels = input_channels
+        self.output_channels = output_channels
+        self.nside = nside
+        self.encoder = encoder
+        self.decoder = decoder
+
+    def _level_pitches(self, width: int) -> Dict[int, int]:
+        """row pitch per face width: the width of that level's padded faces (the largest padding any layer of the level uses)"""
+        pads: Dict[int, int] = {}
+        w = width
+        for level in self.encoder.encoder:
+            for mod in level:
+                if isinstance(mod, (AvgPool, MaxPool)):
+                    w //= 2
+            p = max([m._pad for m in level.modules() if isinstance(m, HEALPixLayer)] + [0])
+            pads[w] = max(pads.get(w, 0), p)
+        for n, level in enumerate(self.decoder.decoder):
+            if level.upsamp is not None:
+                w *= 2
+            p = max([m._pad for m in level.conv.modules() if isinstance(m, HEALPixLayer)] + [0])
+            pads[w] = max(pads.get(w, 0), p)
+        return {wd: wd + 2 * p for wd, p in pads.items()}
+
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        if inputs.ndim != 5:
+            raise ValueError(f"HEALPixUNet expects a 5D input [B, F, C, H, W]; got tensor with shape {tuple(inputs.shape)}")
+        if inputs.shape[self.CHANNEL_DIM] != self.input_channels:
+            raise ValueError(f"Expected input to have {self.input_channels} channels at dim {self.CHANNEL_DIM}, got "
+                             f"{inputs.shape[self.CHANNEL_DIM]}.")
+        if inputs.shape[1] != 12:
+            raise ValueError(f"expected 12 HEALPix faces at dim 1, got {inputs.shape[1]}")
+        h, w = inputs.shape[-2], inputs.shape[-1]
+        if self.nside is not None and (h != self.nside[0] or w != self.nside[0]):
+            raise ValueError(f"Input face size ({h}, {w}) does not match nside[0]={self.nside[0]}")
+        if h != w:
+            raise ValueError("HEALPix faces are square")
+        if not inputs.is_cuda:
+            raise RuntimeError("HEALPixUNet (ace_amd) runs on an MI355X only: move the module and its input to 'cuda'. There is no "
+                               "CPU fallback.")
+        if torch.is_grad_enabled() and inputs.requires_grad:
+            raise RuntimeError("ace_amd implements the inference forward only; call under torch.no_grad()")
+        B = inputs.shape[0]
+        _RT.pitch = self._level_pitches(w)
+        x = Hpx(inputs.reshape(B * 12, self.input_channels, h, w).float().contiguous(), w)   # fold (healpix_paddings.py:133-151)
+        out = self.decoder(self.encoder(x))
+        y = out.data[..., : out.width]
+        return y.reshape(B, 12, self.output_channels, h, w).contiguous()                     # unfold
+
+
+@ModuleSelector.register("HEALPixUNet")
+@dataclasses.dataclass
+class HEALPixUNetBuilder(ModuleConfig):
+    """fme/ace/registry/hpx.py:14-111."""
+
+    encoder: Any
+    decoder: Any
+    hpx_padding_mode: str = "earth2grid"
+    nside: Optional[Sequence[int]] = None
+
+    def __post_init__(self):
+        if isinstance(self.encoder, Mapping):
+            self.encoder = UNetEncoderConfig(**self.encoder)
+        if isinstance(self.decoder, Mapping):
+            self.decoder = UNetDecoderConfig(**self.decoder)
+        if self.hpx_padding_mode not in ("earth2grid", "karlbauer", "isolatitude"):
+            raise ValueError(f"Unknown hpx_padding_mode: {self.hpx_padding_mode!r}")
+
+    def build(self, n_in_channels: int, n_out_channels: int, dataset_info) -> nn.Module:
+        if len(getattr(dataset_info, "all_labels", ())) > 0:
+            raise ValueError("HEALPixUNet does not support labels")
+        return self._build(input_channels=n_in_channels, output_channels=n_out_channels)
+
+    def _build(self, input_channels: int, output_channels: int) -> HEALPixUNet:
+        levels = len(self.encoder.n_channels)
+        if len(self.decoder.n_channels) != levels:
+            raise ValueError(f"encoder and decoder must have same number of levels; got {levels} vs {len(self.decoder.n_channels)}")
+        if self.hpx_padding_mode == "isolatitude" and self.nside is None:
+            raise ValueError('hpx_padding_mode="isolatitude" requires nside (one int per UNet level)')
+        nside_resolved: Optional[Tuple[int, ...]] = None
+        if self.nside is not None:
+            nside_resolved = tuple(int(v) for v in self.nside)
+            if len(nside_resolved) != levels:
+                raise ValueError(f"nside length must match UNet levels; got {len(nside_resolved)} vs {levels}")
+            if any(v < 1 for v in nside_resolved):
+                raise ValueError(f"nside values must be positive; got {nside_resolved}")
+        ctx = HEALPixBuildContext(hpx_padding_mode=self.hpx_padding_mode, nside_levels=nside_resolved)
+        encoder = self.encoder.build(input_channels=input_channels, ctx=ctx)
+        decoder = self.decoder.build(output_channels=output_channels, ctx=ctx)
+        return HEALPixUNet(encoder=encoder, decoder=decoder, input_channels=input_channels, output_channels=output_channels,
+                           nside=nside_resolved)

@@ -277,6 +277,35 @@ int ace_physics_get_reference(ace_physics* phys, double* ref_dev, int* have_host
 /* One step.  `fields` is a HOST struct of device planes (copied into the kernel arguments). */
 int ace_physics_apply(ace_physics* phys, const ace_phys_fields* fields, int batch, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * HEALPix variant (BASELINE configs[4]): the operators of the reference's HEALPix UNet (fme/ace/models/healpix/) on
+ * the 12-face mesh.  Activations of one UNet level are [image = item * 12 + face][channel][row][pitch] fp32 with a row
+ * pitch >= the face width (the pitch of that level's padded faces, so that a shifted view of a padded tensor is a plain
+ * GEMM operand).  No allocation, no host synchronisation: capture-safe.
+ * ------------------------------------------------------------------------------------------ */
+const char* ace_hpx_last_error(void);
+/* HEALPixPadding (healpix_paddings.py:239-611, Karlbauer et al.; "earth2grid" gives the same result): for every cell of
+ * the padded mesh [12][nside + 2p][nside + 2p] the two source cells of the unpadded mesh, packed face << 24 | row << 12 |
+ * column; padded = 0.5 a + 0.5 b (b == a: plain copy).  Host only. */
+int ace_hpx_pad_table_host(int nside, int p, int* idx_a_host, int* idx_b_host);
+/* y[item * 12 + face][c0 + ch][m][m] (m = nside + 2p, compact) from x[image][ch][row][x_pitch] by the table (device copies
+ * of idx_a / idx_b).  Two calls with different c0 concatenate two sources along the channels (decoder skip connections). */
+int ace_hpx_pad(const float* x, long x_img_stride, long x_chan_stride, int x_pitch, float* y, int y_chans, int c0, int c,
+                const int* idx_a_dev, const int* idx_b_dev, int items, int nside, int p, void* stream);
+/* nn.Conv2d(k, dilation, padding 0) on already padded faces (+ bias, + residual, activation 0 none / 1 GELU(erf) / 2 ReLU,
+ * clamped from above by `cap`: CappedGELU healpix_activations.py:41-85; cap = +inf: none).  x: [imgs][cin][H + (k-1) dil][pitch],
+ * optional second source x2 (channels cin .. cin + cin2 - 1, k = 1 only), wt: the weight TAP-major [ky][kx][cout][cin + cin2],
+ * R / y: [imgs][cout][H][pitch].  k^2 accumulated fp32-MFMA GEMMs. */
+int ace_hpx_conv(const float* x, const float* x2, int cin, int cin2, const float* wt, const float* bias, const float* R, float* y,
+                 int imgs, int cout, int H, int W, int pitch, int k, int dil, int act, float cap, void* stream);
+/* nn.AvgPool2d(2) / nn.MaxPool2d(2) on `planes` = imgs * channels planes. */
+int ace_hpx_pool2(const float* x, float* y, long planes, int H, int W, int pitch_in, long plane_stride_in, int pitch_out,
+                  long plane_stride_out, int is_max, void* stream);
+/* nn.ConvTranspose2d(cin, cout, 2, stride 2) + activation (healpix_blocks.py:636-697).  wt: [dy][dx][cout][cin];
+ * tmp: 4 * imgs * cout * H * pitch_in floats of scratch; y: [imgs][cout][2 H][pitch_out]. */
+int ace_hpx_tconv2(const float* x, const float* wt, const float* bias, float* tmp, float* y, int imgs, int cin, int cout, int H, int W,
+                   int pitch_in, int pitch_out, long plane_stride_out, int act, float cap, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -256,6 +256,30 @@ def load_csfno():
     return _csfno
 
 
+_hpx = None
+
+
+def load_healpix():
+    """The REAL HEALPix UNet (fme/ace/models/healpix/*, pure torch; its optional earth2grid padding backend is absent here, the
+    'karlbauer' backend - documented there as giving the same result - is used).  Returns a namespace with the reference's
+    configuration dataclasses, HEALPixUNet and HEALPixPadding."""
+    global _hpx
+    if _hpx is not None:
+        return _hpx
+    load()
+    for pkg in ["fme.ace.models.healpix"]:
+        if pkg not in sys.modules:
+            _ns(pkg, os.path.join(REF, *pkg.split(".")))
+    blocks = importlib.import_module("fme.ace.models.healpix.healpix_blocks")
+    enc = importlib.import_module("fme.ace.models.healpix.healpix_encoder")
+    dec = importlib.import_module("fme.ace.models.healpix.healpix_decoder")
+    unet = importlib.import_module("fme.ace.models.healpix.healpix_unet")
+    act = importlib.import_module("fme.ace.models.healpix.healpix_activations")
+    pads = importlib.import_module("fme.ace.models.healpix.healpix_paddings")
+    _hpx = types.SimpleNamespace(blocks=blocks, encoder=enc, decoder=dec, unet=unet, activations=act, paddings=pads)
+    return _hpx
+
+
 _stepper = None
 
 

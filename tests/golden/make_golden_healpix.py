@@ -1,0 +1,93 @@
+"""Golden vectors for the HEALPix variant, emitted by the REAL reference modules imported under stubs
+(oracle/ref_loader.load_healpix) - build container only.
+  * padding: HEALPixPadding (fme/ace/models/healpix/healpix_paddings.py:239-611) applied to random faces for several
+    (nside, padding) pairs, incl. padding == nside and the equatorial corner means;
+  * HEALPixUNet cases (fme/ace/models/healpix/healpix_unet.py + blocks): the reference's own test configuration family
+    (fme/ace/registry/test_hpx.py: ConvNeXt blocks with CappedGELU, AvgPool, TransposedConvUpsample, dilations 1 / 2 / 4) and a
+    MaxPool / BasicConvBlock variant; each case stores the configuration as the plain dict the registry takes, the
+    reference's seeded state_dict, the input and the reference output."""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import ref_loader  # noqa: E402
+
+CAP = {"cap_value": 10}
+CASES = {
+    "convnext_avgpool_tconv": dict(
+        nside=16, n_in=5, n_out=3, batch=2,
+        config=dict(
+            encoder=dict(conv_block=dict(block_type="ConvNeXtBlock", kernel_size=3, upscale_factor=4, activation=CAP),
+                         down_sampling_block=dict(block_type="AvgPool", pooling=2), n_channels=[16, 8, 4], dilations=[1, 2, 4]),
+            decoder=dict(conv_block=dict(block_type="ConvNeXtBlock", kernel_size=3, upscale_factor=4, activation=CAP),
+                         up_sampling_block=dict(block_type="TransposedConvUpsample", stride=2, activation=CAP),
+                         output_layer=dict(block_type="BasicConvBlock", kernel_size=1, n_layers=1),
+                         n_channels=[4, 8, 16], dilations=[4, 2, 1]),
+            hpx_padding_mode="karlbauer")),
+    "basic_maxpool": dict(
+        nside=8, n_in=3, n_out=2, batch=1,
+        config=dict(
+            encoder=dict(conv_block=dict(block_type="BasicConvBlock", kernel_size=3, n_layers=2, activation=CAP),
+                         down_sampling_block=dict(block_type="MaxPool", pooling=2), n_channels=[12, 6], n_layers=[2, 1]),
+            decoder=dict(conv_block=dict(block_type="BasicConvBlock", kernel_size=3, n_layers=1, activation=CAP),
+                         up_sampling_block=dict(block_type="TransposedConvUpsample", stride=2),
+                         output_layer=dict(block_type="BasicConvBlock", kernel_size=3, n_layers=1),
+                         n_channels=[6, 12], n_layers=[1, 2]),
+            hpx_padding_mode="karlbauer", nside=[8, 4])),
+}
+
+
+def build_reference(ref, case):
+    b, a = ref.blocks, ref.activations
+
+    def block(d):
+        d = dict(d)
+        cls = {"ConvNeXtBlock": b.ConvNeXtBlockConfig, "BasicConvBlock": b.BasicConvBlockConfig, "AvgPool": b.AvgPoolDownsamplingBlockConfig,
+               "MaxPool": b.MaxPoolDownsamplingBlockConfig, "TransposedConvUpsample": b.TransposedConvUpsampleBlockConfig}[d.pop("block_type")]
+        if d.get("activation") is not None:
+            d["activation"] = a.CappedGELUConfig(**d["activation"])
+        return cls(**d)
+
+    cfg = case["config"]
+    e, d = dict(cfg["encoder"]), dict(cfg["decoder"])
+    enc = ref.encoder.UNetEncoderConfig(conv_block=block(e.pop("conv_block")), down_sampling_block=block(e.pop("down_sampling_block")), **e)
+    dec = ref.decoder.UNetDecoderConfig(conv_block=block(d.pop("conv_block")), up_sampling_block=block(d.pop("up_sampling_block")),
+                                        output_layer=block(d.pop("output_layer")), **d)
+    nside = tuple(cfg["nside"]) if cfg.get("nside") is not None else None
+    ctx = b.HEALPixBuildContext(hpx_padding_mode=cfg["hpx_padding_mode"], nside_levels=nside)
+    torch.manual_seed(0)
+    encoder = enc.build(input_channels=case["n_in"], ctx=ctx)
+    decoder = dec.build(output_channels=case["n_out"], ctx=ctx)
+    return ref.unet.HEALPixUNet(encoder=encoder, decoder=decoder, input_channels=case["n_in"], output_channels=case["n_out"], nside=nside)
+
+
+def main():
+    ref = ref_loader.load_healpix()
+    out = {"padding": {}, "unet": {}}
+    g = torch.Generator().manual_seed(3)
+    for nside, p in [(4, 1), (8, 2), (8, 4), (16, 3), (6, 6), (5, 2)]:
+        x = torch.randn(2 * 12, 3, nside, nside, generator=g)
+        out["padding"][(nside, p)] = {"x": x, "padded": ref.paddings.HEALPixPadding(p)(x)}
+    for name, case in CASES.items():
+        model = build_reference(ref, case).eval()
+        with torch.no_grad():      # biases start at their default init; scale the weights up so that the capped GELU is exercised
+            for k, prm in model.named_parameters():
+                if k.endswith("weight"):
+                    prm.mul_(3.0)
+        x = torch.randn(case["batch"], 12, case["n_in"], case["nside"], case["nside"], generator=g) * 2.0
+        with torch.no_grad():
+            y = model(x)
+        out["unet"][name] = {"case": {k: v for k, v in case.items()}, "state_dict": {k: v.clone() for k, v in model.state_dict().items()},
+                             "x": x, "y": y}
+        print(name, tuple(x.shape), "->", tuple(y.shape), "max|y|", float(y.abs().max()), "capped share",
+              float((y.abs() >= 9.999).float().mean()))
+    dst = os.path.join(HERE, "gen_healpix.pt")
+    torch.save(out, dst)
+    print("wrote", dst, os.path.getsize(dst) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -886,3 +886,49 @@ def test_fused_physics_ocean_and_prescribed(dev, interpolate):
     torch.cuda.synchronize()
     assert torch.equal(out["sst"][:, 0].cpu(), o["expected"][interpolate]["sst"])
     assert torch.equal(out["q"][:, 0].cpu(), o["gen"]["q"] + 1.0)
+
+
+# ---- HEALPix variant (csrc/healpix.hip, ace_amd/healpix.py) ---------------------------------------------------------------
+def test_healpix_padding_kernel_vs_reference(dev):
+    """ace_hpx_pad on the device against the reference's HEALPixPadding outputs (bitwise), reading a source with a row pitch
+    larger than the face and writing into a channel window of a wider padded tensor (how concatenations are formed)."""
+    import numpy as np
+    from ace_amd import _lib
+    L = _lib.lib()
+    gold = load_golden("gen_healpix.pt")
+    for (nside, p), d in gold["padding"].items():
+        m = nside + 2 * p
+        ia = np.zeros(12 * m * m, dtype=np.int32)
+        ib = np.zeros_like(ia)
+        assert L.ace_hpx_pad_table_host(nside, p, ia.ctypes.data, ib.ctypes.data) == 0
+        iad, ibd = torch.from_numpy(ia).to(dev), torch.from_numpy(ib).to(dev)
+        pitch = nside + 3
+        src = torch.full((24, 3, nside, pitch), float("nan"), device=dev)
+        src[..., :nside] = d["x"].to(dev)
+        y = torch.full((24, 5, m, m), -7.0, device=dev)
+        assert L.ace_hpx_pad(src.data_ptr(), src.stride(0), src.stride(1), pitch, y.data_ptr(), 5, 1, 3, iad.data_ptr(), ibd.data_ptr(),
+                             2, nside, p, _lib.current_stream()) == 0, L.ace_hpx_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(y[:, 1:4].cpu(), d["padded"]), (nside, p)
+        assert bool((y[:, 0] == -7.0).all()) and bool((y[:, 4] == -7.0).all())
+
+
+@pytest.mark.parametrize("name", ["convnext_avgpool_tconv", "basic_maxpool"])
+def test_healpix_unet_vs_reference(dev, name):
+    """The HEALPix UNet through the registry (ModuleSelector type "HEALPixUNet") with the REFERENCE's weights against the
+    reference's own output (tests/golden/make_golden_healpix.py): ConvNeXt blocks with capped GELU, dilated 3 x 3 convolutions
+    on padded faces (dilations 1 / 2 / 4), average / max pooling, transposed-convolution upsampling, skip concatenations.
+    Exact-fp32 MFMA arithmetic: 1e-5 of the output's maximum."""
+    import ace_amd
+    g = load_golden("gen_healpix.pt")["unet"][name]
+    case = g["case"]
+    mod = ace_amd.ModuleSelector(type="HEALPixUNet", config=case["config"]).build(case["n_in"], case["n_out"],
+                                                                                 ace_amd.DatasetInfo((case["nside"], case["nside"])))
+    net = mod.torch_module.to(dev)
+    net.load_state_dict(g["state_dict"], strict=True)
+    with torch.no_grad():
+        y = net(g["x"].to(dev))
+        y2 = net(g["x"].to(dev))
+    assert y.shape == g["y"].shape
+    assert torch.equal(y, y2)
+    assert rel_max(y, g["y"]) <= NET_TOL, rel_max(y, g["y"])

@@ -38,3 +38,24 @@ while k + 2 < 512 and t[k + 1] > t[k] > 0:
     n += 1
 if n:
     print(f"{n} tiles, {max(t) - t[0]} cycles from kernel start to the end of the last epilogue")
+
+# every workgroup's first / last stamp (wave 0): how long each lives, how late it starts (per XCC: the counters of different
+# XCCs are not synchronised)
+spans = (ctypes.c_ulonglong * (4096 * 3))()
+fn2 = L.ace_debug_wg_spans
+fn2.restype = ctypes.c_int
+fn2.argtypes = [ctypes.c_void_p]
+if fn2(spans) == 0:
+    import collections
+    per = collections.defaultdict(list)
+    for b in range(4096):
+        s0, s1, xcc = spans[3 * b], spans[3 * b + 1], spans[3 * b + 2]
+        if s1 > s0 > 0:
+            per[int(xcc)].append((s0, s1, b))
+    for xcc, v in sorted(per.items()):
+        t0 = min(a for a, _, _ in v)
+        dur = sorted(e - a for a, e, _ in v)
+        late = sorted(a - t0 for a, _, _ in v)
+        end = max(e for _, e, _ in v) - t0
+        print(f"XCC {xcc}: {len(v)} workgroups, lifetime min/med/max {dur[0]} / {dur[len(dur) // 2]} / {dur[-1]} cycles, "
+              f"start delay med/max {late[len(late) // 2]} / {late[-1]}, last end {end} cycles after the first start")
