@@ -366,9 +366,14 @@ class ConvNeXtBlock(nn.Module):
         first = self.convblock[0]
         target = x.width + 2 * first._pad if first._pad > 0 else x.pitch
         if self.skip_module is None:
-            if x2 is not None:
-                raise ValueError("identity skip with a concatenated input")
-            skip = _repitch(x, target)
+            if x2 is not None:   # identity skip of a concatenated input (decoder level with 2 C_in == C_out): the residual IS the
+                cat = torch.empty(x.data.shape[0], x.data.shape[1] + x2.data.shape[1], x.rows, target, dtype=torch.float32,
+                                  device=x.data.device)                       # concatenation, materialised once in the target pitch
+                cat[:, : x.data.shape[1], :, : x.width] = x.data[..., : x.width]
+                cat[:, x.data.shape[1]:, :, : x.width] = x2.data[..., : x.width]
+                skip = Hpx(cat, x.width)
+            else:
+                skip = _repitch(x, target)
         else:
             skip = self.skip_module.conv(_repitch(x, target), x2=_repitch(x2, target) if x2 is not None else None)
         return _run_convblock(self.convblock, x, x2=x2, residual=skip)

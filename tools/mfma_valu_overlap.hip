@@ -23,8 +23,12 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
                  : "v"(a), "v"(b))
 
 // MODE 0: M, 1: V, 2: MV, 3: interleaved with KV VALU per MFMA
-template <int MODE, int KV>
+// BIGLDS: the workgroup also declares 147 KiB of LDS (as conv_wl.hip / conv_ws.hip do): does launching 256 such workgroups
+// cost wall time that no wave sees?
+template <int MODE, int KV, bool BIGLDS = false>
 __global__ __launch_bounds__(512) void probe(float* out, const float* in, int nm, int nv, unsigned long long* ticks) {
+    __shared__ float big[BIGLDS ? 147 * 256 : 1];
+    if (BIGLDS) { big[threadIdx.x] = in[threadIdx.x]; __syncthreads(); }
     const int wave = threadIdx.x >> 6;
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     f32x16 acc[4];
@@ -60,19 +64,20 @@ __global__ __launch_bounds__(512) void probe(float* out, const float* in, int nm
     float s = 0.f;
     for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
     for (int e = 0; e < 8; ++e) s += x[e];
+    if (BIGLDS) s += big[(threadIdx.x * 7) & 511];
     out[blockIdx.x * 512 + threadIdx.x] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = __builtin_amdgcn_s_memtime() - t_start;   // s_memtime ticks of wave 0
 }
 
 static unsigned long long* g_ticks = nullptr;
 static unsigned long long last_ticks() { unsigned long long t = 0; (void)hipMemcpy(&t, g_ticks, 8, hipMemcpyDeviceToHost); return t; }
-template <int MODE, int KV>
+template <int MODE, int KV, bool BIGLDS = false>
 static double run(float* out, const float* in, int nm, int nv) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((probe<MODE, KV>), dim3(256), dim3(512), 0, 0, out, in, nm, nv, g_ticks);
+    hipLaunchKernelGGL((probe<MODE, KV, BIGLDS>), dim3(256), dim3(512), 0, 0, out, in, nm, nv, g_ticks);
     (void)hipEventRecord(e0, 0);
-    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((probe<MODE, KV>), dim3(256), dim3(512), 0, 0, out, in, nm, nv, g_ticks);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((probe<MODE, KV, BIGLDS>), dim3(256), dim3(512), 0, 0, out, in, nm, nv, g_ticks);
     (void)hipEventRecord(e1, 0);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
@@ -94,6 +99,14 @@ int main() {
         const unsigned long long tk = last_ticks();
         printf("clock check: M run %.1f us, wave 0 spans %llu s_memtime ticks = %.3f ticks/ns; the matrix pipe needs %d cycles "
                "=> >= %.2f GHz if a tick is a shader cycle\n", us, tk, (double)tk / (us * 1e3), 2 * nm * 32, 2.0 * nm * 32 / (us * 1e3));
+    }
+    for (int small : {2000, 4000}) {   // conv-sized launches (a 1-degree fc1 is ~3500 MFMAs per wave): wall time vs what wave 0 sees
+        const double us = run<0, 0, false>(out, in, small, 0);
+        const unsigned long long tk = last_ticks();
+        const double usb = run<0, 0, true>(out, in, small, 0);
+        const unsigned long long tkb = last_ticks();
+        printf("launch of 256 workgroups x 8 waves x %d MFMAs: %.1f us wall, wave 0 lives %llu cycles;  with 147 KiB of LDS per workgroup: "
+               "%.1f us wall, %llu cycles\n", small, us, tk, usb, tkb);
     }
     for (int ratio : {4, 7, 8}) {      // VALU per MFMA (fc1's epilogue: 6.7)
         const int nv = nm * ratio;

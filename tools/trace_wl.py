@@ -13,6 +13,7 @@ import bench  # noqa: E402
 from ace_amd import _lib  # noqa: E402
 
 dev = torch.device("cuda", 0)
+bench.ACE2 = dict(bench.ACE2, num_layers=1)      # ONE block: one conv_wl launch per forward, so the stamps are of one launch
 stepper, forcing, prog, diag = bench.build_stepper(dev, seed=0)
 net = stepper.modules[0]
 net.set_precision("f16x3")
