@@ -28,3 +28,14 @@ def test_conv_ws_work_decomposition(tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "shapes ok" in res.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_small_fft_templates(tmp_path):
+    """ace_amd/csrc/small_fft.h (the compile-time mixed-radix FFTs of the longitude transform, fft.hip) compiled for the host:
+    complex forward / inverse and real-input half spectra against direct double-precision sums, every level length in use."""
+    exe = str(tmp_path / "small_fft_emul")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "emul", "small_fft_emul.cpp")], check=True)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "small ffts ok" in res.stdout
