@@ -1,8 +1,11 @@
 """The index algebra of ace_amd/csrc/fft.hip (two-level Cooley-Tukey form of the longitude DFT), restated in numpy and
 checked against the direct sums the matrix kernels / the reference compute (fme/fft.py:61-96 under sht_fix's 2 pi scaling):
-the Hermitian shortcuts (k1 > N1/2 from conj(.) w_N2^b; inverse only k1 <= N1/2), the mirrored reads of the half spectrum,
-the dropped imaginary parts at m = 0 / Nyquist, the truncation at mmax and the paired (P, Q) outputs.  The kernels
-themselves are exercised by the GPU SHT / network tests at W = 16, 24, 48 and 360."""
+level 2 as ONE full N2-point transform per column k1 <= N1/2 whose outputs are stored twice (q <= N2/2 directly, conjugated
+as the mirrored column N1 - k1 at k2 = N2 - 1 - q), the inverse's per-k2 choice of stored entry (direct below N2/2, the
+conjugate of column N1 - k1 of block N2 - 1 - k2 above, W/2 itself or mirrored at N2/2), the dropped imaginary parts at
+m = 0 / Nyquist, the truncation at mmax and the paired (P, Q) outputs.  The small transforms themselves
+(ace_amd/csrc/small_fft.h) are compiled for the host in test_strip_emul_cpu.py; the kernels are exercised by the GPU SHT /
+network tests at W = 16, 24, 48 and 360."""
 import numpy as np
 import pytest
 
@@ -21,13 +24,21 @@ def forward_two_level(x, N1, N2, Mm):
         for k1 in range(H1):
             Z[b, k1] = sum(x[N2 * a + b] * w(a * k1, N1) for a in range(N1)) * (2 * np.pi / W) * w(b * k1, W)
     X = np.zeros(Mm, complex)
-    for k1 in range(N1):
-        cj = k1 > N1 // 2
-        z = [np.conj(Z[b, N1 - k1]) * w(b, N2) if cj else Z[b, k1] for b in range(N2)]
-        for k2 in range(N2 // 2 + 1):
-            m = k1 + N1 * k2
-            if m < Mm:
-                X[m] = sum(z[b] * w(b * k2, N2) for b in range(N2))
+    written = np.zeros(Mm, int)
+    for k1 in range(H1):
+        out = [sum(Z[b, k1] * w(b * q, N2) for b in range(N2)) for q in range(N2)]     # all N2 outputs of column k1
+        for q in range(N2):
+            if q <= N2 // 2:
+                m = k1 + N1 * q
+                if m < Mm:
+                    X[m] = out[q]
+                    written[m] += 1
+            if q >= N2 // 2 and 0 < k1 < N1 // 2:
+                m = (N1 - k1) + N1 * (N2 - 1 - q)
+                if m < Mm:
+                    X[m] = np.conj(out[q])
+                    written[m] += 1
+    assert (written == 1).all()             # every stored wavenumber exactly once
     return X
 
 
@@ -38,11 +49,12 @@ def inverse_two_level(S, N1, N2, Mm):
     for k1 in range(H1):
         f = np.zeros(N2, complex)
         for k2 in range(N2):
-            kk = k1 + N1 * k2
-            mir = 2 * kk > W
-            m = W - kk if mir else kk
+            mir = k2 > N2 // 2 or (k2 == N2 // 2 and k1 > 0)
+            blk = (N2 - 1 - k2) if mir else k2
+            m = ((N1 - k1) if mir else k1) + N1 * blk
+            assert m == (W - (k1 + N1 * k2) if 2 * (k1 + N1 * k2) > W else k1 + N1 * k2)
             re, im = (S[m].real, S[m].imag) if m < Mm else (0.0, 0.0)
-            if m == 0 or 2 * m == W:
+            if (k2 == 0 and k1 == 0) or (k2 == N2 // 2 and k1 == 0):
                 im = 0.0
             f[k2] = complex(re, -im if mir else im)
         for j in range(M2):
