@@ -119,14 +119,17 @@ FDEV void fft_unit(int& cblk, int& lat) {
 #ifndef ACE_FFT_FWD_WAVES
 #define ACE_FFT_FWD_WAVES 0
 #endif
+#ifndef ACE_FFT_QROWS
+#define ACE_FFT_QROWS 8    // channel rows per workgroup at W = 1440 (46 KiB of LDS per 8 rows)
+#endif
 #ifndef ACE_FFT_INV_ROWS
 #define ACE_FFT_INV_ROWS 32
 #endif
 #ifndef ACE_FFT_INV_WAVES
-#define ACE_FFT_INV_WAVES 0
+#define ACE_FFT_INV_WAVES 7   // three 9-wave workgroups per CU (LDS allows three) need <= 72 registers
 #endif
 template <int N1, int N2, int R>
-__global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_FWD_WAVES : 0) void dft_forward_fft_kernel(DftArgs p) {
+__global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_FWD_WAVES : (N1 * N2 == 1440 && R == 8 ? 4 : 0)) void dft_forward_fft_kernel(DftArgs p) {
     constexpr int W = N1 * N2, H1 = N1 / 2 + 1, NT = R * N2;
     constexpr int PITCH = W + 4;     // 16-byte aligned rows; PITCH = 4 (mod 8): the 16 rows x 4 b of a wave's level-1 read hit 64 banks
     constexpr int K2N = N2 / 2 + 1;  // k = k1 + N1 k2 <= W / 2  =>  k2 <= N2 / 2
@@ -267,7 +270,7 @@ hipError_t launch_fwd(const DftArgs& a, hipStream_t s) {
 //     y[N2 a + b] = Re U[0] + (-1)^a Re U[N1/2] + 2 sum_{0<k1<N1/2} Re(w_N1^(-k1 a) U[k1][b])      (pairs a, N1 - a share sums)
 // grid = (ceil(C / 16), H, Bt); block = 16 * max(N2, N1/2 + 1).  The spectral-filter bias is added on the way out.
 template <int N1, int N2, int R, bool XCD>
-__global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_INV_WAVES : 0) void dft_inverse_fft_kernel(DftArgs p) {
+__global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_INV_WAVES : (N1 * N2 == 1440 && R == 8 ? 4 : 0)) void dft_inverse_fft_kernel(DftArgs p) {
     constexpr int W = N1 * N2, H1 = N1 / 2 + 1, NT = R * N2;
     constexpr int PITCH = W + 4;   // 16-byte aligned rows
     static_assert(N1 % 2 == 0 && N2 % 2 == 0 && N1 >= 4 && N2 >= H1 && W % 4 == 0, "even factors");
@@ -413,7 +416,7 @@ bool launch_dft_forward_fft(const DftArgs& a, hipStream_t s, hipError_t* err) {
         return false;
     switch (a.W) {
         case 360: *err = launch_fwd<20, 18>(a, s); return true;
-        case 1440: *err = launch_fwd<40, 36, 8>(a, s); return true;    // 0.25-degree grid: 8 channel rows per workgroup (46 KiB)
+        case 1440: *err = launch_fwd<40, 36, ACE_FFT_QROWS>(a, s); return true;    // 0.25-degree grid: 8 channel rows per workgroup (46 KiB)
         case 720: *err = launch_fwd<30, 24, 8>(a, s); return true;
         case 48: *err = launch_fwd<8, 6>(a, s); return true;
         case 24: *err = launch_fwd<6, 4>(a, s); return true;
@@ -427,7 +430,7 @@ bool launch_dft_inverse_fft(const DftArgs& a, hipStream_t s, hipError_t* err) {
         return false;
     switch (a.W) {
         case 360: *err = launch_inv<20, 18, ACE_FFT_INV_ROWS>(a, s); return true;   // 32 channel rows per workgroup: 128-byte runs on the spectral side (r02: 81.7 -> 75.6 us; the forward kernel is faster with 16)
-        case 1440: *err = launch_inv<40, 36, 8>(a, s); return true;
+        case 1440: *err = launch_inv<40, 36, ACE_FFT_QROWS>(a, s); return true;
         case 720: *err = launch_inv<30, 24, 8>(a, s); return true;
         case 48: *err = launch_inv<8, 6>(a, s); return true;
         case 24: *err = launch_inv<6, 4>(a, s); return true;
