@@ -95,12 +95,18 @@ SIGNATURES = {
     "ace_unpack_denormalize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p]),
     "ace_hpx_last_error": (c_char_p, []),
     "ace_hpx_pad_table_host": (c_int, [c_int, c_int, c_void_p, c_void_p]),
-    "ace_hpx_pad": (c_int, [c_void_p, c_long, c_long, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "ace_hpx_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                             c_int, c_int, c_int, c_float, c_void_p]),
+    "ace_hpx_pad": (c_int, [c_void_p, c_long, c_long, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                            c_void_p, c_void_p]),
+    "ace_hpx_absmax": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
+    "ace_hpx_weight_create": (c_int, [c_void_p, c_int, c_int, c_void_p, POINTER(c_void_p)]),
+    "ace_hpx_weight_destroy": (None, [c_void_p]),
+    # x, x2, cin, cin2, w, row_off, bias, R, y, imgs, cout, H, W, pitch, k, dil, act, cap, xmax, x2max, ymax, stream
+    "ace_hpx_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                             c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ace_hpx_pool2": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_void_p]),
+    # x, w, bias, tmp, y, imgs, cin, cout, H, W, pitch_in, pitch_out, plane_stride_out, act, cap, xmax, ymax, stream
     "ace_hpx_tconv2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_long,
-                               c_int, c_float, c_void_p]),
+                               c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "ace_physics_last_error": (c_char_p, []),
     "ace_physics_create": (c_int, [POINTER(PhysConfig), c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "ace_physics_destroy": (None, [c_void_p]),

@@ -5,13 +5,21 @@
 //     backend gives the same result): every halo cell of a padded face is ONE cell of a neighbouring face (rotated for the
 //     polar faces) or, on the diagonal of the two corners an equatorial face has no neighbour for, the mean of two.  Built
 //     once on the host as a gather table (ace_hpx_pad_table_host), applied by one gather kernel;
-//   * k x k (dilated) convolution of a padded face = k^2 accumulated GEMMs W_tap (Cout x Cin) . X shifted by the tap's
-//     constant offset: activations of one UNet level are stored as [channels][rows][P] with the row pitch P = W + 2 p of that
-//     level's padded faces, so a shifted view of the padded tensor IS a plain row-major operand of the fp32 MFMA engine
-//     (kernels.hip: exact fp32 on v_mfma_f32_32x32x2_f32; bias on the first tap, residual / capped GELU on the last);
-//   * 2 x 2 average / max pooling, 2 x 2 stride-2 transposed convolution (four GEMMs + an interleaving scatter with the
-//     bias and activation), channel concatenation by writing two sources into one padded tensor.
-// First version: correct and on the matrix cores, not yet tuned (k^2 passes over the output per convolution).
+//   * k x k (dilated) convolution of a padded face = ONE contraction over (tap, input channel): activations of one UNet
+//     level are stored as [channels][rows][P] with the row pitch P (a multiple of 4) of that level's padded faces, so row
+//     (tap, i) of the B operand is channel i of the padded tensor shifted by the tap's constant offset - a row-offset table
+//     (GemmArgs::brow) instead of an im2col copy.  The engine is the compensated-fp16 one (kernels.hip gemm3: weights
+//     pre-split into fp16 hi/lo planes once per parameter, activations split on the fly, fp32 accumulation - the same
+//     fp32-class arithmetic as the SFNO path), with bias, residual, capped GELU and the output's magnitude bound in the
+//     epilogue.  (Round 3's first version ran k^2 accumulated fp32-MFMA GEMMs per convolution: 9 read-modify-write passes
+//     over the output; 16.8 ms per forward at nside 64.)
+//   * dynamic range: every tensor carries a 64-shard slot with a bound on max|x| (written by its producer: the padding
+//     gather, a convolution's epilogue, the transposed convolution's scatter; pooling passes its input's bound on);
+//   * gap columns [W, P) of a row are always DEFINED (zeros from the padding kernel / zero-initialised buffers, finite values
+//     from convolutions): the contraction runs over whole rows and its results in the gaps are never read as data;
+//   * 2 x 2 average / max pooling; 2 x 2 stride-2 transposed convolution = one GEMM with the four taps stacked along the
+//     output rows + an interleaving scatter with the bias and activation; channel concatenation by writing two sources
+//     into one padded tensor / two row sources of one GEMM.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -22,6 +30,8 @@
 #include "kernels.h"
 
 using namespace ace;
+
+#define ACE_HPX_SLACK 16   // floats the caller keeps behind a padded tensor (read, never used, by the last taps of the last row)
 
 static thread_local std::string g_herr;
 static int hfail(int code, const std::string& m) { g_herr = m; return code; }
@@ -186,27 +196,50 @@ extern "C" int ace_hpx_pad_table_host(int nside, int p, int* idx_a_host, int* id
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 
-// y[item][face][c0 + c][row][col] (padded, compact m x m) = 0.5 x[a] + 0.5 x[b];  x: [item * 12 + face][c][rows][x_pitch]
+// one atomicMax per workgroup into the 64-shard bound slot (a wave-level atomic per 64 cells serialises at the L2: 0.35 ms per call)
+__device__ __forceinline__ void block_amax(float vmax, unsigned* __restrict__ amax) {
+    __shared__ float wmax[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax + (blockIdx.x & 63), __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+}
+
+// y[item][face][c0 + c][row][col] (padded: m rows of pitch mp >= m, gap columns zero) = 0.5 x[a] + 0.5 x[b];
+// x: [item * 12 + face][c][rows][x_pitch].  amax (optional): 64-shard atomicMax of bits(max|y|).  The last workgroup also
+// zeroes `slack` floats behind the tensor (the k x k contraction reads (k - 1) dil elements past the last row).
 __global__ __launch_bounds__(256) void hpx_pad_kernel(const float* __restrict__ x, long x_img_stride, long x_chan_stride, int x_pitch,
-                                                      float* __restrict__ y, int y_chans, int c0, int c, int m,
-                                                      const int* __restrict__ ia, const int* __restrict__ ib, int items) {
-    const long cells = (long)m * m;
+                                                      float* __restrict__ y, int y_chans, int c0, int c, int m, int mp,
+                                                      const int* __restrict__ ia, const int* __restrict__ ib, int items,
+                                                      unsigned* __restrict__ amax, int slack) {
+    const long cells = (long)m * mp;
     const long total = (long)items * 12 * c * cells;
+    float vmax = 0.f;
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-        const int cell = (int)(t % cells);
+        const int cellp = (int)(t % cells);
+        const int row = cellp / mp, col = cellp % mp;
         long q = t / cells;
         const int ch = (int)(q % c);
         q /= c;
         const int face = (int)(q % 12), item = (int)(q / 12);
-        const int a = ia[(long)face * cells + cell], b = ib[(long)face * cells + cell];
-        auto src = [&](int s) {
-            const int sf = s >> 24, sy = (s >> 12) & 4095, sx = s & 4095;
-            return x[(long)(item * 12 + sf) * x_img_stride + (long)ch * x_chan_stride + (long)sy * x_pitch + sx];
-        };
-        const float va = src(a);
-        const float v = a == b ? va : 0.5f * va + 0.5f * src(b);
-        y[((long)(item * 12 + face) * y_chans + c0 + ch) * cells + cell] = v;
+        float v = 0.f;
+        if (col < m) {
+            const long cell = (long)row * m + col;
+            const int a = ia[(long)face * m * m + cell], b = ib[(long)face * m * m + cell];
+            auto src = [&](int s) {
+                const int sf = s >> 24, sy = (s >> 12) & 4095, sx = s & 4095;
+                return x[(long)(item * 12 + sf) * x_img_stride + (long)ch * x_chan_stride + (long)sy * x_pitch + sx];
+            };
+            const float va = src(a);
+            v = a == b ? va : 0.5f * va + 0.5f * src(b);
+        }
+        y[((long)(item * 12 + face) * y_chans + c0 + ch) * cells + cellp] = v;
+        vmax = fmaxf(vmax, fabsf(v));
     }
+    if (slack > 0 && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < slack && c0 + c == y_chans)
+        y[(long)items * 12 * y_chans * cells + threadIdx.x] = 0.f;
+    if (amax) block_amax(vmax, amax);
 }
 
 // 2 x 2 pooling, stride 2: x [imgs * c][H][px] -> y [imgs * c][H / 2][py]
@@ -229,71 +262,126 @@ __device__ __forceinline__ float hpx_act(float v, int act, float cap) {
     else if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
     return fminf(v, cap);
 }
-// interleave the four (dy, dx) GEMM results of a 2 x 2 stride-2 transposed convolution, add the bias, activate:
-// t [4][imgs][cout][H][pin] -> y [imgs][cout][2 H][pout]
+// interleave the four (dy, dx) row blocks of a 2 x 2 stride-2 transposed convolution's GEMM, add the bias, activate:
+// t [imgs][4][cout][H][pin] -> y [imgs][cout][2 H][pout];  amax: bound of the result
 __global__ __launch_bounds__(256) void hpx_tconv_scatter_kernel(const float* __restrict__ t, const float* __restrict__ bias,
                                                                 float* __restrict__ y, long imgs, int cout, int H, int W, int pin,
-                                                                int pout, long s_out_plane, int act, float cap) {
+                                                                int pout, long s_out_plane, int act, float cap,
+                                                                unsigned* __restrict__ amax) {
     const long total = imgs * cout * (long)(2 * H) * (2 * W);
-    const long tap_stride = imgs * cout * (long)H * pin;
+    float vmax = 0.f;
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
         const int xo = (int)(q % (2 * W)), yo = (int)((q / (2 * W)) % (2 * H));
         const long pl = q / ((long)4 * W * H);       // image * cout + channel
+        const long img = pl / cout;
+        const int o = (int)(pl % cout);
         const int tap = (yo & 1) * 2 + (xo & 1);
-        float v = t[tap * tap_stride + pl * (long)H * pin + (long)(yo >> 1) * pin + (xo >> 1)];
-        v += bias ? bias[pl % cout] : 0.f;
-        y[pl * s_out_plane + (long)yo * pout + xo] = hpx_act(v, act, cap);
+        float v = t[((img * 4 + tap) * cout + o) * (long)H * pin + (long)(yo >> 1) * pin + (xo >> 1)];
+        v += bias ? bias[o] : 0.f;
+        v = hpx_act(v, act, cap);
+        y[pl * s_out_plane + (long)yo * pout + xo] = v;
+        vmax = fmaxf(vmax, fabsf(v));
     }
+    if (amax) block_amax(vmax, amax);
 }
 
 unsigned grid_for(long total) {
     long g = (total + 255) / 256;
-    return (unsigned)(g < 1 ? 1 : (g > 65535 ? 65535 : g));
+    return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));   // grid-stride kernels: 16 workgroups per CU are plenty
 }
 
 }  // namespace
 
 extern "C" int ace_hpx_pad(const float* x, long x_img_stride, long x_chan_stride, int x_pitch, float* y, int y_chans, int c0, int c,
-                           const int* idx_a_dev, const int* idx_b_dev, int items, int nside, int p, void* stream) {
-    if (!x || !y || !idx_a_dev || !idx_b_dev || items < 1 || c < 1 || c0 < 0 || c0 + c > y_chans || nside < 1 || p < 1)
-        return hfail(ACE_ERR_INVALID, "ace_hpx_pad: bad argument");
+                           const int* idx_a_dev, const int* idx_b_dev, int items, int nside, int p, int y_pitch, unsigned* amax,
+                           void* stream) {
     const int m = nside + 2 * p;
-    const long total = (long)items * 12 * c * m * m;
+    if (!x || !y || !idx_a_dev || !idx_b_dev || items < 1 || c < 1 || c0 < 0 || c0 + c > y_chans || nside < 1 || p < 1 || y_pitch < m)
+        return hfail(ACE_ERR_INVALID, "ace_hpx_pad: bad argument");
+    const long total = (long)items * 12 * c * m * y_pitch;
     hipLaunchKernelGGL(hpx_pad_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, x_img_stride,
-                       x_chan_stride, x_pitch, y, y_chans, c0, c, m, idx_a_dev, idx_b_dev, items);
+                       x_chan_stride, x_pitch, y, y_chans, c0, c, m, y_pitch, idx_a_dev, idx_b_dev, items, amax, ACE_HPX_SLACK);
     HPX_TRY(hipGetLastError());
     return ACE_OK;
 }
 
-// y[img][o][r][c] = act( bias[o] + sum_{i, ky, kx} w[ky][kx][o][i] x[img][i][r + ky dil][c + kx dil] (+ R[img][o][r][c]) ), capped.
-// x: [imgs][cin (+ cin2 from x2)][rows_in][pitch] with rows_in = H + (k - 1) dil; y / R: [imgs][cout][H][pitch].  wt: tap-major.
-extern "C" int ace_hpx_conv(const float* x, const float* x2, int cin, int cin2, const float* wt, const float* bias, const float* R,
-                            float* y, int imgs, int cout, int H, int W, int pitch, int k, int dil, int act, float cap, void* stream) {
-    if (!x || !wt || !y || imgs < 1 || cin < 1 || cout < 1 || H < 1 || W < 1 || pitch < W + (k - 1) * dil || k < 1 || dil < 1 || cin2 < 0 ||
-        (cin2 > 0 && (!x2 || k != 1)) || (R && k != 1))
-        return hfail(ACE_ERR_INVALID, "ace_hpx_conv: bad argument (two sources and a residual only with k = 1)");
+extern "C" int ace_hpx_absmax(const float* x, long n, unsigned* amax, void* stream) {
+    if (!x || n < 1 || !amax) return hfail(ACE_ERR_INVALID, "ace_hpx_absmax: bad argument");
+    HPX_TRY(launch_absmax(x, n, amax, static_cast<hipStream_t>(stream)));
+    return ACE_OK;
+}
+
+// ---- prepared weights: fp16 hi/lo planes [rows16][pitch] scaled by a power of two (what ace_sfno_set_weight does per parameter)
+struct ace_hpx_weight {
+    _Float16* hi = nullptr; _Float16* lo = nullptr;
+    int rows = 0, cols = 0, pitch = 0;
+    float ascale = 1.f;
+};
+extern "C" void ace_hpx_weight_destroy(ace_hpx_weight* w) {
+    if (!w) return;
+    if (w->hi) (void)hipFree(w->hi);
+    if (w->lo) (void)hipFree(w->lo);
+    delete w;
+}
+extern "C" int ace_hpx_weight_create(const float* w_dev, int rows, int cols, void* stream, ace_hpx_weight** out) {
+    if (!w_dev || rows < 1 || cols < 1 || !out) return hfail(ACE_ERR_INVALID, "ace_hpx_weight_create: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<float> host((size_t)rows * cols);
+    HPX_TRY(hipStreamSynchronize(s));
+    HPX_TRY(hipMemcpy(host.data(), w_dev, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+    float mx = 0.f;
+    for (float v : host) {
+        if (!std::isfinite(v)) return hfail(ACE_ERR_INVALID, "ace_hpx_weight_create: non-finite weight");
+        mx = std::max(mx, std::fabs(v));
+    }
+    int e = 0;
+    if (mx > 0.f) { (void)std::frexp(mx, &e); e = 10 - e; }
+    ace_hpx_weight* w = new ace_hpx_weight;
+    w->rows = rows; w->cols = cols; w->pitch = (cols + 31) & ~31;
+    w->ascale = std::ldexp(1.0f, e);
+    const size_t halves = (size_t)((rows + 15) / 16 * 16) * w->pitch;
+    if (hipMalloc(reinterpret_cast<void**>(&w->hi), halves * 2) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&w->lo), halves * 2) != hipSuccess) {
+        ace_hpx_weight_destroy(w);
+        return hfail(ACE_ERR_RUNTIME, "ace_hpx_weight_create: out of device memory");
+    }
+    hipError_t er = hipMemsetAsync(w->hi, 0, halves * 2, s);
+    if (er == hipSuccess) er = hipMemsetAsync(w->lo, 0, halves * 2, s);
+    if (er == hipSuccess) er = launch_split_f16(w_dev, cols, w->hi, w->lo, w->pitch, rows, cols, w->ascale, s);
+    if (er == hipSuccess) er = hipStreamSynchronize(s);
+    if (er != hipSuccess) { ace_hpx_weight_destroy(w); return hfail(ACE_ERR_RUNTIME, std::string("ace_hpx_weight_create: ") + hipGetErrorString(er)); }
+    *out = w;
+    return ACE_OK;
+}
+
+// y[img][o][r][c] = act( bias[o] + sum_{ky, kx, i} w[o][(ky k + kx) cin + i] x[img][i][r + ky dil][c + kx dil] (+ R[img][o][r][c]) ), capped.
+// x: [imgs][cin][rows_in][pitch] with rows_in = H + (k - 1) dil (+ ACE_HPX_SLACK floats behind it when k > 1); k = 1 may take a
+// second source x2 [imgs][cin2][H][pitch] (rows cin .. of the contraction) and a residual R; y / R: [imgs][cout][H][pitch].
+// row_off (k > 1): k k cin element offsets (ky dil pitch + kx dil + i rows_in pitch), device.  xmax / x2max: bound slots of the
+// sources; ymax (optional): bound slot of the result (zeroed by the caller).  pitch % 4 == 0, all bases 16-byte aligned.
+extern "C" int ace_hpx_conv(const float* x, const float* x2, int cin, int cin2, const ace_hpx_weight* w, const long* row_off,
+                            const float* bias, const float* R, float* y, int imgs, int cout, int H, int W, int pitch, int k, int dil,
+                            int act, float cap, const unsigned* xmax, const unsigned* x2max, unsigned* ymax, void* stream) {
+    if (!x || !w || !y || !xmax || imgs < 1 || cin < 1 || cout < 1 || H < 1 || W < 1 || pitch < W + (k - 1) * dil || (pitch & 3) || k < 1 ||
+        dil < 1 || cin2 < 0 || (cin2 > 0 && (!x2 || !x2max || k != 1)) || (R && k != 1) || (k > 1 && !row_off))
+        return hfail(ACE_ERR_INVALID, "ace_hpx_conv: bad argument (two sources and a residual only with k = 1; pitch % 4 == 0)");
     if (!(act == ACT_NONE || act == ACT_GELU || act == ACT_RELU)) return hfail(ACE_ERR_INVALID, "ace_hpx_conv: activation must be none, gelu or relu");
+    const int K = (cin + cin2) * k * k;
+    if (w->rows != cout || w->cols != K) return hfail(ACE_ERR_INVALID, "ace_hpx_conv: prepared weight is " + std::to_string(w->rows) + " x " +
+                                                      std::to_string(w->cols) + ", expected " + std::to_string(cout) + " x " + std::to_string(K));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int rows_in = H + (k - 1) * dil;
-    const int K = cin + cin2;
-    for (int ky = 0; ky < k; ++ky)
-        for (int kx = 0; kx < k; ++kx) {
-            const int tap = ky * k + kx;
-            const bool first = tap == 0, last = tap == k * k - 1;
-            GemmArgs g;
-            g.A = wt + (long)tap * cout * K; g.lda = K; g.sA = 0;
-            const long off = (long)ky * dil * pitch + (long)kx * dil;
-            g.B = x + off; g.ldb = (long)rows_in * pitch; g.sB = (long)cin * rows_in * pitch;
-            if (cin2 > 0) { g.B2 = x2; g.ldb2 = (long)rows_in * pitch; g.sB2 = (long)cin2 * rows_in * pitch; g.K1 = cin; }
-            g.C = y; g.ldc = (long)H * pitch; g.sC = (long)cout * H * pitch;
-            g.bias = first ? bias : nullptr;
-            if (!first) { g.R = y; g.ldr = g.ldc; g.sR = g.sC; }        // accumulate over the taps, in place
-            else if (R) { g.R = R; g.ldr = g.ldc; g.sR = g.sC; }
-            g.M = cout; g.N = (H - 1) * pitch + W; g.K = K; g.nbatch = imgs;
-            g.act = last ? act : ACT_NONE;
-            g.cap = last ? cap : INFINITY;
-            HPX_TRY(launch_gemm(g, s));
-        }
+    GemmArgs g;
+    g.lda = w->pitch; g.sA = 0; g.a_kpad = w->pitch;
+    g.B = x; g.ldb = (long)rows_in * pitch; g.sB = (long)cin * rows_in * pitch;
+    if (k > 1) g.brow = row_off;
+    if (cin2 > 0) { g.B2 = x2; g.ldb2 = (long)H * pitch; g.sB2 = (long)cin2 * H * pitch; g.K1 = cin; }
+    g.C = y; g.ldc = (long)H * pitch; g.sC = (long)cout * H * pitch;
+    g.bias = bias;
+    if (R) { g.R = R; g.ldr = g.ldc; g.sR = g.sC; }
+    g.M = cout; g.N = H * pitch; g.K = K; g.nbatch = imgs;
+    g.act = act; g.cap = cap;
+    if (!gemm_f16x3_eligible(g)) return hfail(ACE_ERR_INVALID, "ace_hpx_conv: operands must be 16-byte aligned");
+    HPX_TRY(launch_gemm_f16x3(g, w->hi, w->lo, w->ascale, 1.0f, s, xmax, ymax, cin2 > 0 ? x2max : nullptr));
     return ACE_OK;
 }
 
@@ -308,23 +396,25 @@ extern "C" int ace_hpx_pool2(const float* x, float* y, long planes, int H, int W
     return ACE_OK;
 }
 
-// nn.ConvTranspose2d(cin, cout, 2, stride 2) + activation: wt tap-major [dy][dx][cout][cin]; tmp: 4 * imgs * cout * H * pitch_in floats
-extern "C" int ace_hpx_tconv2(const float* x, const float* wt, const float* bias, float* tmp, float* y, int imgs, int cin, int cout, int H,
-                              int W, int pitch_in, int pitch_out, long plane_stride_out, int act, float cap, void* stream) {
-    if (!x || !wt || !tmp || !y || imgs < 1 || cin < 1 || cout < 1 || H < 1 || W < 1) return hfail(ACE_ERR_INVALID, "ace_hpx_tconv2: bad argument");
+// nn.ConvTranspose2d(cin, cout, 2, stride 2) + activation: w prepared from [(dy, dx, cout)][cin] (4 cout rows); tmp: imgs * 4 cout * H *
+// pitch_in floats; x: [imgs][cin][H][pitch_in] with bound slot xmax; ymax (optional, zeroed by the caller): bound of the result
+extern "C" int ace_hpx_tconv2(const float* x, const ace_hpx_weight* w, const float* bias, float* tmp, float* y, int imgs, int cin, int cout,
+                              int H, int W, int pitch_in, int pitch_out, long plane_stride_out, int act, float cap, const unsigned* xmax,
+                              unsigned* ymax, void* stream) {
+    if (!x || !w || !tmp || !y || !xmax || imgs < 1 || cin < 1 || cout < 1 || H < 1 || W < 1 || (pitch_in & 3))
+        return hfail(ACE_ERR_INVALID, "ace_hpx_tconv2: bad argument");
+    if (w->rows != 4 * cout || w->cols != cin) return hfail(ACE_ERR_INVALID, "ace_hpx_tconv2: prepared weight has the wrong shape");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const long tap_stride = (long)imgs * cout * H * pitch_in;
-    for (int tap = 0; tap < 4; ++tap) {
-        GemmArgs g;
-        g.A = wt + (long)tap * cout * cin; g.lda = cin;
-        g.B = x; g.ldb = (long)H * pitch_in; g.sB = (long)cin * H * pitch_in;
-        g.C = tmp + tap * tap_stride; g.ldc = (long)H * pitch_in; g.sC = (long)cout * H * pitch_in;
-        g.M = cout; g.N = (H - 1) * pitch_in + W; g.K = cin; g.nbatch = imgs;
-        HPX_TRY(launch_gemm(g, s));
-    }
+    GemmArgs g;
+    g.lda = w->pitch; g.sA = 0; g.a_kpad = w->pitch;
+    g.B = x; g.ldb = (long)H * pitch_in; g.sB = (long)cin * H * pitch_in;
+    g.C = tmp; g.ldc = (long)H * pitch_in; g.sC = (long)4 * cout * H * pitch_in;
+    g.M = 4 * cout; g.N = H * pitch_in; g.K = cin; g.nbatch = imgs;
+    if (!gemm_f16x3_eligible(g)) return hfail(ACE_ERR_INVALID, "ace_hpx_tconv2: operands must be 16-byte aligned");
+    HPX_TRY(launch_gemm_f16x3(g, w->hi, w->lo, w->ascale, 1.0f, s, xmax, nullptr, nullptr));
     const long total = (long)imgs * cout * 4 * H * W;
     hipLaunchKernelGGL(hpx_tconv_scatter_kernel, dim3(grid_for(total)), dim3(256), 0, s, tmp, bias, y, (long)imgs, cout, H, W, pitch_in,
-                       pitch_out, plane_stride_out, act, cap);
+                       pitch_out, plane_stride_out, act, cap, ymax);
     HPX_TRY(hipGetLastError());
     return ACE_OK;
 }

@@ -34,6 +34,9 @@ struct GemmArgs {
     const float* B = nullptr; long ldb = 0; long sB = 0;
     // rows k >= K1 of B come from B2 (row k - K1): the big-skip concat without a copy.  K1 < 0: unused
     const float* B2 = nullptr; long ldb2 = 0; long sB2 = 0; int K1 = -1;
+    // optional (f16x3 on-the-fly-split engine only): row k of B starts at B + brow[k] instead of B + k * ldb - the k x k taps of
+    // a convolution as ONE contraction over (tap, channel) without an im2col copy; rows need 4-byte alignment only
+    const long* brow = nullptr;
     // per-k-row affine applied to B on load: b = b * bsc[k] + bsh[k] (fused instance norm / normalisation)
     const float* bsc = nullptr; const float* bsh = nullptr; long sbs = 0;
     float* C = nullptr; long ldc = 0; long sC = 0;

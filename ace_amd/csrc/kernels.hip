@@ -874,6 +874,7 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
         const _Float16* Alo = q.Alo + (long)batch * p.sA;
         const float* B = p.B + (long)batch * p.sB;
         const float* B2 = p.B2 ? p.B2 + (long)batch * p.sB2 : nullptr;
+        const long* brow = p.brow;
         const float bscale = bscale_k;
         // A DMA: piece = 16 rows x 64 B; lane -> (row, physical slot), fetches the XOR-swizzled logical slot
         long aoff[ACW];
@@ -902,12 +903,32 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
                 glds16(reinterpret_cast<const float*>(Alo + aoff[c] + k0), reinterpret_cast<float*>(Ab + APL + ca * 512));
             }
         };
-        auto issue_b = [&](int k0, BRegs& r) {  // exactly 8 row loads
+        // row-offset table (convolution taps): the offsets of the NEXT call's rows are fetched by this call, so that a stage's
+        // row loads do not wait for a dependent table load (the calls walk k0 = kbeg, kbeg + BKT, ... in order).  The table loads
+        // are issued BEFORE the call's 8 row loads: VMEM returns in order, so reading them back at the next call waits for nothing
+        // younger, and the counted vmcnt(8) below still means "everything but this stage's row loads has landed"
+        long rowoff[8];
+        auto fetch_rowoff = [&](int k0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int k = k0 + 8 * bkg + e;
+                k = k < K ? k : K - 1;
+                rowoff[e] = brow[k];
+            }
+        };
+        if (brow) fetch_rowoff(kbeg);
+        auto issue_b = [&](int k0, BRegs& r) {  // exactly 8 row loads (+ 8 table loads with a row table)
+            long cur[8];
+            if (brow) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cur[e] = rowoff[e];
+                fetch_rowoff(k0 + BKT);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 int k = k0 + 8 * bkg + e;
                 k = k < K ? k : K - 1;  // rows past K meet zero A columns
-                const float* src = (K1 >= 0 && k >= K1) ? (B2 + (long)(k - K1) * ldb2 + bn) : (B + (long)k * ldb + bn);
+                const float* src = brow ? (B + cur[e] + bn) : (K1 >= 0 && k >= K1) ? (B2 + (long)(k - K1) * ldb2 + bn) : (B + (long)k * ldb + bn);
                 if (NPT == 4) {
                     const float4 v = *reinterpret_cast<const float4*>(src);
                     r.v[e][0] = v.x; r.v[e][1] = v.y; r.v[e][NPT - 2] = v.z; r.v[e][NPT - 1] = v.w;
@@ -1074,6 +1095,7 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
         _Float16* Ph = q.Chi ? q.Chi + (long)batch * p.sC : nullptr;
         _Float16* Pl = q.Chi ? q.Clo + (long)batch * p.sC : nullptr;
         // four rows at a time: this kernel is capped at 128 VGPRs (8 waves per workgroup, 2 workgroups per CU)
+        const float capv = p.cap;
         dispatch_act(actk, [&](auto at) {
         constexpr int AC = decltype(at)::value;
 #pragma unroll 1
@@ -1107,7 +1129,7 @@ __global__ __launch_bounds__(128 * WM * WN, 4) void gemm3_f16x3_kernel(Gemm3Args
                 for (int e = 0; e < 4; ++e) {
                     float v = fmaf(o[e], osc_acc, bvv[jj]);
                     if (RES) v += fmaf(r4[e], rsv[jj], rtv[jj]);
-                    v = act_const<AC>(v, actk);
+                    v = fminf(act_const<AC>(v, actk), capv);
                     o[e] = fmaf(v, osv[jj], otv[jj]);
                 }
                 if (row < M && cok) {
@@ -1302,6 +1324,7 @@ static hipError_t launch_gemm_cfg(const GemmArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
+    if (a.brow) return hipErrorInvalidValue;   // row tables: f16x3 engine only
     // 128x128 when the row count tiles well by 128, else 64x256 (M = 180/181-row spectral problems, M = 50)
     const int waste128 = ((a.M + 127) / 128) * 128 - a.M;
     const int waste64 = ((a.M + 63) / 64) * 64 - a.M;
@@ -1310,6 +1333,9 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
 }
 
 
+#ifndef ACE_G3_W128_PCT
+#define ACE_G3_W128_PCT 0   // f16x3 engine: take the 128 x 128 tile when it wastes at most this share of its rows (else 64 x 256)
+#endif
 template <int WM, int WN>
 static hipError_t launch_gemm3_cfg(const Gemm3Args& a, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN, NT = 128 * WM * WN;  // MMA waves + loader waves
@@ -1357,7 +1383,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& g, const void* Ahi, const void* Alo
     a.omax = omax;
     const int waste128 = ((g.M + 127) / 128) * 128 - g.M;
     const int waste64 = ((g.M + 63) / 64) * 64 - g.M;
-    if (g.M >= 128 && waste128 <= waste64) return launch_gemm3_cfg<2, 2>(a, s);
+    if (g.M >= 128 && (waste128 <= waste64 || waste128 * 100 <= ACE_G3_W128_PCT * (g.M + waste128))) return launch_gemm3_cfg<2, 2>(a, s);
     return launch_gemm3_cfg<1, 4>(a, s);
 }
 

@@ -12,8 +12,10 @@ the same result; one gather table serves both).  Not built (raise at constructio
 smoothed-interpolate resamplers, the symmetric ConvNeXt variants.
 
 Runtime layout: an activation of one UNet level is ``[image = item * 12 + face][channel][row][pitch]`` fp32 with the row pitch
-of that level's padded faces (``Hpx``), so every k x k convolution is k^2 accumulated fp32-MFMA GEMMs on shifted views of the
-padded tensor.  There is no CPU path: tensors must live on an MI355X."""
+of that level's padded faces rounded up to a multiple of 4 (``Hpx``), so every k x k convolution is ONE contraction over
+(tap, channel) on shifted views of the padded tensor (a row-offset table, no im2col copy) in the compensated-fp16 MFMA mode of
+the SFNO path; every tensor carries a 64-word "bound slot" (max |x|, produced by the kernel that wrote the tensor) from which the
+consuming convolution derives its power-of-two scale.  There is no CPU path: tensors must live on an MI355X."""
 import ctypes
 import dataclasses
 from typing import Any, Callable, Dict, List, Mapping, Optional, Sequence, Tuple
@@ -37,9 +39,11 @@ def _check(rc: int) -> None:
 
 @dataclasses.dataclass
 class Hpx:
-    """An activation in the runtime layout: data [images, channels, rows, pitch] (contiguous), valid columns [0, width)."""
+    """An activation in the runtime layout: data [images, channels, rows, pitch] (contiguous, pitch % 4 == 0, gap columns
+    [width, pitch) defined), valid columns [0, width); amax: its bound slot (64 int32 words) or None (not produced yet)."""
     data: torch.Tensor
     width: int
+    amax: Optional[torch.Tensor] = None
 
     @property
     def pitch(self) -> int:
@@ -50,16 +54,35 @@ class Hpx:
         return self.data.shape[-2]
 
 
+def _round4(n: int) -> int:
+    return (n + 3) & ~3
+
+
 class _Runtime:
-    """Per-forward context: row pitch per face width (a level's tensors share the pitch of that level's padded faces) and the
-    padding gather tables (device copies), cached per (nside, padding)."""
+    """Per-forward context: row pitch per face width (a level's tensors share the pitch of that level's padded faces), the
+    padding gather tables (device copies, cached per (nside, padding)) and the pool of bound slots (zeroed once per forward)."""
+
+    SLOTS = 512
 
     def __init__(self):
         self.pitch: Dict[int, int] = {}
         self._tables: Dict[Tuple[int, int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._pool: Optional[torch.Tensor] = None
+        self._next = 0
+
+    def begin(self, device) -> None:
+        self._pool = torch.zeros(self.SLOTS * 64, dtype=torch.int32, device=device)
+        self._next = 0
+
+    def slot(self, device) -> torch.Tensor:
+        if self._pool is None or self._next >= self.SLOTS or self._pool.device != device:
+            self.begin(device)
+        v = self._pool[self._next * 64:(self._next + 1) * 64]
+        self._next += 1
+        return v
 
     def pitch_for(self, width: int) -> int:
-        return self.pitch.get(width, width)
+        return self.pitch.get(width, _round4(width))
 
     def table(self, nside: int, p: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
         key = (nside, p, str(device))
@@ -73,14 +96,23 @@ class _Runtime:
 
 
 _RT = _Runtime()
+_SLACK = 16   # ACE_HPX_SLACK_FLOATS
 
 
 def _repitch(x: Hpx, pitch: int) -> Hpx:
     if x.pitch == pitch:
         return x
-    out = torch.empty(*x.data.shape[:-1], pitch, dtype=torch.float32, device=x.data.device)
+    out = torch.zeros(*x.data.shape[:-1], pitch, dtype=torch.float32, device=x.data.device)
     out[..., : x.width] = x.data[..., : x.width]
-    return Hpx(out, x.width)
+    return Hpx(out, x.width, x.amax)
+
+
+def _bound(x: Hpx) -> torch.Tensor:
+    """The tensor's bound slot; a tensor nothing native produced (the network input) gets one from a reduction pass."""
+    if x.amax is None:
+        x.amax = _RT.slot(x.data.device)
+        _check(_lib.lib().ace_hpx_absmax(x.data.data_ptr(), x.data.numel(), x.amax.data_ptr(), _lib.current_stream()))
+    return x.amax
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -146,24 +178,46 @@ class HEALPixLayer(nn.Module):
         self.layers = torch.nn.Sequential(*layers)
         self._pad = padding
         self._k, self._dil = kernel_size, dilation
-        self._prep: Optional[Tuple[Tuple[int, int], torch.Tensor]] = None
+        self._prep: Optional[Tuple[Tuple[int, int], int]] = None            # (weight stamp, native prepared-weight handle)
+        self._rows: Dict[Tuple[int, int, int, str], torch.Tensor] = {}
+
+    def __del__(self):
+        try:
+            if self._prep is not None:
+                _lib.lib().ace_hpx_weight_destroy(ctypes.c_void_p(self._prep[1]))
+        except Exception:
+            pass
 
     # -- native execution
     @property
     def base(self) -> nn.Module:
         return self.layers[-1]
 
-    def _taps(self) -> torch.Tensor:
-        """Weight in tap-major order [ky][kx][cout][cin] (ConvTranspose2d: [dy][dx][cout][cin]); re-made when it changes."""
+    def _weight(self) -> ctypes.c_void_p:
+        """The weight prepared for the compensated-fp16 engine (fp16 hi / lo planes), rows = output channels (x 4 taps for the
+        transposed convolution), columns = (tap, input channel); re-made when the parameter changes."""
         w = self.base.weight
         stamp = (w.data_ptr(), w._version)
         if self._prep is None or self._prep[0] != stamp:
-            if isinstance(self.base, nn.ConvTranspose2d):
-                t = w.detach().permute(2, 3, 1, 0).contiguous().float()
-            else:
-                t = w.detach().permute(2, 3, 0, 1).contiguous().float()
-            self._prep = (stamp, t)
-        return self._prep[1]
+            if isinstance(self.base, nn.ConvTranspose2d):      # [cin][cout][dy][dx] -> [(dy, dx, cout)][cin]
+                t = w.detach().permute(2, 3, 1, 0).reshape(4 * w.shape[1], w.shape[0]).contiguous().float()
+            else:                                              # [cout][cin][ky][kx] -> [cout][(ky, kx, cin)]
+                t = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous().float()
+            h = ctypes.c_void_p()
+            _check(_lib.lib().ace_hpx_weight_create(t.data_ptr(), t.shape[0], t.shape[1], _lib.current_stream(), ctypes.byref(h)))
+            if self._prep is not None:
+                _lib.lib().ace_hpx_weight_destroy(ctypes.c_void_p(self._prep[1]))
+            self._prep = (stamp, h.value)
+        return ctypes.c_void_p(self._prep[1])
+
+    def _row_offsets(self, cin: int, rows_in: int, pitch: int, device) -> torch.Tensor:
+        key = (cin, rows_in, pitch, str(device))
+        if key not in self._rows:
+            k, d = self._k, self._dil
+            taps = torch.tensor([ky * d * pitch + kx * d for ky in range(k) for kx in range(k)], dtype=torch.int64)
+            chan = torch.arange(cin, dtype=torch.int64) * (rows_in * pitch)
+            self._rows[key] = (taps[:, None] + chan[None, :]).reshape(-1).contiguous().to(device)
+        return self._rows[key]
 
     def conv(self, x: Hpx, x2: Optional[Hpx] = None, residual: Optional[Hpx] = None, act: Tuple[int, float] = (ACT_NONE, _INF)) -> Hpx:
         base = self.base
@@ -171,36 +225,46 @@ class HEALPixLayer(nn.Module):
             raise TypeError("conv() on a non-convolution HEALPixLayer")
         L = _lib.lib()
         st = _lib.current_stream()
+        dev = x.data.device
         imgs, H, W = x.data.shape[0], x.rows, x.width
         cin = x.data.shape[1]
         cin2 = x2.data.shape[1] if x2 is not None else 0
         cout = base.out_channels
         bias = base.bias
-        wt = self._taps()
+        w = self._weight()
+        ymax = _RT.slot(dev)
         if self._pad > 0:
             p, m = self._pad, W + 2 * self._pad
-            ia, ib = _RT.table(W, p, x.data.device)
-            xp = torch.empty(imgs, cin + cin2, m, m, dtype=torch.float32, device=x.data.device)
+            mp = max(_RT.pitch_for(W), _round4(m))
+            ia, ib = _RT.table(W, p, dev)
+            ctot = cin + cin2
+            flat = torch.empty(imgs * ctot * m * mp + _SLACK, dtype=torch.float32, device=dev)
+            xmax = _RT.slot(dev)
             for src, c0 in ((x, 0), (x2, cin)):
                 if src is None:
                     continue
                 d = src.data
-                _check(L.ace_hpx_pad(d.data_ptr(), d.stride(0), d.stride(1), src.pitch, xp.data_ptr(), cin + cin2, c0, d.shape[1],
-                                     ia.data_ptr(), ib.data_ptr(), imgs // 12, W, p, st))
-            y = torch.empty(imgs, cout, H, m, dtype=torch.float32, device=x.data.device)
-            _check(L.ace_hpx_conv(xp.data_ptr(), None, cin + cin2, 0, wt.data_ptr(), _lib.ptr(bias) if bias is not None else None, None,
-                                  y.data_ptr(), imgs, cout, H, W, m, self._k, self._dil, act[0], act[1], st))
-            return Hpx(y, W)
+                _check(L.ace_hpx_pad(d.data_ptr(), d.stride(0), d.stride(1), src.pitch, flat.data_ptr(), ctot, c0, d.shape[1],
+                                     ia.data_ptr(), ib.data_ptr(), imgs // 12, W, p, mp, xmax.data_ptr(), st))
+            y = torch.empty(imgs, cout, H, mp, dtype=torch.float32, device=dev)
+            rows = self._row_offsets(ctot, m, mp, dev)
+            _check(L.ace_hpx_conv(flat.data_ptr(), None, ctot, 0, w, rows.data_ptr(), _lib.ptr(bias) if bias is not None else None, None,
+                                  y.data_ptr(), imgs, cout, H, W, mp, self._k, self._dil, act[0], act[1], xmax.data_ptr(), None,
+                                  ymax.data_ptr(), st))
+            return Hpx(y, W, ymax)
+        if x.pitch % 4:
+            x = _repitch(x, _round4(x.pitch))
         pitch = x.pitch
         if x2 is not None and x2.pitch != pitch:
             x2 = _repitch(x2, pitch)
         if residual is not None and residual.pitch != pitch:
             residual = _repitch(residual, pitch)
-        y = torch.empty(imgs, cout, H, pitch, dtype=torch.float32, device=x.data.device)
-        _check(L.ace_hpx_conv(x.data.data_ptr(), x2.data.data_ptr() if x2 is not None else None, cin, cin2, wt.data_ptr(),
+        y = torch.empty(imgs, cout, H, pitch, dtype=torch.float32, device=dev)
+        _check(L.ace_hpx_conv(x.data.data_ptr(), x2.data.data_ptr() if x2 is not None else None, cin, cin2, w, None,
                               _lib.ptr(bias) if bias is not None else None, residual.data.data_ptr() if residual is not None else None,
-                              y.data_ptr(), imgs, cout, H, W, pitch, 1, 1, act[0], act[1], st))
-        return Hpx(y, W)
+                              y.data_ptr(), imgs, cout, H, W, pitch, 1, 1, act[0], act[1], _bound(x).data_ptr(),
+                              _bound(x2).data_ptr() if x2 is not None else None, ymax.data_ptr(), st))
+        return Hpx(y, W, ymax)
 
     def pool(self, x: Hpx) -> Hpx:
         base = self.base
@@ -209,24 +273,28 @@ class HEALPixLayer(nn.Module):
             raise NotImplementedError("only 2 x 2 pooling (the reference's configurations) is built")
         imgs, C, H, W = x.data.shape[0], x.data.shape[1], x.rows, x.width
         po = _RT.pitch_for(W // 2)
-        y = torch.empty(imgs, C, H // 2, po, dtype=torch.float32, device=x.data.device)
+        y = torch.zeros(imgs, C, H // 2, po, dtype=torch.float32, device=x.data.device)
         _check(_lib.lib().ace_hpx_pool2(x.data.data_ptr(), y.data_ptr(), imgs * C, H, W, x.pitch, H * x.pitch, po, (H // 2) * po,
                                         1 if isinstance(base, nn.MaxPool2d) else 0, _lib.current_stream()))
-        return Hpx(y, W // 2)
+        return Hpx(y, W // 2, x.amax)      # |mean| and max of four values are bounded by the input's bound
 
     def tconv(self, x: Hpx, act: Tuple[int, float]) -> Hpx:
         base = self.base
         if not (isinstance(base, nn.ConvTranspose2d) and base.kernel_size == (2, 2) and base.stride == (2, 2)):
             raise NotImplementedError("only the 2 x 2 stride-2 transposed convolution (the reference's configurations) is built")
+        if x.pitch % 4:
+            x = _repitch(x, _round4(x.pitch))
         imgs, cin, H, W = x.data.shape[0], x.data.shape[1], x.rows, x.width
         cout = base.out_channels
         po = _RT.pitch_for(2 * W)
-        tmp = torch.empty(4 * imgs * cout * H * x.pitch, dtype=torch.float32, device=x.data.device)
-        y = torch.empty(imgs, cout, 2 * H, po, dtype=torch.float32, device=x.data.device)
-        _check(_lib.lib().ace_hpx_tconv2(x.data.data_ptr(), self._taps().data_ptr(), _lib.ptr(base.bias) if base.bias is not None else None,
+        dev = x.data.device
+        tmp = torch.empty(4 * imgs * cout * H * x.pitch, dtype=torch.float32, device=dev)
+        y = torch.zeros(imgs, cout, 2 * H, po, dtype=torch.float32, device=dev)
+        ymax = _RT.slot(dev)
+        _check(_lib.lib().ace_hpx_tconv2(x.data.data_ptr(), self._weight(), _lib.ptr(base.bias) if base.bias is not None else None,
                                          tmp.data_ptr(), y.data_ptr(), imgs, cin, cout, H, W, x.pitch, po, 2 * H * po, act[0], act[1],
-                                         _lib.current_stream()))
-        return Hpx(y, 2 * W)
+                                         _bound(x).data_ptr(), ymax.data_ptr(), _lib.current_stream()))
+        return Hpx(y, 2 * W, ymax)
 
 
 def _act_code(m: Optional[nn.Module]) -> Tuple[int, float]:
@@ -364,10 +432,10 @@ class ConvNeXtBlock(nn.Module):
     def forward(self, x: Hpx, x2: Optional[Hpx] = None) -> Hpx:
         # the convolutions' outputs carry the pitch of this level's padded faces; the skip branch is brought to it
         first = self.convblock[0]
-        target = x.width + 2 * first._pad if first._pad > 0 else x.pitch
+        target = max(_RT.pitch_for(x.width), _round4(x.width + 2 * first._pad)) if first._pad > 0 else _round4(x.pitch)
         if self.skip_module is None:
             if x2 is not None:   # identity skip of a concatenated input (decoder level with 2 C_in == C_out): the residual IS the
-                cat = torch.empty(x.data.shape[0], x.data.shape[1] + x2.data.shape[1], x.rows, target, dtype=torch.float32,
+                cat = torch.zeros(x.data.shape[0], x.data.shape[1] + x2.data.shape[1], x.rows, target, dtype=torch.float32,
                                   device=x.data.device)                       # concatenation, materialised once in the target pitch
                 cat[:, : x.data.shape[1], :, : x.width] = x.data[..., : x.width]
                 cat[:, x.data.shape[1]:, :, : x.width] = x2.data[..., : x.width]
@@ -634,7 +702,7 @@ class HEALPixUNet(nn.Module):
                 w *= 2
             p = max([m._pad for m in level.conv.modules() if isinstance(m, HEALPixLayer)] + [0])
             pads[w] = max(pads.get(w, 0), p)
-        return {wd: wd + 2 * p for wd, p in pads.items()}
+        return {wd: _round4(wd + 2 * p) for wd, p in pads.items()}
 
     def forward(self, inputs: torch.Tensor) -> torch.Tensor:
         if inputs.ndim != 5:
@@ -656,6 +724,7 @@ class HEALPixUNet(nn.Module):
             raise RuntimeError("ace_amd implements the inference forward only; call under torch.no_grad()")
         B = inputs.shape[0]
         _RT.pitch = self._level_pitches(w)
+        _RT.begin(inputs.device)
         x = Hpx(inputs.reshape(B * 12, self.input_channels, h, w).float().contiguous(), w)   # fold (healpix_paddings.py:133-151)
         out = self.decoder(self.encoder(x))
         y = out.data[..., : out.width]

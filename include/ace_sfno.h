@@ -280,31 +280,48 @@ int ace_physics_apply(ace_physics* phys, const ace_phys_fields* fields, int batc
 /* ------------------------------------------------------------------------------------------
  * HEALPix variant (BASELINE configs[4]): the operators of the reference's HEALPix UNet (fme/ace/models/healpix/) on
  * the 12-face mesh.  Activations of one UNet level are [image = item * 12 + face][channel][row][pitch] fp32 with a row
- * pitch >= the face width (the pitch of that level's padded faces, so that a shifted view of a padded tensor is a plain
- * GEMM operand).  No allocation, no host synchronisation: capture-safe.
+ * pitch >= the face width, a multiple of 4 (the pitch of that level's padded faces, so that a shifted view of a padded
+ * tensor is a plain GEMM operand); gap columns [width, pitch) hold defined values (zeros or finite results).  Every tensor
+ * has a "bound slot": 64 unsigned words whose maximum is the bit pattern of a bound on max|x| - zeroed by the caller,
+ * written by the producing call, read by the consuming convolution (compensated-fp16 arithmetic, fp32 accumulation: the
+ * same fp32-class mode as the SFNO path).  No allocation or host synchronisation outside ace_hpx_weight_create.
  * ------------------------------------------------------------------------------------------ */
+#define ACE_HPX_SLACK_FLOATS 16   /* floats a caller keeps allocated behind a padded tensor (zeroed by ace_hpx_pad) */
 const char* ace_hpx_last_error(void);
 /* HEALPixPadding (healpix_paddings.py:239-611, Karlbauer et al.; "earth2grid" gives the same result): for every cell of
  * the padded mesh [12][nside + 2p][nside + 2p] the two source cells of the unpadded mesh, packed face << 24 | row << 12 |
  * column; padded = 0.5 a + 0.5 b (b == a: plain copy).  Host only. */
 int ace_hpx_pad_table_host(int nside, int p, int* idx_a_host, int* idx_b_host);
-/* y[item * 12 + face][c0 + ch][m][m] (m = nside + 2p, compact) from x[image][ch][row][x_pitch] by the table (device copies
- * of idx_a / idx_b).  Two calls with different c0 concatenate two sources along the channels (decoder skip connections). */
+/* y[item * 12 + face][c0 + ch][m][y_pitch] (m = nside + 2p rows and valid columns, gap columns zero) from
+ * x[image][ch][row][x_pitch] by the table (device copies of idx_a / idx_b).  Two calls with different c0 concatenate two
+ * sources along the channels (decoder skip connections); the call that writes the last channels also zeroes
+ * ACE_HPX_SLACK_FLOATS behind the tensor.  amax (optional): bound slot of y (accumulates over the calls). */
 int ace_hpx_pad(const float* x, long x_img_stride, long x_chan_stride, int x_pitch, float* y, int y_chans, int c0, int c,
-                const int* idx_a_dev, const int* idx_b_dev, int items, int nside, int p, void* stream);
+                const int* idx_a_dev, const int* idx_b_dev, int items, int nside, int p, int y_pitch, unsigned* amax, void* stream);
+/* bound slot of a tensor no ace_hpx_* call produced (the network input): amax[64] (zeroed by the caller) <- bits(max|x|). */
+int ace_hpx_absmax(const float* x, long n, unsigned* amax, void* stream);
+/* A convolution weight prepared for the compensated-fp16 engine: [rows][cols] row-major fp32 on the device ->
+ * fp16 hi / lo planes under a power-of-two scale.  Synchronises the stream (once per parameter version). */
+typedef struct ace_hpx_weight ace_hpx_weight;
+int ace_hpx_weight_create(const float* w_dev, int rows, int cols, void* stream, ace_hpx_weight** out);
+void ace_hpx_weight_destroy(ace_hpx_weight* w);
 /* nn.Conv2d(k, dilation, padding 0) on already padded faces (+ bias, + residual, activation 0 none / 1 GELU(erf) / 2 ReLU,
- * clamped from above by `cap`: CappedGELU healpix_activations.py:41-85; cap = +inf: none).  x: [imgs][cin][H + (k-1) dil][pitch],
- * optional second source x2 (channels cin .. cin + cin2 - 1, k = 1 only), wt: the weight TAP-major [ky][kx][cout][cin + cin2],
- * R / y: [imgs][cout][H][pitch].  k^2 accumulated fp32-MFMA GEMMs. */
-int ace_hpx_conv(const float* x, const float* x2, int cin, int cin2, const float* wt, const float* bias, const float* R, float* y,
-                 int imgs, int cout, int H, int W, int pitch, int k, int dil, int act, float cap, void* stream);
-/* nn.AvgPool2d(2) / nn.MaxPool2d(2) on `planes` = imgs * channels planes. */
+ * clamped from above by `cap`: CappedGELU healpix_activations.py:41-85; cap = +inf: none) as ONE contraction over
+ * (tap, channel).  x: [imgs][cin][H + (k-1) dil][pitch]; optional second source x2 (channels cin .. cin + cin2 - 1) and
+ * residual R with k = 1 only; w: prepared from [cout][(ky k + kx) (cin + cin2) + i]; row_off (k > 1, device): element
+ * offset of contraction row (tap, i) = ky dil pitch + kx dil + i (H + (k-1) dil) pitch; R / y: [imgs][cout][H][pitch].
+ * xmax / x2max: bound slots of the sources; ymax (optional): bound slot of y. */
+int ace_hpx_conv(const float* x, const float* x2, int cin, int cin2, const ace_hpx_weight* w, const long* row_off, const float* bias,
+                 const float* R, float* y, int imgs, int cout, int H, int W, int pitch, int k, int dil, int act, float cap,
+                 const unsigned* xmax, const unsigned* x2max, unsigned* ymax, void* stream);
+/* nn.AvgPool2d(2) / nn.MaxPool2d(2) on `planes` = imgs * channels planes (the input's bound also bounds the result). */
 int ace_hpx_pool2(const float* x, float* y, long planes, int H, int W, int pitch_in, long plane_stride_in, int pitch_out,
                   long plane_stride_out, int is_max, void* stream);
-/* nn.ConvTranspose2d(cin, cout, 2, stride 2) + activation (healpix_blocks.py:636-697).  wt: [dy][dx][cout][cin];
- * tmp: 4 * imgs * cout * H * pitch_in floats of scratch; y: [imgs][cout][2 H][pitch_out]. */
-int ace_hpx_tconv2(const float* x, const float* wt, const float* bias, float* tmp, float* y, int imgs, int cin, int cout, int H, int W,
-                   int pitch_in, int pitch_out, long plane_stride_out, int act, float cap, void* stream);
+/* nn.ConvTranspose2d(cin, cout, 2, stride 2) + activation (healpix_blocks.py:636-697).  w: prepared from
+ * [(dy 2 + dx) cout + o][cin]; tmp: imgs * 4 cout * H * pitch_in floats of scratch; y: [imgs][cout][2 H][pitch_out]. */
+int ace_hpx_tconv2(const float* x, const ace_hpx_weight* w, const float* bias, float* tmp, float* y, int imgs, int cin, int cout, int H,
+                   int W, int pitch_in, int pitch_out, long plane_stride_out, int act, float cap, const unsigned* xmax, unsigned* ymax,
+                   void* stream);
 
 #ifdef __cplusplus
 }

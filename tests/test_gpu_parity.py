@@ -905,12 +905,22 @@ def test_healpix_padding_kernel_vs_reference(dev):
         pitch = nside + 3
         src = torch.full((24, 3, nside, pitch), float("nan"), device=dev)
         src[..., :nside] = d["x"].to(dev)
-        y = torch.full((24, 5, m, m), -7.0, device=dev)
-        assert L.ace_hpx_pad(src.data_ptr(), src.stride(0), src.stride(1), pitch, y.data_ptr(), 5, 1, 3, iad.data_ptr(), ibd.data_ptr(),
-                             2, nside, p, _lib.current_stream()) == 0, L.ace_hpx_last_error()
+        mp = (m + 3) // 4 * 4 + 4                      # a pitch wider than the padded face: gap columns must come out zero
+        flat = torch.full((24 * 5 * m * mp + 16,), -7.0, device=dev)
+        y = flat[: 24 * 5 * m * mp].view(24, 5, m, mp)
+        amax = torch.zeros(64, dtype=torch.int32, device=dev)
+        assert L.ace_hpx_pad(src.data_ptr(), src.stride(0), src.stride(1), pitch, flat.data_ptr(), 5, 1, 3, iad.data_ptr(), ibd.data_ptr(),
+                             2, nside, p, mp, amax.data_ptr(), _lib.current_stream()) == 0, L.ace_hpx_last_error()
         torch.cuda.synchronize()
-        assert torch.equal(y[:, 1:4].cpu(), d["padded"]), (nside, p)
+        assert torch.equal(y[:, 1:4, :, :m].cpu(), d["padded"]), (nside, p)
+        assert bool((y[:, 1:4, :, m:] == 0).all())
         assert bool((y[:, 0] == -7.0).all()) and bool((y[:, 4] == -7.0).all())
+        assert bool((flat[-16:] == -7.0).all())        # the slack is zeroed only by the call that writes the last channels
+        assert float(amax.view(torch.float32).max()) == float(d["padded"].abs().max())
+        assert L.ace_hpx_pad(src.data_ptr(), src.stride(0), src.stride(1), pitch, flat.data_ptr(), 5, 2, 3, iad.data_ptr(), ibd.data_ptr(),
+                             2, nside, p, mp, None, _lib.current_stream()) == 0, L.ace_hpx_last_error()
+        torch.cuda.synchronize()
+        assert bool((flat[-16:] == 0).all())
 
 
 @pytest.mark.parametrize("name", ["convnext_avgpool_tconv", "basic_maxpool"])
@@ -918,7 +928,7 @@ def test_healpix_unet_vs_reference(dev, name):
     """The HEALPix UNet through the registry (ModuleSelector type "HEALPixUNet") with the REFERENCE's weights against the
     reference's own output (tests/golden/make_golden_healpix.py): ConvNeXt blocks with capped GELU, dilated 3 x 3 convolutions
     on padded faces (dilations 1 / 2 / 4), average / max pooling, transposed-convolution upsampling, skip concatenations.
-    Exact-fp32 MFMA arithmetic: 1e-5 of the output's maximum."""
+    Compensated-fp16 MFMA arithmetic (fp32-class, as the SFNO path): 1e-5 of the output's maximum."""
     import ace_amd
     g = load_golden("gen_healpix.pt")["unet"][name]
     case = g["case"]

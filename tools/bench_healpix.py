@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """BASELINE configs[4]: the HEALPix UNet (reference default channel schedule 136 / 68 / 34, ConvNeXt blocks with capped GELU,
 dilations 1 / 2 / 4, average pooling, transposed-convolution upsampling) at nside 64 (12 x 64 x 64 = 49 152 cells, ~1 degree),
-44 in / 50 out channels, B = 1, random init: ms per forward on one MI355X.  First version of the variant: correct and on the fp32
-matrix cores, not tuned (k^2 passes per convolution).  usage: python tools/bench_healpix.py [--nside 64] [--iters 10]"""
+44 in / 50 out channels, B = 1, random init: ms per forward on one MI355X (compensated-fp16 MFMA, one contraction per
+convolution).  usage: python tools/bench_healpix.py [--nside 64] [--iters 10]"""
 import argparse
 import json
 import os
@@ -44,5 +44,5 @@ with torch.no_grad():
     e1.record()
     torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / args.iters
-print(json.dumps({"workload": f"HEALPixUNet 136/68/34 ConvNeXt, nside {args.nside}, 44 -> 50 channels, B=1, fp32 MFMA", "ms_per_forward": round(ms, 3),
+print(json.dumps({"workload": f"HEALPixUNet 136/68/34 ConvNeXt, nside {args.nside}, 44 -> 50 channels, B=1, f16x3 MFMA", "ms_per_forward": round(ms, 3),
                   "forwards_per_s": round(1e3 / ms, 2), "finite": bool(torch.isfinite(y).all()), "parameters": sum(p.numel() for p in net.parameters())}))
