@@ -1209,7 +1209,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     float* sh1 = sc1 + (size_t)n->Bmax * C;
     const bool norm = c.normalization_layer == 1;
     // NoiseConditionedSFNO: conditional layer norms are materialised in place (fp32) with their true max in the slot of
-    // the instance-norm bound; the convolutions then run on the on-the-fly-split engine (v3) / the fp32 engines
+    // the instance-norm bound; the convolutions then run on the packed-operand engine (one pack pass per conv input)
     const bool cln = c.normalization_layer == 2;
     const float* skip_in = in;               // second source of the big-skip concat
     const unsigned* skip_in_slot = slot(0);
@@ -1333,7 +1333,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         // block input; the spectrally round-tripped residual of mixed-grid blocks has no range slot -> fp32 engine
         const unsigned* skip_max = scale_residual ? nullptr : ((norm || cln) ? slot(sb + 3) : hslot(i));
         const bool skip_f16 = f16 && skip_max != nullptr;
-        const bool pk = skip_f16 && !cln && packed_ok(n, C) && (!c.use_mlp || n->hid % 8 == 0);
+        const bool pk = skip_f16 && packed_ok(n, C) && (!c.use_mlp || n->hid % 8 == 0);
         _Float16* Ph = reinterpret_cast<_Float16*>(n->P.p);
         _Float16* Pl = Ph + (size_t)n->Bmax * C * HW;
         const bool fused = pk && norm && c.use_mlp && n->P2.p != nullptr;
@@ -1506,7 +1506,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             const Weight& w1 = *n->weights[n->index.at(p + "mlp.fwd.0.weight")];
             const Weight& b1w = *n->weights[n->index.at(p + "mlp.fwd.0.bias")];
             const Weight& w2 = *n->weights[n->index.at(p + "mlp.fwd.2.weight")];
-            const unsigned* tmax = norm ? slot(sb + 5) : slot(sb + 4);
+            const unsigned* tmax = (norm || cln) ? slot(sb + 5) : slot(sb + 4);
             _Float16* Uh = reinterpret_cast<_Float16*>(n->U.p);
             _Float16* Ul = Uh + (size_t)n->Bmax * n->hid * HW;
             ACE_TRY(pack_act(n, n->T.p, actB, C, a1, b1, tmax, Ph, Pl, B, s));
