@@ -541,6 +541,22 @@ __global__ __launch_bounds__(256) void pack_conv_frag_kernel(const float* __rest
                                                              const float* __restrict__ b, const float* __restrict__ bias,
                                                              float* __restrict__ bf) {
     const int smp = blockIdx.y;
+    if ((int)blockIdx.x >= (O / 32) * (I / 16)) {   // extra workgroups: folded bias of one 32-row tile, bias + W b (8 threads per row,
+        const int T = (int)blockIdx.x - (O / 32) * (I / 16);   // 16 bytes per load) - beside the packing, not after it
+        const int r = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+        const long row = 32L * T + r;
+        const float4* w4 = reinterpret_cast<const float4*>(W + row * ldw);
+        const float4* b4 = reinterpret_cast<const float4*>(b + (long)smp * I);
+        float acc = 0.f;
+        for (int q = l8; q < I / 4; q += 8) {
+            const float4 w = w4[q], v = b4[q];
+            acc = fmaf(w.x, v.x, acc); acc = fmaf(w.y, v.y, acc); acc = fmaf(w.z, v.z, acc); acc = fmaf(w.w, v.w, acc);
+        }
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (l8 == 0) bf[(long)smp * O + row] = (bias ? bias[row] : 0.f) + acc;
+        return;
+    }
     float scale = scale_static;
     if (a) {   // one scale for all samples (as fold_affine_f16_kernel)
         __shared__ float red[4];
@@ -573,23 +589,14 @@ __global__ __launch_bounds__(256) void pack_conv_frag_kernel(const float* __rest
         out[t] = h;
         out[512 + t] = (_Float16)(x - (float)h);
     }
-    if (bf && J == 0) {   // folded bias of the 32 rows of this tile: bias + W b (8 threads per row)
-        const int r = threadIdx.x >> 3, l8 = threadIdx.x & 7;
-        const long row = 32L * T + r;
-        const float* bs = b + (long)smp * I;
-        float acc = 0.f;
-        for (int q = l8; q < I; q += 8) acc = fmaf(W[row * ldw + q], bs[q], acc);
-#pragma unroll
-        for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (l8 == 0) bf[(long)smp * O + row] = (bias ? bias[row] : 0.f) + acc;
-    }
 }
 
 hipError_t launch_pack_conv_frag(const float* W, long ldw, int O, int I, int order, const float* a, float wmax,
                                  float scale_static, unsigned* wslot, void* dst, long sDst, int nsamples, hipStream_t s,
                                  const float* b, const float* bias, float* bf) {
     if (O % 32 != 0 || I % 16 != 0 || (order == 1 && I % 32 != 0) || (a && !wslot) || (bf && !b)) return hipErrorInvalidValue;
-    dim3 grid((unsigned)((O / 32) * (I / 16)), (unsigned)nsamples);
+    if (bf && ((ldw & 3) != 0 || (reinterpret_cast<uintptr_t>(W) & 15) != 0 || (reinterpret_cast<uintptr_t>(b) & 15) != 0)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((O / 32) * (I / 16) + (bf ? O / 32 : 0)), (unsigned)nsamples);
     hipLaunchKernelGGL(pack_conv_frag_kernel, grid, dim3(256), 0, s, W, ldw, O, I, order, a, wmax, scale_static, wslot,
                        static_cast<_Float16*>(dst), sDst, b, bias, bf);
     return hipGetLastError();

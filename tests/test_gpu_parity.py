@@ -123,6 +123,10 @@ def test_sht_golden_regression(dev):
     (9, 18, None, None, "lobatto", 1), (9, 18, None, None, "equiangular", 5), (6, 12, None, None, "legendre-gauss", 3),
     (12, 24, 8, 9, "legendre-gauss", 4), (45, 90, None, None, "legendre-gauss", 16), (13, 27, None, None, "equiangular", 2),
     (64, 128, 40, 50, "legendre-gauss", 7),
+    # widths with an instantiated two-level FFT (csrc/fft.hip: 16, 24, 48, 360, 720, 1440), truncated mmax, channel counts that
+    # leave the last 8 / 16 / 32-row channel block ragged
+    (8, 16, None, None, "equiangular", 3), (24, 48, 20, 17, "legendre-gauss", 33), (180, 360, 120, 100, "legendre-gauss", 17),
+    (30, 720, 24, 15, "equiangular", 9), (20, 1440, 16, 12, "legendre-gauss", 5),
 ])
 @pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 def test_sht_vs_oracle(dev, nlat, nlon, lmax, mmax, grid, n, precision):
@@ -942,6 +946,28 @@ def test_healpix_unet_vs_reference(dev, name):
     assert y.shape == g["y"].shape
     assert torch.equal(y, y2)
     assert rel_max(y, g["y"]) <= NET_TOL, rel_max(y, g["y"])
+
+
+def test_healpix_weight_update_is_seen(dev):
+    """The prepared (fp16 hi / lo) copy of a convolution weight is re-made when the parameter changes in place: doubling the
+    output layer's weight and bias (a 1 x 1 convolution without activation) doubles the output."""
+    import ace_amd
+    g = load_golden("gen_healpix.pt")["unet"]["convnext_avgpool_tconv"]
+    case = g["case"]
+    net = ace_amd.ModuleSelector(type="HEALPixUNet", config=case["config"]).build(
+        case["n_in"], case["n_out"], ace_amd.DatasetInfo((case["nside"], case["nside"]))).torch_module.to(dev)
+    net.load_state_dict(g["state_dict"], strict=True)
+    x = g["x"].to(dev)
+    with torch.no_grad():
+        y0 = net(x)
+        out_conv = [m for m in net.decoder.output_layer.modules() if isinstance(m, torch.nn.Conv2d)]
+        assert len(out_conv) == 1 and out_conv[0].kernel_size == (1, 1)
+        out_conv[0].weight.mul_(2.0)
+        if out_conv[0].bias is not None:
+            out_conv[0].bias.mul_(2.0)
+        y1 = net(x)
+    assert rel_max(y1, 2.0 * y0) <= 1e-6
+    assert rel_max(y0, g["y"]) <= NET_TOL
 
 
 def test_healpix_stepper_rollout(dev):
