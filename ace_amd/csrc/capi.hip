@@ -54,6 +54,7 @@ Switches read_switches() {
     sw.no_pk_sht = on("ACE_NO_PK_SHT");
     sw.no_enc_ws = on("ACE_NO_ENC_WS");
     if (const char* e = std::getenv("ACE_CONV_WL")) sw.conv_wl = !(e[0] == '0' && !e[1]);
+    if (const char* e = std::getenv("ACE_PLANES_STREAM")) sw.planes_stream = !(e[0] == '0' && !e[1]);
     if (const char* e = std::getenv("ACE_CONV_WS")) {
         const std::string v(e);
         if (v == "all" || v == "1") sw.conv_ws_roles = 7;
@@ -181,10 +182,12 @@ static int plan_build(int nlat, int nlon, int lmax, int mmax, Grid g, std::uniqu
 
 // X[m][k][b][ri][c] <- longitude DFT of x (Bt, C, H, W), optional per-(b,c) affine on load
 static int run_dft_forward(const ace_sht_plan& pl, const float* x, const float* sc, const float* sh, float* X, int Bt,
-                           int C, hipStream_t s, unsigned* xmax = nullptr) {
+                           int C, hipStream_t s, unsigned* xmax = nullptr, const _Float16* xhi = nullptr,
+                           const _Float16* xlo = nullptr, long sxp = 0, const unsigned* xslot = nullptr) {
     DftArgs a;
     a.omax = xmax;
-    a.x = x; a.spec_out = X; a.tc = pl.fc.p; a.ts = pl.fs.p; a.ldt = pl.Kfp; a.sc = sc; a.sh = sh;
+    a.xhi = xhi; a.xlo = xlo; a.sxp = sxp; a.xslot = xslot;   // the field as P-format planes instead of fp32 (FFT form only)
+    a.x = xhi ? nullptr : x; a.spec_out = X; a.tc = pl.fc.p; a.ts = pl.fs.p; a.ldt = pl.Kfp; a.sc = sc; a.sh = sh;
     a.Bt = Bt; a.C = C; a.H = pl.nlat; a.W = pl.nlon; a.Mm = pl.mmax; a.no_fft = pl.sw.no_fft;
     HIP_TRY(launch_dft_forward(a, s));
     return ACE_OK;
@@ -947,6 +950,13 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
         const bool is_enc2 = wn == "encoder." + std::to_string(2 * n->cfg.encoder_layers) + ".weight";
         const bool is_skip = wn.size() > 17 && wn.compare(wn.size() - 17, 17, "inner_skip.weight") == 0;
         const bool is_fc2 = wn.size() > 16 && wn.compare(wn.size() - 16, 16, "mlp.fwd.2.weight") == 0;
+        // fc1 without an instance norm in front of it (nothing to fold per step): static fragments for conv_wl.hip
+        const bool is_fc1 = wn.size() > 16 && wn.compare(wn.size() - 16, 16, "mlp.fwd.0.weight") == 0;
+        if (is_fc1 && n->cfg.normalization_layer != 1 && n->sw.conv_wl && conv_wl_eligible(w.cols, w.rows, n->HW)) {
+            if (!w.frag0.p) HIP_TRY(w.frag0.alloc((size_t)w.rows * w.cols, false));
+            HIP_TRY(launch_pack_conv_frag(w.buf.p, w.pitch, w.rows, w.cols, 0, nullptr, 0.f, w.ascale, nullptr, w.frag0.p,
+                                          0, 1, s));
+        }
         if ((is_skip || is_fc2 || is_enc2) && conv_ws_eligible(w.cols, w.rows, n->HW, is_skip ? 0 : 2, n->sw.conv_ws_roles)) {
             if (!w.frag0.p) HIP_TRY(w.frag0.alloc((size_t)w.rows * w.cols, false));
             HIP_TRY(launch_pack_conv_frag(w.buf.p, w.pitch, w.rows, w.cols, 0, nullptr, 0.f, w.ascale, nullptr, w.frag0.p,
@@ -1231,6 +1241,11 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     _Float16* PBh = reinterpret_cast<_Float16*>(n->P2.p);                 // h planes
     _Float16* PBl = PBh ? PBh + (size_t)n->Bmax * C * HW : nullptr;
 
+    // Residual stream as planes only: once a block's fc2 (conv_ws mode 4) has written h' as P-format planes, the next block reads
+    // them everywhere - longitude FFT, inner skip, outer-skip residual - and no fp32 copy of h' exists (fc2: 520 -> 420 MB).
+    const bool stream_ok = n->sw.planes_stream && f16 && !n->taps_on && n->plan_data == n->plan_lg.get() && C % 16 == 0 &&
+                           !n->plan_lg->sw.no_fft && dft_fft_has_width(n->W);
+    bool h_planes_only = false;
     // ---- blocks (sfnonet.py:217-252)
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string p = "blocks." + std::to_string(i) + ".";
@@ -1260,7 +1275,10 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         }
         // spectral filter (s2convolutions.py:162-197): SHT -> contraction -> inverse SHT + bias
         unsigned *xmax = slot(sb + 0), *dmax = slot(sb + 1), *emax = slot(sb + 2);
-        ACE_TRY(run_dft_forward(fwd, h, a0, b0, n->X.p, B, C, s, xmax));
+        if (h_planes_only)   // the block input exists as planes only (written by the previous block's fc2, mode 4)
+            ACE_TRY(run_dft_forward(fwd, nullptr, a0, b0, n->X.p, B, C, s, xmax, PBh, PBl, (long)C * HW, hslot(i)));
+        else
+            ACE_TRY(run_dft_forward(fwd, h, a0, b0, n->X.p, B, C, s, xmax));
         MARK(ST_DFT_FWD);
         // packed dhconv: D goes from the Legendre epilogue to the filter GEMM as fp16 planes (never fp32)
         const bool dplanes = f16 && !n->sw.no_pk_sht && c.operator_type == 1 && n->wx_hi[i].p && !scale_residual && fwd.f16 &&
@@ -1337,6 +1355,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         _Float16* Ph = reinterpret_cast<_Float16*>(n->P.p);
         _Float16* Pl = Ph + (size_t)n->Bmax * C * HW;
         const bool fused = pk && norm && c.use_mlp && n->P2.p != nullptr;
+        const bool have_ph_in = have_ph;   // P2 holds the RAW block input as planes (bound in hslot(i)), from a producer epilogue
         if (fused) {
             // Packed-operand path with the instance norms fused away: every conv input is P-format planes written by
             // its producer's epilogue, the norm affine is folded into the consumer's weights, the norm statistics come
@@ -1443,8 +1462,14 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 k.Xhi = Uh; k.Xlo = Ul; k.ldn = HW; k.sX = (long)n->hid * HW; k.xslot = slot(sb + 6);
                 k.A = reinterpret_cast<const _Float16*>(w2.frag0.p); k.sA = 0; k.ascale = w2.ascale;
                 k.bias = b2w.buf.p; k.sbias = 0;
-                k.R = res; k.sR = actB; k.rsc = ra; k.rsh = rb; k.srs = C;
-                k.Cf = hn; k.sCf = actB;
+                // residual = a0 h + b0: from the fp32 h, or - when the block input came as planes from a producer epilogue (raw h,
+                // bound in hslot(i)) - from those planes; then a mid block writes h' as planes only
+                const bool rpl = stream_ok && have_ph_in;
+                k.rsc = ra; k.rsh = rb; k.srs = C;
+                if (rpl) { k.Rhi = PBh; k.Rlo = PBl; k.sRp = (long)C * HW; k.rslot = hslot(i); }
+                else { k.R = res; k.sR = actB; }
+                if (last || !rpl) { k.Cf = hn; k.sCf = actB; }
+                h_planes_only = !last && rpl;
                 k.C = n->hid; k.M = C; k.HW = (int)HW; k.nbatch = B; k.act = ACT_NONE;
                 const int nparts = (int)((HW + 31) / 32);
                 if (!last) {
@@ -1470,6 +1495,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 }
                 ACE_TRY(conv_pk2(n, f2, B, s));
                 h_nparts = gemm4_strips(C, (int)HW);
+                h_planes_only = false;
             }
             have_ph = have_hstats = !last;
         } else if (pk) {
@@ -1510,8 +1536,21 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             _Float16* Uh = reinterpret_cast<_Float16*>(n->U.p);
             _Float16* Ul = Uh + (size_t)n->Bmax * n->hid * HW;
             ACE_TRY(pack_act(n, n->T.p, actB, C, a1, b1, tmax, Ph, Pl, B, s));
-            ACE_TRY(conv_pk(n, w1, b1w.buf.p, Ph, Pl, C, tmax, nullptr, n->hid, nullptr, 0, nullptr, nullptr, act, B, s,
-                            nullptr, Uh, Ul, b1w.absmax, slot(sb + 6)));
+            const bool gelu1 = act == ACT_GELU || act == ACT_GELU_FAST;
+            if (w1.frag0.p && !a1 && gelu1 && n->sw.conv_wl && conv_wl_eligible(C, n->hid, HW)) {
+                // weights in LDS, unsynchronised waves (conv_wl.hip): the noise-conditioned nets' fc1 (no norm affine to fold)
+                ConvStripArgs k;
+                k.Xhi = Ph; k.Xlo = Pl; k.ldn = HW; k.sX = (long)C * HW; k.xslot = tmax;
+                k.A = reinterpret_cast<const _Float16*>(w1.frag0.p); k.sA = 0; k.ascale = w1.ascale;
+                k.bias = b1w.buf.p; k.sbias = 0;
+                k.cw = w1.winf; k.cb = b1w.absmax;
+                k.Chi = Uh; k.Clo = Ul; k.sCp = (long)n->hid * HW; k.cslot = slot(sb + 6);
+                k.C = C; k.M = n->hid; k.HW = (int)HW; k.nbatch = B; k.act = ACT_GELU;
+                HIP_TRY(launch_conv_wl(k, s));
+            } else {
+                ACE_TRY(conv_pk(n, w1, b1w.buf.p, Ph, Pl, C, tmax, nullptr, n->hid, nullptr, 0, nullptr, nullptr, act, B, s,
+                                nullptr, Uh, Ul, b1w.absmax, slot(sb + 6)));
+            }
             MARK(ST_MLP_FC1);
             ACE_TRY(conv_pk(n, w2, W(p + "mlp.fwd.2.bias"), Uh, Ul, n->hid, slot(sb + 6), hn, C, res, actB, ra, rb, ACT_NONE,
                             B, s, hslot(i + 1)));

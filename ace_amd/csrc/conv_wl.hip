@@ -252,7 +252,7 @@ extern "C" int ace_debug_wg_spans(void* dst) { return (int)hipMemcpyFromSymbol(d
 // K: input channels, M: output channels.  GELU + P-format output, no residual, no statistics (the first MLP convolution)
 bool conv_wl_eligible(int K, int M, long HW) {
     if (K == 384) return M % 96 == 0 && M / 96 <= 32 && (long)M * HW * 2 < 0x7fffff00L;
-    if (K == 256 || K == 128) return M % 64 == 0 && M / 64 <= 32 && (long)M * HW * 2 < 0x7fffff00L;   // two row tiles per workgroup
+    if (K == 512 || K == 256 || K == 128) return M % 64 == 0 && M / 64 <= 32 && (long)M * HW * 2 < 0x7fffff00L;   // two row tiles per workgroup (K = 512: 128 KiB of weights)
     return false;
 }
 
@@ -261,6 +261,7 @@ hipError_t launch_conv_wl(const ConvStripArgs& a, hipStream_t s) {
         !(a.act == ACT_GELU || a.act == ACT_GELU_FAST))
         return hipErrorInvalidValue;
     switch (a.C) {
+        case 512: return launch_wl<32, 2, 4>(a, s);
         case 384: return launch_wl<24, 3, 4>(a, s);
         case 256: return launch_wl<16, 2, 4>(a, s);
         case 128: return launch_wl<8, 2, 4>(a, s);

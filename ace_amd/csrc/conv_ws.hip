@@ -37,6 +37,12 @@ constexpr int WS_OOBV = 0x7fffff00;   // buffer offset beyond every resource of 
 #ifndef ACE_WS_FINE
 #define ACE_WS_FINE 1     // GELU modes: the epilogue of the previous tile goes into the MFMA stream a quarter of a value (~7 VALU) per
 #endif                    // MFMA instead of a whole value (~30 VALU) per k-step
+#ifndef ACE_WS_HOLD4
+#define ACE_WS_HOLD4 0   // mode 4 at K = 768: hold the store data through the stage instead of retiring the stores first
+#endif
+#ifndef ACE_WS_FD4
+#define ACE_WS_FD4 1     // fragment read-ahead of the K = 768 planes + statistics modes (r03 same-box: mode 4 155.8 -> 149.1 us; holding the store data instead: 153.2)
+#endif
 #ifndef ACE_WS_VSPAN
 #define ACE_WS_VSPAN 8    // interleaved epilogue: its eight values are spread over the first VSPAN twelfths of the stage
 #endif
@@ -45,9 +51,10 @@ template <int KSW, int NSTG, int MODE>
 struct WsGeom {
     static constexpr int KH = KSW * NSTG;          // k16-steps per wave: its half of the contraction
     static constexpr int SLOT = 2 * KSW * 2048;    // one stage of activation fragments, both halves
-    static constexpr bool F32 = MODE >= 2, STATS = MODE == 0 || MODE == 2;
-    static constexpr int BMAX = F32 ? 1024 : 2048; // output rows with LDS-resident epilogue parameters
-    static constexpr int TAB = BMAX * 4 * (F32 ? 2 : 1);
+    static constexpr bool F32 = MODE == 2 || MODE == 3 || MODE == 5, STATS = MODE == 0 || MODE == 2 || MODE == 4;
+    static constexpr bool AFFRES = MODE >= 2;      // fc2 modes: residual with a per-row affine (scale table Ps, shift folded into Pb)
+    static constexpr int BMAX = AFFRES ? 1024 : 2048; // output rows with LDS-resident epilogue parameters
+    static constexpr int TAB = BMAX * 4 * (AFFRES ? 2 : 1);
     static constexpr int XCH = 2 * 8 * 2048;       // accumulator exchange: [tile parity][wave][2 planes][64 lanes][16 B]
     static constexpr int STP = 36;                 // pitch of the statistics transpose (floats)
     static constexpr bool RSTATS = MODE == 0;      // statistics accumulated in registers over the workgroup's pixel range
@@ -59,6 +66,8 @@ struct WsGeom {
 // MODE 0: inner skip  (fp32 residual, GELU, P-format planes + row statistics)       1: fc1 (GELU, P-format planes)
 //      2: fc2, mid block (residual with per-row affine, fp32 output + P-format planes + row statistics)
 //      3: fc2, last block (fp32 output, optional range maximum)
+//      4: as 2 with the residual read from P-format planes and NO fp32 output: the residual stream of the blocks exists as planes
+//         only (520 -> 420 MB of traffic per launch)                                 5: as 3 with the residual from planes
 // Modes 0 / 1 (K <= 384, registers to spare): the epilogue of pixel tile t - 1 runs between the MFMAs of tile t.
 // H: contraction half of the calling wave (compile time, see conv_split.hip)
 template <int KSW, int NSTG, int MODE, int H>
@@ -66,9 +75,10 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     using G = WsGeom<KSW, NSTG, MODE>;
     constexpr int KH = G::KH, SLOT = G::SLOT, BMAX = G::BMAX, TAB = G::TAB, XCH = G::XCH, STP = G::STP;
     constexpr int PW = KSW / 2;             // 1-KiB pieces per wave per stage
-    constexpr bool GELU = MODE <= 1, RES = MODE != 1, PK = MODE != 3, F32 = G::F32, STATS = G::STATS, RSTATS = G::RSTATS;
+    constexpr bool GELU = MODE <= 1, RES = MODE != 1, PK = MODE != 3 && MODE != 5, F32 = G::F32, STATS = G::STATS, RSTATS = G::RSTATS;
+    constexpr bool AFFRES = G::AFFRES, RPL = MODE >= 4;   // RPL: the residual comes as planes
     constexpr bool INTER = MODE <= 1;       // epilogue of tile t - 1 between the MFMAs of tile t
-    constexpr bool HOLD = KH < 24;          // registers to hold the store data through a stage (else: stores retired first; holding them at K = 768 spills 22 VGPRs)
+    constexpr bool HOLD = KH < 24 || (MODE == 4 && ACE_WS_HOLD4);   // registers to hold the store data through a stage (else: stores retired first; holding them at K = 768 in mode 2 spills 22 VGPRs)
     constexpr bool ACC2 = INTER && ((ACE_WS_ACC2 >> MODE) & 1);
     static_assert(!INTER || NSTG == 1, "interleaved epilogue: single-stage tiles");
     constexpr int h = H;
@@ -102,17 +112,18 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     const unsigned raw_a = p.aslot ? slot_load(p.aslot + lane) : 0u;
     const unsigned raw_c = p.cinb ? slot_load(p.cinb + lane) : 0u;
     const unsigned raw_r = p.rmax ? slot_load(p.rmax + lane) : 0u;
+    const unsigned raw_p = (RPL && p.rslot) ? slot_load(p.rslot + lane) : 0u;
 
     {   // epilogue parameters of this sample -> LDS
         const float* b = p.bias + (long)smp * p.sbias;
-        const float* rsc = (F32 && p.rsc) ? p.rsc + (long)smp * p.srs : nullptr;
-        const float* rsh = (F32 && p.rsc) ? p.rsh + (long)smp * p.srs : nullptr;
+        const float* rsc = (AFFRES && p.rsc) ? p.rsc + (long)smp * p.srs : nullptr;
+        const float* rsh = (AFFRES && p.rsc) ? p.rsh + (long)smp * p.srs : nullptr;
 #pragma unroll
         for (int k = 0; k < BMAX / 512; ++k) {
             const int r = tid + 512 * k;
             if (r < p.M) {
                 Pb[r] = b[r] + (rsh ? rsh[r] : 0.f);
-                if (F32) Ps[r] = rsc ? rsc[r] : 1.f;
+                if (AFFRES) Ps[r] = rsc ? rsc[r] : 1.f;
             }
         }
     }
@@ -120,6 +131,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     const float inv_x = ldexpf(1.0f, -pow2_exponent_for(xbound));
     const float inv_a = p.aslot ? ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_a))) : 1.0f / p.ascale;
     const float s_acc = inv_x * inv_a;
+    const float inv_r = RPL ? ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_p))) : 1.f;   // scale of the residual planes, undone
     float cscale = 1.f;
     if (PK) {   // bound of this launch's output, identical in every workgroup; the consumer reads it from cslot
         const float inb = p.cinb ? wave_max_bits(raw_c) : xbound;
@@ -130,7 +142,9 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     }
 
     const int fbytes = p.M * p.HW * 4, pbytes = p.M * p.HW * 2;
-    const auto rsR = __builtin_amdgcn_make_buffer_rsrc(RES ? const_cast<float*>(p.R + (long)smp * p.sR) : nullptr, 0, RES ? fbytes : 0, 0x00020000);
+    const auto rsR = __builtin_amdgcn_make_buffer_rsrc((RES && !RPL) ? const_cast<float*>(p.R + (long)smp * p.sR) : nullptr, 0, (RES && !RPL) ? fbytes : 0, 0x00020000);
+    const auto rsRh = __builtin_amdgcn_make_buffer_rsrc(RPL ? const_cast<_Float16*>(p.Rhi + (long)smp * p.sRp) : nullptr, 0, RPL ? pbytes : 0, 0x00020000);
+    const auto rsRl = __builtin_amdgcn_make_buffer_rsrc(RPL ? const_cast<_Float16*>(p.Rlo + (long)smp * p.sRp) : nullptr, 0, RPL ? pbytes : 0, 0x00020000);
     const auto rsC = __builtin_amdgcn_make_buffer_rsrc(F32 ? p.Cf + (long)smp * p.sCf : nullptr, 0, F32 ? fbytes : 0, 0x00020000);
     const auto rsH = __builtin_amdgcn_make_buffer_rsrc(PK ? p.Chi + (long)smp * p.sCp : nullptr, 0, PK ? pbytes : 0, 0x00020000);
     const auto rsL = __builtin_amdgcn_make_buffer_rsrc(PK ? p.Clo + (long)smp * p.sCp : nullptr, 0, PK ? pbytes : 0, 0x00020000);
@@ -190,6 +204,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
 
     // ---- epilogue state of the tile being finished: rows row0 + 8 g + e, pixel 32 (tile0 + pt) + i
     float own[8], res[8], resn[8];
+    u32x4 rph = {0u, 0u, 0u, 0u}, rpl = rph;   // RPL: the residual's P entry (hi, lo) of the tile being finished
     f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
     struct EpiOut {                        // data registers of the epilogue's stores (held until the stores retired)
         half8 hh8, ll8;
@@ -228,7 +243,14 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
             constexpr int e = k;
             const int row = row0 + 8 * g + e;
             float val = fmaf(own[e] + (e < 4 ? pa[e & 3] : pb[e & 3]), s_acc, Pb[row]);
-            if (RES) val = F32 ? fmaf(resn[e], Ps[row], val) : val + res[e];   // light epilogues consume the fetched rows in place
+            if (RES) {
+                if constexpr (RPL) {   // rows row0 + 8 g + e of this pixel = ONE P entry: (hi + lo) / scale
+                    const half8 rh8 = __builtin_bit_cast(half8, rph), rl8 = __builtin_bit_cast(half8, rpl);
+                    val = fmaf(((float)rh8[e] + (float)rl8[e]) * inv_r, Ps[row], val);
+                } else {
+                    val = AFFRES ? fmaf(resn[e], Ps[row], val) : val + res[e];   // light epilogues consume the fetched rows in place
+                }
+            }
             if (GELU) val = act_fn<ACT_GELU_FAST>(val);
             if (F32) {
                 o.vals[e] = val;
@@ -331,17 +353,26 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
         const int n0 = 32 * (tile0 + pt);
         int vf_lane, vp_lane, vs_lane, i, g;
         lane_offsets(vf_lane, vp_lane, vs_lane, i, g);
-        const int vo = n0 + i < p.HW ? vf_lane : WS_OOBV;
+        if constexpr (RPL) {
+            const int vo = n0 + i < p.HW ? vp_lane : WS_OOBV;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rph) : "v"(vo), "s"(rsRh), "s"(n0 * 16));
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rpl) : "v"(vo), "s"(rsRl), "s"(n0 * 16));
+        } else {
+            const int vo = n0 + i < p.HW ? vf_lane : WS_OOBV;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(resn[e]) : "v"(vo), "s"(rsR), "s"((e * p.HW + n0) * 4));
+            for (int e = 0; e < 8; ++e)
+                asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(resn[e]) : "v"(vo), "s"(rsR), "s"((e * p.HW + n0) * 4));
+        }
     };
     auto stage_top = [&]() {
         // lgkmcnt: the accumulator halves written for the partner must be IN the LDS before the barrier releases it
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                     : "+v"(resn[0]), "+v"(resn[1]), "+v"(resn[2]), "+v"(resn[3]), "+v"(resn[4]), "+v"(resn[5]), "+v"(resn[6]), "+v"(resn[7])
-                     :
-                     : "memory");
+        if constexpr (RPL)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(rph), "+v"(rpl) : : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                         : "+v"(resn[0]), "+v"(resn[1]), "+v"(resn[2]), "+v"(resn[3]), "+v"(resn[4]), "+v"(resn[5]), "+v"(resn[6]), "+v"(resn[7])
+                         :
+                         : "memory");
         __builtin_amdgcn_s_barrier();
     };
     auto read_partner = [&](int pt) {      // the partner's half of pixel tile pt
@@ -353,7 +384,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     f32x16 v, v2;   // v2: second accumulator of the ACC2 form (the MFMA stream alternates v, v2, v, v2, ...)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { v[r] = 0.f; v2[r] = 0.f; }
-    constexpr int FDEPTH = (MODE == 2 && KH == 24) ? 0 : 1;   // fragment read-ahead; 0 where the registers are gone (K = 768 + planes + statistics)
+    constexpr int FDEPTH = ((MODE == 2 || MODE == 4) && KH == 24) ? ACE_WS_FD4 : 1;   // fragment read-ahead; 0 where the registers are gone (K = 768 + planes + statistics)
     // Loop body = one stage followed by the wait + barrier that opens the next (stage 0 was opened by the prologue); an
     // asm-loaded register still in flight is never live across the back edge (hipcc believes the value is there and may copy it).
     constexpr int VSPAN = ACE_WS_VSPAN * KSW / 12 > 0 ? ACE_WS_VSPAN * KSW / 12 : 1;   // interleaved epilogue: the eight values over the first VSPAN k-steps, the stores right after
@@ -524,6 +555,8 @@ hipError_t launch_ws_k(const ConvStripArgs& a, int mode, hipStream_t s) {
     }
     if (mode == 2) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 2>), grid, block, 0, s, a, pl);
     if (mode == 3) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 3>), grid, block, 0, s, a, pl);
+    if (mode == 4) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 4>), grid, block, 0, s, a, pl);
+    if (mode == 5) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 5>), grid, block, 0, s, a, pl);
     return hipGetLastError();
 }
 
@@ -622,12 +655,15 @@ bool conv_ws_eligible(int K, int M, long HW, int role, int roles_on) {
 hipError_t launch_conv_ws(const ConvStripArgs& a, hipStream_t s) {
     if (!conv_ws_eligible(a.C, a.M, a.HW, -2) || !a.bias || !a.xslot || !a.A) return hipErrorInvalidValue;
     const bool f32 = a.Cf != nullptr, pk = a.Chi != nullptr, stats = a.part != nullptr, res = a.R != nullptr;
+    const bool rpl = a.Rhi != nullptr && a.Rlo != nullptr && a.rslot != nullptr && !a.R;
     const bool gelu = a.act == ACT_GELU || a.act == ACT_GELU_FAST;
     int mode = -1;
     if (gelu && res && pk && stats && !f32) mode = 0;
     else if (gelu && !res && pk && !stats && !f32) mode = 1;
     else if (a.act == ACT_NONE && res && f32 && pk && stats) mode = 2;
     else if (a.act == ACT_NONE && res && f32 && !pk && !stats) mode = 3;
+    else if (a.act == ACT_NONE && rpl && !f32 && pk && stats) mode = 4;
+    else if (a.act == ACT_NONE && rpl && f32 && !pk && !stats) mode = 5;
     if (mode < 0 || (pk && (!a.Clo || !a.cslot)) || (f32 && a.M > 1024)) return hipErrorInvalidValue;
     if (mode <= 1 && a.C > 384) return hipErrorInvalidValue;
     switch (a.C) {

@@ -17,6 +17,7 @@
 
 #include "kernels.h"
 #include "small_fft.h"
+#include "strip_common.h"
 
 namespace ace {
 namespace {
@@ -128,8 +129,8 @@ FDEV void fft_unit(int& cblk, int& lat) {
 #ifndef ACE_FFT_INV_WAVES
 #define ACE_FFT_INV_WAVES 7   // three 9-wave workgroups per CU (LDS allows three) need <= 72 registers
 #endif
-template <int N1, int N2, int R>
-__global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_FWD_WAVES : (N1 * N2 == 1440 && R == 8 ? 4 : 0)) void dft_forward_fft_kernel(DftArgs p) {
+template <int N1, int N2, int R, bool PLN>
+__global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? 7 : ACE_FFT_FWD_WAVES) : (N1 * N2 == 1440 && R == 8 ? 4 : 0)) void dft_forward_fft_kernel(DftArgs p) {
     constexpr int W = N1 * N2, H1 = N1 / 2 + 1, NT = R * N2;
     constexpr int PITCH = W + 4;     // 16-byte aligned rows; PITCH = 4 (mod 8): the 16 rows x 4 b of a wave's level-1 read hit 64 banks
     constexpr int K2N = N2 / 2 + 1;  // k = k1 + N1 k2 <= W / 2  =>  k2 <= N2 / 2
@@ -152,6 +153,42 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_FWD_WAVES : (N1 * 
     constexpr int NPF = (R * (W / 4) + NT - 1) / NT;   // 16-byte row pieces per thread
     const int rlast = (p.C - c0 < R ? p.C - c0 : R) - 1;   // ragged last channel block: its missing rows repeat the last one
 
+    // fused instance-norm affine of this thread's row in level 1 (one load pair per thread, applied in registers)
+    const int r1 = tid % R, b1 = tid / R;
+    const int cr = c0 + (r1 < rlast ? r1 : rlast);
+    const float sc = p.sc ? p.sc[(long)b * p.C + cr] : 1.f, sh = p.sc ? p.sh[(long)b * p.C + cr] : 0.f;
+    if constexpr (PLN) {
+        // the field arrives as P-format planes [C/8][H W][8] (hi | lo): an entry = 8 channels of one pixel, 16 bytes per plane;
+        // this workgroup's R rows are R / 8 k-groups.  (hi + lo) / scale is the producer's 22-bit value, exactly.
+        static_assert(R % 8 == 0, "whole k-groups");
+        constexpr int NE = (R / 8) * W, NPE = (NE + NT - 1) / NT;
+        const int kgmax = p.C / 8 - 1;
+        const auto rsh = wide_rsrc(p.xhi + (long)b * p.sxp + (long)k * W * 8);
+        const auto rsl = wide_rsrc(p.xlo + (long)b * p.sxp + (long)k * W * 8);
+        const float inv = ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(slot_load(p.xslot + (tid & 63)))));
+        u32x4 eh[NPE], el[NPE];
+#pragma unroll
+        for (int q = 0; q < NPE; ++q) {
+            const int idx = tid + q * NT;
+            if (idx < NE) {
+                int kg = c0 / 8 + idx / W;
+                kg = kg < kgmax ? kg : kgmax;
+                const int off = (int)(((unsigned)kg * (unsigned)HW + (unsigned)(idx % W)) * 16u);
+                eh[q] = __builtin_amdgcn_raw_buffer_load_b128(rsh, off, 0, 0);
+                el[q] = __builtin_amdgcn_raw_buffer_load_b128(rsl, off, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NPE; ++q) {
+            const int idx = tid + q * NT;
+            if (idx < NE) {
+                const half8 h8 = __builtin_bit_cast(half8, eh[q]), l8 = __builtin_bit_cast(half8, el[q]);
+                float* d = xs + (8 * (idx / W)) * PITCH + idx % W;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[e * PITCH] = ((float)h8[e] + (float)l8[e]) * inv;
+            }
+        }
+    } else {
     // rows -> registers (all pieces of the thread in flight at once) -> LDS, 16 bytes per lane each way.  Every global access
     // of the kernel is (uniform 64-bit base) + (32-bit lane offset): no per-access 64-bit vector arithmetic.
     const auto rsx = wide_rsrc(p.x + ((long)b * p.C + c0) * HW + (long)k * W);
@@ -169,10 +206,6 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_FWD_WAVES : (N1 * 
 #endif
         }
     }
-    // fused instance-norm affine of this thread's row in level 1 (one load pair per thread, applied in registers)
-    const int r1 = tid % R, b1 = tid / R;
-    const int cr = c0 + (r1 < rlast ? r1 : rlast);
-    const float sc = p.sc ? p.sc[(long)b * p.C + cr] : 1.f, sh = p.sc ? p.sh[(long)b * p.C + cr] : 0.f;
 #pragma unroll
     for (int q = 0; q < NPF; ++q) {
         const int idx = tid + q * NT;
@@ -180,6 +213,7 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_FWD_WAVES : (N1 * 
             const int r = idx / (W / 4), j = idx % (W / 4);
             *reinterpret_cast<float4*>(xs + r * PITCH + 4 * j) = pf[q];
         }
+    }
     }
     __syncthreads();
 
@@ -256,7 +290,12 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_FWD_WAVES : (N1 * 
 template <int N1, int N2, int R = FFT_ROWS>
 hipError_t launch_fwd(const DftArgs& a, hipStream_t s) {
     dim3 grid((unsigned)((a.C + R - 1) / R), (unsigned)a.H, (unsigned)a.Bt), block(R * N2);
-    hipLaunchKernelGGL((dft_forward_fft_kernel<N1, N2, R>), grid, block, 0, s, a);
+    if (a.xhi) {
+        if (!a.xlo || !a.xslot || a.C % 8 != 0) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((dft_forward_fft_kernel<N1, N2, R, true>), grid, block, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((dft_forward_fft_kernel<N1, N2, R, false>), grid, block, 0, s, a);
+    }
     return hipGetLastError();
 }
 
@@ -412,7 +451,7 @@ bool lane_offsets_fit(const DftArgs& a) {
 
 // true when the FFT form handled the launch (sizes with an instantiated factorisation, 16-byte aligned rows)
 bool launch_dft_forward_fft(const DftArgs& a, hipStream_t s, hipError_t* err) {
-    if (a.no_fft || (reinterpret_cast<uintptr_t>(a.x) & 15) != 0 || a.Mm > a.W / 2 + 1 || a.H > 65535 || a.Bt > 65535 || !lane_offsets_fit(a))
+    if (a.no_fft || (!a.xhi && (reinterpret_cast<uintptr_t>(a.x) & 15) != 0) || a.Mm > a.W / 2 + 1 || a.H > 65535 || a.Bt > 65535 || !lane_offsets_fit(a))
         return false;
     switch (a.W) {
         case 360: *err = launch_fwd<20, 18>(a, s); return true;
@@ -424,6 +463,8 @@ bool launch_dft_forward_fft(const DftArgs& a, hipStream_t s, hipError_t* err) {
         default: return false;
     }
 }
+
+bool dft_fft_has_width(int W) { return W == 360 || W == 1440 || W == 720 || W == 48 || W == 24 || W == 16; }
 
 bool launch_dft_inverse_fft(const DftArgs& a, hipStream_t s, hipError_t* err) {
     if (a.no_fft || (reinterpret_cast<uintptr_t>(a.y) & 15) != 0 || a.Mm > a.W / 2 + 1 || a.H > 65535 || a.Bt > 65535 || !lane_offsets_fit(a))

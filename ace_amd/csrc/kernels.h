@@ -16,6 +16,7 @@ struct Switches {
     bool no_enc_ws = false;        // ACE_NO_ENC_WS: last encoder convolution on the v3 engine
     int conv_ws_roles = 7;         // ACE_CONV_WS=skip,fc1,fc2|all|none: roles on conv_ws.hip (bit 0 inner skip, 1 fc1, 2 fc2)
     bool conv_wl = true;           // ACE_CONV_WL=0: fc1 on conv_ws.hip instead of conv_wl.hip (weights in LDS, unsynchronised waves)
+    bool planes_stream = true;     // ACE_PLANES_STREAM=0: fc2 also writes the block output as fp32 (the residual stream round-trips twice)
 };
 Switches read_switches();
 
@@ -178,6 +179,9 @@ struct ConvStripArgs {
     const unsigned* aslot = nullptr; float ascale = 1.f;   // dynamic (folded) or static weight scale
     const float* bias = nullptr; long sbias = 0;
     const float* R = nullptr; long sR = 0;            // optional fp32 residual (M x HW per sample), added before the activation
+    // ... or the residual as P-format planes [M/8][HW][8] (hi | lo) scaled from the bound in rslot: the fc2 modes of a block whose
+    // input exists as planes only (the residual stream never round-trips as fp32)
+    const _Float16* Rhi = nullptr; const _Float16* Rlo = nullptr; long sRp = 0; const unsigned* rslot = nullptr;
     float cw = 0.f, cb = 0.f; const unsigned* cinb = nullptr; const unsigned* rmax = nullptr;   // output bound (see Gemm4Args)
     _Float16* Chi = nullptr; _Float16* Clo = nullptr; long sCp = 0; unsigned* cslot = nullptr;  // output planes [M/8][HW][8]
     float4* part = nullptr; int nstrips32 = 0;        // optional row statistics per (sample, 32-pixel strip, row)
@@ -215,6 +219,9 @@ hipError_t launch_dhconv_strip(const DhconvStripArgs& a, hipStream_t s);
 //   D[l][m][b][ri][c]  (after the Legendre stage)    index ((l*Mm + m)*Bt + b)*2C + ri*C + c
 struct DftArgs {
     const float* x = nullptr;  // (Bt, C, H, W) grid-space field
+    // ... or (forward, FFT form only, C % 8 == 0) the field as P-format fp16 planes [C/8][H W][8] hi | lo, scaled from the bound
+    // in xslot; sxp = halves per sample
+    const _Float16* xhi = nullptr; const _Float16* xlo = nullptr; long sxp = 0; const unsigned* xslot = nullptr;
     float* y = nullptr;        // grid-space output (inverse)
     const float* spec = nullptr;  // spectral input (inverse)
     float* spec_out = nullptr;    // spectral output (forward)
@@ -230,6 +237,7 @@ hipError_t launch_dft_inverse(const DftArgs& a, hipStream_t s);
 // two-level FFT forms on the vector ALUs (fft.hip); return false when the size / alignment is not covered
 bool launch_dft_forward_fft(const DftArgs& a, hipStream_t s, hipError_t* err);
 bool launch_dft_inverse_fft(const DftArgs& a, hipStream_t s, hipError_t* err);
+bool dft_fft_has_width(int W);   // widths with an instantiated two-level FFT
 
 // per-(b,c) instance-norm statistics over H*W -> affine (scale, shift):
 //   scale = gamma[c] * rsqrt(var + eps),  shift = beta[c] - mean * scale   (biased var, fp64 accumulation)

@@ -2395,6 +2395,7 @@ __global__ __launch_bounds__(256) void dft_forward_kernel(DftArgs p, int tilesM,
 hipError_t launch_dft_forward(const DftArgs& a, hipStream_t s) {
     hipError_t ferr = hipSuccess;
     if (launch_dft_forward_fft(a, s, &ferr)) return ferr;
+    if (!a.x) return hipErrorInvalidValue;   // planes input: FFT form only
     constexpr int BM = 64, BN = 128;
     const int ncols = a.H * a.Bt * a.C;
     const int tilesM = (a.Mm + BM - 1) / BM, tilesN = (ncols + BN - 1) / BN;

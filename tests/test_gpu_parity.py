@@ -407,6 +407,33 @@ def test_noise_conditioned_sfno_vs_reference(dev, name, precision):
     assert torch.isfinite(a).all() and not torch.equal(a, b)
 
 
+@pytest.mark.parametrize("embed", [128, 256])
+def test_noise_conditioned_sfno_wide_vs_oracle(dev, embed):
+    """Channel widths at which the noise-conditioned net's fc1 runs on csrc/conv_wl.hip (weights in LDS; K = 128 / 256 here,
+    512 at the ERA5 configuration) and the other convolutions on the packed-operand engine: against the fp64 oracle with the
+    module's own (reference-order) initial weights.  The small reference-emitted goldens stay on the tile engines."""
+    import ace_amd
+    from oracle.csfno import CSFNOConfig, CSFNOOracle
+    kwargs = dict(embed_dim=embed, noise_embed_dim=8, noise_type="gaussian", num_layers=2, use_mlp=True, mlp_ratio=2.0,
+                  affine_norms=True, normalize_big_skip=True)
+    cfg = CSFNOConfig(in_chans=5, out_chans=4, img_shape=(16, 32), **kwargs)
+    torch.manual_seed(11)
+    net = ace_amd.ModuleSelector(type="NoiseConditionedSFNO", config=dict(kwargs)).build(5, 4, ace_amd.DatasetInfo((16, 32))).torch_module
+    state = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    for k, v in state.items():                      # biases / norm affines / noise projections away from their trivial initial values
+        if v.ndim <= 1 or "W_scale" in k or "W_bias" in k:
+            state[k] = v + 0.1 * torch.randn(v.shape, generator=g)
+    net.load_state_dict(state, strict=True)
+    net.to(dev).set_precision("f16x3")
+    x = torch.randn(2, 5, 16, 32, generator=g)
+    noise = _csfno_noise(cfg, 2, 17)
+    with torch.no_grad():
+        y = net(x.to(dev), noise=noise.to(dev))
+    ref64 = CSFNOOracle(cfg, state, dtype=torch.float64).forward(x, noise=noise)
+    assert rel_max(y, ref64) <= NET_TOL, rel_max(y, ref64)
+
+
 def test_noise_conditioned_sfno_errors(dev):
     import ace_amd
     sel = ace_amd.ModuleSelector(type="NoiseConditionedSFNO", config={"embed_dim": 8, "noise_embed_dim": 4, "num_layers": 1})
