@@ -149,6 +149,37 @@ def test_fused_mlp_shapes_vs_fp64(dev, C, hw, routing, monkeypatch):
     assert rel_max(y, ref) <= NET_TOL
 
 
+@pytest.mark.parametrize("C,hw", [(384, (45, 90)), (128, (24, 48)), (256, (20, 40))])
+def test_planes_only_residual_stream_vs_fp64(dev, C, hw, monkeypatch):
+    """Default routing WITHOUT taps: from the first block on, fc2 (conv_ws modes 4 / 5) takes the outer-skip residual from the
+    P-format planes of the block input and writes h' as planes only, and the longitude FFT reads those planes - no fp32 copy of
+    the residual stream exists between the blocks.  Final output against the fp64 oracle, and against the same network with
+    ACE_PLANES_STREAM=0 (fp32 residual stream, round 2's form): the two differ by the 22-bit rounding of h' only."""
+    from oracle.sfno import SFNOConfig, SFNOOracle, init_state
+    cfg = SFNOConfig(in_chans=6, out_chans=5, img_shape=hw, embed_dim=C, num_layers=4, operator_type="dhconv")
+    state = init_state(cfg, seed=23)
+    g = torch.Generator().manual_seed(24)
+    for k in state:
+        if ".norm" in k and k.endswith("weight"):
+            state[k] = 1.0 + 0.3 * torch.randn(state[k].shape, generator=g)
+        if ".norm" in k and k.endswith("bias"):
+            state[k] = 0.2 * torch.randn(state[k].shape, generator=g)
+    x = torch.randn(3, 6, *hw, generator=g) * 0.8 + 0.5
+    ref = SFNOOracle(cfg, state, dtype=torch.float64).forward(x)
+    outs = {}
+    for stream in ("1", "0"):
+        monkeypatch.setenv("ACE_PLANES_STREAM", stream)
+        net = build_native_net(cfg, state, dev, "f16x3")
+        with torch.no_grad():
+            y = net(x.to(dev))
+            assert torch.equal(y, net(x.to(dev)))
+            assert torch.equal(y[1:2], net(x[1:2].to(dev)))          # batch 3 == per sample
+        assert rel_max(y, ref) <= NET_TOL, (stream, rel_max(y, ref))
+        outs[stream] = y
+    assert rel_max(outs["1"], outs["0"]) <= 3e-6
+    assert not torch.equal(outs["1"], outs["0"])                      # the switch does route differently
+
+
 def test_weight_update_after_graph_capture(dev):
     """ace_sfno_set_weight drops captured graphs: scales baked into kernel arguments must follow a weight update."""
     from oracle.sfno import SFNOConfig, init_state
