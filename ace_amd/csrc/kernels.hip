@@ -2676,39 +2676,30 @@ __global__ __launch_bounds__(512) void instnorm_stats_kernel(const float* __rest
 
 // Second half of the fused instance norm: reduce the per-strip row statistics written by the producing GEMM's epilogue
 // (Gemm4Args::part) to the per-(sample, channel) affine, in fp64 and in a fixed order (deterministic).
-template <int NT>
-__global__ __launch_bounds__(NT) void instnorm_finalize_kernel(const float4* __restrict__ part, int nparts, int C,
-                                                               long HW, const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, float eps,
-                                                               float* __restrict__ scale, float* __restrict__ shift,
-                                                               unsigned* omax) {
-    // one workgroup per 4 channels (a 64-byte run of the partials): thread = (channel sub-index, strip residue of NT / 4);
-    // strips are summed thread-strided in fp64, eight loads in flight at a time, then across the residues with a fixed shuffle
-    // tree and a fixed order over the waves (deterministic).  With the 2025 partials per channel that fc2 writes (one per
-    // 32-pixel tile) the kernel takes 10 us, with the 256 of the inner skip 5: its 64-byte reads are 6 KiB apart, one DRAM page
-    // each - 1024 threads per workgroup did not change that (r03 same-box: 11.2 vs 10.6 us); fewer partials would.
-    constexpr int NR = NT / 4, NW = NT / 64;
+__global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float4* __restrict__ part, int nparts, int C,
+                                                                long HW, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps,
+                                                                float* __restrict__ scale, float* __restrict__ shift,
+                                                                unsigned* omax) {
+    // one workgroup per 4 channels: thread = (channel sub-index, strip residue of 64); strips are summed thread-strided
+    // in fp64, then across the residues with a fixed shuffle tree and a fixed order over the 4 waves (deterministic).
+    // With the 2025 partials per channel that fc2 writes (one per 32-pixel tile) it takes 10 us, with the 256 of the inner skip
+    // 5: its 64-byte reads are 6 KiB apart, one DRAM page each.  r03 same-box: 1024 threads per workgroup 11.2 us, eight
+    // range-checked loads in flight per thread 16.7 us - neither helps; fewer partials would.
     const int b = blockIdx.y;
-    const int cs = threadIdx.x & 3, pr = threadIdx.x >> 2;
+    const int cs = threadIdx.x & 3, pr = threadIdx.x >> 2;   // 0..3, 0..63
     const int c = blockIdx.x * 4 + cs;
     double s = 0.0, ss = 0.0;
     float lo = 3.0e38f, hi = -3.0e38f;
     if (c < C) {
         const float4* base = part + (long)b * nparts * C + c;
-        for (int p0 = pr; p0 < nparts; p0 += 8 * NR) {
-            float4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int p = p0 + u * NR;
-                v[u] = p < nparts ? base[(long)p * C] : make_float4(0.f, 0.f, 3.0e38f, -3.0e38f);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                s += (double)v[u].x;
-                ss += (double)v[u].y;
-                lo = fminf(lo, v[u].z);
-                hi = fmaxf(hi, v[u].w);
-            }
+#pragma unroll 4
+        for (int p = pr; p < nparts; p += 64) {
+            const float4 v = base[(long)p * C];
+            s += (double)v.x;
+            ss += (double)v.y;
+            lo = fminf(lo, v.z);
+            hi = fmaxf(hi, v.w);
         }
     }
 #pragma unroll
@@ -2718,14 +2709,14 @@ __global__ __launch_bounds__(NT) void instnorm_finalize_kernel(const float4* __r
         lo = fminf(lo, __shfl_xor(lo, off, 64));
         hi = fmaxf(hi, __shfl_xor(hi, off, 64));
     }
-    __shared__ double rs[NW][4], rss[NW][4];
-    __shared__ float rlo[NW][4], rhi[NW][4];
+    __shared__ double rs[4][4], rss[4][4];
+    __shared__ float rlo[4][4], rhi[4][4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane < 4) { rs[wave][lane] = s; rss[wave][lane] = ss; rlo[wave][lane] = lo; rhi[wave][lane] = hi; }
     __syncthreads();
     if (threadIdx.x < 4 && c < C) {
         s = rs[0][cs]; ss = rss[0][cs]; lo = rlo[0][cs]; hi = rhi[0][cs];
-        for (int k = 1; k < NW; ++k) {
+        for (int k = 1; k < 4; ++k) {
             s += rs[k][cs]; ss += rss[k][cs];
             lo = fminf(lo, rlo[k][cs]); hi = fmaxf(hi, rhi[k][cs]);
         }
@@ -2745,8 +2736,8 @@ __global__ __launch_bounds__(NT) void instnorm_finalize_kernel(const float4* __r
 hipError_t launch_instnorm_finalize(const float4* part, int nparts, int Bt, int C, long HW, const float* gamma,
                                     const float* beta, float eps, float* scale, float* shift, unsigned* omax,
                                     hipStream_t s) {
-    dim3 grid((unsigned)((C + 3) / 4), (unsigned)Bt);
-    hipLaunchKernelGGL(instnorm_finalize_kernel<256>, grid, dim3(256), 0, s, part, nparts, C, HW, gamma, beta, eps, scale, shift, omax);
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((unsigned)((C + 3) / 4), (unsigned)Bt), dim3(256), 0, s, part, nparts,
+                       C, HW, gamma, beta, eps, scale, shift, omax);
     return hipGetLastError();
 }
 

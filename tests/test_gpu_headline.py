@@ -149,7 +149,7 @@ def test_fused_mlp_shapes_vs_fp64(dev, C, hw, routing, monkeypatch):
     assert rel_max(y, ref) <= NET_TOL
 
 
-@pytest.mark.parametrize("C,hw", [(384, (45, 90)), (128, (24, 48)), (256, (20, 40))])
+@pytest.mark.parametrize("C,hw", [(384, (12, 24)), (128, (24, 48)), (256, (8, 16))])   # widths with a two-level FFT: the stream engages
 def test_planes_only_residual_stream_vs_fp64(dev, C, hw, monkeypatch):
     """Default routing WITHOUT taps: from the first block on, fc2 (conv_ws modes 4 / 5) takes the outer-skip residual from the
     P-format planes of the block input and writes h' as planes only, and the longitude FFT reads those planes - no fp32 copy of
@@ -173,7 +173,7 @@ def test_planes_only_residual_stream_vs_fp64(dev, C, hw, monkeypatch):
         with torch.no_grad():
             y = net(x.to(dev))
             assert torch.equal(y, net(x.to(dev)))
-            assert torch.equal(y[1:2], net(x[1:2].to(dev)))          # batch 3 == per sample
+            assert rel_max(y[1:2], net(x[1:2].to(dev))) <= 2e-6      # batch 3 vs per sample (the range bounds span the batch: not bitwise)
         assert rel_max(y, ref) <= NET_TOL, (stream, rel_max(y, ref))
         outs[stream] = y
     assert rel_max(outs["1"], outs["0"]) <= 3e-6

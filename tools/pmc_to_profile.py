@@ -8,7 +8,8 @@ dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03_pmc_traffic.json"
 sha = sys.argv[3] if len(sys.argv) > 3 else None   # sha256 of the library the passes ran on (bench.py compares it)
 d = json.load(open(src))
 RULES = [  # (regex on kernel key, stage, reads are wide (x2 correction applies))
-    (r"^dft_forward_fft_kernel", "forward_transform.dft", True),
+    (r"^dft_forward_fft_kernel<.*, true>", "forward_transform.dft", True),                 # planes input (every block but the first)
+    (r"^dft_forward_fft_kernel<.*, false>", "forward_transform.dft(first block)", True),   # fp32 rows
     (r"^dft_inverse_fft_kernel", "inverse_transform.dft", False),   # spectral side: 4-byte loads in 64-byte runs
     (r"^legendre_strip_kernel<0", "forward_transform.legendre", True),
     (r"^legendre_strip_kernel<1", "inverse_transform.legendre", True),
@@ -16,8 +17,8 @@ RULES = [  # (regex on kernel key, stage, reads are wide (x2 correction applies)
     (r"^conv_ws_kernel<12, 1, 0>", "inner_skip+activation", True),
     (r"^conv_ws_kernel<12, 1, 1>", "mlp.fc1", True),
     (r"^conv_wl_kernel<24, 3", "mlp.fc1", True),
-    (r"^conv_ws_kernel<12, 2, 2>", "mlp.fc2+outer_skip", True),
-    (r"^conv_ws_kernel<12, 2, 3>", "mlp.fc2+outer_skip(last block)", True),
+    (r"^conv_ws_kernel<12, 2, [24]>", "mlp.fc2+outer_skip", True),               # mode 4: residual from planes, h' as planes only
+    (r"^conv_ws_kernel<12, 2, [35]>", "mlp.fc2+outer_skip(last block)", True),
     (r"^gemm3_f16x3_kernel<2, 2, false, true, false>", "decoder", True),
     (r"^gemm3_f16x3_kernel<2, 2, false, false, false>", "encoder", True),
 ]
