@@ -32,6 +32,18 @@ def _header_time() -> float:
     return max(_mtime(os.path.join(CSRC, h)) for h in HEADERS)
 
 
+def source_sha256() -> str:
+    """sha256 over the kernel sources, headers and compile flags: identifies the CODE a library was built from (hipcc's output is
+    not bit-reproducible across object paths, so profiles/ stamps its counter files with this as well as with the .so's hash)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True

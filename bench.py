@@ -261,14 +261,18 @@ def lib_sha256():
 
 
 def measured_counters():
-    """{(mode, stage): entry} from PMC_FILE if it was taken on the library loaded now, else ({}, reason)."""
+    """{(mode, stage): entry} from PMC_FILE if it was taken on the library loaded now - the same binary, or one built from the
+    same kernel sources and flags - else ({}, reason)."""
     try:
         with open(PMC_FILE) as f:
             d = json.load(f)
     except (OSError, ValueError):
         return {}, "no counter file (profiles/r03_pmc_traffic.json)"
-    if d.get("_lib_sha256") != lib_sha256():
-        return {}, f"counter file is of another build (sha256 {str(d.get('_lib_sha256'))[:12]} != timed {lib_sha256()[:12]})"
+    from ace_amd import build as _build
+    if d.get("_lib_sha256") != lib_sha256() and d.get("_src_sha256") != _build.source_sha256():
+        # neither the binary nor (hipcc output is not bit-reproducible: a rebuilt library differs) the kernel sources match
+        return {}, (f"counter file is of another build (library sha256 {str(d.get('_lib_sha256'))[:12]} != timed {lib_sha256()[:12]}, "
+                    f"kernel sources {str(d.get('_src_sha256'))[:12]} != {_build.source_sha256()[:12]})")
     return {tuple(k.split("|")): v for k, v in d.items() if not k.startswith("_") and isinstance(v, dict)}, None
 
 

@@ -235,3 +235,19 @@ def test_stepper_loop_bookkeeping_with_a_stub_module():
     for k in ["p", "d"]:
         torch.testing.assert_close(out[k], torch.stack([o[k] for o in ref], 1))
     assert torch.equal(state["p"], out["p"][:, -1:])
+
+
+def test_counter_file_is_tied_to_a_build():
+    """bench.py takes `roofline.traffic` / `mfma_busy_pmc` from profiles/r03_pmc_traffic.json only when that file was collected on
+    the library that is loaded now or on one built from the same kernel sources and flags (tools/pmc_collect.sh stamps both
+    hashes); otherwise it says why it reports null.  The stamps must be present and well-formed."""
+    import json
+    import bench
+    from ace_amd import build
+    with open(bench.PMC_FILE) as f:
+        d = json.load(f)
+    for k in ("_lib_sha256", "_src_sha256"):
+        assert isinstance(d.get(k), str) and len(d[k]) == 64 and int(d[k], 16) >= 0, k
+    assert len(build.source_sha256()) == 64
+    data, reason = bench.measured_counters()
+    assert (reason is None and ("f16x3", "mlp.fc2+outer_skip") in data) or (isinstance(reason, str) and data == {})

@@ -18,5 +18,6 @@ pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT
 pass sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM
 python tools/pmc_summarize.py --merge gpurun_out/pmc_$tag > gpurun_out/pmc_$tag.json
 grep -h "^lib_sha256" /tmp/pmc_fetch.log | head -1 | awk '{print $2}' > gpurun_out/pmc_$tag.sha256
-python tools/pmc_to_profile.py gpurun_out/pmc_$tag.json gpurun_out/pmc_${tag}_traffic.json "$(cat gpurun_out/pmc_$tag.sha256)" > gpurun_out/pmc_${tag}_table.txt; cat gpurun_out/pmc_${tag}_table.txt
+grep -h "^src_sha256" /tmp/pmc_fetch.log | head -1 | awk '{print $2}' > gpurun_out/pmc_$tag.src_sha256
+python tools/pmc_to_profile.py gpurun_out/pmc_$tag.json gpurun_out/pmc_${tag}_traffic.json "$(cat gpurun_out/pmc_$tag.sha256)" "$(cat gpurun_out/pmc_$tag.src_sha256)" > gpurun_out/pmc_${tag}_table.txt; cat gpurun_out/pmc_${tag}_table.txt
 head -c 3000 gpurun_out/pmc_$tag.json

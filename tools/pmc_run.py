@@ -23,3 +23,5 @@ with torch.no_grad():
 torch.cuda.synchronize()
 print("pmc_run done", tuple(y.shape), float(y.abs().max()))
 print("lib_sha256", bench.lib_sha256(), _lib.LIB_PATH)
+from ace_amd import build as _build
+print("src_sha256", _build.source_sha256())

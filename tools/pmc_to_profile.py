@@ -6,6 +6,7 @@ import json, re, sys
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_r03.json"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03_pmc_traffic.json"
 sha = sys.argv[3] if len(sys.argv) > 3 else None   # sha256 of the library the passes ran on (bench.py compares it)
+src_sha = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] else None   # ... and of its kernel sources + flags (ace_amd/build.py)
 d = json.load(open(src))
 RULES = [  # (regex on kernel key, stage, reads are wide (x2 correction applies))
     (r"^dft_forward_fft_kernel<.*, true>", "forward_transform.dft", True),                 # planes input (every block but the first)
@@ -22,7 +23,7 @@ RULES = [  # (regex on kernel key, stage, reads are wide (x2 correction applies)
     (r"^gemm3_f16x3_kernel<2, 2, false, true, false>", "decoder", True),
     (r"^gemm3_f16x3_kernel<2, 2, false, false, false>", "encoder", True),
 ]
-out = {"_source": src, "_lib_sha256": sha, "_note": "per-launch means over the dispatches of 2 eager forwards; separate rocprofv3 --pmc passes "
+out = {"_source": src, "_lib_sha256": sha, "_src_sha256": src_sha, "_note": "per-launch means over the dispatches of 2 eager forwards; separate rocprofv3 --pmc passes "
        "(FETCH_SIZE | WRITE_SIZE TCC_HIT TCC_MISS | SQ busy | SQ insts), never combined with API traces"}
 rows = []
 for k, v in d.items():
