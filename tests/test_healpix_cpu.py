@@ -69,3 +69,33 @@ def test_unbuilt_variants_are_loud(gold):
         net(torch.zeros(1, 12, 3, 8, 8))
     with pytest.raises(ValueError, match="5D"):
         net(torch.zeros(12, 3, 8, 8))
+
+
+@pytest.mark.parametrize("k,dil,cin,W", [(3, 1, 5, 8), (3, 2, 4, 8), (3, 4, 3, 16), (5, 1, 2, 8)])
+def test_row_offset_table_is_the_convolution(k, dil, cin, W):
+    """The k x k (dilated) convolution runs as ONE contraction over (tap, channel) whose B rows are the padded tensor shifted by
+    the tap's offset (GemmArgs::brow): the host side builds the row-offset table and lays the weight out as [cout][(ky, kx, cin)]
+    (HEALPixLayer._row_offsets / ._weight).  Evaluate exactly that contraction with torch on the CPU - rows gathered through the
+    table from the flat padded buffer, all H * pitch columns incl. the gap columns - against nn.functional.conv2d."""
+    from ace_amd.healpix import HEALPixLayer, _round4
+    torch.manual_seed(k * 100 + dil)
+    layer = HEALPixLayer(layer=torch.nn.Conv2d, in_channels=cin, out_channels=6, kernel_size=k, dilation=dil, hpx_padding_mode="karlbauer")
+    p = layer._pad
+    assert p == (k - 1) // 2 * dil
+    H, m = W, W + 2 * p
+    mp = _round4(m) + 4                                   # a pitch wider than the padded face
+    xp = torch.zeros(cin, m, mp)
+    xp[:, :, :m] = torch.randn(cin, m, m)
+    flat = torch.cat([xp.reshape(-1), torch.zeros(16)])   # + ACE_HPX_SLACK_FLOATS
+    rows = layer._row_offsets(cin, m, mp, torch.device("cpu"))
+    w = layer.base.weight.detach()
+    A = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)     # what _weight() hands to ace_hpx_weight_create
+    assert rows.shape == (k * k * cin,) and A.shape[1] == rows.numel()
+    N = H * mp
+    cols = torch.arange(N)
+    B = flat[rows[:, None] + cols[None, :]]               # never reads past the slack
+    y = (A.double() @ B.double()).reshape(-1, H, mp)[:, :, :W]
+    ref = torch.nn.functional.conv2d(xp[None, :, :, :m].double(), w.double(), dilation=dil)[0]
+    assert ref.shape == y.shape
+    assert float((y - ref).abs().max()) <= 1e-12
+    assert int(rows.max()) + N <= flat.numel()
