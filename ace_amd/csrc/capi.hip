@@ -1180,6 +1180,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     // packed path: its epilogue then writes h0 as fp32 AND as P-format planes with the row statistics of norm0, so block 0
     // starts like every other block (no pack pass, no statistics pass over h0).
     bool enc_planes = false;
+    int enc_nparts = 0;          // statistics partials per row the last encoder convolution wrote
     {
         const Weight& we = *n->weights[n->index.at("encoder." + std::to_string(2 * c.encoder_layers) + ".weight")];
         const bool enc_off = n->sw.no_enc_ws;
@@ -1200,8 +1201,8 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             k.Cf = h; k.sCf = actB;
             k.Chi = Hh; k.Clo = Hl; k.sCp = (long)C * HW; k.cslot = hslot(0);
             k.cw = we.winf; k.cb = 0.f; k.rmax = reinterpret_cast<const unsigned*>(n->pe_slot.p);
-            k.part = reinterpret_cast<float4*>(n->part.p); k.nstrips32 = (int)((HW + 31) / 32);
             k.C = C; k.M = C; k.HW = (int)HW; k.nbatch = B; k.act = ACT_NONE;
+            k.part = reinterpret_cast<float4*>(n->part.p); k.nstrips32 = conv_ws_stat_parts(k); enc_nparts = k.nstrips32;
             HIP_TRY(launch_conv_ws(k, s));
             enc_planes = true;
         }
@@ -1233,7 +1234,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
 
     // fused-norm state of the packed-operand path: does P2 hold the block input in P format / `part_h` its statistics?
     bool have_ph = enc_planes, have_hstats = enc_planes;
-    int h_nparts = enc_planes ? (int)((HW + 31) / 32) : 0;   // statistics partials per row in part_h (depends on which kernel produced them)
+    int h_nparts = enc_planes ? enc_nparts : 0;   // statistics partials per row in part_h (depends on which kernel produced them)
     float* part_h = n->part.p;
     float* part_t = n->part.p ? n->part.p + (size_t)n->Bmax * n->nstrips * C * 4 : nullptr;
     _Float16* PAh = reinterpret_cast<_Float16*>(n->P.p);                  // T planes / pack fallback
@@ -1471,7 +1472,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 if (last || !rpl) { k.Cf = hn; k.sCf = actB; }
                 h_planes_only = !last && rpl;
                 k.C = n->hid; k.M = C; k.HW = (int)HW; k.nbatch = B; k.act = ACT_NONE;
-                const int nparts = (int)((HW + 31) / 32);
+                const int nparts = conv_ws_stat_parts(k);   // one partial per workgroup and row (accumulated in LDS)
                 if (!last) {
                     k.Chi = PBh; k.Clo = PBl; k.sCp = (long)C * HW; k.cslot = hslot(i + 1);
                     k.cw = w2.winf; k.cb = b2w.absmax; k.rmax = slot(sb + 3);

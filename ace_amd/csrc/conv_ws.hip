@@ -41,7 +41,7 @@ constexpr int WS_OOBV = 0x7fffff00;   // buffer offset beyond every resource of 
 #define ACE_WS_HOLD4 0   // mode 4 at K = 768: hold the store data through the stage instead of retiring the stores first
 #endif
 #ifndef ACE_WS_FD4
-#define ACE_WS_FD4 1     // fragment read-ahead of the K = 768 planes + statistics modes (r03 same-box: mode 4 155.8 -> 149.1 us; holding the store data instead: 153.2)
+#define ACE_WS_FD4 1     // fragment read-ahead of mode 4 at K = 768 (mode 2 there has no registers for it) (r03 same-box: mode 4 155.8 -> 149.1 us; holding the store data instead: 153.2)
 #endif
 #ifndef ACE_WS_VSPAN
 #define ACE_WS_VSPAN 8    // interleaved epilogue: its eight values are spread over the first VSPAN twelfths of the stage
@@ -59,7 +59,8 @@ struct WsGeom {
     static constexpr int STP = 36;                 // pitch of the statistics transpose (floats)
     static constexpr bool RSTATS = MODE == 0;      // statistics accumulated in registers over the workgroup's pixel range
     static constexpr int STB = (STATS && !RSTATS) ? 8 * 16 * STP * 4 : 0;
-    static constexpr int LDS = 2 * SLOT + TAB + XCH + STB;
+    static constexpr int LACC = (STATS && !RSTATS) ? 8 * 16 * 16 : 0;   // fc2 modes: running row statistics of a segment, per wave 16 rows x float4
+    static constexpr int LDS = 2 * SLOT + TAB + XCH + STB + LACC;
     static_assert(KSW % 2 == 0 && LDS <= 160 * 1024, "LDS budget");
 };
 
@@ -90,6 +91,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, g = lane >> 5;
     float* St = reinterpret_cast<float*>(smem + 2 * SLOT + TAB + XCH) + wave * (16 * STP);
+    f32x4* Lacc = reinterpret_cast<f32x4*>(smem + 2 * SLOT + TAB + XCH + G::STB) + wave * 16;   // LSTATS: this wave's 16 rows
 
     // ---- which sample, XCD and workgroup of the XCD; its segments (runs of pixel tiles of one channel slice): ws_plan.h
     const int per_smp = 8 * ws_workgroups_per_xcd(pl);
@@ -99,7 +101,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     const WsWork wk = ws_work(pl, (p.HW + 31) / 32, xcd, w);
     const int part_q = wk.part_q, nseg = wk.nseg;
     auto segment = [&](int k) { return ws_segment(pl, wk, w, k); };
-    if (RSTATS) {
+    if (STATS) {
         // The norm finaliser sums slot part_q over ALL rows.  An extra workgroup owns its slot alone: rows of the slices it
         // does not reach get a neutral partial; a group's slot is shared by its nslice workgroups, each answers for its slice.
         float4* pq = p.part + ((long)smp * p.nstrips32 + part_q) * p.M;
@@ -157,6 +159,9 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     const int T = sg.slice * 4 + (wave & 3);   // 32-row tile of the output channels
     const int NU = np * NSTG;
     if (!first) __syncthreads();               // the ring and the exchange buffers of the previous segment are free
+    if constexpr (STATS && !RSTATS) {          // running row statistics of this segment (lanes 0 - 15 of a wave own its 16 rows)
+        if (lane < 16) Lacc[lane] = f32x4{0.f, 0.f, 3.0e38f, -3.0e38f};
+    }
     // ---- streamed activation: piece k (of PW) of this wave for stage u -> slot u % 2; stages past the end re-fetch the last.
     //      Piece pc = (block pc / 2 of the stage: half hh, k-step jj; plane pc % 2): lane (i, g) fetches k-group 2 J + g, pixel i
     const _Float16* Xh = p.Xhi + (long)smp * p.sX;
@@ -298,8 +303,13 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
                     mn = fminf(mn, __shfl_xor(mn, off, 64));
                     mx = fmaxf(mx, __shfl_xor(mx, off, 64));
                 }
-                o.stv = f32x4{sm, sq, mn, mx};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.stv), rsP, c.vo_s, (c.n0 >> 5) * p.M * 16, 0);
+                // ONE partial per workgroup and row instead of one per 32-pixel tile (r03: the norm finaliser read 2025 partials per
+                // channel, 6 KiB apart, and took 10 us): the row's running statistics live in LDS, always updated by the same lane
+                if (c.vo_s != WS_OOBV) {
+                    f32x4 acc = Lacc[ln];
+                    acc[0] += sm; acc[1] += sq; acc[2] = fminf(acc[2], mn); acc[3] = fmaxf(acc[3], mx);
+                    Lacc[ln] = acc;
+                }
             }
         }
     };
@@ -346,7 +356,6 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     };
     auto hold = [&](EpiOut& o) {           // gfx950 store-data rule (profiles/r02_store_data_hazard.txt)
         if constexpr (PK) asm volatile("" ::"v"(o.hh8), "v"(o.ll8));
-        if constexpr (STATS && !RSTATS) asm volatile("" ::"v"(o.stv));
         if constexpr (F32) asm volatile("" ::"v"(o.vals[0]), "v"(o.vals[1]), "v"(o.vals[2]), "v"(o.vals[3]), "v"(o.vals[4]), "v"(o.vals[5]), "v"(o.vals[6]), "v"(o.vals[7]));
     };
     auto load_residual = [&](int pt) {     // rows of pixel tile pt this wave will finish -> resn (retired by the next stage-top wait)
@@ -384,7 +393,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     f32x16 v, v2;   // v2: second accumulator of the ACC2 form (the MFMA stream alternates v, v2, v, v2, ...)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { v[r] = 0.f; v2[r] = 0.f; }
-    constexpr int FDEPTH = ((MODE == 2 || MODE == 4) && KH == 24) ? ACE_WS_FD4 : 1;   // fragment read-ahead; 0 where the registers are gone (K = 768 + planes + statistics)
+    constexpr int FDEPTH = (MODE == 2 && KH == 24) ? 0 : ((MODE == 4 && KH == 24) ? ACE_WS_FD4 : 1);   // fragment read-ahead; 0 where the registers are gone (K = 768 + planes + statistics)
     // Loop body = one stage followed by the wait + barrier that opens the next (stage 0 was opened by the prologue); an
     // asm-loaded register still in flight is never live across the back edge (hipcc believes the value is there and may copy it).
     constexpr int VSPAN = ACE_WS_VSPAN * KSW / 12 > 0 ? ACE_WS_VSPAN * KSW / 12 : 1;   // interleaved epilogue: the eight values over the first VSPAN k-steps, the stores right after
@@ -506,9 +515,16 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, st8[e]), rsG, vo, e * 16, 0);
         }
     }
+    f32x4 lst = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (STATS && !RSTATS) {   // the segment's row statistics: one partial per row, slot part_q of this workgroup
+        const auto rsG = __builtin_amdgcn_make_buffer_rsrc(p.part + ((long)smp * p.nstrips32 + part_q) * p.M, 0, p.M * 16, 0x00020000);
+        lst = Lacc[lane & 15];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lst), rsG, lane < 16 ? (row0 + lane) * 16 : WS_OOBV, 0, 0);
+    }
     // the next segment loads weights into registers (and the range reduction below shuffles): every store of this segment
     // has read its data by then
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (STATS && !RSTATS) asm volatile("" ::"v"(lst));
     if constexpr (RSTATS) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(st8[e]));
@@ -637,8 +653,7 @@ hipError_t launch_pack_conv_frag(const float* W, long ldw, int O, int I, int ord
 
 // statistics partials per row the launch described by `a` writes (a.nstrips32 must be at least this)
 int conv_ws_stat_parts(const ConvStripArgs& a) {
-    const bool skip_mode = (a.act == ACT_GELU || a.act == ACT_GELU_FAST) && a.R && a.part && !a.Cf;
-    if (!skip_mode) return (a.HW + 31) / 32;
+    // one partial per workgroup of a channel slice (inner skip: accumulated in registers; fc2 modes: in LDS)
     const WsPlan pl = ws_plan(a.M, a.HW, a.C <= 384);
     return ws_stat_slots(pl);
 }
