@@ -246,6 +246,14 @@ class AtmosphereData:
         self._set("frozen_precipitation_rate", value)
 
     @property
+    def net_surface_energy_flux_without_frozen_precip(self) -> torch.Tensor:
+        """metrics.py:299-334 without the frozen-precipitation term (atmosphere_data.py:217-226; the slab ocean's forcing)."""
+        radiative = (self._get("sfc_down_sw_radiative_flux") - self._get("sfc_up_sw_radiative_flux")
+                     + self._get("sfc_down_lw_radiative_flux") - self._get("sfc_up_lw_radiative_flux"))
+        turbulent = -self._get("latent_heat_flux") - self._get("sensible_heat_flux")
+        return radiative + turbulent - 0.0
+
+    @property
     def net_surface_energy_flux(self) -> torch.Tensor:
         """metrics.py:299-334 with the frozen-precipitation term."""
         radiative = (self._get("sfc_down_sw_radiative_flux") - self._get("sfc_up_sw_radiative_flux")

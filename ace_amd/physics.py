@@ -81,6 +81,8 @@ class FusedPhysics:
             cfg.energy_budget, cfg.unaccounted_heating = 1, float(eb.constant_unaccounted_heating)
         cfg.timestep_seconds = float(corrector._dt) if (corrector is not None and corrector._dt is not None) else 0.0
         cfg.ocean = 0 if ocean is None else (2 if ocean.prescriber.interpolate else 1)
+        if ocean is not None and getattr(ocean, "is_slab", False):
+            raise NotImplementedError("fused ocean kernel: prescribed SST only (the slab ocean runs as torch ops)")
         if ocean is not None and ocean.prescriber.mask_value != 1:
             raise NotImplementedError("fused ocean kernel: mask_value must be 1 (what Ocean builds)")
         vc = corrector._vc if corrector is not None else None

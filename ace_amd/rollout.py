@@ -108,7 +108,8 @@ class RolloutEngine:
         # Post-step physics as four HIP kernels per step (ace_amd/physics.py, csrc/physics.hip) instead of captured torch ops
         # (round 2: +29 % step time).  ACE_NO_FUSED_PHYSICS=1 keeps the torch ops (A/B).
         self._physics = None
-        if (self._corrector is not None or self._ocean is not None or self.prescribed) and not os.environ.get("ACE_NO_FUSED_PHYSICS"):
+        slab = self._ocean is not None and getattr(self._ocean, "is_slab", False)   # the fused kernel knows the prescribed SST only
+        if (self._corrector is not None or self._ocean is not None or self.prescribed) and not slab and not os.environ.get("ACE_NO_FUSED_PHYSICS"):
             self._physics = self._build_physics()
         self._window_graph = None
         self._window_graph_key = None   # (native handle, its weights generation) the window graph was captured against

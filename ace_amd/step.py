@@ -94,9 +94,7 @@ class SingleModuleStepConfig:
         if isinstance(self.ocean, dict):
             self.ocean = OceanConfig.from_state(self.ocean)
         if self.ocean is not None and not isinstance(self.ocean, OceanConfig):
-            raise NotImplementedError("SingleModuleStepConfig.ocean must be an OceanConfig (prescribed SST) or its state")
-        if self.ocean is not None and self.ocean.slab is not None:
-            raise NotImplementedError("the slab ocean is outside the accelerated hot path")
+            raise NotImplementedError("SingleModuleStepConfig.ocean must be an OceanConfig (prescribed SST or slab ocean) or its state")
         if not isinstance(self.corrector, (AtmosphereCorrectorConfig, dict, type(None))):
             raise NotImplementedError("SingleModuleStepConfig.corrector must be an AtmosphereCorrectorConfig or its state")
         if self.corrector is None or isinstance(self.corrector, dict):

@@ -90,6 +90,19 @@ def main():
                                       ).build(["sst", "frac", "q"], ["sst", "q"], timestep)
         out["ocean"]["expected"][interp] = {k: v.clone() for k, v in ocean(oc_in, oc_gen, oc_target).items()}
         out["ocean"].setdefault("forcing_names", sorted(ocean.forcing_names))
+    # slab ocean (fme/core/ocean.py:14-29, 64-92, 233-254): SST_next = SST_in + (F_net + Q) / (rho c_p depth) * dt over ocean
+    flux_names = ["DLWRFsfc", "ULWRFsfc", "DSWRFsfc", "USWRFsfc", "LHTFLsfc", "SHTFLsfc"]
+    sl_gen = dict(oc_gen)
+    for i, n in enumerate(flux_names):
+        sl_gen[n] = 150.0 + 40.0 * torch.randn(2, 8, 16, generator=g) + 10.0 * i
+    sl_target = {"frac": frac, "mld": 20.0 + 60.0 * torch.rand(2, 8, 16, generator=g), "qflux": 15.0 * torch.randn(2, 8, 16, generator=g)}
+    out["slab_ocean"] = {"input": oc_in, "gen": sl_gen, "target": sl_target, "expected": {}, "timestep_seconds": timestep.total_seconds()}
+    for interp in (False, True):
+        ocean = ocean_mod.OceanConfig(surface_temperature_name="sst", ocean_fraction_name="frac", interpolate=interp,
+                                      slab=ocean_mod.SlabOceanConfig(mixed_layer_depth_name="mld", q_flux_name="qflux")
+                                      ).build(["sst", "frac", "q"], ["sst", "q"] + flux_names, timestep)
+        out["slab_ocean"]["expected"][interp] = {k: v.clone() for k, v in ocean(oc_in, sl_gen, sl_target).items()}
+        out["slab_ocean"].setdefault("forcing_names", sorted(ocean.forcing_names))
     path = os.path.join(HERE, "gen_corrector.pt")
     torch.save(out, path)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -142,3 +142,40 @@ def test_ocean_matches_reference(gold, interpolate):
     assert set(out) == set(o["expected"][interpolate])
     for k, v in o["expected"][interpolate].items():
         assert torch.equal(out[k], v), k
+
+
+@pytest.mark.parametrize("interpolate", [False, True])
+def test_slab_ocean_matches_reference(gold, interpolate):
+    """slab ocean (fme/core/ocean.py:14-29, 64-92, 233-254): SST_in + (F_net + Q) / (rho c_p depth) dt over ocean, F_net the
+    generated net surface energy flux without the frozen-precipitation term - bitwise against the reference's own output;
+    configuration from dataclasses and from the state-dict form a checkpoint holds."""
+    import datetime
+    from ace_amd.ocean import OceanConfig, SlabOceanConfig
+    o = gold["slab_ocean"]
+    dt = datetime.timedelta(seconds=o["timestep_seconds"])
+    flux = ["DLWRFsfc", "ULWRFsfc", "DSWRFsfc", "USWRFsfc", "LHTFLsfc", "SHTFLsfc"]
+    for cfg in (OceanConfig("sst", "frac", interpolate, SlabOceanConfig(mixed_layer_depth_name="mld", q_flux_name="qflux")),
+                OceanConfig.from_state({"surface_temperature_name": "sst", "ocean_fraction_name": "frac", "interpolate": interpolate,
+                                        "slab": {"mixed_layer_depth_name": "mld", "q_flux_name": "qflux"}})):
+        assert cfg.is_slab and sorted(cfg.forcing_names) == o["forcing_names"]
+        ocean = cfg.build(["sst", "frac", "q"], ["sst", "q"] + flux, dt)
+        out = ocean(o["input"], o["gen"], o["target"])
+        assert set(out) == set(o["expected"][interpolate])
+        for k, v in o["expected"][interpolate].items():
+            assert torch.equal(out[k], v), k
+    with pytest.raises(ValueError):
+        cfg.build(["sst", "frac"], ["sst"] + flux, None)               # no timestep
+    with pytest.raises(ValueError):
+        OceanConfig.from_state({"surface_temperature_name": "sst", "ocean_fraction_name": "frac", "slab": {"depth": "mld"}})
+
+
+def test_slab_ocean_through_the_step_config():
+    """SingleModuleStepConfig accepts the slab form (state-dict as in a checkpoint) and asks for its forcings."""
+    import ace_amd
+    cfg = ace_amd.SingleModuleStepConfig(
+        builder=ace_amd.ModuleSelector(type="SphericalFourierNeuralOperatorNet", config={"embed_dim": 8, "num_layers": 1}),
+        in_names=["sst", "frac", "a"], out_names=["sst", "a"],
+        normalization=ace_amd.step.NormalizationConfig(means={k: 0.0 for k in ("sst", "frac", "a")}, stds={k: 1.0 for k in ("sst", "frac", "a")}),
+        ocean={"surface_temperature_name": "sst", "ocean_fraction_name": "frac", "slab": {"mixed_layer_depth_name": "mld", "q_flux_name": "qflux"}})
+    assert cfg.ocean.is_slab
+    assert {"mld", "qflux", "frac"} <= set(cfg.get_next_step_forcing_names()) | set(cfg.ocean.forcing_names)

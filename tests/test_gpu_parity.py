@@ -688,6 +688,49 @@ def test_rollout_engine_with_hooks_matches_stepper(dev, graph):
     assert torch.equal(out["sst"][ocean_cells], forcing["sst"][:, 1:][ocean_cells])
 
 
+@pytest.mark.parametrize("graph", [None, "window"])
+def test_rollout_engine_with_slab_ocean_matches_stepper(dev, graph):
+    """slab ocean (fme/core/ocean.py:64-92) in the static-buffer engine: the fused physics kernels know the prescribed SST only,
+    so the engine applies the slab update as the same torch ops the Stepper runs (captured in the graph modes) - engine ==
+    Stepper == the formula applied by hand to the Stepper's own output of the first step."""
+    import datetime
+    import ace_amd
+    from ace_amd.rollout import RolloutEngine
+    from ace_amd.step import NormalizationConfig
+    flux = ["DLWRFsfc", "ULWRFsfc", "DSWRFsfc", "USWRFsfc", "LHTFLsfc", "SHTFLsfc"]
+    in_names = ["f0", "sst", "frac"]
+    out_names = ["sst"] + flux
+    names = sorted(set(in_names + out_names))
+    config = ace_amd.SingleModuleStepConfig(
+        builder=ace_amd.ModuleSelector(type="SphericalFourierNeuralOperatorNet",
+                                       config={"embed_dim": 16, "num_layers": 2, "operator_type": "dhconv"}),
+        in_names=in_names, out_names=out_names,
+        normalization=NormalizationConfig(means={k: 0.1 * (i + 1) for i, k in enumerate(names)},
+                                          stds={k: 1.0 + 0.1 * i for i, k in enumerate(names)}),
+        ocean={"surface_temperature_name": "sst", "ocean_fraction_name": "frac",
+               "slab": {"mixed_layer_depth_name": "mld", "q_flux_name": "qflux"}})
+    torch.manual_seed(0)
+    info = ace_amd.DatasetInfo((12, 24), timestep=datetime.timedelta(hours=6))
+    stepper = ace_amd.Stepper.from_config(config, info, device=dev)
+    stepper.set_eval()
+    B, T = 2, 3
+    ic = {"sst": 290.0 + torch.randn(B, 1, 12, 24, device=dev)}
+    forcing = {"f0": torch.randn(B, T + 1, 12, 24, device=dev), "frac": torch.rand(B, T + 1, 12, 24, device=dev),
+               "mld": 20.0 + 60.0 * torch.rand(B, T + 1, 12, 24, device=dev), "qflux": 15.0 * torch.randn(B, T + 1, 12, 24, device=dev)}
+    ref, _ = stepper.predict(ic, forcing)
+    eng = RolloutEngine(stepper, batch=B, n_forward_steps=T, graph=graph)
+    assert eng._physics is None                                   # torch-op hooks, not the fused kernels
+    out, _ = eng.predict(ic, forcing)
+    torch.cuda.synchronize()
+    for k in out_names:
+        assert rel_max(out[k], ref[k]) <= 2e-6, k
+    # first step by hand: over ocean, SST = SST_in + (F_net + Q) / (rho c_p depth) * dt
+    f_net = (ref["DSWRFsfc"][:, 0] - ref["USWRFsfc"][:, 0] + ref["DLWRFsfc"][:, 0] - ref["ULWRFsfc"][:, 0]) + (-ref["LHTFLsfc"][:, 0] - ref["SHTFLsfc"][:, 0])
+    want = ic["sst"][:, 0] + (f_net + forcing["qflux"][:, 1]) / (1000.0 * forcing["mld"][:, 1] * 4000.0) * 21600.0
+    ocean_cells = torch.round(forcing["frac"][:, 1]) == 1
+    assert rel_max(ref["sst"][:, 0][ocean_cells], want[ocean_cells]) <= 1e-6
+
+
 @pytest.mark.parametrize("graph", [None, "step", "window"])
 def test_rollout_engine_matches_stepper(dev, graph):
     """hipGraph rollout with static buffers vs the dict-of-tensors Stepper loop (which normalises with torch
