@@ -178,10 +178,10 @@ def test_step_hook_order_corrector_then_ocean_then_prescribed():
     assert float(out["q"].max()) == 0.0                                    # network output was negative everywhere
     assert torch.equal(out["sst"], torch.where(frac == 1, nxt["sst"], inp["sst"] - 10.0))
     assert torch.equal(out["d"], inp["f"])
-    with pytest.raises(NotImplementedError):
-        ace_amd.SingleModuleStepConfig(builder=cfg.builder, in_names=IN, out_names=OUT, normalization=norm,
-                                       ocean={"surface_temperature_name": "sst", "ocean_fraction_name": "frac",
-                                              "slab": {"q_flux_name": "qf", "mixed_layer_depth_name": "mld"}})
+    slab = ace_amd.SingleModuleStepConfig(builder=cfg.builder, in_names=IN, out_names=OUT, normalization=norm,
+                                          ocean={"surface_temperature_name": "sst", "ocean_fraction_name": "frac",
+                                                 "slab": {"q_flux_name": "qf", "mixed_layer_depth_name": "mld"}})
+    assert slab.ocean.is_slab and {"qf", "mld", "frac"} == set(slab.ocean.forcing_names)   # the checkpoint form of the slab ocean
     with pytest.raises(NotImplementedError):
         ace_amd.SingleModuleStepConfig(builder=cfg.builder, in_names=IN, out_names=OUT, normalization=norm,
                                        corrector={"conserve_dry_air": True}).get_step(ace_amd.DatasetInfo((4, 8)))
