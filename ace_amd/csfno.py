@@ -10,9 +10,12 @@ Mirror of the reference's plugin API for this model family:
     (ace_sfno_forward_conditioned).  ``forward(x, noise=...)`` takes the noise from the caller instead (parity tests).
 
 Supported: filter_type "linear", dhconv, gaussian / isotropic noise, affine_norms, normalize_big_skip,
-filter_num_groups, use_mlp, activation, encoder_layers, pos_embed, big_skip, data_grid.  Everything else the reference
-builder accepts (labels, positional context embedding, LoRA, spectral_ratio < 1, local blocks, filter_residual /
-filter_output, global_layer_norm, clip_latent_global_means, filter_preserves_global_mean) raises at build time.
+filter_num_groups, use_mlp, activation, encoder_layers, pos_embed, big_skip, data_grid, and the label / positional context
+(dataset_info.all_labels, label_embed_dim, context_pos_embed_dim: stochastic_sfno.py:88-175, layers.py:160-318) - the host
+forms ONE conditioning field cat(noise, positional context, label planes, ones) and merges the per-norm weights accordingly, so
+the native conditional norm is unchanged.  Everything else the reference builder accepts (LoRA, spectral_ratio < 1, local blocks,
+filter_residual / filter_output, global_layer_norm, clip_latent_global_means, filter_preserves_global_mean) raises at build
+time.
 """
 import ctypes
 import dataclasses
@@ -30,19 +33,44 @@ from .sht import InverseRealSHT
 
 
 class _CondNorm(nn.Module):
-    """parameter holder of ConditionalLayerNorm (conditional_sfno/layers.py:143-243), noise conditioning only"""
+    """parameter holder of ConditionalLayerNorm (conditional_sfno/layers.py:143-243) in the reference's registration order:
+    label, noise and positional conditioning (embed_dim_scalar is 0 in this family), then the channel norm's affine"""
 
-    def __init__(self, n_channels: int, noise_dim: int, affine: bool):
+    def __init__(self, n_channels: int, noise_dim: int, affine: bool, label_dim: int = 0, pos_dim: int = 0):
         super().__init__()
+        if label_dim > 0:
+            self.W_scale_labels = nn.Linear(label_dim, n_channels)
+            self.W_bias_labels = nn.Linear(label_dim, n_channels)
+            for lin in (self.W_scale_labels, self.W_bias_labels):
+                nn.init.constant_(lin.weight, 0.0)
+                nn.init.constant_(lin.bias, 0.0)
         if noise_dim > 0:
             self.W_scale_2d = nn.Conv2d(noise_dim, n_channels, 1, bias=False)
             self.W_bias_2d = nn.Conv2d(noise_dim, n_channels, 1, bias=False)
             nn.init.constant_(self.W_scale_2d.weight, 0.0)
             nn.init.constant_(self.W_bias_2d.weight, 0.0)
+        if pos_dim > 0:
+            self.W_scale_pos = nn.Conv2d(pos_dim, n_channels, 1, bias=False)
+            self.W_bias_pos = nn.Conv2d(pos_dim, n_channels, 1, bias=False)
+            nn.init.constant_(self.W_scale_pos.weight, 0.0)
+            nn.init.constant_(self.W_bias_pos.weight, 0.0)
         if affine:
             self.norm = nn.Module()
             self.norm.weight = nn.Parameter(torch.ones(n_channels))
             self.norm.bias = nn.Parameter(torch.zeros(n_channels))
+
+    def merged(self, which: str) -> torch.Tensor:
+        """[C, J_total] weight of ONE 1 x 1 convolution over the merged conditioning field cat(noise, positional context, label
+        planes, ones): [W_2d | W_pos | W_labels.weight | W_labels.bias] - the native conditional norm knows one conditioning
+        field; labels enter as constant planes (their value per sample) and the label bias as an all-ones plane."""
+        parts = []
+        for name in (f"W_{which}_2d", f"W_{which}_pos"):
+            if hasattr(self, name):
+                parts.append(getattr(self, name).weight.detach()[:, :, 0, 0])
+        if hasattr(self, f"W_{which}_labels"):
+            lin = getattr(self, f"W_{which}_labels")
+            parts += [lin.weight.detach(), lin.bias.detach()[:, None]]
+        return torch.cat(parts, dim=1).float().contiguous()
 
 
 class _Filter(nn.Module):
@@ -58,12 +86,12 @@ class _Filter(nn.Module):
 
 
 class _Block(nn.Module):
-    def __init__(self, C, L, G, noise_dim, affine, use_mlp, mlp_ratio, act_layer):
+    def __init__(self, C, L, G, noise_dim, affine, use_mlp, mlp_ratio, act_layer, label_dim=0, pos_dim=0):
         super().__init__()
-        self.norm0 = _CondNorm(C, noise_dim, affine)
+        self.norm0 = _CondNorm(C, noise_dim, affine, label_dim, pos_dim)
         self.filter = _Filter(C, L, G)
         self.inner_skip = nn.Conv2d(C, C, 1, 1)
-        self.norm1 = _CondNorm(C, noise_dim, affine)
+        self.norm1 = _CondNorm(C, noise_dim, affine, label_dim, pos_dim)
         if use_mlp:
             hid = int(C * mlp_ratio)
             self.mlp = nn.Module()
@@ -73,9 +101,10 @@ class _Block(nn.Module):
 class _ConditionalNet(nn.Module):
     """parameter tree of the conditional SphericalFourierNeuralOperatorNet (conditional_sfno/sfnonet.py:496-768)"""
 
-    def __init__(self, cfg: "NoiseConditionedSFNOBuilder", in_chans, out_chans, img_shape):
+    def __init__(self, cfg: "NoiseConditionedSFNOBuilder", in_chans, out_chans, img_shape, label_dim: int = 0):
         super().__init__()
         C = cfg.embed_dim
+        pos_dim = cfg.context_pos_embed_dim
         L = int(img_shape[0] * 1.0)
         act_layer = _ACT_LAYER[cfg.activation_function]
         enc, cur = [], in_chans
@@ -85,7 +114,7 @@ class _ConditionalNet(nn.Module):
         enc.append(nn.Conv2d(cur, C, 1, bias=False))
         self.encoder = nn.Sequential(*enc)
         self.blocks = nn.ModuleList([_Block(C, L, cfg.filter_num_groups, cfg.noise_embed_dim, cfg.affine_norms, cfg.use_mlp,
-                                            cfg.mlp_ratio, act_layer) for _ in range(cfg.num_layers)])
+                                            cfg.mlp_ratio, act_layer, label_dim, pos_dim) for _ in range(cfg.num_layers)])
         dec, cur = [], C + int(cfg.big_skip) * in_chans
         for _ in range(cfg.encoder_layers):
             dec += [nn.Conv2d(cur, C, 1, bias=True), act_layer()]
@@ -96,17 +125,37 @@ class _ConditionalNet(nn.Module):
             self.pos_embed = nn.Parameter(torch.zeros(1, C, img_shape[0], img_shape[1]))
             trunc_normal_(self.pos_embed, std=0.02)
         if cfg.normalize_big_skip and cfg.big_skip:
-            self.norm_big_skip = _CondNorm(in_chans, cfg.noise_embed_dim, cfg.affine_norms)
+            self.norm_big_skip = _CondNorm(in_chans, cfg.noise_embed_dim, cfg.affine_norms, label_dim, pos_dim)
 
 
 class NoiseConditionedSFNO(nn.Module):
-    def __init__(self, cfg: "NoiseConditionedSFNOBuilder", in_chans: int, out_chans: int, img_shape):
+    """NoiseConditionedModel (stochastic_sfno.py:50-180) around the conditional network: draws the noise, embeds the labels,
+    forms the positional context (pos_embed + labels . label_pos_embed) and hands the native network ONE conditioning field
+    cat(noise, positional context, label planes, ones) with the per-norm weights merged accordingly (_CondNorm.merged)."""
+
+    def __init__(self, cfg: "NoiseConditionedSFNOBuilder", in_chans: int, out_chans: int, img_shape, n_labels: int = 0):
         super().__init__()
         self.cfg = cfg
         self.in_chans, self.out_chans = in_chans, out_chans
         self.img_shape = (int(img_shape[0]), int(img_shape[1]))
         self.embed_dim = cfg.noise_embed_dim                       # the reference wrapper's attribute (noise channels)
-        self.conditional_model = _ConditionalNet(cfg, in_chans, out_chans, self.img_shape)
+        if cfg.label_embed_dim > 0 and n_labels == 0:
+            raise ValueError("label_embed_dim > 0 requires n_labels > 0")
+        self.n_labels = n_labels
+        self.label_dim = cfg.label_embed_dim if cfg.label_embed_dim > 0 else n_labels      # effective_label_dim
+        self.pos_dim = cfg.context_pos_embed_dim
+        # registration order as the reference's wrapper: conditional_model, label_embedding, pos_embed, label_pos_embed
+        self.conditional_model = _ConditionalNet(cfg, in_chans, out_chans, self.img_shape, self.label_dim)
+        if cfg.label_embed_dim > 0:
+            self.label_embedding = nn.Linear(n_labels, cfg.label_embed_dim)
+        if self.pos_dim > 0:
+            self.pos_embed = nn.Parameter(torch.zeros(1, self.pos_dim, *self.img_shape))
+            trunc_normal_(self.pos_embed, std=0.02)
+            if self.label_dim > 0:
+                self.label_pos_embed = nn.Parameter(torch.zeros(self.label_dim, self.pos_dim, *self.img_shape))
+                trunc_normal_(self.label_pos_embed, std=0.02)
+        # conditioning channels the native network sees: noise | positional context | label planes | ones (label bias)
+        self.cond_dim = cfg.noise_embed_dim + self.pos_dim + (self.label_dim + 1 if self.label_dim > 0 else 0)
         self._lmax = self.img_shape[0]
         self._mmax = self.img_shape[1] // 2 + 1
         self._isht: Optional[InverseRealSHT] = None
@@ -124,7 +173,7 @@ class NoiseConditionedSFNO(nn.Module):
             operator_type=1, normalization_layer=2, activation_function=_ACT[c.activation_function],
             use_mlp=int(c.use_mlp), mlp_ratio=float(c.mlp_ratio), encoder_layers=c.encoder_layers,
             pos_embed=int(c.pos_embed), big_skip=int(c.big_skip), data_grid=_GRID[c.data_grid], max_batch=max_batch,
-            precision=_PRECISION[self.precision], noise_embed_dim=c.noise_embed_dim, affine_norms=int(c.affine_norms),
+            precision=_PRECISION[self.precision], noise_embed_dim=self.cond_dim, affine_norms=int(c.affine_norms),
             normalize_big_skip=int(c.normalize_big_skip), filter_num_groups=c.filter_num_groups)
 
     def set_precision(self, precision: str):
@@ -165,7 +214,26 @@ class NoiseConditionedSFNO(nn.Module):
         L = _lib.lib()
         stream = _lib.current_stream()
         changed = 0
+        merged_context = self.pos_dim > 0 or self.label_dim > 0
+        if merged_context:
+            # the conditional norms' label / positional weights ride on the native W_scale_2d / W_bias_2d (merged along the
+            # conditioning channels); the wrapper's own parameters are consumed on the host (forward)
+            for mname, mod in self.conditional_model.named_modules():
+                if not isinstance(mod, _CondNorm):
+                    continue
+                for which in ("scale", "bias"):
+                    parts = [p for n, p in mod.named_parameters() if n.startswith(f"W_{which}_")]
+                    stamp = tuple((p.data_ptr(), p._version) for p in parts)
+                    key = f"{mname}.W_{which}_2d.weight#merged"
+                    if not force and self._uploaded.get(key) == stamp:
+                        continue
+                    t = mod.merged(which)
+                    _lib.check(L.ace_sfno_set_weight(self._native, f"{mname}.W_{which}_2d.weight".encode(), _lib.ptr(t), t.numel(), stream))
+                    self._uploaded[key] = stamp
+                    changed += 1
         for name, p in self.state_dict(keep_vars=True).items():
+            if merged_context and (".W_scale_" in name or ".W_bias_" in name or not name.startswith("conditional_model.")):
+                continue
             stamp = (p.data_ptr(), p._version)
             if not force and self._uploaded.get(name) == stamp:
                 continue
@@ -194,9 +262,11 @@ class NoiseConditionedSFNO(nn.Module):
             return self._isht(alm)
         return torch.randn(torch.Size([batch, J, *self.img_shape]), device=device, dtype=torch.float32)
 
-    def forward(self, x: torch.Tensor, labels=None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if labels is not None:
-            raise NotImplementedError("label conditioning is outside the accelerated hot path")
+    def forward(self, x: torch.Tensor, labels: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if labels is not None and self.label_dim == 0:
+            raise ValueError("labels were provided but the model was built without labels (dataset_info.all_labels is empty)")
+        if labels is None and self.label_dim > 0:
+            raise ValueError("labels must be provided")
         x = x.reshape(-1, *x.shape[-3:])
         if x.shape[1] != self.in_chans or tuple(x.shape[-2:]) != self.img_shape:
             raise AssertionError(f"expected input (B, {self.in_chans}, {self.img_shape[0]}, {self.img_shape[1]}), "
@@ -211,6 +281,24 @@ class NoiseConditionedSFNO(nn.Module):
         noise = noise.to(device=x.device, dtype=torch.float32).contiguous()
         if tuple(noise.shape) != (B, self.cfg.noise_embed_dim, *self.img_shape):
             raise ValueError(f"noise must have shape {(B, self.cfg.noise_embed_dim, *self.img_shape)}, got {tuple(noise.shape)}")
+        if self.pos_dim > 0 or self.label_dim > 0:       # the merged conditioning field (stochastic_sfno.py:147-175)
+            fields = [noise]
+            lab = None
+            if self.label_dim > 0:
+                lab = labels.to(device=x.device, dtype=torch.float32)
+                if tuple(lab.shape) != (B, self.n_labels):
+                    raise ValueError(f"labels must have shape {(B, self.n_labels)}, got {tuple(lab.shape)}")
+                if hasattr(self, "label_embedding"):
+                    lab = torch.nn.functional.linear(lab, self.label_embedding.weight, self.label_embedding.bias)
+            if self.pos_dim > 0:
+                pos = self.pos_embed.detach().repeat(B, 1, 1, 1)
+                if lab is not None:
+                    pos = pos + torch.einsum("bl,lpxy->bpxy", lab, self.label_pos_embed.detach())
+                fields.append(pos)
+            if lab is not None:
+                fields.append(lab[:, :, None, None].expand(B, self.label_dim, *self.img_shape))
+                fields.append(torch.ones(B, 1, *self.img_shape, dtype=torch.float32, device=x.device))
+            noise = torch.cat(fields, dim=1).contiguous()
         self._ensure_native(x.device, B)
         self.sync_weights()
         out = torch.empty(B, self.out_chans, *self.img_shape, dtype=torch.float32, device=x.device)
@@ -280,7 +368,7 @@ class NoiseConditionedSFNOBuilder(ModuleConfig):
         out = []
         if self.filter_type != "linear":
             out.append(f"filter_type='{self.filter_type}'")
-        for name, default in (("context_pos_embed_dim", 0), ("label_embed_dim", 0), ("global_layer_norm", False),
+        for name, default in (("global_layer_norm", False),
                               ("filter_residual", False), ("filter_output", False), ("lora_rank", 0),
                               ("spectral_lora_rank", 0), ("filter_preserves_global_mean", False), ("spectral_ratio", 1.0),
                               ("clip_latent_global_means", False), ("residual_filter_factor", 1)):
@@ -291,8 +379,7 @@ class NoiseConditionedSFNOBuilder(ModuleConfig):
         return out
 
     def build(self, n_in_channels: int, n_out_channels: int, dataset_info) -> nn.Module:
-        if len(getattr(dataset_info, "all_labels", ()) or ()) > 0:
-            raise NotImplementedError("label conditioning is outside the accelerated hot path")
+        n_labels = len(getattr(dataset_info, "all_labels", ()) or ())
         bad = self._unsupported()
         if bad:
             raise NotImplementedError("NoiseConditionedSFNO options outside the accelerated hot path: " + ", ".join(bad))
@@ -302,4 +389,4 @@ class NoiseConditionedSFNOBuilder(ModuleConfig):
             raise ValueError(f"Unknown activation function {self.activation_function}")
         if self.embed_dim % self.filter_num_groups != 0:
             raise ValueError("embed_dim must be divisible by filter_num_groups")
-        return NoiseConditionedSFNO(self, n_in_channels, n_out_channels, dataset_info.img_shape)
+        return NoiseConditionedSFNO(self, n_in_channels, n_out_channels, dataset_info.img_shape, n_labels=n_labels)

@@ -64,7 +64,7 @@ CONDITIONAL_BUILDERS = ["NoiseConditionedSFNO", "LocalNet", "SwinTransformer", "
 
 
 class Module:
-    """module.py:69-122 (label encodings: only the unconditional case is on this path)."""
+    """module.py:69-122: the built nn.Module behind a call boundary that owns the label encoding of a conditional model."""
 
     def __init__(self, module: nn.Module, label_encoding=None):
         self._module = module
@@ -74,7 +74,10 @@ class Module:
         if labels is not None and self._label_encoding is None:
             raise TypeError("Labels are not allowed for unconditional models")
         if self._label_encoding is not None:
-            raise NotImplementedError("conditional models are outside the SFNO hot path")
+            if labels is None:
+                raise TypeError("Labels are required for conditional models")
+            encoded = labels.conform_to_encoding(self._label_encoding)      # a BatchLabels (ace_amd/labels.py)
+            return self._module(input, labels=encoded.tensor)
         return self._module(input)
 
     @property
@@ -82,12 +85,17 @@ class Module:
         return self._module
 
     def get_state(self) -> Dict[str, Any]:
-        return {**self._module.state_dict(), "label_encoding": None}
+        enc = self._label_encoding.get_state() if self._label_encoding is not None else None
+        return {**self._module.state_dict(), "label_encoding": enc}
 
     def load_state(self, state: Dict[str, Any]) -> None:
+        from .labels import LabelEncoding
         state = dict(state)
         if state.get("label_encoding") is not None:
-            raise NotImplementedError("conditional models are outside the SFNO hot path")
+            if self._label_encoding is None:
+                self._label_encoding = LabelEncoding.from_state(state.pop("label_encoding"))
+            else:
+                self._label_encoding.conform_to_state(state.pop("label_encoding"))
         state.pop("label_encoding", None)
         self._module.load_state_dict(state)
 
@@ -130,10 +138,14 @@ class ModuleSelector:
     def build(self, n_in_channels: int, n_out_channels: int, dataset_info) -> Module:
         if self.conditional and len(dataset_info.all_labels) == 0:
             raise ValueError("Conditional predictions require labels")
+        label_encoding = None
+        if self.conditional:
+            from .labels import LabelEncoding
+            label_encoding = LabelEncoding(sorted(list(dataset_info.all_labels)))
         module = self._instance.build(
             n_in_channels=n_in_channels, n_out_channels=n_out_channels, dataset_info=dataset_info
         )
-        return Module(module, None)
+        return Module(module, label_encoding)
 
     @classmethod
     def get_available_types(cls):

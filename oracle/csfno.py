@@ -45,6 +45,8 @@ class CSFNOConfig:
     affine_norms: bool = False
     filter_num_groups: int = 1
     hard_thresholding_fraction: float = 1.0
+    context_pos_embed_dim: int = 0     # learned positional context (stochastic_sfno.py:105-125)
+    label_embed_dim: int = 0           # > 0: Linear(n_labels, label_embed_dim) in front of the label conditioning
 
 
 _ACT = {"gelu": F.gelu, "relu": F.relu, "silu": F.silu}
@@ -70,9 +72,16 @@ class CSFNOOracle:
         self.cfg = cfg
         self.dtype = dtype
         strip = lambda k: k.removeprefix("module.").removeprefix("conditional_model.")
-        self.p = {strip(k): v.detach().to("cpu").to(dtype) for k, v in state.items() if torch.is_floating_point(v)}
+        inner = lambda k: k.removeprefix("module.").startswith("conditional_model.")
+        # parameters of the conditional network (prefix stripped) and of the NoiseConditionedModel wrapper around it
+        # (stochastic_sfno.py:88-125: label_embedding.*, pos_embed = the positional CONTEXT, label_pos_embed)
+        self.p = {strip(k): v.detach().to("cpu").to(dtype) for k, v in state.items() if torch.is_floating_point(v) and inner(k)}
+        self.wrap = {k.removeprefix("module."): v.detach().to("cpu").to(dtype) for k, v in state.items()
+                     if torch.is_floating_point(v) and not inner(k)}
+        if not self.p:      # a state without the wrapper prefix: everything belongs to the conditional network
+            self.p, self.wrap = self.wrap, {}
         for k in self.p:
-            if "lora" in k or "label" in k or "W_scale_pos" in k or "W_scale." in k or k.endswith("_gm_min"):
+            if "lora" in k or "W_scale." in k or k.endswith("_gm_min"):
                 raise NotImplementedError(f"parameter {k}: outside the oracle's configuration family")
         h, w = cfg.img_shape
         L = int(h * cfg.hard_thresholding_fraction)
@@ -83,9 +92,10 @@ class CSFNOOracle:
         self.trans, self.itrans = mk(RealSHT, "legendre-gauss"), mk(InverseRealSHT, "legendre-gauss")
         self.act = _ACT[cfg.activation_function]
 
-    # ---- layers.py:95-141 + 245-318 (noise conditioning only)
-    def _cln(self, prefix: str, x: torch.Tensor, noise: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    # ---- layers.py:95-141 + 245-318: noise, label and positional conditioning (embed_dim_scalar = 0 in this family)
+    def _cln(self, prefix: str, x: torch.Tensor, ctx, eps: float = 1e-5) -> torch.Tensor:
         p = self.p
+        noise, labels, pos = ctx if isinstance(ctx, tuple) else (ctx, None, None)
         mean = x.mean(dim=-3, keepdim=True)
         var = x.var(dim=-3, keepdim=True, unbiased=False)
         y = (x - mean) * torch.rsqrt(var + eps)
@@ -96,6 +106,16 @@ class CSFNOOracle:
         if prefix + "W_scale_2d.weight" in p:
             scale = scale + F.conv2d(noise, p[prefix + "W_scale_2d.weight"])
             bias = bias + F.conv2d(noise, p[prefix + "W_bias_2d.weight"])
+        if prefix + "W_scale_labels.weight" in p:
+            if labels is None:
+                raise ValueError("labels must be provided")
+            scale = scale + F.linear(labels, p[prefix + "W_scale_labels.weight"], p[prefix + "W_scale_labels.bias"])[:, :, None, None]
+            bias = bias + F.linear(labels, p[prefix + "W_bias_labels.weight"], p[prefix + "W_bias_labels.bias"])[:, :, None, None]
+        if prefix + "W_scale_pos.weight" in p:
+            if pos is None:
+                raise ValueError("embedding_pos must be provided")
+            scale = scale + F.conv2d(pos, p[prefix + "W_scale_pos.weight"])
+            bias = bias + F.conv2d(pos, p[prefix + "W_bias_pos.weight"])
         return y * scale + bias
 
     # ---- s2convolutions.py:367-433 (spectral_ratio 1, no LoRA)
@@ -133,9 +153,10 @@ class CSFNOOracle:
             y = F.conv2d(y, p[pre + "mlp.fwd.2.weight"], p[pre + "mlp.fwd.2.bias"])
         return y + residual                                            # outer skip = identity on the filter's residual
 
-    def forward(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x: (B, in_chans, H, W).  ``noise`` (B, noise_embed_dim, H, W): if None it is drawn from torch's global RNG
-        exactly as the reference does (seed with torch.manual_seed to reproduce)."""
+        exactly as the reference does (seed with torch.manual_seed to reproduce).  ``labels`` (B, n_labels): one-hot (or
+        soft) label encoding, stochastic_sfno.py:128-175."""
         cfg, p = self.cfg, self.p
         x = x.reshape(-1, *x.shape[-3:]).to(self.dtype)
         if noise is None:
@@ -144,6 +165,17 @@ class CSFNOOracle:
             else:
                 noise = torch.randn(torch.Size([x.shape[0], cfg.noise_embed_dim, *x.shape[-2:]]), dtype=torch.float32)
         noise = noise.to(self.dtype)
+        w = self.wrap
+        if labels is not None:
+            labels = labels.to(self.dtype)
+            if "label_embedding.weight" in w:
+                labels = F.linear(labels, w["label_embedding.weight"], w["label_embedding.bias"])
+        pos = None
+        if cfg.context_pos_embed_dim > 0:
+            pos = w["pos_embed"].repeat(noise.shape[0], 1, 1, 1)
+            if "label_pos_embed" in w and labels is not None:
+                pos = pos + torch.einsum("bl,lpxy->bpxy", labels, w["label_pos_embed"])
+        noise = (noise, labels, pos)       # the Context every conditional norm reads
         if cfg.big_skip:
             residual = self._cln("norm_big_skip.", x, noise) if cfg.normalize_big_skip else x
         h = x

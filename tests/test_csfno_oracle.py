@@ -35,48 +35,81 @@ def test_csfno_oracle_matches_reference(gold, name):
 def test_csfno_oracle_rejects_what_it_does_not_model(gold):
     case = gold["gaussian_groups2"]
     state = dict(case["state"])
-    state["conditional_model.blocks.0.norm0.W_scale_labels.weight"] = torch.zeros(16, 3)
+    state["conditional_model.blocks.0.norm0.W_scale.weight"] = torch.zeros(16, 3)     # scalar context embedding: not in this family
     with pytest.raises(NotImplementedError):
         CSFNOOracle(CSFNOConfig(5, 4, (12, 24), **case["kwargs"]), state)
 
 
-@pytest.mark.parametrize("name", ["isotropic_affine_bigskipnorm", "gaussian_groups2", "equiangular_nomlp"])
-def test_native_module_names_and_seeded_init_match_reference(gold, name):
-    """The ace_amd module holds the reference's parameters: same state_dict names in the same order, strict load, and -
-    built under the same seed - the same initial values bit for bit (the golden state differs from the seeded init only
-    in the conditioning / affine / filter-bias tensors the generator randomised afterwards)."""
-    import ace_amd
-    case = gold[name]
-    torch.manual_seed(0)
-    net = ace_amd.ModuleSelector(type="NoiseConditionedSFNO", config=dict(case["kwargs"])).build(
-        5, 4, ace_amd.DatasetInfo((12, 24))).torch_module
-    sd, ref = net.state_dict(), case["state"]
-    assert list(sd) == list(ref)
-    touched = ("W_scale_2d", "W_bias_2d", ".norm.weight", ".norm.bias", "filter.filter.bias")
-    for k in ref:
-        assert sd[k].shape == ref[k].shape, k
-        if not any(t in k for t in touched):
-            assert torch.equal(sd[k], ref[k]), k
-    net.load_state_dict(ref, strict=True)
-    with pytest.raises(RuntimeError):          # no CPU fallback
-        net(case["x"])
+# ---- label / positional context (stochastic_sfno.py:88-175, conditional_sfno/layers.py:160-318)
+CTX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gen_csfno_context.pt")
 
 
-def test_checkpoint_with_noise_conditioned_builder(gold):
-    """load_stepper resolves the builder type through the registry: a stepper state whose module is a
-    NoiseConditionedSFNO (what ACE ships today) loads under the reference's parameter names."""
+@pytest.fixture(scope="module")
+def ctx_gold():
+    return torch.load(CTX, map_location="cpu", weights_only=False)
+
+
+class _Info:
+    def __init__(self, shape, labels):
+        self.img_shape = shape
+        self.all_labels = set(labels)
+
+
+@pytest.mark.parametrize("name", ["labels3_pos4", "labels3_embed2_pos2_isotropic", "labels2_nopos"])
+def test_csfno_oracle_with_labels_and_positional_context(ctx_gold, name):
+    """one-hot and soft labels, optional label embedding, positional context with its label interaction: the oracle against the
+    reference's own output (same RNG draws for the noise)"""
+    case = ctx_gold[name]
+    cfg = CSFNOConfig(in_chans=5, out_chans=4, img_shape=(12, 24), **case["kwargs"])
+    torch.manual_seed(case["forward_seed"])
+    y = CSFNOOracle(cfg, case["state"], dtype=torch.float32).forward(case["x"], labels=case["labels"])
+    torch.testing.assert_close(y, case["y"], rtol=2e-5, atol=2e-6)
+    with pytest.raises(ValueError):
+        CSFNOOracle(cfg, case["state"]).forward(case["x"])                       # labels must be provided
+
+
+@pytest.mark.parametrize("name", ["labels3_pos4", "labels3_embed2_pos2_isotropic", "labels2_nopos"])
+def test_native_module_mirrors_the_context_parameters_and_merges_them(ctx_gold, name):
+    """ace_amd's NoiseConditionedSFNO: (1) the reference's state_dict names, order and shapes incl. the wrapper's label_embedding /
+    pos_embed / label_pos_embed and every norm's W_*_labels / W_*_pos, strict load; (2) the host-side merge the native path relies
+    on - ONE 1 x 1 convolution over cat(noise, positional context, label planes, ones) with [W_2d | W_pos | W_labels.weight |
+    W_labels.bias] - equals the reference formula scale = 1 + W_2d(noise) + W_labels(labels) + W_pos(pos) (layers.py:262-318)."""
     import ace_amd
-    case = gold["isotropic_affine_bigskipnorm"]
-    names = ["a", "b", "c", "d", "e"]
-    state = {"config": {"step": {"type": "single_module", "config": {
-        "builder": {"type": "NoiseConditionedSFNO", "config": dict(case["kwargs"])},
-        "in_names": names, "out_names": names[:4],
-        "normalization": {"network": {"means": {n: 0.0 for n in names}, "stds": {n: 1.0 for n in names}}},
-        "ocean": None, "corrector": {"force_positive_names": ["a"]}}}},
-        "dataset_info": {"img_shape": (12, 24), "timestep": 6 * 3600 * 10**6},
-        "step": {"module": {**{f"module.{k}": v for k, v in case["state"].items()}, "label_encoding": None}}}
-    loaded = ace_amd.load_stepper(state, device="cpu")
-    sd = loaded.stepper.modules[0].state_dict()
-    for k, v in case["state"].items():
-        assert torch.equal(sd[k], v), k
-    assert loaded.stepper._step_obj._corrector.force_positive_names == ["a"]
+    from ace_amd.labels import BatchLabels
+    case = ctx_gold[name]
+    mod = ace_amd.ModuleSelector(type="NoiseConditionedSFNO", config=dict(case["kwargs"]), conditional=True).build(
+        5, 4, _Info((12, 24), case["all_labels"]))
+    net = mod.torch_module
+    assert list(net.state_dict()) == list(case["state"])
+    assert all(tuple(v.shape) == tuple(case["state"][k].shape) for k, v in net.state_dict().items())
+    mod.load_state({**case["state"], "label_encoding": {"labels": case["all_labels"]}})
+    assert mod._label_encoding.names == case["all_labels"]
+    assert mod.get_state()["label_encoding"] == {"labels": case["all_labels"]}
+    B, H, W = 3, 12, 24
+    g = torch.Generator().manual_seed(5)
+    noise = torch.randn(B, net.cfg.noise_embed_dim, H, W, generator=g)
+    lab = case["labels"]
+    if hasattr(net, "label_embedding"):
+        lab = torch.nn.functional.linear(lab, net.label_embedding.weight, net.label_embedding.bias)
+    fields = [noise]
+    pos = None
+    if net.pos_dim > 0:
+        pos = net.pos_embed.detach().repeat(B, 1, 1, 1) + torch.einsum("bl,lpxy->bpxy", lab, net.label_pos_embed.detach())
+        fields.append(pos)
+    fields += [lab[:, :, None, None].expand(B, lab.shape[1], H, W), torch.ones(B, 1, H, W)]
+    cond = torch.cat(fields, dim=1).detach()
+    assert cond.shape[1] == net.cond_dim
+    n0 = net.conditional_model.blocks[0].norm0
+    for which in ("scale", "bias"):
+        merged = torch.nn.functional.conv2d(cond.double(), n0.merged(which).double()[:, :, None, None])
+        want = torch.nn.functional.conv2d(noise.double(), getattr(n0, f"W_{which}_2d").weight.detach().double())
+        lin = getattr(n0, f"W_{which}_labels")
+        want = want + torch.nn.functional.linear(lab.detach().double(), lin.weight.detach().double(), lin.bias.detach().double())[:, :, None, None]
+        if pos is not None:
+            want = want + torch.nn.functional.conv2d(pos.detach().double(), getattr(n0, f"W_{which}_pos").weight.detach().double())
+        assert float((merged - want).abs().max()) <= 1e-12
+    # the registry wrapper conforms BatchLabels to the module's encoding (module.py:74-84)
+    bl = BatchLabels(torch.eye(len(case["all_labels"]))[:, list(reversed(range(len(case["all_labels"]))))], list(reversed(case["all_labels"])))
+    assert torch.equal(bl.conform_to_encoding(mod._label_encoding).tensor, torch.eye(len(case["all_labels"])))
+    with pytest.raises(TypeError):
+        mod(torch.zeros(1, 5, 12, 24))                                           # labels are required for conditional models

@@ -434,6 +434,45 @@ def test_noise_conditioned_sfno_wide_vs_oracle(dev, embed):
     assert rel_max(y, ref64) <= NET_TOL, rel_max(y, ref64)
 
 
+@pytest.mark.parametrize("name", ["labels3_pos4", "labels3_embed2_pos2_isotropic", "labels2_nopos"])
+def test_noise_conditioned_sfno_with_labels_and_positional_context(dev, name, precision):
+    """label and positional conditioning (stochastic_sfno.py:88-175, conditional_sfno/layers.py:160-318) through the registry
+    with conditional=True: BatchLabels conformed to the module's encoding, positional context pos_embed + labels . label_pos_embed,
+    every conditional norm's label / positional weights merged into the one conditioning field the native kernel reads -
+    against the REAL reference's output (tests/golden/gen_csfno_context.pt) and the fp64 oracle, with the reference's own noise
+    draw."""
+    import ace_amd
+    from ace_amd.labels import BatchLabels
+    from oracle.csfno import CSFNOConfig, CSFNOOracle
+    case = load_golden("gen_csfno_context.pt")[name]
+    cfg = CSFNOConfig(in_chans=5, out_chans=4, img_shape=(12, 24), **case["kwargs"])
+    noise = _csfno_noise(cfg, 3, case["forward_seed"])
+
+    class Info:
+        img_shape = (12, 24)
+        all_labels = set(case["all_labels"])
+
+    mod = ace_amd.ModuleSelector(type="NoiseConditionedSFNO", config=dict(case["kwargs"]), conditional=True).build(5, 4, Info())
+    mod.load_state({**case["state"], "label_encoding": {"labels": case["all_labels"]}})
+    net = mod.torch_module.to(dev).set_precision(precision)
+    labels = case["labels"].to(dev)
+    with torch.no_grad():
+        y = net(case["x"].to(dev), labels=labels, noise=noise.to(dev))
+    assert rel_max(y, case["y"]) <= NET_TOL, rel_max(y, case["y"])
+    ref64 = CSFNOOracle(cfg, case["state"], dtype=torch.float64).forward(case["x"], noise=noise, labels=case["labels"])
+    assert rel_max(y, ref64) <= NET_TOL
+    with torch.no_grad():                                         # through the registry wrapper, columns in another order
+        perm = list(reversed(range(len(case["all_labels"]))))
+        bl = BatchLabels(labels[:, perm], [case["all_labels"][i] for i in perm])
+        torch.manual_seed(7)
+        a = ace_amd.registry.Module(net, mod._label_encoding)(case["x"].to(dev), labels=bl)
+        torch.manual_seed(7)
+        b = net(case["x"].to(dev), labels=labels)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    with pytest.raises(ValueError):
+        net(case["x"].to(dev))                                    # labels must be provided
+
+
 def test_noise_conditioned_sfno_errors(dev):
     import ace_amd
     sel = ace_amd.ModuleSelector(type="NoiseConditionedSFNO", config={"embed_dim": 8, "noise_embed_dim": 4, "num_layers": 1})
