@@ -136,7 +136,7 @@ class Stepper:
         return AtmosphericDeriveFn(self._step_obj._vertical_coordinate, self._step_obj._timestep)
 
     def predict(self, initial_condition: TensorMapping, forcing: TensorMapping,
-                n_forward_steps: Optional[int] = None, compute_derived_variables: bool = False
+                n_forward_steps: Optional[int] = None, compute_derived_variables: bool = False, labels=None
                 ) -> Tuple[TensorDict, TensorDict]:
         """single_module.py:1169-1259 on plain dicts: initial_condition name -> (B, 1, H, W) prognostic state,
         forcing name -> (B, 1 + n_forward_steps, H, W).  Returns (output name -> (B, n_forward_steps, H, W),
@@ -150,7 +150,7 @@ class Stepper:
             if v.shape[self.TIME_DIM] != self.n_ic_timesteps:
                 raise ValueError(f"Initial condition must have {self.n_ic_timesteps} timesteps, got {v.shape[1]}.")
         with torch.no_grad():
-            outs = list(self.predict_generator(initial_condition, forcing, n_forward_steps,
+            outs = list(self.predict_generator(initial_condition, forcing, n_forward_steps, labels=labels,   # BatchLabels of a conditional module
                                                stepper_state=getattr(initial_condition, "stepper_state", None)))
         data = {k: torch.stack([o.output[k] for o in outs], dim=self.TIME_DIM) for k in outs[0].output}
         if compute_derived_variables:

@@ -473,6 +473,52 @@ def test_noise_conditioned_sfno_with_labels_and_positional_context(dev, name, pr
         net(case["x"].to(dev))                                    # labels must be provided
 
 
+def test_conditional_stepper_rollout_with_labels(dev):
+    """A conditional module behind the SAME stepper API: SingleModuleStepConfig with ModuleSelector(conditional=True) on a
+    dataset with labels; Stepper.predict(..., labels=BatchLabels) hands the labels to every step (single_module.py:420-428).
+    Same seed -> same rollout; other labels -> another rollout; missing labels -> TypeError (module.py:80-82)."""
+    import ace_amd
+    from ace_amd.labels import BatchLabels
+    from ace_amd.step import NormalizationConfig
+    in_names, out_names = ["f0", "p0"], ["p0", "d0"]
+    names = sorted(set(in_names + out_names))
+    cfg = ace_amd.SingleModuleStepConfig(
+        builder=ace_amd.ModuleSelector(type="NoiseConditionedSFNO", conditional=True,
+                                       config={"embed_dim": 16, "noise_embed_dim": 4, "num_layers": 2, "pos_embed": False,
+                                               "context_pos_embed_dim": 2}),
+        in_names=in_names, out_names=out_names,
+        normalization=NormalizationConfig(means={k: 0.0 for k in names}, stds={k: 1.0 for k in names}))
+    torch.manual_seed(0)
+    stepper = ace_amd.Stepper.from_config(cfg, ace_amd.DatasetInfo((12, 24), all_labels={"era5", "shield"}), device=dev)
+    stepper.set_eval()
+    net = stepper.modules[0]
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if ".W_scale_" in k or ".W_bias_" in k or k in ("label_pos_embed",):
+                p.copy_((0.3 * torch.randn(p.shape, generator=g)).to(dev))
+    B, T = 2, 3
+    ic = {"p0": torch.randn(B, 1, 12, 24, generator=g).to(dev)}
+    forcing = {"f0": torch.randn(B, T + 1, 12, 24, generator=g).to(dev)}
+    enc = stepper._step_obj.module._label_encoding
+    assert enc.names == ["era5", "shield"]
+    la = enc.encode([{"era5"}, {"shield"}], dev)
+    lb = enc.encode([{"shield"}, {"shield"}], dev)
+    assert isinstance(la, BatchLabels)
+    torch.manual_seed(3)
+    a, _ = stepper.predict(ic, forcing, labels=la)
+    torch.manual_seed(3)
+    a2, _ = stepper.predict(ic, forcing, labels=la)
+    torch.manual_seed(3)
+    b, _ = stepper.predict(ic, forcing, labels=lb)
+    assert all(torch.equal(a[k], a2[k]) and torch.isfinite(a[k]).all() and a[k].shape == (B, T, 12, 24) for k in out_names)
+    assert not torch.equal(a["p0"][0], b["p0"][0])                 # sample 0 changed its label
+    assert rel_max(a["p0"][1, 0], b["p0"][1, 0]) <= 2e-6           # sample 1 did not (first step: same noise draw, same label;
+                                                                   #  the range bounds span the batch, so not bitwise)
+    with pytest.raises(TypeError):
+        stepper.predict(ic, forcing)
+
+
 def test_noise_conditioned_sfno_errors(dev):
     import ace_amd
     sel = ace_amd.ModuleSelector(type="NoiseConditionedSFNO", config={"embed_dim": 8, "noise_embed_dim": 4, "num_layers": 1})
