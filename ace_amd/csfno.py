@@ -262,6 +262,40 @@ class NoiseConditionedSFNO(nn.Module):
             return self._isht(alm)
         return torch.randn(torch.Size([batch, J, *self.img_shape]), device=device, dtype=torch.float32)
 
+    def conditioning_field(self, batch: int, device: torch.device, labels: Optional[torch.Tensor] = None,
+                           noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The (batch, cond_dim, H, W) field every conditional norm of the native network reads: the noise (drawn here unless
+        given) and - with a label / positional context - cat(noise, pos_embed + labels . label_pos_embed, label planes, ones)
+        (stochastic_sfno.py:128-175)."""
+        if labels is not None and self.label_dim == 0:
+            raise ValueError("labels were provided but the model was built without labels (dataset_info.all_labels is empty)")
+        if labels is None and self.label_dim > 0:
+            raise ValueError("labels must be provided")
+        if noise is None:
+            noise = self.draw_noise(batch, device)
+        noise = noise.to(device=device, dtype=torch.float32).contiguous()
+        if tuple(noise.shape) != (batch, self.cfg.noise_embed_dim, *self.img_shape):
+            raise ValueError(f"noise must have shape {(batch, self.cfg.noise_embed_dim, *self.img_shape)}, got {tuple(noise.shape)}")
+        if self.pos_dim == 0 and self.label_dim == 0:
+            return noise
+        fields = [noise]
+        lab = None
+        if self.label_dim > 0:
+            lab = labels.to(device=device, dtype=torch.float32)
+            if tuple(lab.shape) != (batch, self.n_labels):
+                raise ValueError(f"labels must have shape {(batch, self.n_labels)}, got {tuple(lab.shape)}")
+            if hasattr(self, "label_embedding"):
+                lab = torch.nn.functional.linear(lab, self.label_embedding.weight.detach(), self.label_embedding.bias.detach())
+        if self.pos_dim > 0:
+            pos = self.pos_embed.detach().repeat(batch, 1, 1, 1)
+            if lab is not None:
+                pos = pos + torch.einsum("bl,lpxy->bpxy", lab, self.label_pos_embed.detach())
+            fields.append(pos)
+        if lab is not None:
+            fields.append(lab[:, :, None, None].expand(batch, self.label_dim, *self.img_shape))
+            fields.append(torch.ones(batch, 1, *self.img_shape, dtype=torch.float32, device=device))
+        return torch.cat(fields, dim=1).contiguous()
+
     def forward(self, x: torch.Tensor, labels: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
         if labels is not None and self.label_dim == 0:
             raise ValueError("labels were provided but the model was built without labels (dataset_info.all_labels is empty)")
@@ -276,29 +310,7 @@ class NoiseConditionedSFNO(nn.Module):
                                "'cuda'. There is no CPU fallback.")
         x = x.float().contiguous()
         B = x.shape[0]
-        if noise is None:
-            noise = self.draw_noise(B, x.device)
-        noise = noise.to(device=x.device, dtype=torch.float32).contiguous()
-        if tuple(noise.shape) != (B, self.cfg.noise_embed_dim, *self.img_shape):
-            raise ValueError(f"noise must have shape {(B, self.cfg.noise_embed_dim, *self.img_shape)}, got {tuple(noise.shape)}")
-        if self.pos_dim > 0 or self.label_dim > 0:       # the merged conditioning field (stochastic_sfno.py:147-175)
-            fields = [noise]
-            lab = None
-            if self.label_dim > 0:
-                lab = labels.to(device=x.device, dtype=torch.float32)
-                if tuple(lab.shape) != (B, self.n_labels):
-                    raise ValueError(f"labels must have shape {(B, self.n_labels)}, got {tuple(lab.shape)}")
-                if hasattr(self, "label_embedding"):
-                    lab = torch.nn.functional.linear(lab, self.label_embedding.weight, self.label_embedding.bias)
-            if self.pos_dim > 0:
-                pos = self.pos_embed.detach().repeat(B, 1, 1, 1)
-                if lab is not None:
-                    pos = pos + torch.einsum("bl,lpxy->bpxy", lab, self.label_pos_embed.detach())
-                fields.append(pos)
-            if lab is not None:
-                fields.append(lab[:, :, None, None].expand(B, self.label_dim, *self.img_shape))
-                fields.append(torch.ones(B, 1, *self.img_shape, dtype=torch.float32, device=x.device))
-            noise = torch.cat(fields, dim=1).contiguous()
+        noise = self.conditioning_field(B, x.device, labels=labels, noise=noise)
         self._ensure_native(x.device, B)
         self.sync_weights()
         out = torch.empty(B, self.out_chans, *self.img_shape, dtype=torch.float32, device=x.device)

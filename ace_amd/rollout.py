@@ -41,6 +41,7 @@ class RolloutEngine:
         self.stepper = stepper
         self.net = step.module.torch_module
         self._conditioned = hasattr(self.net, "draw_noise")
+        self._labels = None          # (B, n_labels) tensor in the module's label encoding: set_labels()
         if self._conditioned and graph == "window":
             raise NotImplementedError("graph='window' with a noise-conditioned net: the noise draw is not captured")
         self.B, self.T = batch, n_forward_steps
@@ -150,8 +151,8 @@ class RolloutEngine:
         _lib.check(L.ace_pack_normalize(self._src_ptr_addr[s], self._src_stride_addr[s],
                                         self.in_mean.data_ptr(), self.in_std.data_ptr(), self.x.data_ptr(),
                                         self.B, nin, self.HW, stream))
-        if self._conditioned:   # NoiseConditionedSFNO: fresh conditioning noise every step (stochastic_sfno.py:128-146)
-            noise = self.net.draw_noise(self.B, self.device)
+        if self._conditioned:   # NoiseConditionedSFNO: fresh conditioning noise every step (stochastic_sfno.py:128-146), merged
+            noise = self.net.conditioning_field(self.B, self.device, labels=self._labels)   # with the label / positional context
             _lib.check(L.ace_sfno_forward_conditioned(self.net._native, self.x.data_ptr(), noise.data_ptr(), self.y.data_ptr(),
                                                       self.B, stream))
         else:
@@ -199,6 +200,21 @@ class RolloutEngine:
         for n in self.out_names:
             if new[n] is not gen[n]:
                 gen[n].copy_(new[n])
+
+    def set_labels(self, labels) -> None:
+        """Labels of a conditional module (fme/core/labels.py BatchLabels, or a (B, n_labels) tensor already in the module's
+        encoding) for the following windows; conformed to the module's LabelEncoding as Module.__call__ does."""
+        if labels is None:
+            self._labels = None
+            return
+        enc = getattr(self.stepper._step_obj.module, "_label_encoding", None)
+        if hasattr(labels, "conform_to_encoding"):
+            if enc is None:
+                raise TypeError("Labels are not allowed for unconditional models")
+            labels = labels.conform_to_encoding(enc).tensor
+        self._labels = labels.to(device=self.device, dtype=torch.float32).contiguous()
+        if self._labels.shape[0] != self.B:
+            raise ValueError(f"labels for {self._labels.shape[0]} samples, engine batch is {self.B}")
 
     def load(self, initial_condition: Mapping[str, torch.Tensor], forcing: Mapping[str, torch.Tensor]):
         for n in self.prognostic:

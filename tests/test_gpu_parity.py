@@ -517,6 +517,18 @@ def test_conditional_stepper_rollout_with_labels(dev):
                                                                    #  the range bounds span the batch, so not bitwise)
     with pytest.raises(TypeError):
         stepper.predict(ic, forcing)
+    # the static-buffer engine: labels set once per window series, merged into the conditioning field of every step
+    from ace_amd.rollout import RolloutEngine
+    eng = RolloutEngine(stepper, batch=B, n_forward_steps=T, graph=None)
+    eng.set_labels(la)
+    torch.manual_seed(3)
+    e, _ = eng.predict(ic, forcing)
+    torch.cuda.synchronize()
+    for k in out_names:
+        assert rel_max(e[k], a[k]) <= 2e-6, k
+    eng.set_labels(None)
+    with pytest.raises(ValueError):
+        eng.predict(ic, forcing)                                   # labels must be provided
 
 
 def test_noise_conditioned_sfno_errors(dev):
