@@ -361,7 +361,7 @@ def main():
                             if (main_mode, "forward_transform.dft") in pmc and
                                (main_mode, "forward_transform.legendre") in pmc else None, traffic_note=pmc_note)
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is a single-GPU-run leg (rank 0 at N = 1 only)
             cpu, y_cpu = cpu_baseline(stepper, r["x_cpu"])
             cpu["parity_rel_err_vs_gpu"] = {m: float((runs[m]["y_gpu"] - y_cpu).abs().max() / y_cpu.abs().max()) for m in modes}
         steps_per_s = world * K / r["dt"]
