@@ -8,8 +8,8 @@ seeded construction consumes the RNG in the reference's order): the configuratio
 fme/ace/models/healpix/{healpix_blocks.py, healpix_encoder.py, healpix_decoder.py, healpix_layers.py, healpix_activations.py,
 healpix_unet.py} that the reference's own test configuration uses - ConvNeXtBlock, BasicConvBlock, AvgPool / MaxPool,
 TransposedConvUpsample, CappedGELU, face padding modes "karlbauer" and "earth2grid" (which the reference documents as giving
-the same result; one gather table serves both).  Not built (raise at construction): isolatitude padding, the dealiased /
-smoothed-interpolate resamplers, the symmetric ConvNeXt variants.
+the same result; one gather table serves both) and "isolatitude" (its own table, same gather kernel).  Not built (raise at
+construction): the dealiased / smoothed-interpolate resamplers, the symmetric ConvNeXt variants.
 
 Runtime layout: an activation of one UNet level is ``[image = item * 12 + face][channel][row][pitch]`` fp32 with the row pitch
 of that level's padded faces rounded up to a multiple of 4 (``Hpx``), so every k x k convolution is ONE contraction over
@@ -58,6 +58,88 @@ def _round4(n: int) -> int:
     return (n + 3) & ~3
 
 
+def isolatitude_pad_table(nside: int, p: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Gather table of the ISOLATITUDE face padding (healpix_paddings.py:613-1140) in the format of ace_hpx_pad_table_host: for every
+    cell of the padded mesh [12][nside + 2p][nside + 2p] two source cells packed face << 24 | row << 12 | column (equal where the
+    cell is a plain copy); padded = 0.5 a + 0.5 b.  The rules, restated on index arrays:
+      * polar faces take the strip across their polar edges from the rotated neighbour with a shift along the edge that grows
+        with the distance from it - halo line i (0 = nearest) reads position max(j - (2i + 1), 0) (north: top / left strips) or
+        min(j + (2i + 1), nside - 1) (south: bottom / right strips), so that cells of one latitude ring stay aligned;
+      * equatorial faces take plain strips; their two neighbourless corners are filled diagonal by diagonal with the MEAN of one
+        cell of each adjacent face (every corner cell has two sources);
+      * the other corners and strips are the plain (for the far polar corner: twice rotated) neighbour blocks.
+    Needs p <= nside / 2 (the reference's own bound)."""
+    H = int(nside)
+    if not (1 <= p and 2 * p <= H):
+        raise ValueError(f"Padding {p} must not exceed half the face height/width {H}")
+    rr, cc = np.meshgrid(np.arange(H), np.arange(H), indexing="ij")
+    f = [((k << 24) | (rr << 12) | cc).astype(np.int64) for k in range(12)]
+    ar = np.arange(H)
+
+    def north(c, t, tl, lft, bl, b, br, rgt, tr):
+        tt = np.rot90(t, 1)[-p:, :].copy()
+        ll = np.rot90(lft, -1)[:, -p:].copy()
+        for i in range(p):
+            src = np.maximum(ar - (2 * i + 1), 0)
+            tt[-i - 1, :] = tt[-i - 1, src]
+            ll[:, -i - 1] = ll[src, -i - 1]
+        centre = np.vstack((tt, c, b[:p, :]))
+        left = np.vstack((np.rot90(tl, 2)[-p:, -p:], ll, bl[:p, -p:]))
+        right = np.vstack((tr[-p:, :p], rgt[:, :p], br[:p, :p]))
+        return np.hstack((left, centre, right))
+
+    def south(c, t, tl, lft, bl, b, br, rgt, tr):
+        bb = np.rot90(b, 1)[:p, :].copy()
+        rg = np.rot90(rgt, -1)[:, :p].copy()
+        for i in range(p):
+            src = np.minimum(ar + (2 * i + 1), H - 1)
+            bb[i, :] = bb[i, src]
+            rg[:, i] = rg[src, i]
+        centre = np.vstack((t[-p:, :], c, bb))
+        left = np.vstack((tl[-p:, -p:], lft[:, -p:], bl[:p, -p:]))
+        right = np.vstack((tr[-p:, :p], rg, np.rot90(br, 2)[:p, :p]))
+        return np.hstack((left, centre, right))
+
+    def corner(first, second, rot):       # p x p block, diagonal k = p - 1 - i holds sample i of each of the two faces
+        a = np.zeros((p, p), np.int64)
+        b = np.zeros((p, p), np.int64)
+        for i in range(2 * p - 1):
+            k = p - 1 - i
+            rows = np.arange(max(-k, 0), min(p, p - k))
+            a[rows, rows + k] = first(i)
+            b[rows, rows + k] = second(i)
+        return np.rot90(a, rot), np.rot90(b, rot)
+
+    def equator(c, t, tl_ab, lft, bl, b, br_ab, rgt, tr):
+        out = []
+        for which in (0, 1):
+            centre = np.vstack((t[-p:, :], c, b[:p, :]))
+            left = np.vstack((tl_ab[which], lft[:, -p:], bl[:p, -p:]))
+            right = np.vstack((tr[-p:, :p], rgt[:, :p], br_ab[which]))
+            out.append(np.hstack((left, centre, right)))
+        return out
+
+    def tl(top, lft):
+        return corner(lambda i: top[H - i - 2, 0], lambda i: lft[0, H - i - 2], -1)
+
+    def br(bot, rgt):
+        return corner(lambda i: bot[i + 1, H - 1], lambda i: rgt[H - 1, i + 1], 1)
+
+    A, B = [None] * 12, [None] * 12
+    for k, (t, tl_, lf, bl, b, br_, rg, tr) in enumerate([(1, 2, 3, 3, 4, 8, 5, 1), (2, 3, 0, 0, 5, 9, 6, 2), (3, 0, 1, 1, 6, 10, 7, 3),
+                                                          (0, 1, 2, 2, 7, 11, 4, 0)]):
+        A[k] = B[k] = north(f[k], f[t], f[tl_], f[lf], f[bl], f[b], f[br_], f[rg], f[tr])
+    for k, (t, lf, bl, b, rg, tr, brn) in zip(range(4, 8), [(0, 3, 7, 11, 8, 5, 8), (1, 0, 4, 8, 9, 6, 9), (2, 1, 5, 9, 10, 7, 10),
+                                                           (3, 2, 6, 10, 11, 4, 11)]):
+        A[k], B[k] = equator(f[k], f[t], tl(f[t], f[lf]), f[lf], f[bl], f[b], br(f[b], f[rg]), f[rg], f[tr])
+    for k, (t, tl_, lf, bl, b, br_, rg, tr) in zip(range(8, 12), [(5, 0, 4, 11, 11, 10, 9, 9), (6, 1, 5, 8, 8, 11, 10, 10),
+                                                                  (7, 2, 6, 9, 9, 8, 11, 11), (4, 3, 7, 10, 10, 9, 8, 8)]):
+        A[k] = B[k] = south(f[k], f[t], f[tl_], f[lf], f[bl], f[b], f[br_], f[rg], f[tr])
+    ia = np.stack(A).reshape(-1).astype(np.int32)
+    ib = np.stack(B).reshape(-1).astype(np.int32)
+    return ia, ib
+
+
 class _Runtime:
     """Per-forward context: row pitch per face width (a level's tensors share the pitch of that level's padded faces), the
     padding gather tables (device copies, cached per (nside, padding)) and the pool of bound slots (zeroed once per forward)."""
@@ -66,7 +148,7 @@ class _Runtime:
 
     def __init__(self):
         self.pitch: Dict[int, int] = {}
-        self._tables: Dict[Tuple[int, int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._tables: Dict[Tuple[int, int, str, str], Tuple[torch.Tensor, torch.Tensor]] = {}
         self._pool: Optional[torch.Tensor] = None
         self._next = 0
 
@@ -84,13 +166,16 @@ class _Runtime:
     def pitch_for(self, width: int) -> int:
         return self.pitch.get(width, _round4(width))
 
-    def table(self, nside: int, p: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
-        key = (nside, p, str(device))
+    def table(self, nside: int, p: int, device, mode: str = "karlbauer") -> Tuple[torch.Tensor, torch.Tensor]:
+        key = (nside, p, str(device), mode)
         if key not in self._tables:
-            m = nside + 2 * p
-            ia = np.zeros(12 * m * m, dtype=np.int32)
-            ib = np.zeros_like(ia)
-            _check(_lib.lib().ace_hpx_pad_table_host(nside, p, ia.ctypes.data, ib.ctypes.data))
+            if mode == "isolatitude":         # same table format, other neighbour rules (built on the host in Python)
+                ia, ib = isolatitude_pad_table(nside, p)
+            else:
+                m = nside + 2 * p
+                ia = np.zeros(12 * m * m, dtype=np.int32)
+                ib = np.zeros_like(ia)
+                _check(_lib.lib().ace_hpx_pad_table_host(nside, p, ia.ctypes.data, ib.ctypes.data))
             self._tables[key] = (torch.from_numpy(ia).to(device), torch.from_numpy(ib).to(device))
         return self._tables[key]
 
@@ -140,21 +225,30 @@ class CappedGELU(nn.Module):
 # ---------------------------------------------------------------------------------------------------------------------
 # layers (healpix_layers.py:48-125, healpix_paddings.py)
 class HEALPixPadding(nn.Module):
-    """Face padding as a gather (no parameters; keeps the reference's ``layers.0`` slot)."""
+    """Face padding as a gather (no parameters; keeps the reference's ``layers.0`` slot): the Karlbauer / earth2grid rules
+    (healpix_paddings.py:239-611) or, with ``nside`` given, the isolatitude rules (healpix_paddings.py:613-1140) - one gather
+    kernel, two tables."""
 
-    def __init__(self, padding: int):
+    def __init__(self, padding: int, mode: str = "karlbauer", nside: Optional[int] = None):
         super().__init__()
         if not isinstance(padding, int) or padding < 1:
             raise ValueError(f"invalid value for 'padding', expected int > 0 but got {padding}")
+        if mode == "isolatitude" and (not isinstance(nside, int) or nside < 1):
+            raise ValueError(f"nside must be a positive int, got {nside!r}")
         self.p = padding
+        self.mode = mode
+        self._nside = nside
 
 
 def make_hpx_padding_layer(padding: int, hpx_padding_mode: str, nside: Optional[int] = None) -> nn.Module:
+    """healpix_paddings.py:79-130."""
     if hpx_padding_mode in ("earth2grid", "karlbauer"):
         return HEALPixPadding(padding)
     if hpx_padding_mode == "isolatitude":
-        raise NotImplementedError("hpx_padding_mode='isolatitude' is outside the accelerated path (karlbauer / earth2grid are built)")
-    raise ValueError(f"Unknown hpx_padding_mode: {hpx_padding_mode!r}")
+        if nside is None:
+            raise ValueError('hpx_padding_mode="isolatitude" requires nside (positive int, native face height/width)')
+        return HEALPixPadding(padding, "isolatitude", int(nside))
+    raise ValueError(f"Unknown hpx_padding_mode: {hpx_padding_mode!r}; expected one of 'earth2grid', 'karlbauer', 'isolatitude'.")
 
 
 class HEALPixLayer(nn.Module):
@@ -236,7 +330,11 @@ class HEALPixLayer(nn.Module):
         if self._pad > 0:
             p, m = self._pad, W + 2 * self._pad
             mp = max(_RT.pitch_for(W), _round4(m))
-            ia, ib = _RT.table(W, p, dev)
+            pad_layer = self.layers[0]
+            if pad_layer.mode == "isolatitude" and W != pad_layer._nside:
+                raise ValueError(f"HEALPixPaddingIsolatitude expected face size H={pad_layer._nside} (from init), but input has H={W}. "
+                                 "Make sure that nside was set correctly in the model config.")
+            ia, ib = _RT.table(W, p, dev, pad_layer.mode)
             ctot = cin + cin2
             flat = torch.empty(imgs * ctot * m * mp + _SLACK, dtype=torch.float32, device=dev)
             xmax = _RT.slot(dev)

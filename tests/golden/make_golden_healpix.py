@@ -64,8 +64,47 @@ def build_reference(ref, case):
     return ref.unet.HEALPixUNet(encoder=encoder, decoder=decoder, input_channels=case["n_in"], output_channels=case["n_out"], nside=nside)
 
 
+ISO_CASE = dict(
+    nside=8, n_in=3, n_out=2, batch=2,
+    config=dict(
+        encoder=dict(conv_block=dict(block_type="ConvNeXtBlock", kernel_size=3, upscale_factor=2, activation=CAP),
+                     down_sampling_block=dict(block_type="AvgPool", pooling=2), n_channels=[8, 4], dilations=[1, 2]),
+        decoder=dict(conv_block=dict(block_type="ConvNeXtBlock", kernel_size=3, upscale_factor=2, activation=CAP),
+                     up_sampling_block=dict(block_type="TransposedConvUpsample", stride=2, activation=CAP),
+                     output_layer=dict(block_type="BasicConvBlock", kernel_size=1, n_layers=1),
+                     n_channels=[4, 8], dilations=[2, 1]),
+        hpx_padding_mode="isolatitude", nside=[8, 4]))
+
+
+def isolatitude(ref):
+    """isolatitude padding (healpix_paddings.py:613-1140): the reference's gather indices and padded outputs for several
+    (nside, padding) pairs (padding <= nside / 2), and one UNet with hpx_padding_mode="isolatitude" - own file, gen_healpix.pt stays
+    byte-identical"""
+    out = {"padding": {}, "unet": {}}
+    g = torch.Generator().manual_seed(11)
+    for nside, p in [(4, 1), (4, 2), (8, 2), (8, 4), (16, 3), (6, 3)]:
+        x = torch.randn(2 * 12, 3, nside, nside, generator=g)
+        layer = ref.paddings.HEALPixPaddingIsolatitude(p, nside)
+        idx, valid = ref.paddings.build_isolatitude_gather_index(p, nside)
+        out["padding"][(nside, p)] = {"x": x, "padded": layer(x), "index": idx.clone(), "valid": valid.clone()}
+    model = build_reference(ref, ISO_CASE).eval()
+    with torch.no_grad():
+        for k, prm in model.named_parameters():
+            if k.endswith("weight"):
+                prm.mul_(3.0)
+    x = torch.randn(ISO_CASE["batch"], 12, ISO_CASE["n_in"], ISO_CASE["nside"], ISO_CASE["nside"], generator=g) * 2.0
+    with torch.no_grad():
+        y = model(x)
+    out["unet"]["isolatitude"] = {"case": dict(ISO_CASE), "state_dict": {k: v.clone() for k, v in model.state_dict().items()}, "x": x, "y": y}
+    print("isolatitude unet", tuple(x.shape), "->", tuple(y.shape), "max|y|", float(y.abs().max()))
+    dst = os.path.join(HERE, "gen_healpix_isolatitude.pt")
+    torch.save(out, dst)
+    print("wrote", dst, os.path.getsize(dst) // 1024, "KiB")
+
+
 def main():
     ref = ref_loader.load_healpix()
+    isolatitude(ref)
     out = {"padding": {}, "unet": {}}
     g = torch.Generator().manual_seed(3)
     for nside, p in [(4, 1), (8, 2), (8, 4), (16, 3), (6, 6), (5, 2)]:

@@ -1115,6 +1115,37 @@ def test_healpix_unet_vs_reference(dev, name):
     assert rel_max(y, g["y"]) <= NET_TOL, rel_max(y, g["y"])
 
 
+def test_healpix_isolatitude_padding_and_unet_vs_reference(dev):
+    """hpx_padding_mode="isolatitude" (healpix_paddings.py:613-1140): the same gather kernel with the table
+    ace_amd.healpix.isolatitude_pad_table builds - padded faces against the reference's HEALPixPaddingIsolatitude, and a UNet
+    built with that padding (nside per level) against the reference's output (tests/golden/gen_healpix_isolatitude.pt)."""
+    import ace_amd
+    from ace_amd import _lib
+    from ace_amd.healpix import isolatitude_pad_table
+    L = _lib.lib()
+    gold = load_golden("gen_healpix_isolatitude.pt")
+    for (nside, p), d in gold["padding"].items():
+        m = nside + 2 * p
+        mp = (m + 3) // 4 * 4
+        ia, ib = isolatitude_pad_table(nside, p)
+        iad, ibd = torch.from_numpy(ia).to(dev), torch.from_numpy(ib).to(dev)
+        src = d["x"].to(dev).contiguous()
+        flat = torch.zeros(24 * 3 * m * mp + 16, device=dev)
+        assert L.ace_hpx_pad(src.data_ptr(), src.stride(0), src.stride(1), nside, flat.data_ptr(), 3, 0, 3, iad.data_ptr(), ibd.data_ptr(),
+                             2, nside, p, mp, None, _lib.current_stream()) == 0, L.ace_hpx_last_error()
+        torch.cuda.synchronize()
+        y = flat[: 24 * 3 * m * mp].view(24, 3, m, mp)[..., :m]
+        assert float((y.cpu() - d["padded"]).abs().max()) <= 2.5e-7, (nside, p)
+    g = gold["unet"]["isolatitude"]
+    case = g["case"]
+    net = ace_amd.ModuleSelector(type="HEALPixUNet", config=case["config"]).build(
+        case["n_in"], case["n_out"], ace_amd.DatasetInfo((case["nside"], case["nside"]))).torch_module.to(dev)
+    net.load_state_dict(g["state_dict"], strict=True)
+    with torch.no_grad():
+        out = net(g["x"].to(dev))
+    assert rel_max(out, g["y"]) <= NET_TOL, rel_max(out, g["y"])
+
+
 def test_healpix_weight_update_is_seen(dev):
     """The prepared (fp16 hi / lo) copy of a convolution weight is re-made when the parameter changes in place: doubling the
     output layer's weight and bias (a 1 x 1 convolution without activation) doubles the output."""

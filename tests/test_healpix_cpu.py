@@ -56,8 +56,8 @@ def test_builder_registry_and_state_dict(gold):
 
 def test_unbuilt_variants_are_loud(gold):
     cfg = dict(gold["unet"]["basic_maxpool"]["case"]["config"])
-    with pytest.raises(NotImplementedError, match="isolatitude"):
-        ace_amd.ModuleSelector(type="HEALPixUNet", config={**cfg, "hpx_padding_mode": "isolatitude"}).build(3, 2, ace_amd.DatasetInfo((8, 8)))
+    iso = ace_amd.ModuleSelector(type="HEALPixUNet", config={**cfg, "hpx_padding_mode": "isolatitude"}).build(3, 2, ace_amd.DatasetInfo((8, 8)))
+    assert any(getattr(m, "mode", None) == "isolatitude" for m in iso.torch_module.modules())      # built since round 3 (own table)
     enc = dict(cfg["encoder"])
     enc["conv_block"] = {"block_type": "SymmetricConvNeXtBlock"}
     with pytest.raises(NotImplementedError, match="SymmetricConvNeXtBlock"):
@@ -99,3 +99,52 @@ def test_row_offset_table_is_the_convolution(k, dil, cin, W):
     assert ref.shape == y.shape
     assert float((y - ref).abs().max()) <= 1e-12
     assert int(rows.max()) + N <= flat.numel()
+
+
+ISO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gen_healpix_isolatitude.pt")
+
+
+def test_isolatitude_pad_table_matches_reference_gather_indices():
+    """isolatitude padding (healpix_paddings.py:613-1140): the table built on the host (ace_amd.healpix.isolatitude_pad_table -
+    shifted polar strips, diagonal-mean equatorial corners) names, for EVERY padded cell, exactly the source cells of the
+    reference's own precomputed gather index (build_isolatitude_gather_index), and gathering with it reproduces the reference's
+    padded faces (the reference evaluates a + (b - a) / 2, the kernel 0.5 a + 0.5 b: one rounding apart)."""
+    from ace_amd.healpix import isolatitude_pad_table
+    gold = torch.load(ISO, map_location="cpu", weights_only=False)
+    for (nside, p), d in gold["padding"].items():
+        m = nside + 2 * p
+        ia, ib = isolatitude_pad_table(nside, p)
+        lin = lambda s: (s >> 24) * nside * nside + ((s >> 12) & 4095) * nside + (s & 4095)      # noqa: E731
+        a, b = lin(ia.astype(np.int64)), lin(ib.astype(np.int64))
+        i0 = d["index"][0].numpy()
+        i1 = d["index"][1].numpy()
+        i1 = np.where(i1 < 0, i0, i1)
+        assert bool((((a == i0) & (b == i1)) | ((a == i1) & (b == i0))).all()), (nside, p)
+        assert int((ia != ib).sum()) == int(d["valid"][1].sum())
+        x = d["x"].reshape(2, 12, 3, nside, nside)
+
+        def gather(idx):
+            idx = torch.from_numpy(idx.astype(np.int64)).reshape(12, m, m)
+            return x[:, idx >> 24, :, (idx >> 12) & 4095, idx & 4095].permute(3, 0, 4, 1, 2)
+
+        ga, gb = gather(ia), gather(ib)
+        got = torch.where(torch.from_numpy(ia == ib).reshape(1, 12, 1, m, m), ga, 0.5 * ga + 0.5 * gb).reshape(24, 3, m, m)
+        assert float((got - d["padded"]).abs().max()) <= 2.5e-7, (nside, p)
+    with pytest.raises(ValueError):
+        isolatitude_pad_table(4, 3)                        # padding > nside / 2 (the reference's bound)
+
+
+def test_isolatitude_builder_surface():
+    """hpx_padding_mode="isolatitude" needs nside per level (fme/ace/registry/hpx.py:80-83) and builds padding layers that know it"""
+    gold = torch.load(ISO, map_location="cpu", weights_only=False)["unet"]["isolatitude"]
+    case = gold["case"]
+    net = ace_amd.ModuleSelector(type="HEALPixUNet", config=case["config"]).build(
+        case["n_in"], case["n_out"], ace_amd.DatasetInfo((case["nside"], case["nside"]))).torch_module
+    assert list(net.state_dict()) == list(gold["state_dict"])
+    net.load_state_dict(gold["state_dict"], strict=True)
+    pads = [m for m in net.modules() if type(m).__name__ == "HEALPixPadding"]
+    assert pads and all(m.mode == "isolatitude" and m._nside in (8, 4) for m in pads)
+    bad = dict(case["config"])
+    bad.pop("nside")
+    with pytest.raises(ValueError):
+        ace_amd.ModuleSelector(type="HEALPixUNet", config=bad).build(case["n_in"], case["n_out"], ace_amd.DatasetInfo((8, 8)))
