@@ -9,7 +9,8 @@ fme/ace/models/healpix/{healpix_blocks.py, healpix_encoder.py, healpix_decoder.p
 healpix_unet.py} that the reference's own test configuration uses - ConvNeXtBlock, BasicConvBlock, AvgPool / MaxPool,
 TransposedConvUpsample, CappedGELU, face padding modes "karlbauer" and "earth2grid" (which the reference documents as giving
 the same result; one gather table serves both) and "isolatitude" (its own table, same gather kernel).  Not built (raise at
-construction): the dealiased / smoothed-interpolate resamplers, the symmetric ConvNeXt variants.
+construction): the dealiased / smoothed-interpolate resamplers.  The symmetric ConvNeXt variants (residual added after the
+last activation) close with an identity contraction that carries the residual.
 
 Runtime layout: an activation of one UNet level is ``[image = item * 12 + face][channel][row][pitch]`` fp32 with the row pitch
 of that level's padded faces rounded up to a multiple of 4 (``Hpx``), so every k x k convolution is ONE contraction over
@@ -545,6 +546,92 @@ class ConvNeXtBlock(nn.Module):
         return _run_convblock(self.convblock, x, x2=x2, residual=skip)
 
 
+_IDENTITY: Dict[Tuple[int, str], ctypes.c_void_p] = {}
+
+
+def _add_after_activation(y: Hpx, skip: Hpx) -> Hpx:
+    """y + skip, both in the runtime layout.  The convolution epilogues add a residual BEFORE the activation; a block whose
+    residual comes after it (the symmetric ConvNeXt variants) closes with one more native contraction - the identity over the
+    channels, residual = skip, no activation: exact in the compensated-fp16 mode up to its 22-bit operand split."""
+    C = y.data.shape[1]
+    dev = y.data.device
+    key = (C, str(dev))
+    if key not in _IDENTITY:
+        h = ctypes.c_void_p()
+        eye = torch.eye(C, dtype=torch.float32, device=dev)
+        _check(_lib.lib().ace_hpx_weight_create(eye.data_ptr(), C, C, _lib.current_stream(), ctypes.byref(h)))
+        _IDENTITY[key] = h
+    if y.pitch % 4:
+        y = _repitch(y, _round4(y.pitch))
+    if skip.pitch != y.pitch:
+        skip = _repitch(skip, y.pitch)
+    imgs, H, W = y.data.shape[0], y.rows, y.width
+    out = torch.empty(imgs, C, H, y.pitch, dtype=torch.float32, device=dev)
+    omax = _RT.slot(dev)
+    _check(_lib.lib().ace_hpx_conv(y.data.data_ptr(), None, C, 0, _IDENTITY[key], None, None, skip.data.data_ptr(), out.data_ptr(), imgs, C, H, W,
+                                   y.pitch, 1, 1, ACT_NONE, _INF, _bound(y).data_ptr(), None, omax.data_ptr(), _lib.current_stream()))
+    return Hpx(out, W, omax)
+
+
+class SymmetricConvNeXtBlock(nn.Module):
+    """healpix_blocks.py:1214-1335: skip(x) + [k x k conv, act, 1 x 1 conv (latent -> latent * upscale), act, 1 x 1 conv (back), act,
+    k x k conv (-> out), act](x); the residual is added AFTER the last activation.  The skip is the identity when
+    in_channels == latent_channels (the reference's condition), a 1 x 1 convolution in -> out otherwise."""
+
+    def __init__(self, in_channels: int = 3, latent_channels: int = 1, out_channels: int = 1, kernel_size: int = 3,
+                 dilation: int = 1, upscale_factor: int = 4, activation_factory: Optional[Callable[[], nn.Module]] = None,
+                 hpx_padding_mode: str = "earth2grid", nside: Optional[int] = None):
+        super().__init__()
+        kw = _kw(HEALPixLayerBuildContext(hpx_padding_mode, nside))
+        lat = int(latent_channels)
+        if in_channels == lat:
+            self.skip_module = None
+        else:
+            self.skip_module = HEALPixLayer(layer=torch.nn.Conv2d, in_channels=in_channels, out_channels=out_channels, kernel_size=1, **kw)
+        convblock: List[nn.Module] = []
+        for cin, cout, k in ((in_channels, lat, kernel_size), (lat, int(lat * upscale_factor), 1), (int(lat * upscale_factor), lat, 1),
+                             (lat, out_channels, kernel_size)):
+            convblock.append(HEALPixLayer(layer=torch.nn.Conv2d, in_channels=cin, out_channels=cout, kernel_size=k, dilation=dilation, **kw))
+            if activation_factory is not None:
+                convblock.append(activation_factory())
+        self.convblock = nn.Sequential(*convblock)
+
+    def forward(self, x: Hpx, x2: Optional[Hpx] = None) -> Hpx:
+        if self.skip_module is None:
+            if x2 is not None:      # identity skip of a concatenated input: the residual IS the concatenation
+                cat = torch.zeros(x.data.shape[0], x.data.shape[1] + x2.data.shape[1], x.rows, x.pitch, dtype=torch.float32,
+                                  device=x.data.device)
+                cat[:, : x.data.shape[1], :, : x.width] = x.data[..., : x.width]
+                cat[:, x.data.shape[1]:, :, : x.width] = x2.data[..., : x.width]
+                skip = Hpx(cat, x.width)
+            else:
+                skip = x
+        else:
+            pitch = _round4(x.pitch)
+            skip = self.skip_module.conv(_repitch(x, pitch), x2=_repitch(x2, pitch) if x2 is not None else None)
+        return _add_after_activation(_run_convblock(self.convblock, x, x2=x2), skip)
+
+
+class Multi_SymmetricConvNeXtBlock(nn.Module):
+    """healpix_blocks.py:1337-1402: n_layers SymmetricConvNeXtBlocks in sequence (the first takes in_channels)."""
+
+    def __init__(self, in_channels: int = 3, latent_channels: int = 1, out_channels: int = 1, kernel_size: int = 3,
+                 dilation: int = 1, upscale_factor: int = 4, n_layers: int = 1,
+                 activation_factory: Optional[Callable[[], nn.Module]] = None, hpx_padding_mode: str = "earth2grid",
+                 nside: Optional[int] = None):
+        super().__init__()
+        self.blocks = nn.ModuleList([
+            SymmetricConvNeXtBlock(in_channels=in_channels if i == 0 else out_channels, latent_channels=latent_channels,
+                                   out_channels=out_channels, kernel_size=kernel_size, dilation=dilation, upscale_factor=upscale_factor,
+                                   activation_factory=activation_factory, hpx_padding_mode=hpx_padding_mode, nside=nside)
+            for i in range(n_layers)])
+
+    def forward(self, x: Hpx, x2: Optional[Hpx] = None) -> Hpx:
+        for i, block in enumerate(self.blocks):
+            x = block(x, x2 if i == 0 else None)
+        return x
+
+
 def _not_built(name: str):
     def build(*a, **k):
         raise NotImplementedError(f"{name} is outside the accelerated path (ConvNeXtBlock, BasicConvBlock, AvgPool, MaxPool and "
@@ -624,11 +711,48 @@ class ConvNeXtBlockConfig:
                              hpx_padding_mode=c.hpx_padding_mode, nside=c.nside)
 
 
+@dataclasses.dataclass
+class SymmetricConvNeXtBlockConfig:
+    """healpix_blocks.py:335-369."""
+    block_type: str = "SymmetricConvNeXtBlock"
+    kernel_size: int = 3
+    upscale_factor: int = 4
+    activation: Optional[CappedGELUConfig] = None
+
+    def build(self, in_channels: int, out_channels: int, *, latent_channels: Optional[int] = None, dilation: int = 1,
+              n_layers: Optional[int] = None, ctx: Optional[HEALPixLayerBuildContext] = None) -> nn.Module:
+        c = ctx or HEALPixLayerBuildContext()
+        return SymmetricConvNeXtBlock(in_channels=in_channels, latent_channels=1 if latent_channels is None else latent_channels,
+                                      out_channels=out_channels, kernel_size=self.kernel_size, dilation=dilation,
+                                      upscale_factor=self.upscale_factor,
+                                      activation_factory=self.activation.build if self.activation else None,
+                                      hpx_padding_mode=c.hpx_padding_mode, nside=c.nside)
+
+
+@dataclasses.dataclass
+class MultiSymmetricConvNeXtBlockConfig:
+    """healpix_blocks.py:371-416."""
+    block_type: str = "Multi_SymmetricConvNeXtBlock"
+    kernel_size: int = 3
+    n_layers: int = 1
+    upscale_factor: int = 4
+    activation: Optional[CappedGELUConfig] = None
+
+    def build(self, in_channels: int, out_channels: int, *, latent_channels: Optional[int] = None, dilation: int = 1,
+              n_layers: Optional[int] = None, ctx: Optional[HEALPixLayerBuildContext] = None) -> nn.Module:
+        c = ctx or HEALPixLayerBuildContext()
+        return Multi_SymmetricConvNeXtBlock(in_channels=in_channels, latent_channels=1 if latent_channels is None else latent_channels,
+                                            out_channels=out_channels, kernel_size=self.kernel_size, dilation=dilation,
+                                            upscale_factor=self.upscale_factor, n_layers=self.n_layers if n_layers is None else n_layers,
+                                            activation_factory=self.activation.build if self.activation else None,
+                                            hpx_padding_mode=c.hpx_padding_mode, nside=c.nside)
+
+
 _BLOCK_CONFIGS = {"MaxPool": MaxPoolDownsamplingBlockConfig, "AvgPool": AvgPoolDownsamplingBlockConfig,
                   "TransposedConvUpsample": TransposedConvUpsampleBlockConfig, "BasicConvBlock": BasicConvBlockConfig,
-                  "ConvNeXtBlock": ConvNeXtBlockConfig}
-_KNOWN_UNBUILT = {"DealiasedDownsample", "SmoothedInterpolateConv", "Interpolate", "SymmetricConvNeXtBlock",
-                  "MultiSymmetricConvNeXtBlock"}
+                  "ConvNeXtBlock": ConvNeXtBlockConfig, "SymmetricConvNeXtBlock": SymmetricConvNeXtBlockConfig,
+                  "Multi_SymmetricConvNeXtBlock": MultiSymmetricConvNeXtBlockConfig}
+_KNOWN_UNBUILT = {"DealiasedDownsample", "SmoothedInterpolateConv", "Interpolate"}
 
 
 def _block_from_state(state: Any, default: Optional[type] = None):

@@ -46,7 +46,9 @@ def build_reference(ref, case):
     def block(d):
         d = dict(d)
         cls = {"ConvNeXtBlock": b.ConvNeXtBlockConfig, "BasicConvBlock": b.BasicConvBlockConfig, "AvgPool": b.AvgPoolDownsamplingBlockConfig,
-               "MaxPool": b.MaxPoolDownsamplingBlockConfig, "TransposedConvUpsample": b.TransposedConvUpsampleBlockConfig}[d.pop("block_type")]
+               "MaxPool": b.MaxPoolDownsamplingBlockConfig, "TransposedConvUpsample": b.TransposedConvUpsampleBlockConfig,
+               "SymmetricConvNeXtBlock": b.SymmetricConvNeXtBlockConfig,
+               "Multi_SymmetricConvNeXtBlock": b.MultiSymmetricConvNeXtBlockConfig}[d.pop("block_type")]
         if d.get("activation") is not None:
             d["activation"] = a.CappedGELUConfig(**d["activation"])
         return cls(**d)
@@ -76,6 +78,22 @@ ISO_CASE = dict(
         hpx_padding_mode="isolatitude", nside=[8, 4]))
 
 
+SYM_CASES = {
+    # channel schedule chosen so that the reference's own skip rule works (identity iff in_channels == latent_channels: then the
+    # block must also keep the width) - encoder 4 -> 4 (identity), 4 -> 8 (1 x 1 skip), 8 -> 8; decoder 8 -> 8, cat 16 -> 4, cat 8 -> 4
+    "symmetric": dict(
+        nside=8, n_in=4, n_out=2, batch=1,
+        config=dict(
+            encoder=dict(conv_block=dict(block_type="SymmetricConvNeXtBlock", kernel_size=3, upscale_factor=2, activation=CAP),
+                         down_sampling_block=dict(block_type="AvgPool", pooling=2), n_channels=[4, 8, 8], dilations=[1, 2, 1]),
+            decoder=dict(conv_block=dict(block_type="Multi_SymmetricConvNeXtBlock", kernel_size=3, upscale_factor=2, n_layers=2, activation=CAP),
+                         up_sampling_block=dict(block_type="TransposedConvUpsample", stride=2, activation=CAP),
+                         output_layer=dict(block_type="BasicConvBlock", kernel_size=1, n_layers=1),
+                         n_channels=[8, 8, 4], dilations=[1, 2, 1], n_layers=[2, 1, 2]),
+            hpx_padding_mode="karlbauer")),
+}
+
+
 def isolatitude(ref):
     """isolatitude padding (healpix_paddings.py:613-1140): the reference's gather indices and padded outputs for several
     (nside, padding) pairs (padding <= nside / 2), and one UNet with hpx_padding_mode="isolatitude" - own file, gen_healpix.pt stays
@@ -97,6 +115,18 @@ def isolatitude(ref):
         y = model(x)
     out["unet"]["isolatitude"] = {"case": dict(ISO_CASE), "state_dict": {k: v.clone() for k, v in model.state_dict().items()}, "x": x, "y": y}
     print("isolatitude unet", tuple(x.shape), "->", tuple(y.shape), "max|y|", float(y.abs().max()))
+    # symmetric ConvNeXt variants (healpix_blocks.py:1214-1402): residual added after the last activation; identity and 1 x 1 skips
+    for name, case in SYM_CASES.items():
+        model = build_reference(ref, case).eval()
+        with torch.no_grad():
+            for k, prm in model.named_parameters():
+                if k.endswith("weight"):
+                    prm.mul_(2.0)
+        x = torch.randn(case["batch"], 12, case["n_in"], case["nside"], case["nside"], generator=g) * 2.0
+        with torch.no_grad():
+            y = model(x)
+        out["unet"][name] = {"case": dict(case), "state_dict": {k: v.clone() for k, v in model.state_dict().items()}, "x": x, "y": y}
+        print(name, tuple(x.shape), "->", tuple(y.shape), "max|y|", float(y.abs().max()))
     dst = os.path.join(HERE, "gen_healpix_isolatitude.pt")
     torch.save(out, dst)
     print("wrote", dst, os.path.getsize(dst) // 1024, "KiB")

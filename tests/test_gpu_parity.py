@@ -1146,6 +1146,22 @@ def test_healpix_isolatitude_padding_and_unet_vs_reference(dev):
     assert rel_max(out, g["y"]) <= NET_TOL, rel_max(out, g["y"])
 
 
+def test_healpix_symmetric_convnext_unet_vs_reference(dev):
+    """SymmetricConvNeXtBlock (encoder) and Multi_SymmetricConvNeXtBlock (decoder, two blocks per level, concatenated skip inputs):
+    skip(x) + act(conv(...)) with the residual added after the last activation - here by an identity contraction that carries the
+    residual - against the reference's output."""
+    import ace_amd
+    g = load_golden("gen_healpix_isolatitude.pt")["unet"]["symmetric"]
+    case = g["case"]
+    net = ace_amd.ModuleSelector(type="HEALPixUNet", config=case["config"]).build(
+        case["n_in"], case["n_out"], ace_amd.DatasetInfo((case["nside"], case["nside"]))).torch_module.to(dev)
+    net.load_state_dict(g["state_dict"], strict=True)
+    with torch.no_grad():
+        y = net(g["x"].to(dev))
+        assert torch.equal(y, net(g["x"].to(dev)))
+    assert rel_max(y, g["y"]) <= NET_TOL, rel_max(y, g["y"])
+
+
 def test_healpix_weight_update_is_seen(dev):
     """The prepared (fp16 hi / lo) copy of a convolution weight is re-made when the parameter changes in place: doubling the
     output layer's weight and bias (a 1 x 1 convolution without activation) doubles the output."""

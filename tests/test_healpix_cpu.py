@@ -59,8 +59,8 @@ def test_unbuilt_variants_are_loud(gold):
     iso = ace_amd.ModuleSelector(type="HEALPixUNet", config={**cfg, "hpx_padding_mode": "isolatitude"}).build(3, 2, ace_amd.DatasetInfo((8, 8)))
     assert any(getattr(m, "mode", None) == "isolatitude" for m in iso.torch_module.modules())      # built since round 3 (own table)
     enc = dict(cfg["encoder"])
-    enc["conv_block"] = {"block_type": "SymmetricConvNeXtBlock"}
-    with pytest.raises(NotImplementedError, match="SymmetricConvNeXtBlock"):
+    enc["down_sampling_block"] = {"block_type": "DealiasedDownsample"}
+    with pytest.raises(NotImplementedError, match="DealiasedDownsample"):
         ace_amd.ModuleSelector(type="HEALPixUNet", config={**cfg, "encoder": enc})
     with pytest.raises(ValueError):
         ace_amd.ModuleSelector(type="HEALPixUNet", config={**cfg, "hpx_padding_mode": "nearest"})
@@ -148,3 +148,19 @@ def test_isolatitude_builder_surface():
     bad.pop("nside")
     with pytest.raises(ValueError):
         ace_amd.ModuleSelector(type="HEALPixUNet", config=bad).build(case["n_in"], case["n_out"], ace_amd.DatasetInfo((8, 8)))
+
+
+def test_symmetric_convnext_blocks_mirror_the_reference_parameters():
+    """SymmetricConvNeXtBlock / Multi_SymmetricConvNeXtBlock (healpix_blocks.py:1214-1402): the reference's state_dict names, order
+    and shapes (identity skip iff in_channels == latent_channels, else a 1 x 1 convolution registered BEFORE the conv block)"""
+    gold = torch.load(ISO, map_location="cpu", weights_only=False)["unet"]["symmetric"]
+    case = gold["case"]
+    net = ace_amd.ModuleSelector(type="HEALPixUNet", config=case["config"]).build(
+        case["n_in"], case["n_out"], ace_amd.DatasetInfo((case["nside"], case["nside"]))).torch_module
+    assert list(net.state_dict()) == list(gold["state_dict"])
+    assert all(tuple(v.shape) == tuple(gold["state_dict"][k].shape) for k, v in net.state_dict().items())
+    net.load_state_dict(gold["state_dict"], strict=True)
+    from ace_amd.healpix import Multi_SymmetricConvNeXtBlock, SymmetricConvNeXtBlock
+    blocks = [m for m in net.modules() if isinstance(m, SymmetricConvNeXtBlock)]
+    assert any(b.skip_module is None for b in blocks) and any(b.skip_module is not None for b in blocks)
+    assert any(isinstance(m, Multi_SymmetricConvNeXtBlock) and len(m.blocks) == 2 for m in net.modules())
