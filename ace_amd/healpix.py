@@ -9,8 +9,9 @@ fme/ace/models/healpix/{healpix_blocks.py, healpix_encoder.py, healpix_decoder.p
 healpix_unet.py} that the reference's own test configuration uses - ConvNeXtBlock, BasicConvBlock, AvgPool / MaxPool,
 TransposedConvUpsample, CappedGELU, face padding modes "karlbauer" and "earth2grid" (which the reference documents as giving
 the same result; one gather table serves both) and "isolatitude" (its own table, same gather kernel).  Not built (raise at
-construction): the dealiased / smoothed-interpolate resamplers.  The symmetric ConvNeXt variants (residual added after the
-last activation) close with an identity contraction that carries the residual.
+construction): the dealiased / smoothed-interpolate resamplers, interpolation modes other than "nearest".  The symmetric ConvNeXt
+variants (residual added after the last activation) close with an identity contraction that carries the residual; the "Interpolate"
+upsampling block is the transposed convolution with identity taps.
 
 Runtime layout: an activation of one UNet level is ``[image = item * 12 + face][channel][row][pitch]`` fp32 with the row pitch
 of that level's padded faces rounded up to a multiple of 4 (``Hpx``), so every k x k convolution is ONE contraction over
@@ -573,6 +574,38 @@ def _add_after_activation(y: Hpx, skip: Hpx) -> Hpx:
     return Hpx(out, W, omax)
 
 
+class NearestUpsample(nn.Module):
+    """nn.Upsample(scale_factor=2, mode="nearest") on folded faces (healpix_blocks.py:229-253, the "Interpolate" upsampling block):
+    every cell becomes a 2 x 2 block of itself - the native 2 x 2 stride-2 transposed convolution with the identity as each of its
+    four taps (no parameters; exact up to the 22-bit operand split of the compensated-fp16 mode)."""
+
+    def __init__(self, stride: int = 2, mode: str = "nearest", align_corners: bool = False):
+        super().__init__()
+        if stride != 2 or mode != "nearest" or align_corners:
+            raise NotImplementedError(f"Interpolate upsampling: only stride 2, mode 'nearest' is built (got stride={stride}, mode={mode!r}, "
+                                      f"align_corners={align_corners})")
+
+    def forward(self, x: Hpx) -> Hpx:
+        C = x.data.shape[1]
+        dev = x.data.device
+        key = (-C, str(dev))                      # (negative: the four stacked identities of this width)
+        if key not in _IDENTITY:
+            h = ctypes.c_void_p()
+            eye4 = torch.eye(C, dtype=torch.float32, device=dev).repeat(4, 1).contiguous()
+            _check(_lib.lib().ace_hpx_weight_create(eye4.data_ptr(), 4 * C, C, _lib.current_stream(), ctypes.byref(h)))
+            _IDENTITY[key] = h
+        if x.pitch % 4:
+            x = _repitch(x, _round4(x.pitch))
+        imgs, H, W = x.data.shape[0], x.rows, x.width
+        po = _RT.pitch_for(2 * W)
+        tmp = torch.empty(4 * imgs * C * H * x.pitch, dtype=torch.float32, device=dev)
+        y = torch.zeros(imgs, C, 2 * H, po, dtype=torch.float32, device=dev)
+        ymax = _RT.slot(dev)
+        _check(_lib.lib().ace_hpx_tconv2(x.data.data_ptr(), _IDENTITY[key], None, tmp.data_ptr(), y.data_ptr(), imgs, C, C, H, W, x.pitch, po,
+                                         2 * H * po, ACT_NONE, _INF, _bound(x).data_ptr(), ymax.data_ptr(), _lib.current_stream()))
+        return Hpx(y, 2 * W, ymax)
+
+
 class SymmetricConvNeXtBlock(nn.Module):
     """healpix_blocks.py:1214-1335: skip(x) + [k x k conv, act, 1 x 1 conv (latent -> latent * upscale), act, 1 x 1 conv (back), act,
     k x k conv (-> out), act](x); the residual is added AFTER the last activation.  The skip is the identity when
@@ -712,6 +745,18 @@ class ConvNeXtBlockConfig:
 
 
 @dataclasses.dataclass
+class InterpolateUpsampleBlockConfig:
+    """healpix_blocks.py:229-253."""
+    block_type: str = "Interpolate"
+    stride: int = 2
+    upsample_mode: str = "nearest"
+    align_corners: bool = False
+
+    def build(self, in_channels: int, out_channels: int, *, ctx: Optional[HEALPixLayerBuildContext] = None) -> nn.Module:
+        return NearestUpsample(self.stride, self.upsample_mode, self.align_corners)
+
+
+@dataclasses.dataclass
 class SymmetricConvNeXtBlockConfig:
     """healpix_blocks.py:335-369."""
     block_type: str = "SymmetricConvNeXtBlock"
@@ -751,8 +796,8 @@ class MultiSymmetricConvNeXtBlockConfig:
 _BLOCK_CONFIGS = {"MaxPool": MaxPoolDownsamplingBlockConfig, "AvgPool": AvgPoolDownsamplingBlockConfig,
                   "TransposedConvUpsample": TransposedConvUpsampleBlockConfig, "BasicConvBlock": BasicConvBlockConfig,
                   "ConvNeXtBlock": ConvNeXtBlockConfig, "SymmetricConvNeXtBlock": SymmetricConvNeXtBlockConfig,
-                  "Multi_SymmetricConvNeXtBlock": MultiSymmetricConvNeXtBlockConfig}
-_KNOWN_UNBUILT = {"DealiasedDownsample", "SmoothedInterpolateConv", "Interpolate"}
+                  "Multi_SymmetricConvNeXtBlock": MultiSymmetricConvNeXtBlockConfig, "Interpolate": InterpolateUpsampleBlockConfig}
+_KNOWN_UNBUILT = {"DealiasedDownsample", "SmoothedInterpolateConv"}
 
 
 def _block_from_state(state: Any, default: Optional[type] = None):

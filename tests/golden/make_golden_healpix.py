@@ -47,7 +47,7 @@ def build_reference(ref, case):
         d = dict(d)
         cls = {"ConvNeXtBlock": b.ConvNeXtBlockConfig, "BasicConvBlock": b.BasicConvBlockConfig, "AvgPool": b.AvgPoolDownsamplingBlockConfig,
                "MaxPool": b.MaxPoolDownsamplingBlockConfig, "TransposedConvUpsample": b.TransposedConvUpsampleBlockConfig,
-               "SymmetricConvNeXtBlock": b.SymmetricConvNeXtBlockConfig,
+               "SymmetricConvNeXtBlock": b.SymmetricConvNeXtBlockConfig, "Interpolate": b.InterpolateUpsampleBlockConfig,
                "Multi_SymmetricConvNeXtBlock": b.MultiSymmetricConvNeXtBlockConfig}[d.pop("block_type")]
         if d.get("activation") is not None:
             d["activation"] = a.CappedGELUConfig(**d["activation"])
@@ -90,6 +90,17 @@ SYM_CASES = {
                          up_sampling_block=dict(block_type="TransposedConvUpsample", stride=2, activation=CAP),
                          output_layer=dict(block_type="BasicConvBlock", kernel_size=1, n_layers=1),
                          n_channels=[8, 8, 4], dilations=[1, 2, 1], n_layers=[2, 1, 2]),
+            hpx_padding_mode="karlbauer")),
+    # "Interpolate" upsampling block: nn.Upsample(scale_factor=2, mode="nearest") (healpix_blocks.py:229-253)
+    "interpolate_upsample": dict(
+        nside=8, n_in=3, n_out=2, batch=2,
+        config=dict(
+            encoder=dict(conv_block=dict(block_type="ConvNeXtBlock", kernel_size=3, upscale_factor=2, activation=CAP),
+                         down_sampling_block=dict(block_type="MaxPool", pooling=2), n_channels=[8, 4], dilations=[1, 2]),
+            decoder=dict(conv_block=dict(block_type="ConvNeXtBlock", kernel_size=3, upscale_factor=2, activation=CAP),
+                         up_sampling_block=dict(block_type="Interpolate", stride=2, upsample_mode="nearest"),
+                         output_layer=dict(block_type="BasicConvBlock", kernel_size=1, n_layers=1),
+                         n_channels=[4, 8], dilations=[2, 1]),
             hpx_padding_mode="karlbauer")),
 }
 

@@ -1146,6 +1146,25 @@ def test_healpix_isolatitude_padding_and_unet_vs_reference(dev):
     assert rel_max(out, g["y"]) <= NET_TOL, rel_max(out, g["y"])
 
 
+def test_healpix_interpolate_upsample_unet_vs_reference(dev):
+    """the "Interpolate" upsampling block (nn.Upsample(scale_factor=2, mode="nearest"), healpix_blocks.py:229-253) as the native
+    2 x 2 transposed convolution with identity taps, in a ConvNeXt UNet with max pooling, against the reference's output"""
+    import ace_amd
+    g = load_golden("gen_healpix_isolatitude.pt")["unet"]["interpolate_upsample"]
+    case = g["case"]
+    net = ace_amd.ModuleSelector(type="HEALPixUNet", config=case["config"]).build(
+        case["n_in"], case["n_out"], ace_amd.DatasetInfo((case["nside"], case["nside"]))).torch_module.to(dev)
+    assert list(net.state_dict()) == list(g["state_dict"])
+    net.load_state_dict(g["state_dict"], strict=True)
+    with torch.no_grad():
+        y = net(g["x"].to(dev))
+    assert rel_max(y, g["y"]) <= NET_TOL, rel_max(y, g["y"])
+    with pytest.raises(NotImplementedError):
+        dec = dict(case["config"]["decoder"])
+        dec["up_sampling_block"] = {"block_type": "Interpolate", "upsample_mode": "bilinear"}
+        ace_amd.ModuleSelector(type="HEALPixUNet", config={**case["config"], "decoder": dec}).build(3, 2, ace_amd.DatasetInfo((8, 8)))
+
+
 def test_healpix_symmetric_convnext_unet_vs_reference(dev):
     """SymmetricConvNeXtBlock (encoder) and Multi_SymmetricConvNeXtBlock (decoder, two blocks per level, concatenated skip inputs):
     skip(x) + act(conv(...)) with the residual added after the last activation - here by an identity contraction that carries the
