@@ -20,6 +20,9 @@ from .healpix import HEALPixUNet, HEALPixUNetBuilder  # noqa: F401
 from .corrector import AtmosphereCorrectorConfig  # noqa: F401
 from .ocean import OceanConfig  # noqa: F401
 from .derived_variables import AtmosphericDeriveFn, compute_derived_quantities  # noqa: F401
+from .timeaxis import TimeAxis  # noqa: F401
+from .insolation import InsolationConfig  # noqa: F401
+from .derived_forcings import DerivedForcingsConfig, ForcingDeriver, ForcingWindow  # noqa: F401
 from .stepper import PrognosticState, Stepper  # noqa: F401
 from .inference import EnginePredict, ForcingWindows, InferenceData, Looper, TensorFileWriter, run_inference  # noqa: F401
 

@@ -13,8 +13,9 @@ Module weights are loaded with the strict ``load_state_dict`` the reference uses
 the "module." prefix of wrapped modules is accepted (fme/core/distributed/non_distributed.py:15-28).
 
 What is NOT carried over (and why) is returned in ``LoadedStepper.ignored``: training history, loss configuration,
-parameter-init configuration, an empty mask provider; derived forcings, input masking and a mask provider with masks
-raise unless ``ignore_unsupported=True``.  Latitudes / area weights and the hybrid-sigma
+parameter-init configuration, an empty mask provider; input masking and a mask provider with masks
+raise unless ``ignore_unsupported=True``.  ``derived_forcings`` (the insolation computed from the time axis) is built
+(ace_amd/derived_forcings.py): the stepper then wants the times of every forcing window.  Latitudes / area weights and the hybrid-sigma
 coefficients are kept for the conservation correctors (ace_amd/corrector.py).  Features that change the rollout and are not
 implemented raise ``NotImplementedError`` unless ``ignore_unsupported=True``.
 """
@@ -83,9 +84,12 @@ def _normalization_from_state(norm: Mapping[str, Any]) -> NormalizationConfig:
 
 
 def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool = False):
-    """-> (SingleModuleStepConfig, DatasetInfo, module state dict, list of ignored items)."""
+    """-> (SingleModuleStepConfig, DatasetInfo, module state dict, list of ignored items).  The stepper-level
+    ``derived_forcings`` configuration is attached to the step config as ``_derived_forcings`` (a DerivedForcingsConfig)."""
+    from .derived_forcings import DerivedForcingsConfig
     ignored: List[str] = []
     cfg = state["config"]
+    derived_forcings = DerivedForcingsConfig.from_state(cfg.get("derived_forcings") if "step" in cfg else None)
     if "step" in cfg:                                         # ---- new format
         sel = cfg["step"]
         step_type, step_cfg = sel["type"], dict(sel["config"])
@@ -100,11 +104,11 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
             step_state = step_state["wrapped_step"]
         if step_type not in _STEP_TYPES:
             raise NotImplementedError(f"step type '{step_type}' is outside the accelerated hot path")
-        # both change the rollout in the reference (input_process_func on every step, single_module.py:615-632; forcings
-        # computed from the time axis): never dropped silently
-        for k in ("input_masking", "derived_forcings"):
+        # changes the rollout in the reference (input_process_func on every step, single_module.py:615-632): never dropped
+        # silently.  (derived_forcings - the insolation computed from the time axis - is built: ace_amd/derived_forcings.py.)
+        for k in ("input_masking",):
             v = cfg.get(k)
-            if v not in (None, {}, {"insolation": None}):
+            if v not in (None, {}):
                 if not ignore_unsupported:
                     raise NotImplementedError(f"StepperConfig.{k} is configured in this checkpoint and is outside the "
                                               "accelerated hot path (pass ignore_unsupported=True to drop it)")
@@ -182,6 +186,13 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
         config._ignore_unsupported = True
     if state.get("training_history"):
         ignored.append("training_history")
+    if derived_forcings.insolation is not None and dataset_info.horizontal_coordinates is None:
+        if not ignore_unsupported:
+            raise NotImplementedError("derived_forcings.insolation needs the latitudes and longitudes of the grid, which the "
+                                      "checkpoint's dataset_info does not carry (pass ignore_unsupported=True to drop it)")
+        ignored.append("derived_forcings")
+        derived_forcings = DerivedForcingsConfig()
+    config._derived_forcings = derived_forcings
     return config, dataset_info, step_state, ignored
 
 
@@ -189,7 +200,7 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
 class StepperOverrideConfig:
     """single_module.py:1848-1870: inference-time overrides of a serialized stepper; ``"keep"`` leaves the option alone.
     ``multi_call``: "keep" or None (multi-call diagnostics are outside the accelerated path either way);
-    ``derived_forcings``: "keep" only."""
+    ``derived_forcings``: "keep" or a DerivedForcingsConfig (its state dict) with the insolation name the network was trained on."""
 
     ocean: Any = "keep"
     multi_call: Any = "keep"
@@ -205,8 +216,8 @@ def apply_stepper_override(stepper: Stepper, override_config: Optional[StepperOv
         stepper.replace_ocean(override_config.ocean)
     if override_config.multi_call not in ("keep", None):
         raise NotImplementedError("multi-call diagnostics are outside the accelerated hot path")
-    if override_config.derived_forcings != "keep":
-        raise NotImplementedError("derived forcings are outside the accelerated hot path")
+    if not (isinstance(override_config.derived_forcings, str) and override_config.derived_forcings == "keep"):
+        stepper.replace_derived_forcings(override_config.derived_forcings)
     if override_config.prescribed_prognostic_names != "keep":
         stepper.replace_prescribed_prognostic_names(override_config.prescribed_prognostic_names)
 
@@ -220,7 +231,7 @@ def load_stepper(checkpoint: Union[str, pathlib.Path, Mapping[str, Any]],
         checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
     state = checkpoint["stepper"] if "stepper" in checkpoint else checkpoint
     config, dataset_info, step_state, ignored = stepper_config_from_state(state, ignore_unsupported)
-    stepper = Stepper.from_config(config, dataset_info, device=device)
+    stepper = Stepper.from_config(config, dataset_info, device=device, derived_forcings=getattr(config, "_derived_forcings", None))
     stepper.load_state({"step": step_state})
     apply_stepper_override(stepper, override_config)
     stepper.set_eval()

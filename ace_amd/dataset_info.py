@@ -1,5 +1,5 @@
 """The slice of DatasetInfo the hot path reads (fme/core/dataset_info.py:151-163, 225-229):
-`img_shape`, `all_labels` and `timestep`.  The reference object (duck-typed: anything
+`img_shape`, `all_labels` and `timestep` (plus the coordinates the post-step physics and the derived forcings read).  The reference object (duck-typed: anything
 with these attributes) can be passed instead."""
 
 import datetime
@@ -18,6 +18,11 @@ class DatasetInfo:
         self._timestep = timestep
         self._area_weights = None
         self._vertical_coordinate = None
+        self._horizontal_coordinates = None
+        if lat is not None and lon is not None:
+            from .insolation import LatLonGrid
+            import torch
+            self._horizontal_coordinates = LatLonGrid(torch.as_tensor(lat).detach().cpu(), torch.as_tensor(lon).detach().cpu())
         if area_weights is not None:
             import torch
             self._area_weights = torch.as_tensor(area_weights).detach().cpu()
@@ -39,6 +44,11 @@ class DatasetInfo:
     def area_weights(self):
         """(nlat, nlon) weights summing to 1, or None (fme/core/metrics.py:14-32)."""
         return self._area_weights
+
+    @property
+    def horizontal_coordinates(self):
+        """1-D lat / lon in degrees with a ``meshgrid`` (what the derived insolation reads), or None."""
+        return self._horizontal_coordinates
 
     @property
     def vertical_coordinate(self):

@@ -30,10 +30,12 @@ class ForcingWindows:
     """Iterable over the forcing windows of a rollout, with a one-window-ahead asynchronous upload.
 
     forcing: name -> (n_members, total_forward_steps + 1 [or more], H, W) host tensors (time level 0 = the initial time).
-    members: the member indices this rank processes (``Distributed.local_members``); default: all."""
+    members: the member indices this rank processes (``Distributed.local_members``); default: all.
+    time: the record's ``TimeAxis`` (n_members, total_forward_steps + 1 [or more]) - every window then is a ``ForcingWindow``
+    carrying its slice, which is what a stepper with derived forcings (the insolation) reads."""
 
     def __init__(self, forcing: Mapping[str, torch.Tensor], total_forward_steps: int, forward_steps_in_memory: int,
-                 device=None, members: Optional[Sequence[int]] = None, pin_memory: Optional[bool] = None):
+                 device=None, members: Optional[Sequence[int]] = None, pin_memory: Optional[bool] = None, time=None):
         if total_forward_steps < 1 or forward_steps_in_memory < 1:
             raise ValueError("total_forward_steps and forward_steps_in_memory must be positive")
         for name, t in forcing.items():
@@ -57,6 +59,21 @@ class ForcingWindows:
             t = t[:, : self._total + 1].contiguous()
             self._host[name] = t.pin_memory() if pin else t
         self._copy_stream = torch.cuda.Stream(device=self._device) if cuda else None
+        self._time = None
+        if time is not None:
+            from .timeaxis import as_time_axis
+            t = as_time_axis(time)
+            if t.ndim != 2 or t.shape[1] < self._total + 1:
+                raise ValueError(f"time must be (members, >= {self._total + 1} time levels), got {tuple(t.shape)}")
+            if idx is not None:
+                t = t[idx.numpy()]
+            self._time = t[:, : self._total + 1]
+
+    def _with_time(self, win: TensorDict, index: int):
+        if self._time is None:
+            return win
+        from .derived_forcings import ForcingWindow
+        return ForcingWindow(win, self._time[:, self.window_slice(index)])
 
     def __len__(self) -> int:
         return int(math.ceil(self._total / self._T))
@@ -85,7 +102,7 @@ class ForcingWindows:
                 torch.cuda.current_stream(self._device).wait_event(done)
                 for t in win.values():
                     t.record_stream(torch.cuda.current_stream(self._device))
-            yield win
+            yield self._with_time(win, i)
 
 
 class InferenceData:
@@ -199,6 +216,7 @@ class EnginePredict:
     def __call__(self, initial_condition: TensorDict, forcing: TensorDict,
                  compute_derived_variables: bool = False) -> Tuple[TensorDict, TensorDict]:
         from .rollout import RolloutEngine
+        forcing = self._stepper.forcing_deriver(forcing)      # forcings computed from the window's time axis (the insolation)
         n_steps = next(iter(forcing.values())).shape[1] - 1
         eng = self._engines.get(n_steps)
         if eng is None:

@@ -270,11 +270,15 @@ class RolloutEngine:
             for s in range(self.T):
                 self._enqueue_step(s, self.graph_mode == "step")
 
-    def predict(self, initial_condition, forcing) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
+    def predict(self, initial_condition, forcing, time=None) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
         """Same contract as Stepper.predict for one window of n_forward_steps (a ``PrognosticState`` initial condition
-        carries the corrector state of the previous window in; the returned state carries this window's out)."""
+        carries the corrector state of the previous window in; the returned state carries this window's out).  ``time``: the
+        window's TimeAxis when the stepper derives forcings from it (or `forcing` is a ForcingWindow)."""
         from .step import StepperState
         from .stepper import PrognosticState
+        deriver = self.stepper.forcing_deriver
+        if deriver.needs_time and deriver.insolation.config.insolation_name not in forcing:
+            forcing = deriver(forcing, time, device=self.device)      # once per window, in front of the captured steps
         with torch.no_grad():
             self.load(initial_condition, forcing)
             carried = getattr(initial_condition, "stepper_state", None)

@@ -44,15 +44,21 @@ class Stepper:
     TIME_DIM = 1
     CHANNEL_DIM = -3
 
-    def __init__(self, step_obj: SingleModuleStep):
+    def __init__(self, step_obj: SingleModuleStep, derived_forcings=None, dataset_info=None):
+        from .derived_forcings import DerivedForcingsConfig
         self._step_obj = step_obj
+        self._dataset_info = dataset_info
+        # forcings computed from the time axis (StepperConfig.derived_forcings, single_module.py:532-539, 870)
+        self._derived_forcings = DerivedForcingsConfig.from_state(derived_forcings)
+        self.forcing_deriver = self._derived_forcings.build(dataset_info)
         self._input_process_func: Callable[[TensorMapping], TensorMapping] = lambda x: x
         self._output_masking: Callable[[TensorMapping], TensorDict] = lambda x: dict(x)
 
     @classmethod
-    def from_config(cls, config: SingleModuleStepConfig, dataset_info, device=None) -> "Stepper":
+    def from_config(cls, config: SingleModuleStepConfig, dataset_info, device=None, derived_forcings=None) -> "Stepper":
         normalizer = config.normalization.build(config._normalize_names, device=device)
-        return cls(SingleModuleStep(config, dataset_info, normalizer, device=device))
+        return cls(SingleModuleStep(config, dataset_info, normalizer, device=device), derived_forcings=derived_forcings,
+                   dataset_info=dataset_info)
 
     # -- properties (single_module.py:960-1043)
     @property
@@ -98,6 +104,23 @@ class Stepper:
         step._config = dataclasses.replace(step._config, prescribed_prognostic_names=list(names))
         step._config._ignore_unsupported = keep
 
+    def replace_derived_forcings(self, derived_forcings) -> None:
+        """single_module.py:998-1006: new derived-forcing configuration (same insolation name as trained on)."""
+        from .derived_forcings import DerivedForcingsConfig
+        new = DerivedForcingsConfig.from_state(derived_forcings)
+        self._derived_forcings.validate_replacement(new)
+        self._derived_forcings = new
+        self.forcing_deriver = new.build(self._dataset_info)
+
+    @property
+    def derived_forcings(self):
+        return self._derived_forcings
+
+    def forcing_names_from_data(self) -> List[str]:
+        """The input-only names a forcing record has to hold (StepperConfig.get_forcing_window_data_requirements,
+        single_module.py:555-573): a derived forcing is computed, a named solar constant is read instead."""
+        return self._derived_forcings.update_names(sorted(self._input_only_names))
+
     def get_prescribed_prognostic_names(self) -> List[str]:
         return list(self._step_obj.config.prescribed_prognostic_names)
 
@@ -136,13 +159,17 @@ class Stepper:
         return AtmosphericDeriveFn(self._step_obj._vertical_coordinate, self._step_obj._timestep)
 
     def predict(self, initial_condition: TensorMapping, forcing: TensorMapping,
-                n_forward_steps: Optional[int] = None, compute_derived_variables: bool = False, labels=None
-                ) -> Tuple[TensorDict, TensorDict]:
+                n_forward_steps: Optional[int] = None, compute_derived_variables: bool = False, labels=None,
+                time=None, compute_derived_forcings: bool = True) -> Tuple[TensorDict, TensorDict]:
         """single_module.py:1169-1259 on plain dicts: initial_condition name -> (B, 1, H, W) prognostic state,
         forcing name -> (B, 1 + n_forward_steps, H, W).  Returns (output name -> (B, n_forward_steps, H, W),
         final prognostic state name -> (B, 1, H, W)).  The returned state is a ``PrognosticState`` (a dict) that carries
         the per-sample ``stepper_state`` (corrector dry-air reference) the way the reference's does
-        (fme/ace/data_loading/batch_data.py:214-235): feed it back as the next window's initial condition."""
+        (fme/ace/data_loading/batch_data.py:214-235): feed it back as the next window's initial condition.
+        ``time``: the (B, 1 + n_forward_steps) ``TimeAxis`` of the forcing window (or ``forcing`` is a ``ForcingWindow`` carrying
+        it) - needed only when the stepper derives forcings from it (single_module.py:1202-1203)."""
+        if compute_derived_forcings:
+            forcing = self.forcing_deriver(forcing, time)
         any_forcing = next(iter(forcing.values()))
         if n_forward_steps is None:
             n_forward_steps = any_forcing.shape[self.TIME_DIM] - self.n_ic_timesteps

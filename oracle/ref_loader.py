@@ -354,3 +354,53 @@ def load_stepper_ref():
         LatLonCoordinates=coords.LatLonCoordinates, HybridSigmaPressureCoordinate=coords.HybridSigmaPressureCoordinate,
         NullOptimization=opt.NullOptimization, module=sm)
     return _stepper
+
+
+_insolation = None
+
+
+def load_insolation():
+    """The REAL insolation (fme/ace/stepper/insolation/cm4.py) under the stubs of ``load_corrector`` - build container only.
+    cftime is not in this image; the reference only needs its datetimes to (a) subtract (-> timedelta), (b) carry a
+    ``calendar`` attribute and (c) be constructible from components, so the stand-in is the STANDARD LIBRARY's
+    ``datetime.datetime`` (a proleptic Gregorian calendar; identical to cftime's 'standard' for every date after 1582-10-15)
+    subclassed to carry the attribute.  No calendar arithmetic is written here.  xarray's ``DataArray`` is a holder with
+    ``to_numpy()``.  Returns a namespace with ``cm4`` (the real module), ``Datetime`` (the stand-in class, ``calendar`` set per
+    subclass), ``TimeArray`` and the real ``LatLonCoordinates``."""
+    global _insolation
+    if _insolation is not None:
+        return _insolation
+    load_corrector()
+    import datetime
+
+    import numpy as np
+
+    def make(calendar):
+        return type("Datetime_" + calendar, (datetime.datetime,), {"calendar": calendar})
+
+    std, pg = make("standard"), make("proleptic_gregorian")
+    cf = _ns("cftime")
+    cf.DatetimeGregorian, cf.DatetimeProlepticGregorian = std, pg
+    for other in ["DatetimeNoLeap", "DatetimeJulian", "Datetime360Day", "DatetimeAllLeap"]:
+        setattr(cf, other, type(other, (), {}))          # names the module's table needs at import; never instantiated here
+    if "xarray" not in sys.modules:
+        _ns("xarray")
+    xr = sys.modules["xarray"]
+
+    class TimeArray:
+        def __init__(self, values):
+            self._v = np.asarray(values, dtype=object)
+
+        def to_numpy(self):
+            return self._v
+
+    if not hasattr(xr, "DataArray"):
+        xr.DataArray = TimeArray
+    for pkg in ["fme.ace.stepper", "fme.ace.stepper.insolation"]:
+        if pkg not in sys.modules:
+            _ns(pkg, os.path.join(REF, *pkg.split(".")))
+    cm4 = importlib.import_module("fme.ace.stepper.insolation.cm4")
+    coords = importlib.import_module("fme.core.coordinates")
+    _insolation = types.SimpleNamespace(cm4=cm4, standard=std, proleptic_gregorian=pg, TimeArray=TimeArray,
+                                        LatLonCoordinates=coords.LatLonCoordinates)
+    return _insolation

@@ -265,11 +265,44 @@ def test_stepper_override_config():
     assert over.stepper._step_obj._ocean is not None
     with pytest.raises(ValueError, match="must be in out_names"):
         over.stepper.replace_prescribed_prognostic_names(["HGTsfc"])
-    with pytest.raises(NotImplementedError):
-        apply_stepper_override(over.stepper, StepperOverrideConfig(derived_forcings={"insolation": None}))
+    apply_stepper_override(over.stepper, StepperOverrideConfig(derived_forcings={"insolation": None}))
+    assert not over.stepper.forcing_deriver.needs_time
     with pytest.raises(NotImplementedError):
         apply_stepper_override(over.stepper, StepperOverrideConfig(multi_call={"forcing_name": "co2"}))
     apply_stepper_override(over.stepper, StepperOverrideConfig(multi_call=None))
+
+
+def test_checkpoint_with_derived_insolation():
+    """StepperConfig.derived_forcings of a checkpoint (single_module.py:532-539): the insolation is computed from the window's
+    time axis; the override may change its parameters but not its name (derived_forcings.py:44-62)."""
+    from ace_amd.checkpoint import StepperOverrideConfig, apply_stepper_override
+    from ace_amd.timeaxis import TimeAxis
+    ckpt, _ = _reference_style_checkpoint()
+    name = IN[0] if IN[0] not in OUT else [n for n in IN if n not in OUT][0]
+    ckpt["stepper"]["config"]["derived_forcings"] = {"insolation": {
+        "insolation_name": name, "solar_constant": {"value": 1360.0, "dtype": "float32"}, "obliquity": 23.439,
+        "eccentricity": 0.0167, "longitude_of_perhelion": 102.932}}
+    loaded = load_stepper(ckpt, device="cpu")
+    st = loaded.stepper
+    assert st.forcing_deriver.needs_time and st.derived_forcings.insolation.insolation_name == name
+    assert name not in st.forcing_names_from_data()
+    assert set(st.forcing_names_from_data()) == set(n for n in IN if n not in OUT) - {name}
+    time = TimeAxis.regular((2020, 1, 1), datetime.timedelta(hours=6), 3, 2)
+    win = st.forcing_deriver({}, time)
+    assert win[name].shape == (2, 3, 8, 16) and win[name].max() > 500
+    apply_stepper_override(st, StepperOverrideConfig(derived_forcings={"insolation": {
+        "insolation_name": name, "solar_constant": {"value": 1370.0}}}))
+    assert st.forcing_deriver({}, time)[name].max() > win[name].max()
+    with pytest.raises(ValueError, match="insolation_name"):
+        apply_stepper_override(st, StepperOverrideConfig(derived_forcings={"insolation": {
+            "insolation_name": "something_else", "solar_constant": {"value": 1370.0}}}))
+    # without the grid's coordinates the insolation cannot be computed: loud, or dropped on request
+    bare = copy.deepcopy(ckpt)
+    bare["stepper"]["dataset_info"]["horizontal_coordinates"] = None
+    bare["stepper"]["dataset_info"]["img_shape"] = (8, 16)
+    with pytest.raises(NotImplementedError, match="latitudes"):
+        load_stepper(bare, device="cpu")
+    assert "derived_forcings" in load_stepper(bare, device="cpu", ignore_unsupported=True).ignored
 
 
 @pytest.mark.parametrize("case", ["ace2_like", "residual_prescribed", "ace2_like_override"])

@@ -8,6 +8,8 @@ import re
 
 import numpy as np
 import pytest
+import warnings
+
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -235,6 +237,46 @@ def test_stepper_loop_bookkeeping_with_a_stub_module():
     for k in ["p", "d"]:
         torch.testing.assert_close(out[k], torch.stack([o[k] for o in ref], 1))
     assert torch.equal(state["p"], out["p"][:, -1:])
+
+
+def test_stepper_derives_the_insolation_from_the_window_times():
+    """Stepper.predict with StepperConfig.derived_forcings (single_module.py:1202-1203): the forcing the network reads is computed
+    from the time axis - same rollout as with that forcing handed in, an error when the times are missing."""
+    import datetime
+
+    import ace_amd
+    from ace_amd.derived_forcings import ForcingWindow
+    from ace_amd.registry import Module
+    from ace_amd.step import NormalizationConfig, SingleModuleStep
+    from ace_amd.timeaxis import TimeAxis
+
+    class Mix(torch.nn.Module):  # in: [sun, p] -> out: [p]
+        def forward(self, x):
+            return (0.5 * x[:, 1] + 0.001 * x[:, 0]).unsqueeze(1)
+
+    names = ["sun", "p"]
+    norm = NormalizationConfig(means={k: 0.0 for k in names}, stds={k: 1.0 for k in names})
+    cfg = ace_amd.SingleModuleStepConfig(
+        builder=ace_amd.ModuleSelector(type="SphericalFourierNeuralOperatorNet", config={"embed_dim": 4, "num_layers": 1}),
+        in_names=["sun", "p"], out_names=["p"], normalization=norm, next_step_forcing_names=["sun"])
+    info = ace_amd.DatasetInfo((4, 8), lat=torch.linspace(-67.5, 67.5, 4), lon=torch.arange(8.0) * 45.0)
+    step = SingleModuleStep(cfg, info, cfg.normalization.build(names), device="cpu")
+    step.module = Module(Mix(), None)
+    derived = {"insolation": {"insolation_name": "sun", "solar_constant": {"value": 1360.0}}}
+    stepper = ace_amd.Stepper(step, derived_forcings=derived, dataset_info=info)
+    assert stepper.forcing_names_from_data() == []
+    ic = {"p": torch.ones(2, 1, 4, 8)}
+    time = TimeAxis.regular((2021, 6, 1), datetime.timedelta(hours=6), 4, 2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                     # (the 4 x 8 grid's latitude range looks like radians to the check)
+        out, _ = stepper.predict(ic, {}, n_forward_steps=3, time=time)
+        sun = stepper.forcing_deriver({}, time)["sun"]
+        again, _ = stepper.predict(ic, ForcingWindow({}, time), n_forward_steps=3)
+    explicit, _ = stepper.predict(ic, {"sun": sun}, compute_derived_forcings=False)
+    assert out["p"].shape == (2, 3, 4, 8) and torch.equal(out["p"], explicit["p"]) and torch.equal(again["p"], out["p"])
+    assert (out["p"][:, 0] - 0.5).abs().max() > 0.1          # the sun was seen
+    with pytest.raises(ValueError, match="time axis"):
+        stepper.predict(ic, {}, n_forward_steps=3)
 
 
 def test_counter_file_is_tied_to_a_build():

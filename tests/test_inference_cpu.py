@@ -4,6 +4,7 @@ InferenceDataset (fme/ace/data_loading/inference.py:291-357), the Looper / run_i
 import os
 
 import pytest
+import numpy as np
 import torch
 
 from ace_amd.inference import ForcingWindows, InferenceData, Looper, TensorFileWriter, run_inference
@@ -124,6 +125,29 @@ def test_forcing_windows_tile_the_record_for_any_lengths():
         assert steps == list(map(float, range(1, total + 1)))
 
     check()
+
+
+def test_forcing_windows_carry_their_time_slices():
+    """A record with a time axis yields ForcingWindows whose times are the window's slice (consecutive windows share one level),
+    member selection applies to the times as to the data."""
+    import datetime
+
+    from ace_amd.derived_forcings import ForcingWindow
+    from ace_amd.timeaxis import TimeAxis
+    total, T = 7, 3
+    forcing = {"f": torch.arange(3 * 8, dtype=torch.float32).reshape(3, 8, 1, 1).expand(3, 8, 2, 4).contiguous()}
+    time = TimeAxis.regular((2000, 1, 1), datetime.timedelta(hours=6), 8, 3)
+    time = TimeAxis(time.calendar, time.us + np.arange(3)[:, None] * 86_400_000_000)      # member m starts m days later
+    wins = list(ForcingWindows(forcing, total, T, device="cpu", members=[2, 0], time=time))
+    assert len(wins) == 3 and all(isinstance(w, ForcingWindow) for w in wins)
+    assert [w.time.shape for w in wins] == [(2, 4), (2, 4), (2, 2)]
+    assert wins[1].time[:, :1] == wins[0].time[:, -1:]
+    assert wins[0].time == time[np.array([2, 0])][:, 0:4]
+    assert torch.equal(wins[2]["f"][:, :, 0, 0], forcing["f"][[2, 0]][:, 6:8, 0, 0])
+    plain = list(ForcingWindows(forcing, total, T, device="cpu"))
+    assert not isinstance(plain[0], ForcingWindow)
+    with pytest.raises(ValueError, match="time must be"):
+        ForcingWindows(forcing, total, T, device="cpu", time=time[:, :5])
 
 
 def test_documented_switches_exist_in_the_code():

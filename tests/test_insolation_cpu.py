@@ -1,0 +1,236 @@
+"""Derived forcings (SURVEY 8(f) rank 3 edge; VERDICT r02 missing item 7): the insolation computed from the time axis
+(ace_amd/insolation.py, ace_amd/timeaxis.py, ace_amd/derived_forcings.py) against
+
+  * the golden tensors the reference's own regression test holds (fme/ace/stepper/insolation/testdata/*.pt, copied as
+    tests/golden/ref_insolation_*.pt; its tolerance: rtol 1e-4, test_insolation.py:158);
+  * outputs of the reference's own cm4.py on cases its tests do not hold (tests/golden/make_golden_insolation.py);
+  * the properties the reference's tests assert (test_insolation.py:161-252), restated on this implementation;
+and the calendar arithmetic against the standard library and known day numbers."""
+import datetime
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from ace_amd.dataset_info import DatasetInfo
+from ace_amd.derived_forcings import DerivedForcingsConfig, ForcingDeriver, ForcingWindow
+from ace_amd.insolation import (AUTUMNAL_EQUINOX, CM4Insolation, InsolationConfig, LatLonGrid, NameConfig, ValueConfig,
+                                degrees_to_radians, orbital_angle_table)
+from ace_amd.timeaxis import TimeAxis, US_PER_DAY, days_since_base
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+N_LAT, N_LON, S0 = 8, 16, 1360.0
+LAT = torch.linspace(-90.0, 90.0, N_LAT)
+LON = torch.linspace(0.0, 360.0 - 360.0 / N_LON, N_LON)
+GRID = LatLonGrid(LAT, LON)
+SIX_HOURS = datetime.timedelta(hours=6)
+
+
+def _area_mean(x):
+    w = torch.cos(torch.deg2rad(LAT)).clamp_min(0)[:, None].expand(N_LAT, N_LON)
+    return (x * w).sum(dim=(-2, -1)) / w.sum()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# calendars
+def test_proleptic_gregorian_days_equal_the_standard_library():
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        y, m = int(rng.integers(1, 3000)), int(rng.integers(1, 13))
+        d = int(rng.integers(1, 29))
+        assert int(days_since_base("proleptic_gregorian", y, m, d)) == datetime.date(y, m, d).toordinal() - 1
+    assert int(days_since_base("proleptic_gregorian", 2000, 2, 29)) == datetime.date(2000, 2, 29).toordinal() - 1
+    with pytest.raises(ValueError):
+        days_since_base("proleptic_gregorian", 1900, 2, 29)
+
+
+def test_the_other_calendars():
+    # Julian day numbers: Julian-calendar 0001-01-01 is JDN 1721424, Gregorian 1582-10-15 is JDN 2299161, 2000-01-01 is 2451545
+    assert int(days_since_base("standard", 1582, 10, 15)) == 2299161 - 1721424
+    assert int(days_since_base("standard", 1582, 10, 4)) + 1 == int(days_since_base("standard", 1582, 10, 15))
+    assert int(days_since_base("standard", 2000, 1, 1)) == 2451545 - 1721424
+    assert int(days_since_base("julian", 1582, 10, 4)) == int(days_since_base("standard", 1582, 10, 4))
+    assert int(days_since_base("julian", 1900, 2, 29)) - int(days_since_base("julian", 1900, 2, 28)) == 1     # leap in the Julian rule
+    with pytest.raises(ValueError):
+        days_since_base("standard", 1582, 10, 10)
+    assert int(days_since_base("noleap", 2001, 1, 1)) == 2000 * 365
+    assert int(days_since_base("noleap", 2001, 3, 1)) == 2000 * 365 + 59
+    assert int(days_since_base("all_leap", 2001, 3, 1)) == 2000 * 366 + 60
+    assert int(days_since_base("360_day", 2001, 2, 30)) == 2000 * 360 + 59
+    with pytest.raises(ValueError):
+        days_since_base("noleap", 2000, 2, 29)
+    with pytest.raises(ValueError):
+        days_since_base("lunar", 2000, 1, 1)
+    # differences of standard and proleptic_gregorian dates after the switch agree (what the insolation uses)
+    a = TimeAxis.from_components("standard", [2000, 1, 1, 6]).microseconds_since(AUTUMNAL_EQUINOX)
+    b = TimeAxis.from_components("proleptic_gregorian", [2000, 1, 1, 6]).microseconds_since(AUTUMNAL_EQUINOX)
+    assert int(a) == int(b) == int((datetime.datetime(2000, 1, 1, 6) - datetime.datetime(*AUTUMNAL_EQUINOX)).total_seconds()) * 1_000_000
+
+
+def test_time_axis_constructors_agree():
+    reg = TimeAxis.regular((2000, 1, 1), SIX_HOURS, 5, 2, "noleap")
+    assert reg.shape == (2, 5) and reg.calendar == "noleap"
+    comps = [[(2000, 1, 1 + (6 * k) // 24, (6 * k) % 24) for k in range(5)]] * 2
+    assert reg == TimeAxis.from_components("noleap", comps)
+    dts = [[datetime.datetime(2000, 1, 1) + k * SIX_HOURS for k in range(5)]] * 2
+    pg = TimeAxis.from_datetimes(dts)
+    assert pg.calendar == "proleptic_gregorian" and pg == TimeAxis.regular((2000, 1, 1), SIX_HOURS, 5, 2)
+
+    class Cf(datetime.datetime):           # a cftime-like object: components + a calendar attribute
+        calendar = "noleap"
+    assert TimeAxis.from_datetimes([[Cf(2000, 1, 1) + k * SIX_HOURS for k in range(5)]] * 2) == reg
+    assert (reg - SIX_HOURS)[:, 1:] == reg[:, :-1]
+    assert np.array_equal(reg.microseconds_of_day()[0], (np.arange(5) * 6 % 24) * 3600 * 1_000_000)
+    # noleap: Feb 28 + 1 day = Mar 1
+    assert TimeAxis.from_components("noleap", (2000, 2, 28)) + datetime.timedelta(days=1) == TimeAxis.from_components("noleap", (2000, 3, 1))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# against the reference
+@pytest.mark.parametrize("test_id", ["solar-constant-as-name", "solar-constant-as-value"])
+def test_reference_held_golden(test_id):
+    """The reference's own regression case (test_insolation.py:125-158): 2000-01-01 00:00 and 06:00 of the standard calendar."""
+    sc = NameConfig("solar_constant") if "name" in test_id else ValueConfig(S0)
+    cfg = InsolationConfig("DSWRFtoa", sc)
+    ins = cfg.build(SIX_HOURS, GRID)
+    time = TimeAxis.regular((2000, 1, 1), SIX_HOURS, 2, 3, "standard")
+    shape = (3, 2, N_LAT, N_LON)
+    tensors = {"solar_constant": torch.full(shape, S0)} if "name" in test_id else {}
+    result = ins.compute(time, tensors)
+    assert "DSWRFtoa" not in tensors and set(result) == set(tensors) | {"DSWRFtoa"}      # the input mapping is not mutated
+    out = result["DSWRFtoa"]
+    held = torch.load(os.path.join(GOLD, f"ref_insolation_{test_id}.pt"))
+    assert out.shape == shape and out.dtype == torch.float32
+    torch.testing.assert_close(out, held, rtol=1e-4, atol=0.0)
+    assert out.min() == 0.0 and out.max() > 1000.0
+    torch.testing.assert_close(_area_mean(out), torch.full((3, 2), S0 / 4), rtol=0.1, atol=0.0)
+
+
+def test_against_reference_emitted_cases():
+    """Whole-year, 3-hourly, hourly, pole / dateline, other orbits, fp64 named solar constant - the reference's cm4.py run in the
+    build container.  Tolerance: 1e-3 W/m^2 (7e-7 of the solar constant; two fp32 ulps at 1300 W/m^2 is 2.4e-4) + 1e-6 relative -
+    near the terminator the mean cos zenith is a difference of nearly equal sines over a vanishing daylight length, so a relative
+    bound alone is meaningless there (the reference's CPU and GPU results differ the same way)."""
+    g = torch.load(os.path.join(GOLD, "gen_insolation.pt"))
+    assert len(g["cases"]) >= 7
+    for c in g["cases"]:
+        f = CM4Insolation(*c["orbit"])
+        time = TimeAxis.from_components(c["calendar"], c["components"])
+        lat, lon = torch.meshgrid(c["lat"], c["lon"], indexing="ij")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = f(time, datetime.timedelta(seconds=c["timestep_seconds"]), lat, lon, c["solar_constant"])
+        ref = c["out"]
+        assert out.shape == ref.shape and out.dtype == ref.dtype, c["name"]
+        torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-3, msg=lambda m: f"{c['name']}: {m}")
+        assert int(((out > 0) != (ref > 0)).sum()) <= 2, c["name"]          # day / night agree (up to a cell on the terminator)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's property tests
+@pytest.mark.parametrize("eccentricity", [0.0, 0.0167])
+def test_longitude_of_perhelion_and_eccentricity(eccentricity):
+    time = TimeAxis.from_components("standard", [AUTUMNAL_EQUINOX])
+    means = []
+    for lp in (0.0, 180.0):
+        cfg = InsolationConfig("DSWRFtoa", ValueConfig(S0), eccentricity=eccentricity, longitude_of_perhelion=lp)
+        means.append(_area_mean(cfg.build(SIX_HOURS, GRID).compute(time, {})["DSWRFtoa"]).squeeze())
+    if eccentricity > 0.0:
+        assert means[0] > means[1]
+    else:
+        assert means[0] == means[1]
+
+
+@pytest.mark.parametrize(("obliquity", "same"), [(0.0, True), (23.439, False)])
+def test_obliquity(obliquity, same):
+    time = TimeAxis.regular((2000, 1, 1), datetime.timedelta(days=1), 2, 1, "standard")[0]
+    cfg = InsolationConfig("DSWRFtoa", ValueConfig(S0), eccentricity=0.0, obliquity=obliquity)
+    r = cfg.build(SIX_HOURS, GRID).compute(time, {})["DSWRFtoa"]
+    assert r.shape == (2, N_LAT, N_LON)
+    assert torch.equal(r[0], r[1]) == same
+
+
+def test_timestep_error_and_coordinate_warning():
+    ins = InsolationConfig("DSWRFtoa", ValueConfig(S0)).build(datetime.timedelta(hours=12), GRID)
+    with pytest.raises(NotImplementedError, match="timestep"):
+        ins.compute(TimeAxis.regular((2000, 1, 1), datetime.timedelta(days=1), 2), {})
+    for lat, lon in ((torch.tensor([-0.5, 0.5]), torch.tensor([0.5, 359.5])), (torch.tensor([-89.5, 89.5]), torch.tensor([-2.0, 2.0]))):
+        with pytest.warns(match="degrees"):
+            degrees_to_radians(lat, lon)
+    with pytest.raises(ValueError):
+        ValueConfig(1.0, dtype="float31").torch_dtype
+    assert ValueConfig(1.0, dtype="float64").get({}).dtype == torch.float64
+
+
+def test_every_calendar_and_the_end_of_the_orbital_year():
+    """All six calendars run; at the last 1/3600 of the orbital year (where the reference indexes past its table) the angle
+    continues smoothly."""
+    f = CM4Insolation(23.439, 0.0167, 102.932)
+    lat, lon = GRID.meshgrid
+    for cal in ("noleap", "standard", "proleptic_gregorian", "julian", "360_day", "all_leap"):
+        out = f(TimeAxis.regular((2003, 3, 1), SIX_HOURS, 4, 1, cal), SIX_HOURS, lat, lon, torch.tensor(S0))
+        assert out.shape == (1, 4, N_LAT, N_LON) and torch.isfinite(out).all() and out.max() > 1000
+    theta = orbital_angle_table(torch.tensor(0.0167), torch.tensor(102.932))
+    assert theta.shape == (3602,) and theta[0] == 0
+    d = theta[1:] - theta[:-1]
+    assert (d > 0).all() and abs(float(theta[3600]) - 2 * np.pi) < 1e-4        # one revolution after 3600 steps
+    eq = TimeAxis.from_components("noleap", [AUTUMNAL_EQUINOX])
+    just_before = eq + datetime.timedelta(days=365) - datetime.timedelta(minutes=30) + SIX_HOURS    # interval starts 30 min before the equinox
+    a = f(just_before, SIX_HOURS, lat, lon, torch.tensor(S0))
+    b = f(just_before + datetime.timedelta(hours=3), SIX_HOURS, lat, lon, torch.tensor(S0))
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert abs(float(_area_mean(a)) - float(_area_mean(b))) < 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configuration / stepper plumbing
+def test_update_names():
+    by_name = InsolationConfig("DSWRFtoa", NameConfig("solar_constant"))
+    by_value = InsolationConfig("DSWRFtoa", ValueConfig(S0))
+    assert by_name.update_names(["DSWRFtoa"]) == ["solar_constant"]
+    assert by_value.update_names(["DSWRFtoa"]) == []
+    assert by_name.update_names([]) == [] and by_value.update_names(["a"]) == ["a"]
+    assert DerivedForcingsConfig().update_names(["DSWRFtoa"]) == ["DSWRFtoa"]
+
+
+def test_config_from_state_and_replacement():
+    state = {"insolation": {"insolation_name": "DSWRFtoa", "solar_constant": {"value": 1361.0}}}
+    cfg = DerivedForcingsConfig.from_state(state)
+    assert isinstance(cfg.insolation.solar_constant, ValueConfig) and cfg.insolation.obliquity == 23.439
+    named = DerivedForcingsConfig.from_state({"insolation": {"insolation_name": "DSWRFtoa", "solar_constant": {"name": "s0"}}})
+    assert isinstance(named.insolation.solar_constant, NameConfig)
+    cfg.validate_replacement(named)
+    with pytest.raises(ValueError, match="insolation_name"):
+        cfg.validate_replacement(DerivedForcingsConfig.from_state(
+            {"insolation": {"insolation_name": "other", "solar_constant": {"value": 1.0}}}))
+    DerivedForcingsConfig().validate_replacement(cfg)
+    with pytest.raises(ValueError):
+        DerivedForcingsConfig.from_state({"insolation": None, "albedo": {}})
+    assert DerivedForcingsConfig.from_state(None).insolation is None
+    info = DatasetInfo((N_LAT, N_LON), timestep=SIX_HOURS, lat=LAT, lon=LON)
+    deriver = cfg.build(info)
+    assert isinstance(deriver, ForcingDeriver) and deriver.needs_time
+    assert not DerivedForcingsConfig().build(None).needs_time
+    with pytest.raises(ValueError, match="latitudes"):
+        cfg.build(DatasetInfo((N_LAT, N_LON), timestep=SIX_HOURS))
+
+
+def test_forcing_deriver_on_a_window():
+    info = DatasetInfo((N_LAT, N_LON), timestep=SIX_HOURS, lat=LAT, lon=LON)
+    deriver = DerivedForcingsConfig.from_state(
+        {"insolation": {"insolation_name": "DSWRFtoa", "solar_constant": {"value": S0}}}).build(info)
+    time = TimeAxis.regular((2000, 1, 1), SIX_HOURS, 2, 3, "standard")
+    forcing = {"land": torch.zeros(3, 2, N_LAT, N_LON)}
+    out = deriver(forcing, time)
+    assert isinstance(out, ForcingWindow) and out.time == time and set(out) == {"land", "DSWRFtoa"} and "DSWRFtoa" not in forcing
+    held = torch.load(os.path.join(GOLD, "ref_insolation_solar-constant-as-value.pt"))
+    torch.testing.assert_close(out["DSWRFtoa"], held, rtol=1e-4, atol=0.0)
+    assert torch.equal(deriver(ForcingWindow(forcing, time))["DSWRFtoa"], out["DSWRFtoa"])       # times riding on the window
+    with pytest.raises(ValueError, match="time axis"):
+        deriver(forcing)
+    with pytest.raises(ValueError, match="shape"):
+        deriver(forcing, time[:, :1])
+    passthrough = ForcingDeriver(None)
+    assert passthrough(forcing) is forcing
