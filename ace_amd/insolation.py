@@ -117,6 +117,7 @@ class CM4Insolation:
         self.longitude_of_perhelion = torch.as_tensor(longitude_of_perhelion)
         self._table = orbital_angle_table(self.eccentricity, self.longitude_of_perhelion)
         self._table_on: Dict[str, torch.Tensor] = {}
+        self._radians: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]] = {}
 
     def table(self, device) -> torch.Tensor:
         key = str(device)
@@ -132,7 +133,12 @@ class CM4Insolation:
             raise NotImplementedError(f"Computing insolation via the CM4 implementation is not implemented for a model timestep "
                                       f"greater than or equal to 12 hours. Timestep is {timestep!r}.")
         dev, dtype = lat_deg.device, lat_deg.dtype
-        lat, lon = degrees_to_radians(lat_deg, lon_deg)
+        # the units check reads two ranges back to the host: once per grid, not once per window
+        key = (lat_deg.data_ptr(), lon_deg.data_ptr())
+        hit = self._radians.get(key)
+        if hit is None or hit[0] is not lat_deg or hit[1] is not lon_deg:
+            hit = self._radians[key] = (lat_deg, lon_deg) + degrees_to_radians(lat_deg, lon_deg)
+        lat, lon = hit[2], hit[3]
         begin = time - timestep                                     # the averaging interval ENDS at the given time
         tshape = begin.shape
         expand = tshape + (1,) * lat.ndim
@@ -274,6 +280,7 @@ class Insolation:
         self.timestep = timestep
         self.horizontal_coordinates = horizontal_coordinates
         self.insolation_function = config.build_insolation_function()
+        self._mesh: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
 
     def compute(self, time, tensors: TensorMapping, device=None) -> Dict[str, torch.Tensor]:
         """-> a shallow copy of `tensors` with the insolation (time.shape + grid shape) added under ``insolation_name``.
@@ -283,6 +290,8 @@ class Insolation:
         s0 = self.config.solar_constant.get(out)
         if device is None:
             device = next((v.device for v in out.values() if isinstance(v, torch.Tensor)), self.horizontal_coordinates.lat.device)
-        lat, lon = self.horizontal_coordinates.to(device).meshgrid
+        if str(device) not in self._mesh:
+            self._mesh[str(device)] = tuple(self.horizontal_coordinates.to(device).meshgrid)
+        lat, lon = self._mesh[str(device)]
         out[self.config.insolation_name] = self.insolation_function(time, self.timestep, lat, lon, s0)
         return out

@@ -234,3 +234,69 @@ def test_forcing_deriver_on_a_window():
         deriver(forcing, time[:, :1])
     passthrough = ForcingDeriver(None)
     assert passthrough(forcing) is forcing
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# on the device (the derived forcing is computed where the forcing window lives)
+@pytest.mark.gpu
+def test_insolation_on_the_device_matches_the_reference_cases():
+    """Same cases, computed on the MI355X (ATen elementwise kernels; sin / cos differ from the host's by an ulp): the same
+    absolute bound as on the host."""
+    dev = torch.device("cuda")
+    g = torch.load(os.path.join(GOLD, "gen_insolation.pt"))
+    for c in g["cases"]:
+        f = CM4Insolation(*c["orbit"])
+        time = TimeAxis.from_components(c["calendar"], c["components"])
+        lat, lon = torch.meshgrid(c["lat"].to(dev), c["lon"].to(dev), indexing="ij")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = f(time, datetime.timedelta(seconds=c["timestep_seconds"]), lat, lon, c["solar_constant"].to(dev))
+        assert out.is_cuda and out.dtype == c["out"].dtype
+        torch.testing.assert_close(out.cpu(), c["out"], rtol=1e-5, atol=2e-3, msg=lambda m: f"{c['name']}: {m}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [None, "step"])
+def test_rollout_engine_with_derived_insolation(graph):
+    """RolloutEngine / EnginePredict of a stepper whose checkpoint derives the insolation: the engine computes it once per window
+    from the window's times and feeds it to the captured steps - same numbers as Stepper.predict, and as handing the
+    precomputed field in."""
+    import ace_amd
+    from ace_amd.inference import EnginePredict
+    from ace_amd.rollout import RolloutEngine
+    from ace_amd.step import NormalizationConfig
+    dev = torch.device("cuda")
+    in_names, out_names = ["sun", "p0", "p1", "f1"], ["p1", "d0", "p0"]
+    names = sorted(set(in_names + out_names))
+    config = ace_amd.SingleModuleStepConfig(
+        builder=ace_amd.ModuleSelector(type="SphericalFourierNeuralOperatorNet",
+                                       config={"embed_dim": 16, "num_layers": 2, "operator_type": "dhconv"}),
+        in_names=in_names, out_names=out_names, next_step_forcing_names=["sun"],
+        normalization=NormalizationConfig(means={k: (300.0 if k == "sun" else 0.1 * (i + 1)) for i, k in enumerate(names)},
+                                          stds={k: (400.0 if k == "sun" else 1.0 + 0.1 * i) for i, k in enumerate(names)}))
+    info = ace_amd.DatasetInfo((12, 24), lat=torch.linspace(-82.5, 82.5, 12), lon=torch.arange(24.0) * 15.0)
+    derived = {"insolation": {"insolation_name": "sun", "solar_constant": {"value": 1360.0}}}
+    torch.manual_seed(0)
+    stepper = ace_amd.Stepper.from_config(config, info, device=dev, derived_forcings=derived)
+    stepper.set_eval()
+    B, T = 2, 4
+    ic = {k: torch.randn(B, 1, 12, 24, device=dev) for k in ["p0", "p1"]}
+    forcing = {"f1": torch.randn(B, T + 1, 12, 24, device=dev)}
+    time = TimeAxis.regular((2022, 3, 20, 12), SIX_HOURS, T + 1, B)
+    ref, ref_state = stepper.predict(ic, forcing, time=time)
+    sun = stepper.forcing_deriver(forcing, time)["sun"]
+    assert sun.is_cuda and sun.shape == (B, T + 1, 12, 24) and float(sun.max()) > 800
+    explicit, _ = stepper.predict(ic, {**forcing, "sun": sun}, compute_derived_forcings=False)
+    eng = RolloutEngine(stepper, batch=B, n_forward_steps=T, graph=graph)
+    out, state = eng.predict(ic, forcing, time=time)
+    out = {k: v.clone() for k, v in out.items()}
+    via_predict, _ = EnginePredict(stepper, batch=B, graph=graph)(ic, ace_amd.ForcingWindow(forcing, time))
+    with pytest.raises(ValueError, match="time axis"):
+        eng.predict(ic, forcing)
+    for k in out_names:
+        assert torch.equal(ref[k], explicit[k]), k
+        scale = float(ref[k].abs().max())
+        assert float((out[k] - ref[k]).abs().max()) <= 2e-6 * scale, k          # fused pack / unpack vs torch elementwise: an ulp
+        assert torch.equal(via_predict[k], out[k]), k
+    for k in ["p0", "p1"]:
+        assert float((state[k] - ref_state[k]).abs().max()) <= 2e-6 * float(ref_state[k].abs().max())
