@@ -196,6 +196,8 @@ def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, 
             eng.run_window()                                      # untimed: captures the K-step window and replays it
         else:
             window(max(Wm, 1))                                    # untimed warm-up (graph capture happens here)
+        if world > 1:                                             # ... and of the one collective: RCCL sets its channels / buffers
+            dist.reduce_mean(ens_mean)                            # up on the first all-reduce of a size
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
