@@ -297,6 +297,6 @@ def test_rollout_engine_with_derived_insolation(graph):
         assert torch.equal(ref[k], explicit[k]), k
         scale = float(ref[k].abs().max())
         assert float((out[k] - ref[k]).abs().max()) <= 2e-6 * scale, k          # fused pack / unpack vs torch elementwise: an ulp
-        assert torch.equal(via_predict[k], out[k]), k
+        assert float((via_predict[k] - out[k]).abs().max()) <= 1e-6 * scale, k     # a second engine on the same network
     for k in ["p0", "p1"]:
         assert float((state[k] - ref_state[k]).abs().max()) <= 2e-6 * float(ref_state[k].abs().max())
