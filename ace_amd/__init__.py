@@ -23,6 +23,7 @@ from .derived_variables import AtmosphericDeriveFn, compute_derived_quantities  
 from .timeaxis import TimeAxis  # noqa: F401
 from .insolation import InsolationConfig  # noqa: F401
 from .derived_forcings import DerivedForcingsConfig, ForcingDeriver, ForcingWindow  # noqa: F401
+from .multi_call import MultiCallConfig  # noqa: F401
 from .stepper import PrognosticState, Stepper  # noqa: F401
 from .inference import EnginePredict, ForcingWindows, InferenceData, Looper, TensorFileWriter, run_inference  # noqa: F401
 

@@ -85,9 +85,12 @@ def _normalization_from_state(norm: Mapping[str, Any]) -> NormalizationConfig:
 
 def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool = False):
     """-> (SingleModuleStepConfig, DatasetInfo, module state dict, list of ignored items).  The stepper-level
-    ``derived_forcings`` configuration is attached to the step config as ``_derived_forcings`` (a DerivedForcingsConfig)."""
+    ``derived_forcings`` configuration is attached to the step config as ``_derived_forcings`` (a DerivedForcingsConfig), the
+    multi-call configuration of a ``multi_call`` wrapper as ``_multi_call`` (a MultiCallConfig or None)."""
     from .derived_forcings import DerivedForcingsConfig
+    from .multi_call import MultiCallConfig
     ignored: List[str] = []
+    multi_call = None
     cfg = state["config"]
     derived_forcings = DerivedForcingsConfig.from_state(cfg.get("derived_forcings") if "step" in cfg else None)
     if "step" in cfg:                                         # ---- new format
@@ -95,10 +98,7 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
         step_type, step_cfg = sel["type"], dict(sel["config"])
         step_state = state["step"]
         if step_type == "multi_call":
-            if step_cfg.get("config") is not None:
-                if not ignore_unsupported:
-                    raise NotImplementedError("multi-call diagnostics are outside the accelerated hot path")
-                ignored.append("multi_call")
+            multi_call = MultiCallConfig.from_state(step_cfg.get("config"))      # run by Stepper.step (ace_amd/multi_call.py)
             inner = step_cfg["wrapped_step"]
             step_type, step_cfg = inner["type"], dict(inner["config"])
             step_state = step_state["wrapped_step"]
@@ -117,7 +117,8 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
         normalization = _normalization_from_state(step_cfg["normalization"])
     else:                                                     # ---- legacy single-module stepper
         step_cfg = dict(cfg)
-        for k in ("parameter_init", "loss", "loss_normalization", "residual_normalization", "multi_call",
+        multi_call = MultiCallConfig.from_state(step_cfg.pop("multi_call", None))      # single_module.py:1370-1413 -> MultiCallStep
+        for k in ("parameter_init", "loss", "loss_normalization", "residual_normalization",
                   "include_multi_call_in_loss", "crps_training"):
             if step_cfg.pop(k, None) not in (None, {}, True, False):
                 ignored.append(k)
@@ -193,13 +194,14 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
         ignored.append("derived_forcings")
         derived_forcings = DerivedForcingsConfig()
     config._derived_forcings = derived_forcings
+    config._multi_call = multi_call
     return config, dataset_info, step_state, ignored
 
 
 @dataclasses.dataclass
 class StepperOverrideConfig:
     """single_module.py:1848-1870: inference-time overrides of a serialized stepper; ``"keep"`` leaves the option alone.
-    ``multi_call``: "keep" or None (multi-call diagnostics are outside the accelerated path either way);
+    ``multi_call``: "keep", None (no multi-call diagnostics) or a MultiCallConfig / its state dict;
     ``derived_forcings``: "keep" or a DerivedForcingsConfig (its state dict) with the insolation name the network was trained on."""
 
     ocean: Any = "keep"
@@ -214,8 +216,8 @@ def apply_stepper_override(stepper: Stepper, override_config: Optional[StepperOv
         override_config = StepperOverrideConfig()
     if override_config.ocean != "keep":
         stepper.replace_ocean(override_config.ocean)
-    if override_config.multi_call not in ("keep", None):
-        raise NotImplementedError("multi-call diagnostics are outside the accelerated hot path")
+    if not (isinstance(override_config.multi_call, str) and override_config.multi_call == "keep"):
+        stepper.replace_multi_call(override_config.multi_call)
     if not (isinstance(override_config.derived_forcings, str) and override_config.derived_forcings == "keep"):
         stepper.replace_derived_forcings(override_config.derived_forcings)
     if override_config.prescribed_prognostic_names != "keep":
@@ -231,7 +233,8 @@ def load_stepper(checkpoint: Union[str, pathlib.Path, Mapping[str, Any]],
         checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
     state = checkpoint["stepper"] if "stepper" in checkpoint else checkpoint
     config, dataset_info, step_state, ignored = stepper_config_from_state(state, ignore_unsupported)
-    stepper = Stepper.from_config(config, dataset_info, device=device, derived_forcings=getattr(config, "_derived_forcings", None))
+    stepper = Stepper.from_config(config, dataset_info, device=device, derived_forcings=getattr(config, "_derived_forcings", None),
+                                  multi_call=getattr(config, "_multi_call", None))
     stepper.load_state({"step": step_state})
     apply_stepper_override(stepper, override_config)
     stepper.set_eval()

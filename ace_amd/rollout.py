@@ -27,6 +27,9 @@ class RolloutEngine:
             raise ValueError("graph must be None, 'step' or 'window'")
         step = stepper._step_obj
         cfg = step.config
+        if getattr(stepper, "_multi_call", None) is not None:
+            raise NotImplementedError("RolloutEngine: multi-call diagnostics (extra evaluations of the step with a scaled forcing) are "
+                                      "produced by Stepper.predict; use it, or load with StepperOverrideConfig(multi_call=None)")
         # post-step hooks (corrector, prescribed-SST ocean): torch ops on the static buffers between the fused unpack of
         # step s and the pack of step s + 1 - stream ordered, no host synchronisation.  The corrector state (dry-air
         # reference mass) is seeded by the first step after load() and survives continue_from_last().

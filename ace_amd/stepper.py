@@ -44,9 +44,13 @@ class Stepper:
     TIME_DIM = 1
     CHANNEL_DIM = -3
 
-    def __init__(self, step_obj: SingleModuleStep, derived_forcings=None, dataset_info=None):
+    def __init__(self, step_obj: SingleModuleStep, derived_forcings=None, dataset_info=None, multi_call=None):
         from .derived_forcings import DerivedForcingsConfig
         self._step_obj = step_obj
+        # multi-call diagnostics (the reference's MultiCallStep wrapper, fme/core/step/multi_call.py): held beside the step
+        self._multi_call_config = None
+        self._multi_call = None
+        self.replace_multi_call(multi_call)
         self._dataset_info = dataset_info
         # forcings computed from the time axis (StepperConfig.derived_forcings, single_module.py:532-539, 870)
         self._derived_forcings = DerivedForcingsConfig.from_state(derived_forcings)
@@ -55,10 +59,11 @@ class Stepper:
         self._output_masking: Callable[[TensorMapping], TensorDict] = lambda x: dict(x)
 
     @classmethod
-    def from_config(cls, config: SingleModuleStepConfig, dataset_info, device=None, derived_forcings=None) -> "Stepper":
+    def from_config(cls, config: SingleModuleStepConfig, dataset_info, device=None, derived_forcings=None,
+                    multi_call=None) -> "Stepper":
         normalizer = config.normalization.build(config._normalize_names, device=device)
         return cls(SingleModuleStep(config, dataset_info, normalizer, device=device), derived_forcings=derived_forcings,
-                   dataset_info=dataset_info)
+                   dataset_info=dataset_info, multi_call=multi_call)
 
     # -- properties (single_module.py:960-1043)
     @property
@@ -67,7 +72,22 @@ class Stepper:
 
     @property
     def out_names(self) -> List[str]:
-        return self._step_obj.output_names
+        """multi_call.py:175-177: the step's outputs, then the multi-call diagnostics."""
+        return self._step_obj.output_names + (self._multi_call.names if self._multi_call is not None else [])
+
+    @property
+    def multi_call(self):
+        return self._multi_call_config
+
+    def replace_multi_call(self, multi_call, batched: bool = False) -> None:
+        """single_module.py:1008-1018 / multi_call.py:206-207: a MultiCallConfig, its state dict, or None.  ``batched``: evaluate
+        all multipliers in one step of K x batch (ace_amd/multi_call.py)."""
+        from .multi_call import MultiCallConfig
+        cfg = MultiCallConfig.from_state(multi_call)
+        if cfg is not None:
+            cfg.validate(self._step_obj.input_names, self._step_obj.output_names)
+        self._multi_call_config = cfg
+        self._multi_call = cfg.build(self._step_obj.step, batched=batched) if cfg is not None else None
 
     @property
     def n_ic_timesteps(self) -> int:
@@ -79,6 +99,8 @@ class Stepper:
 
     @property
     def normalizer(self):
+        if self._multi_call_config is not None:
+            return self._multi_call_config.extend_normalizer(self._step_obj.normalizer)
         return self._step_obj.normalizer
 
     @property
@@ -132,7 +154,10 @@ class Stepper:
         """single_module.py:1045-1075."""
         args = args.apply_input_process_func(self._input_process_func)
         result = self._step_obj.step(args=args, wrapper=wrapper)
-        return StepOutput(output=self._output_masking(result.output), stepper_state=result.stepper_state)
+        output = result.output
+        if self._multi_call is not None:     # multi_call.py:296-312: its own state and diagnostics are discarded
+            output = {**self._multi_call.step(args=args, wrapper=wrapper).output, **output}
+        return StepOutput(output=self._output_masking(output), stepper_state=result.stepper_state)
 
     def predict_generator(self, ic_dict: TensorMapping, forcing_dict: TensorMapping, n_forward_steps: int,
                           labels=None, data_mask=None, stepper_state=None) -> Generator[StepOutput, None, None]:

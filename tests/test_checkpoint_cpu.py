@@ -267,7 +267,7 @@ def test_stepper_override_config():
         over.stepper.replace_prescribed_prognostic_names(["HGTsfc"])
     apply_stepper_override(over.stepper, StepperOverrideConfig(derived_forcings={"insolation": None}))
     assert not over.stepper.forcing_deriver.needs_time
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="missing"):
         apply_stepper_override(over.stepper, StepperOverrideConfig(multi_call={"forcing_name": "co2"}))
     apply_stepper_override(over.stepper, StepperOverrideConfig(multi_call=None))
 
