@@ -8,8 +8,9 @@ seeded construction consumes the RNG in the reference's order): the configuratio
 fme/ace/models/healpix/{healpix_blocks.py, healpix_encoder.py, healpix_decoder.py, healpix_layers.py, healpix_activations.py,
 healpix_unet.py} that the reference's own test configuration uses - ConvNeXtBlock, BasicConvBlock, AvgPool / MaxPool,
 TransposedConvUpsample, CappedGELU, face padding modes "karlbauer" and "earth2grid" (which the reference documents as giving
-the same result; one gather table serves both) and "isolatitude" (its own table, same gather kernel).  Not built (raise at
-construction): the dealiased / smoothed-interpolate resamplers, interpolation modes other than "nearest".  The symmetric ConvNeXt
+the same result; one gather table serves both) and "isolatitude" (its own table, same gather kernel), and the
+DealiasedDownsample / SmoothedInterpolateConv resamplers (composed from the same operators).  Not built (raise at
+construction): interpolation modes other than "nearest".  The symmetric ConvNeXt
 variants (residual added after the last activation) close with an identity contraction that carries the residual; the "Interpolate"
 upsampling block is the transposed convolution with identity taps.
 
@@ -49,7 +50,7 @@ class Hpx:
 
     @property
     def pitch(self) -> int:
-        return self.data.shape[-1]
+        return self.data.stride(-2) if self.data.shape[-2] > 1 else self.data.shape[-1]
 
     @property
     def rows(self) -> int:
@@ -187,18 +188,27 @@ _SLACK = 16   # ACE_HPX_SLACK_FLOATS
 
 
 def _repitch(x: Hpx, pitch: int) -> Hpx:
-    if x.pitch == pitch:
+    if x.pitch == pitch and x.data.is_contiguous():
         return x
     out = torch.zeros(*x.data.shape[:-1], pitch, dtype=torch.float32, device=x.data.device)
     out[..., : x.width] = x.data[..., : x.width]
     return Hpx(out, x.width, x.amax)
 
 
+def _dense(x: Hpx) -> Hpx:
+    """`x` as a contiguous [images][channels][rows][pitch % 4 == 0] tensor (a trimmed view of a larger tensor is copied; only
+    the padding gather reads arbitrary strides)"""
+    if x.data.is_contiguous() and x.pitch % 4 == 0:
+        return x
+    return _repitch(x, _round4(max(x.width, 1)) if not x.data.is_contiguous() else _round4(x.pitch))
+
+
 def _bound(x: Hpx) -> torch.Tensor:
     """The tensor's bound slot; a tensor nothing native produced (the network input) gets one from a reduction pass."""
     if x.amax is None:
         x.amax = _RT.slot(x.data.device)
-        _check(_lib.lib().ace_hpx_absmax(x.data.data_ptr(), x.data.numel(), x.amax.data_ptr(), _lib.current_stream()))
+        d = x.data if x.data.is_contiguous() else x.data.contiguous()
+        _check(_lib.lib().ace_hpx_absmax(d.data_ptr(), d.numel(), x.amax.data_ptr(), _lib.current_stream()))
     return x.amax
 
 
@@ -274,13 +284,13 @@ class HEALPixLayer(nn.Module):
         self.layers = torch.nn.Sequential(*layers)
         self._pad = padding
         self._k, self._dil = kernel_size, dilation
-        self._prep: Optional[Tuple[Tuple[int, int], int]] = None            # (weight stamp, native prepared-weight handle)
+        self._prep: Optional[Tuple[Tuple[int, int], int, Any]] = None       # (weight stamp, native prepared-weight handle, its destroyer)
         self._rows: Dict[Tuple[int, int, int, str], torch.Tensor] = {}
 
     def __del__(self):
         try:
             if self._prep is not None:
-                _lib.lib().ace_hpx_weight_destroy(ctypes.c_void_p(self._prep[1]))
+                self._prep[2](ctypes.c_void_p(self._prep[1]))
         except Exception:
             pass
 
@@ -302,8 +312,8 @@ class HEALPixLayer(nn.Module):
             h = ctypes.c_void_p()
             _check(_lib.lib().ace_hpx_weight_create(t.data_ptr(), t.shape[0], t.shape[1], _lib.current_stream(), ctypes.byref(h)))
             if self._prep is not None:
-                _lib.lib().ace_hpx_weight_destroy(ctypes.c_void_p(self._prep[1]))
-            self._prep = (stamp, h.value)
+                self._prep[2](ctypes.c_void_p(self._prep[1]))
+            self._prep = (stamp, h.value, _lib.lib().ace_hpx_weight_destroy)      # freed by the library that made it
         return ctypes.c_void_p(self._prep[1])
 
     def _row_offsets(self, cin: int, rows_in: int, pitch: int, device) -> torch.Tensor:
@@ -352,12 +362,11 @@ class HEALPixLayer(nn.Module):
                                   y.data_ptr(), imgs, cout, H, W, mp, self._k, self._dil, act[0], act[1], xmax.data_ptr(), None,
                                   ymax.data_ptr(), st))
             return Hpx(y, W, ymax)
-        if x.pitch % 4:
-            x = _repitch(x, _round4(x.pitch))
+        x = _dense(x)
         pitch = x.pitch
-        if x2 is not None and x2.pitch != pitch:
+        if x2 is not None:
             x2 = _repitch(x2, pitch)
-        if residual is not None and residual.pitch != pitch:
+        if residual is not None:
             residual = _repitch(residual, pitch)
         y = torch.empty(imgs, cout, H, pitch, dtype=torch.float32, device=dev)
         _check(L.ace_hpx_conv(x.data.data_ptr(), x2.data.data_ptr() if x2 is not None else None, cin, cin2, w, None,
@@ -371,6 +380,7 @@ class HEALPixLayer(nn.Module):
         k = base.kernel_size if isinstance(base.kernel_size, int) else base.kernel_size[0]
         if k != 2:
             raise NotImplementedError("only 2 x 2 pooling (the reference's configurations) is built")
+        x = _dense(x)
         imgs, C, H, W = x.data.shape[0], x.data.shape[1], x.rows, x.width
         po = _RT.pitch_for(W // 2)
         y = torch.zeros(imgs, C, H // 2, po, dtype=torch.float32, device=x.data.device)
@@ -382,8 +392,7 @@ class HEALPixLayer(nn.Module):
         base = self.base
         if not (isinstance(base, nn.ConvTranspose2d) and base.kernel_size == (2, 2) and base.stride == (2, 2)):
             raise NotImplementedError("only the 2 x 2 stride-2 transposed convolution (the reference's configurations) is built")
-        if x.pitch % 4:
-            x = _repitch(x, _round4(x.pitch))
+        x = _dense(x)
         imgs, cin, H, W = x.data.shape[0], x.data.shape[1], x.rows, x.width
         cout = base.out_channels
         po = _RT.pitch_for(2 * W)
@@ -562,10 +571,8 @@ def _add_after_activation(y: Hpx, skip: Hpx) -> Hpx:
         eye = torch.eye(C, dtype=torch.float32, device=dev)
         _check(_lib.lib().ace_hpx_weight_create(eye.data_ptr(), C, C, _lib.current_stream(), ctypes.byref(h)))
         _IDENTITY[key] = h
-    if y.pitch % 4:
-        y = _repitch(y, _round4(y.pitch))
-    if skip.pitch != y.pitch:
-        skip = _repitch(skip, y.pitch)
+    y = _dense(y)
+    skip = _repitch(skip, y.pitch)
     imgs, H, W = y.data.shape[0], y.rows, y.width
     out = torch.empty(imgs, C, H, y.pitch, dtype=torch.float32, device=dev)
     omax = _RT.slot(dev)
@@ -585,7 +592,8 @@ class NearestUpsample(nn.Module):
             raise NotImplementedError(f"Interpolate upsampling: only stride 2, mode 'nearest' is built (got stride={stride}, mode={mode!r}, "
                                       f"align_corners={align_corners})")
 
-    def forward(self, x: Hpx) -> Hpx:
+    def forward(self, x: Hpx, slack: bool = False) -> Hpx:
+        """slack: leave the readable slack of a k > 1 contraction's input behind the result (and give it the exact pitch % 4)"""
         C = x.data.shape[1]
         dev = x.data.device
         key = (-C, str(dev))                      # (negative: the four stacked identities of this width)
@@ -594,16 +602,228 @@ class NearestUpsample(nn.Module):
             eye4 = torch.eye(C, dtype=torch.float32, device=dev).repeat(4, 1).contiguous()
             _check(_lib.lib().ace_hpx_weight_create(eye4.data_ptr(), 4 * C, C, _lib.current_stream(), ctypes.byref(h)))
             _IDENTITY[key] = h
-        if x.pitch % 4:
-            x = _repitch(x, _round4(x.pitch))
+        x = _dense(x)
         imgs, H, W = x.data.shape[0], x.rows, x.width
-        po = _RT.pitch_for(2 * W)
+        po = _round4(2 * W) if slack else _RT.pitch_for(2 * W)
         tmp = torch.empty(4 * imgs * C * H * x.pitch, dtype=torch.float32, device=dev)
-        y = torch.zeros(imgs, C, 2 * H, po, dtype=torch.float32, device=dev)
+        flat = torch.zeros(imgs * C * 2 * H * po + (_SLACK if slack else 0), dtype=torch.float32, device=dev)
+        y = flat[: imgs * C * 2 * H * po].view(imgs, C, 2 * H, po)
         ymax = _RT.slot(dev)
         _check(_lib.lib().ace_hpx_tconv2(x.data.data_ptr(), _IDENTITY[key], None, tmp.data_ptr(), y.data_ptr(), imgs, C, C, H, W, x.pitch, po,
                                          2 * H * po, ACT_NONE, _INF, _bound(x).data_ptr(), ymax.data_ptr(), _lib.current_stream()))
         return Hpx(y, 2 * W, ymax)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# resamplers built from the same operators (healpix_blocks.py:499-634, 699-866)
+def _diagonal_taps(taps: torch.Tensor, channels: int, device) -> torch.Tensor:
+    """[channels][(ky, kx, channel)] weight of a DEPTHWISE k x k filter for the dense (tap, channel) contraction: the filter's tap
+    on the diagonal of every tap block.  (channels x more multiplications than a depthwise kernel would do; these layers are a
+    few percent of a UNet level's convolutions.)"""
+    k2 = taps.numel()
+    w = torch.zeros(channels, k2, channels, dtype=torch.float32, device=device)
+    idx = torch.arange(channels, device=device)
+    w[idx, :, idx] = taps.reshape(1, k2).to(device=device, dtype=torch.float32)
+    return w.reshape(channels, k2 * channels).contiguous()
+
+
+class _FixedFilter:
+    """A prepared depthwise filter per (device, channels): handle cache for the parameter-free resampling filters."""
+
+    def __init__(self):
+        self._h: Dict[Tuple[str, int], Tuple[ctypes.c_void_p, Any]] = {}
+
+    def get(self, taps: torch.Tensor, channels: int, device) -> ctypes.c_void_p:
+        key = (str(device), channels)
+        if key not in self._h or self._h[key][1] is not _lib.lib():
+            h = ctypes.c_void_p()
+            w = _diagonal_taps(taps, channels, device)
+            _check(_lib.lib().ace_hpx_weight_create(w.data_ptr(), w.shape[0], w.shape[1], _lib.current_stream(), ctypes.byref(h)))
+            self._h[key] = (h, _lib.lib())
+        return self._h[key][0]
+
+
+def _valid_depthwise(x_flat: torch.Tensor, imgs: int, C: int, rows_in: int, pitch: int, k: int, w: ctypes.c_void_p,
+                     xmax: torch.Tensor, device) -> Hpx:
+    """k x k 'valid' depthwise filter of a [imgs][C][rows_in][pitch] tensor (+ slack behind it): -> Hpx of (rows_in - k + 1)^2"""
+    Ho = rows_in - k + 1
+    taps = torch.tensor([ky * pitch + kx for ky in range(k) for kx in range(k)], dtype=torch.int64)
+    rows = (taps[:, None] + (torch.arange(C, dtype=torch.int64) * (rows_in * pitch))[None, :]).reshape(-1).contiguous().to(device)
+    y = torch.empty(imgs, C, Ho, pitch, dtype=torch.float32, device=device)
+    ymax = _RT.slot(device)
+    _check(_lib.lib().ace_hpx_conv(x_flat.data_ptr(), None, C, 0, w, rows.data_ptr(), None, None, y.data_ptr(), imgs, C, Ho, Ho, pitch, k, 1,
+                                   ACT_NONE, _INF, xmax.data_ptr(), None, ymax.data_ptr(), _lib.current_stream()))
+    return Hpx(y, Ho, ymax)
+
+
+class DealiasBlurConv2d(nn.Module):
+    """healpix_blocks.py:499-559: fixed separable blur f f^T / sum, depthwise, strided (parameter holder: the buffer ``weight`` keeps
+    the reference's state-dict entry)."""
+
+    def __init__(self, in_channels: int, stride: int = 1, resample_filter: Optional[Sequence[float]] = None, **kwargs):
+        super().__init__()
+        filt = tuple(float(v) for v in (resample_filter if resample_filter is not None else [1.0, 2.0, 1.0]))
+        if len(filt) < 1:
+            raise ValueError("resample_filter must be non-empty")
+        if sum(filt) == 0:
+            raise ValueError("resample_filter must not sum to zero")
+        self.in_channels = in_channels
+        self.stride = stride
+        f = torch.as_tensor(filt, dtype=torch.float32)
+        f2d = f[:, None] * f[None, :]
+        f2d = f2d / f2d.sum()
+        self.register_buffer("weight", f2d.unsqueeze(0).unsqueeze(0).expand(in_channels, 1, len(filt), len(filt)).clone())
+
+
+_SUBSAMPLE: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def _subsample2(y: Hpx, out_width: int) -> Hpx:
+    """out[r][c] = y[2 r][2 c] for r, c < out_width, per face and channel - the padding GATHER with a table that points at every
+    second cell (ace_hpx_pad places a (nside' + 2 p')^2 mesh; here nside' = out_width - 2, p' = 1)."""
+    dev = y.data.device
+    imgs, C = y.data.shape[0], y.data.shape[1]
+    po = _RT.pitch_for(out_width)
+    if out_width < 3:          # a mesh this small has no (nside' >= 1, p' >= 1) form: the handful of cells is copied by torch
+        out = torch.zeros(imgs, C, out_width, po, dtype=torch.float32, device=dev)
+        out[..., :out_width] = y.data[:, :, 0:2 * out_width:2, 0:2 * out_width:2]
+        return Hpx(out, out_width)
+    key = (out_width, str(dev))
+    if key not in _SUBSAMPLE:
+        r, c = np.meshgrid(np.arange(out_width), np.arange(out_width), indexing="ij")
+        cell = ((2 * r) << 12) | (2 * c)
+        t = np.stack([(f << 24) | cell for f in range(12)]).reshape(-1).astype(np.int32)
+        _SUBSAMPLE[key] = (torch.from_numpy(t).to(dev), torch.from_numpy(t.copy()).to(dev))
+    ia, ib = _SUBSAMPLE[key]
+    d = y.data
+    flat = torch.empty(imgs * C * out_width * po + _SLACK, dtype=torch.float32, device=dev)
+    omax = _RT.slot(dev)
+    _check(_lib.lib().ace_hpx_pad(d.data_ptr(), d.stride(0), d.stride(1), y.pitch, flat.data_ptr(), C, 0, C, ia.data_ptr(), ib.data_ptr(),
+                                  imgs // 12, out_width - 2, 1, po, omax.data_ptr(), _lib.current_stream()))
+    return Hpx(flat[: imgs * C * out_width * po].view(imgs, C, out_width, po), out_width, omax)
+
+
+class DealiasedDownsample(nn.Module):
+    """healpix_blocks.py:562-634: log2(stride) stages of [face padding, fixed depthwise blur with stride 2].  Native form of a stage:
+    the padding gather, the blur as one (tap, channel) contraction with a diagonal weight at stride 1, every second cell taken by
+    the gather kernel again (a table that points at cells (2 r, 2 c))."""
+
+    def __init__(self, in_channels: int = 3, resample_filter: Optional[Sequence[float]] = None, stride: int = 2,
+                 hpx_padding_mode: str = "earth2grid", nside: Optional[int] = None):
+        super().__init__()
+        filt = tuple(float(v) for v in (resample_filter if resample_filter is not None else [1.0, 2.0, 1.0]))
+        if len(filt) < 1:
+            raise ValueError("resample_filter must be non-empty")
+        if sum(filt) == 0:
+            raise ValueError("resample_filter must not sum to zero")
+        if stride < 1 or (stride & (stride - 1)) != 0:
+            raise ValueError("stride must be a positive power of 2")
+        n_layers = stride.bit_length() - 1
+        kw = _kw(HEALPixLayerBuildContext(hpx_padding_mode, nside))
+        self.pool = nn.Sequential(*[
+            HEALPixLayer(layer=DealiasBlurConv2d, in_channels=in_channels, out_channels=in_channels, kernel_size=len(filt), stride=2,
+                         padding=0, groups=in_channels, bias=False, dilation=1, resample_filter=filt, **kw) for _ in range(n_layers)])
+        self.downsample_factor = stride
+        self._filters = _FixedFilter()
+
+    def _stage(self, layer: HEALPixLayer, x: Hpx) -> Hpx:
+        dev = x.data.device
+        imgs, C, W = x.data.shape[0], x.data.shape[1], x.width
+        k, p = layer._k, layer._pad
+        w = self._filters.get(layer.base.weight[0, 0], C, dev)
+        if p > 0:
+            pad_layer = layer.layers[0]
+            if pad_layer.mode == "isolatitude" and W != pad_layer._nside:
+                raise ValueError(f"HEALPixPaddingIsolatitude expected face size H={pad_layer._nside} (from init), but input has H={W}. "
+                                 "Make sure that nside was set correctly in the model config.")
+            m = W + 2 * p
+            mp = max(_RT.pitch_for(W), _round4(m))
+            ia, ib = _RT.table(W, p, dev, pad_layer.mode)
+            flat = torch.empty(imgs * C * m * mp + _SLACK, dtype=torch.float32, device=dev)
+            xmax = _RT.slot(dev)
+            d = x.data
+            _check(_lib.lib().ace_hpx_pad(d.data_ptr(), d.stride(0), d.stride(1), x.pitch, flat.data_ptr(), C, 0, C, ia.data_ptr(),
+                                          ib.data_ptr(), imgs // 12, W, p, mp, xmax.data_ptr(), _lib.current_stream()))
+        else:
+            xd = _dense(x)
+            m, mp = W, xd.pitch
+            flat = torch.zeros(imgs * C * m * mp + _SLACK, dtype=torch.float32, device=dev)
+            flat[: imgs * C * m * mp] = xd.data.reshape(-1)
+            xmax = _bound(xd)
+        blurred = _valid_depthwise(flat, imgs, C, m, mp, k, w, xmax, dev)
+        return _subsample2(blurred, (m - k) // 2 + 1)
+
+    def forward(self, x: Hpx) -> Hpx:
+        for layer in self.pool:
+            x = self._stage(layer, x)
+        return x
+
+
+class SmoothedInterpolate(nn.Module):
+    """healpix_blocks.py:699-759 (parameter holder: the buffer ``smoother_kernel`` keeps the reference's state-dict entry)."""
+
+    def __init__(self, in_channels: int = 3, scale_factor: int = 2, mode: str = "nearest", trim_size: int = 0):
+        super().__init__()
+        if scale_factor != 2 or mode != "nearest":
+            raise NotImplementedError(f"SmoothedInterpolate: only scale_factor 2, mode 'nearest' is built (got {scale_factor}, {mode!r})")
+        self.in_channels, self.scale_factor, self.mode, self.trim_size = in_channels, scale_factor, mode, trim_size
+        cross = torch.tensor([[0.0, 1.0, 0.0], [1.0, 0.0, 1.0], [0.0, 1.0, 0.0]])
+        self.register_buffer("smoother_kernel", cross.unsqueeze(0).unsqueeze(0).repeat((in_channels, 1, 1, 1)))
+
+
+class SmoothedInterpolateConv(nn.Module):
+    """healpix_blocks.py:762-866: [face padding (1 cell), nearest x 2, four-point smoother / 4, trim 1 cell], then a k x k convolution
+    on padded faces of the doubled mesh [+ activation].  Native form: the padding gather; the x 2 replication of the PADDED faces as
+    the transposed convolution with identity taps; the smoother as one 'valid' (tap, channel) contraction with a diagonal weight; the
+    trim is a view (the next padding gather reads any strides); the convolution as everywhere."""
+
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, kernel_size: int = 3, dilation: int = 1, scale_factor: int = 2,
+                 mode: str = "nearest", activation_factory: Optional[Callable[[], nn.Module]] = None,
+                 hpx_padding_mode: str = "earth2grid", nside: Optional[int] = None, nside_after: Optional[int] = None):
+        super().__init__()
+        if dilation > 1:
+            raise ValueError(f"dilation > 1 is not supported for HEALPix resize convolutions, got {dilation}")
+        if nside is not None and nside_after is None:
+            if hpx_padding_mode == "isolatitude":
+                raise ValueError('SmoothedInterpolateConv requires nside_after when nside is set and hpx_padding_mode="isolatitude"')
+            nside_after = nside
+        if nside is not None and nside_after is not None and nside_after != nside * scale_factor:
+            raise ValueError(f"nside_after ({nside_after}) must equal nside ({nside}) * scale_factor ({scale_factor})")
+        block: List[nn.Module] = [
+            HEALPixLayer(layer=SmoothedInterpolate, in_channels=in_channels, scale_factor=scale_factor, mode=mode, trim_size=1,
+                         **_kw(HEALPixLayerBuildContext(hpx_padding_mode, nside))),
+            HEALPixLayer(layer=nn.Conv2d, in_channels=in_channels, out_channels=out_channels, kernel_size=kernel_size, dilation=dilation,
+                         **_kw(HEALPixLayerBuildContext(hpx_padding_mode, nside_after)))]
+        if activation_factory is not None:
+            block.append(activation_factory())
+        self.block = nn.Sequential(*block)
+        self._filters = _FixedFilter()
+        self._up = NearestUpsample()
+
+    def forward(self, x: Hpx) -> Hpx:
+        dev = x.data.device
+        layer = self.block[0]
+        imgs, C, W = x.data.shape[0], x.data.shape[1], x.width
+        pad_layer = layer.layers[0]
+        if pad_layer.mode == "isolatitude" and W != pad_layer._nside:
+            raise ValueError(f"HEALPixPaddingIsolatitude expected face size H={pad_layer._nside} (from init), but input has H={W}. "
+                             "Make sure that nside was set correctly in the model config.")
+        m = W + 2                                                    # faces padded by one cell
+        mp = max(_RT.pitch_for(W), _round4(m))
+        ia, ib = _RT.table(W, 1, dev, pad_layer.mode)
+        flat = torch.empty(imgs * C * m * mp + _SLACK, dtype=torch.float32, device=dev)
+        xmax = _RT.slot(dev)
+        d = x.data
+        _check(_lib.lib().ace_hpx_pad(d.data_ptr(), d.stride(0), d.stride(1), x.pitch, flat.data_ptr(), C, 0, C, ia.data_ptr(), ib.data_ptr(),
+                                      imgs // 12, W, 1, mp, xmax.data_ptr(), _lib.current_stream()))
+        padded = Hpx(flat[: imgs * C * m * mp].view(imgs, C, m, mp), m, xmax)
+        up = self._up(padded, slack=True)                            # (2 W + 4)^2, every cell a 2 x 2 block of itself
+        cross = layer.base.smoother_kernel[0, 0] / 4.0
+        smooth = _valid_depthwise(up.data, imgs, C, up.rows, up.pitch, 3, self._filters.get(cross, C, dev), _bound(up), dev)   # (2 W + 2)^2
+        t = layer.base.trim_size
+        trimmed = Hpx(smooth.data[:, :, t:smooth.rows - t, t:smooth.width - t], smooth.width - 2 * t, smooth.amax)
+        act = self.block[2] if len(self.block) > 2 else None
+        return self.block[1].conv(trimmed, act=_act_code(act))
 
 
 class SymmetricConvNeXtBlock(nn.Module):
@@ -696,6 +916,42 @@ class AvgPoolDownsamplingBlockConfig:
     def build(self, *, in_channels: Optional[int] = None, ctx: Optional[HEALPixLayerBuildContext] = None) -> nn.Module:
         c = ctx or HEALPixLayerBuildContext()
         return AvgPool(pooling=self.pooling, hpx_padding_mode=c.hpx_padding_mode, nside=c.nside)
+
+
+@dataclasses.dataclass
+class DealiasedDownsampleBlockConfig:
+    """healpix_blocks.py:129-160."""
+    block_type: str = "DealiasedDownsample"
+    pooling: int = 2
+    resample_filter: Sequence[float] = dataclasses.field(default_factory=lambda: [1.0, 2.0, 1.0])
+
+    def downsample_spatial_factor(self) -> int:
+        return self.pooling
+
+    def build(self, *, in_channels: Optional[int] = None, ctx: Optional[HEALPixLayerBuildContext] = None) -> nn.Module:
+        if in_channels is None:
+            raise ValueError("DealiasedDownsample requires in_channels to be passed to build()")
+        c = ctx or HEALPixLayerBuildContext()
+        return DealiasedDownsample(in_channels=in_channels, resample_filter=self.resample_filter, stride=self.pooling,
+                                   hpx_padding_mode=c.hpx_padding_mode, nside=c.nside)
+
+
+@dataclasses.dataclass
+class SmoothedInterpolateConvBlockConfig:
+    """healpix_blocks.py:195-226."""
+    block_type: str = "SmoothedInterpolateConv"
+    stride: int = 2
+    kernel_size: int = 3
+    dilation: int = 1
+    upsample_mode: str = "nearest"
+    activation: Optional[CappedGELUConfig] = None
+
+    def build(self, in_channels: int, out_channels: int, *, ctx: Optional[HEALPixLayerBuildContext] = None) -> nn.Module:
+        c = ctx or HEALPixLayerBuildContext()
+        return SmoothedInterpolateConv(in_channels=in_channels, out_channels=out_channels, kernel_size=self.kernel_size,
+                                       dilation=self.dilation, scale_factor=self.stride, mode=self.upsample_mode,
+                                       activation_factory=self.activation.build if self.activation else None,
+                                       hpx_padding_mode=c.hpx_padding_mode, nside=c.nside, nside_after=c.nside_after)
 
 
 @dataclasses.dataclass
@@ -796,8 +1052,9 @@ class MultiSymmetricConvNeXtBlockConfig:
 _BLOCK_CONFIGS = {"MaxPool": MaxPoolDownsamplingBlockConfig, "AvgPool": AvgPoolDownsamplingBlockConfig,
                   "TransposedConvUpsample": TransposedConvUpsampleBlockConfig, "BasicConvBlock": BasicConvBlockConfig,
                   "ConvNeXtBlock": ConvNeXtBlockConfig, "SymmetricConvNeXtBlock": SymmetricConvNeXtBlockConfig,
-                  "Multi_SymmetricConvNeXtBlock": MultiSymmetricConvNeXtBlockConfig, "Interpolate": InterpolateUpsampleBlockConfig}
-_KNOWN_UNBUILT = {"DealiasedDownsample", "SmoothedInterpolateConv"}
+                  "Multi_SymmetricConvNeXtBlock": MultiSymmetricConvNeXtBlockConfig, "Interpolate": InterpolateUpsampleBlockConfig,
+                  "DealiasedDownsample": DealiasedDownsampleBlockConfig, "SmoothedInterpolateConv": SmoothedInterpolateConvBlockConfig}
+_KNOWN_UNBUILT: set = set()
 
 
 def _block_from_state(state: Any, default: Optional[type] = None):
@@ -962,6 +1219,8 @@ class HEALPixUNet(nn.Module):
             for mod in level:
                 if isinstance(mod, (AvgPool, MaxPool)):
                     w //= 2
+                elif isinstance(mod, DealiasedDownsample):
+                    w //= mod.downsample_factor
             p = max([m._pad for m in level.modules() if isinstance(m, HEALPixLayer)] + [0])
             pads[w] = max(pads.get(w, 0), p)
         for n, level in enumerate(self.decoder.decoder):
@@ -989,7 +1248,12 @@ class HEALPixUNet(nn.Module):
                                "CPU fallback.")
         if torch.is_grad_enabled() and inputs.requires_grad:
             raise RuntimeError("ace_amd implements the inference forward only; call under torch.no_grad()")
+        return self._run(inputs)
+
+    def _run(self, inputs: torch.Tensor) -> torch.Tensor:
+        """fold the faces into the batch, encoder, decoder, unfold (the checks are forward's)"""
         B = inputs.shape[0]
+        h, w = inputs.shape[-2], inputs.shape[-1]
         _RT.pitch = self._level_pitches(w)
         _RT.begin(inputs.device)
         x = Hpx(inputs.reshape(B * 12, self.input_channels, h, w).float().contiguous(), w)   # fold (healpix_paddings.py:133-151)

@@ -48,7 +48,9 @@ def build_reference(ref, case):
         cls = {"ConvNeXtBlock": b.ConvNeXtBlockConfig, "BasicConvBlock": b.BasicConvBlockConfig, "AvgPool": b.AvgPoolDownsamplingBlockConfig,
                "MaxPool": b.MaxPoolDownsamplingBlockConfig, "TransposedConvUpsample": b.TransposedConvUpsampleBlockConfig,
                "SymmetricConvNeXtBlock": b.SymmetricConvNeXtBlockConfig, "Interpolate": b.InterpolateUpsampleBlockConfig,
-               "Multi_SymmetricConvNeXtBlock": b.MultiSymmetricConvNeXtBlockConfig}[d.pop("block_type")]
+               "Multi_SymmetricConvNeXtBlock": b.MultiSymmetricConvNeXtBlockConfig,
+               "DealiasedDownsample": b.DealiasedDownsampleBlockConfig,
+               "SmoothedInterpolateConv": b.SmoothedInterpolateConvBlockConfig}[d.pop("block_type")]
         if d.get("activation") is not None:
             d["activation"] = a.CappedGELUConfig(**d["activation"])
         return cls(**d)
@@ -105,6 +107,73 @@ SYM_CASES = {
 }
 
 
+RESAMPLER_CASES = {
+    # dealiased (blur + stride 2) downsampling and smoothed-interpolate + convolution upsampling (healpix_blocks.py:499-634, 699-866)
+    "dealiased_smoothed": dict(
+        nside=16, n_in=3, n_out=2, batch=2,
+        config=dict(
+            encoder=dict(conv_block=dict(block_type="ConvNeXtBlock", kernel_size=3, upscale_factor=2, activation=CAP),
+                         down_sampling_block=dict(block_type="DealiasedDownsample", pooling=2), n_channels=[8, 6, 4], dilations=[1, 2, 1]),
+            decoder=dict(conv_block=dict(block_type="ConvNeXtBlock", kernel_size=3, upscale_factor=2, activation=CAP),
+                         up_sampling_block=dict(block_type="SmoothedInterpolateConv", stride=2, kernel_size=3, activation=CAP),
+                         output_layer=dict(block_type="BasicConvBlock", kernel_size=1, n_layers=1),
+                         n_channels=[4, 6, 8], dilations=[1, 2, 1]),
+            hpx_padding_mode="karlbauer")),
+    # the same resamplers with the isolatitude padding (nside per level), a 5-tap filter, stride-4 pooling is NOT used by the UNet
+    # builder (factor 2 between levels), so the filter length is what varies; no activation on the upsampling convolution
+    "dealiased_smoothed_isolatitude": dict(
+        nside=16, n_in=2, n_out=2, batch=1,
+        config=dict(
+            encoder=dict(conv_block=dict(block_type="BasicConvBlock", kernel_size=3, n_layers=1, activation=CAP),
+                         down_sampling_block=dict(block_type="DealiasedDownsample", pooling=2, resample_filter=[1.0, 3.0, 4.0, 3.0, 1.0]),
+                         n_channels=[6, 4], n_layers=[1, 1]),
+            decoder=dict(conv_block=dict(block_type="BasicConvBlock", kernel_size=3, n_layers=1, activation=CAP),
+                         up_sampling_block=dict(block_type="SmoothedInterpolateConv", stride=2, kernel_size=3),
+                         output_layer=dict(block_type="BasicConvBlock", kernel_size=1, n_layers=1),
+                         n_channels=[4, 6], n_layers=[1, 1]),
+            hpx_padding_mode="isolatitude", nside=[16, 8])),
+}
+
+
+def resamplers(ref):
+    """the two resampler blocks inside UNets, and the blocks on their own (stride 4 = two blur stages; an even filter length) -
+    own file, the other fixtures stay byte-identical"""
+    out = {"unet": {}, "blocks": {}}
+    g = torch.Generator().manual_seed(23)
+    for name, case in RESAMPLER_CASES.items():
+        model = build_reference(ref, case).eval()
+        with torch.no_grad():
+            for k, prm in model.named_parameters():
+                if k.endswith("weight"):
+                    prm.mul_(2.0)
+        x = torch.randn(case["batch"], 12, case["n_in"], case["nside"], case["nside"], generator=g) * 2.0
+        with torch.no_grad():
+            y = model(x)
+        out["unet"][name] = {"case": dict(case), "state_dict": {k: v.clone() for k, v in model.state_dict().items()}, "x": x, "y": y}
+        print(name, tuple(x.shape), "->", tuple(y.shape), "max|y|", float(y.abs().max()))
+    b = ref.blocks
+    for name, kw, nside in [("stride4", dict(in_channels=5, resample_filter=[1.0, 2.0, 1.0], stride=4, hpx_padding_mode="karlbauer"), 16),
+                            ("even_filter", dict(in_channels=3, resample_filter=[1.0, 3.0, 3.0, 1.0], stride=2, hpx_padding_mode="karlbauer"), 8),
+                            ("tiny_faces", dict(in_channels=2, resample_filter=[1.0, 2.0, 1.0], stride=2, hpx_padding_mode="karlbauer"), 4)]:
+        blk = b.DealiasedDownsample(**kw).eval()
+        x = torch.randn(12, kw["in_channels"], nside, nside, generator=g)
+        with torch.no_grad():
+            y = blk(x)
+        out["blocks"][name] = {"kind": "DealiasedDownsample", "kwargs": kw, "x": x, "y": y, "state_keys": list(blk.state_dict())}
+        print(name, tuple(x.shape), "->", tuple(y.shape))
+    torch.manual_seed(5)
+    blk = b.SmoothedInterpolateConv(in_channels=4, out_channels=3, kernel_size=3, hpx_padding_mode="karlbauer").eval()
+    x = torch.randn(24, 4, 8, 8, generator=g)
+    with torch.no_grad():
+        y = blk(x)
+    out["blocks"]["smoothed"] = {"kind": "SmoothedInterpolateConv", "kwargs": dict(in_channels=4, out_channels=3, kernel_size=3, hpx_padding_mode="karlbauer"),
+                                 "x": x, "y": y, "state_dict": {k: v.clone() for k, v in blk.state_dict().items()}}
+    print("smoothed", tuple(x.shape), "->", tuple(y.shape))
+    dst = os.path.join(HERE, "gen_healpix_resamplers.pt")
+    torch.save(out, dst)
+    print("wrote", dst, os.path.getsize(dst) // 1024, "KiB")
+
+
 def isolatitude(ref):
     """isolatitude padding (healpix_paddings.py:613-1140): the reference's gather indices and padded outputs for several
     (nside, padding) pairs (padding <= nside / 2), and one UNet with hpx_padding_mode="isolatitude" - own file, gen_healpix.pt stays
@@ -145,6 +214,9 @@ def isolatitude(ref):
 
 def main():
     ref = ref_loader.load_healpix()
+    if "--resamplers" in sys.argv:
+        resamplers(ref)
+        return
     isolatitude(ref)
     out = {"padding": {}, "unet": {}}
     g = torch.Generator().manual_seed(3)

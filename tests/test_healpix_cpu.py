@@ -59,8 +59,14 @@ def test_unbuilt_variants_are_loud(gold):
     iso = ace_amd.ModuleSelector(type="HEALPixUNet", config={**cfg, "hpx_padding_mode": "isolatitude"}).build(3, 2, ace_amd.DatasetInfo((8, 8)))
     assert any(getattr(m, "mode", None) == "isolatitude" for m in iso.torch_module.modules())      # built since round 3 (own table)
     enc = dict(cfg["encoder"])
-    enc["down_sampling_block"] = {"block_type": "DealiasedDownsample"}
-    with pytest.raises(NotImplementedError, match="DealiasedDownsample"):
+    enc["down_sampling_block"] = {"block_type": "DealiasedDownsample"}       # built since round 3 (same operators, tests/test_healpix_resamplers.py)
+    ace_amd.ModuleSelector(type="HEALPixUNet", config={**cfg, "encoder": enc}).build(3, 2, ace_amd.DatasetInfo((8, 8)))
+    dec = dict(cfg["decoder"])
+    dec["up_sampling_block"] = {"block_type": "SmoothedInterpolateConv", "upsample_mode": "bilinear"}
+    with pytest.raises(NotImplementedError, match="nearest"):
+        ace_amd.ModuleSelector(type="HEALPixUNet", config={**cfg, "decoder": dec}).build(3, 2, ace_amd.DatasetInfo((8, 8)))
+    enc["down_sampling_block"] = {"block_type": "FancyPool"}
+    with pytest.raises(ValueError, match="FancyPool"):
         ace_amd.ModuleSelector(type="HEALPixUNet", config={**cfg, "encoder": enc})
     with pytest.raises(ValueError):
         ace_amd.ModuleSelector(type="HEALPixUNet", config={**cfg, "hpx_padding_mode": "nearest"})

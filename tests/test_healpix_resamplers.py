@@ -1,0 +1,118 @@
+"""HEALPix UNet host logic under an emulation of the ``ace_hpx_*`` operators (tests/_fake_hpx.py, CPU, ``-m "not gpu"``) and on
+the real kernels (``-m gpu``), against outputs of the reference itself (tests/golden/make_golden_healpix.py):
+
+  * every reference-emitted UNet case the GPU suite holds (ConvNeXt / basic / symmetric blocks, avg / max pooling, transposed
+    convolution and nearest upsampling, the three padding modes) - on the emulation this checks layouts, pitches, padding and
+    row-offset tables, weight preparation order, skip handling, i.e. everything but the kernels' arithmetic;
+  * the DealiasedDownsample (fixed depthwise blur + stride 2) and SmoothedInterpolateConv (padding, nearest x 2, four-point
+    smoother, trim, convolution) resamplers (healpix_blocks.py:499-634, 699-866), inside UNets and on their own (two blur stages,
+    an even filter length, faces too small for the gather form).
+Tolerance: 1e-5 of the output's maximum (the network tolerance of the GPU suite; the emulation is fp64 contractions on fp32 data)."""
+import pytest
+import torch
+
+import ace_amd
+from ace_amd.healpix import DealiasedDownsample, Hpx, SmoothedInterpolateConv, _RT
+from _fake_hpx import fake_hpx
+from _util import load_golden, rel_max
+
+NET_TOL = 1e-5
+UNETS = [("gen_healpix.pt", "convnext_avgpool_tconv"), ("gen_healpix.pt", "basic_maxpool"),
+         ("gen_healpix_isolatitude.pt", "isolatitude"), ("gen_healpix_isolatitude.pt", "symmetric"),
+         ("gen_healpix_isolatitude.pt", "interpolate_upsample"), ("gen_healpix_resamplers.pt", "dealiased_smoothed"),
+         ("gen_healpix_resamplers.pt", "dealiased_smoothed_isolatitude")]
+
+
+def _build(case, state, device="cpu"):
+    net = ace_amd.ModuleSelector(type="HEALPixUNet", config=case["config"]).build(
+        case["n_in"], case["n_out"], ace_amd.DatasetInfo((case["nside"], case["nside"]))).torch_module.to(device)
+    assert list(net.state_dict()) == list(state)           # the reference's parameter / buffer names, in its order
+    net.load_state_dict(state, strict=True)
+    return net
+
+
+def _block(kind, kwargs):
+    return {"DealiasedDownsample": DealiasedDownsample, "SmoothedInterpolateConv": SmoothedInterpolateConv}[kind](**kwargs)
+
+
+def _run_block(blk, x, device):
+    _RT.pitch = {}
+    _RT.begin(device)
+    out = blk(Hpx(x.to(device).float().contiguous(), x.shape[-1]))
+    return out.data[..., : out.width]
+
+
+@pytest.mark.parametrize("file,name", UNETS)
+def test_unet_host_logic_on_the_emulated_operators(file, name):
+    g = load_golden(file)["unet"][name]
+    net = _build(g["case"], g["state_dict"])
+    with fake_hpx() as fake, torch.no_grad():
+        y = net._run(g["x"])
+    assert y.shape == g["y"].shape
+    assert rel_max(y, g["y"]) <= NET_TOL, rel_max(y, g["y"])
+    assert "pad" in fake.calls and any(c.startswith("conv") for c in fake.calls)
+    with pytest.raises(RuntimeError, match="MI355X"):       # the product path still refuses host tensors
+        net(g["x"])
+
+
+def test_resampler_blocks_on_the_emulated_operators():
+    gold = load_golden("gen_healpix_resamplers.pt")["blocks"]
+    for name, g in gold.items():
+        torch.manual_seed(5)
+        blk = _block(g["kind"], g["kwargs"]).eval()
+        if "state_dict" in g:
+            assert list(blk.state_dict()) == list(g["state_dict"])
+            blk.load_state_dict(g["state_dict"], strict=True)
+        else:
+            assert list(blk.state_dict()) == g["state_keys"]
+        with fake_hpx(), torch.no_grad():
+            y = _run_block(blk, g["x"], "cpu")
+        assert y.shape == g["y"].shape, name
+        assert rel_max(y, g["y"]) <= 2e-6, (name, rel_max(y, g["y"]))
+
+
+def test_resampler_configuration_surface():
+    from ace_amd.healpix import (DealiasedDownsampleBlockConfig, SmoothedInterpolateConvBlockConfig, _block_from_state)
+    d = _block_from_state({"block_type": "DealiasedDownsample", "pooling": 4, "resample_filter": [1.0, 1.0]})
+    assert isinstance(d, DealiasedDownsampleBlockConfig) and d.downsample_spatial_factor() == 4
+    assert len(d.build(in_channels=3).pool) == 2
+    with pytest.raises(ValueError, match="in_channels"):
+        d.build()
+    with pytest.raises(ValueError, match="power of 2"):
+        DealiasedDownsample(in_channels=2, stride=3)
+    with pytest.raises(ValueError, match="sum to zero"):
+        DealiasedDownsample(in_channels=2, resample_filter=[1.0, -1.0])
+    u = _block_from_state({"block_type": "SmoothedInterpolateConv", "activation": {"cap_value": 10}})
+    assert isinstance(u, SmoothedInterpolateConvBlockConfig) and u.stride == 2
+    with pytest.raises(ValueError, match="dilation"):
+        SmoothedInterpolateConv(in_channels=2, out_channels=2, dilation=2)
+    with pytest.raises(ValueError, match="nside_after"):
+        SmoothedInterpolateConv(in_channels=2, out_channels=2, hpx_padding_mode="isolatitude", nside=8)
+    with pytest.raises(ValueError, match="must equal"):
+        SmoothedInterpolateConv(in_channels=2, out_channels=2, nside=8, nside_after=12)
+    with pytest.raises(NotImplementedError, match="nearest"):
+        SmoothedInterpolateConv(in_channels=2, out_channels=2, mode="bilinear")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dealiased_smoothed", "dealiased_smoothed_isolatitude"])
+def test_resampler_unets_vs_reference(name):
+    g = load_golden("gen_healpix_resamplers.pt")["unet"][name]
+    net = _build(g["case"], g["state_dict"], "cuda")
+    with torch.no_grad():
+        y = net(g["x"].to("cuda"))
+        assert torch.equal(y, net(g["x"].to("cuda")))
+    assert rel_max(y, g["y"]) <= NET_TOL, rel_max(y, g["y"])
+
+
+@pytest.mark.gpu
+def test_resampler_blocks_vs_reference():
+    gold = load_golden("gen_healpix_resamplers.pt")["blocks"]
+    for name, g in gold.items():
+        blk = _block(g["kind"], g["kwargs"]).eval().to("cuda")
+        if "state_dict" in g:
+            blk.load_state_dict(g["state_dict"], strict=True)
+        with torch.no_grad():
+            y = _run_block(blk, g["x"], torch.device("cuda"))
+        assert rel_max(y, g["y"]) <= 2e-6, (name, rel_max(y, g["y"]))
