@@ -285,7 +285,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
     def _release_native(self):
         if self._native is not None:
             try:
-                _lib.lib().ace_sfno_destroy(self._native)
+                self.__dict__.get("_native_destroy", _lib.lib().ace_sfno_destroy)(self._native)
             except Exception:
                 pass
         self._native, self._native_key, self._uploaded = None, None, {}
@@ -294,7 +294,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         try:
             native = self.__dict__.get("_native")
             if native is not None:
-                _lib.lib().ace_sfno_destroy(native)
+                self.__dict__.get("_native_destroy", _lib.lib().ace_sfno_destroy)(native)
                 self.__dict__["_native"] = None
         except Exception:  # interpreter shutdown
             pass
@@ -308,6 +308,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             with torch.cuda.device(device):
                 _lib.check(_lib.lib().ace_sfno_create(ctypes.byref(cfg), ctypes.byref(handle)))
             self._native, self._native_key = handle, (device.index, batch)
+            self.__dict__["_native_destroy"] = _lib.lib().ace_sfno_destroy      # freed by the library that made it
         del key
 
     def sync_weights(self, force: bool = False):

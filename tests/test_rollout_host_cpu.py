@@ -1,0 +1,171 @@
+"""Host logic of the rollout engine on an emulation of the C ABI (tests/_fake_sfno.py: the forward is the CPU oracle network built
+from the weights the engine uploads; pack / unpack walk the engine's pointer tables) - static buffers, per-step pointer tables and
+strides, forcing indices (next-step forcing), state feedback, residual prediction, prescribed prognostics, post-step hooks as torch
+ops, derived forcings, the window feeder - against the oracle's stepper loop (fme/ace/stepper/single_module.py:1124-1167 restated in
+oracle/stepper.py) and against ``Stepper.predict`` with the same oracle network as its module."""
+import datetime
+import warnings
+
+import pytest
+import torch
+
+import ace_amd
+from ace_amd.registry import Module
+from ace_amd.rollout import RolloutEngine
+from ace_amd.step import NormalizationConfig
+from _fake_sfno import fake_sfno
+
+H, W = 8, 16
+
+
+def _config(in_names, out_names, **kw):
+    names = sorted(set(in_names) | set(out_names))
+    norm = NormalizationConfig(means={k: 0.1 * (i + 1) for i, k in enumerate(names)}, stds={k: 1.0 + 0.1 * i for i, k in enumerate(names)})
+    return ace_amd.SingleModuleStepConfig(
+        builder=ace_amd.ModuleSelector(type="SphericalFourierNeuralOperatorNet",
+                                       config={"embed_dim": 8, "num_layers": 2, "operator_type": "dhconv"}),
+        in_names=in_names, out_names=out_names, normalization=norm, **kw), names, norm
+
+
+def _oracle_net(stepper, n_in, n_out):
+    from oracle.sfno import SFNOConfig, SFNOOracle
+    cfg = SFNOConfig(in_chans=n_in, out_chans=n_out, img_shape=(H, W), embed_dim=8, num_layers=2, operator_type="dhconv")
+    return SFNOOracle(cfg, stepper.modules[0].state_dict(), dtype=torch.float32)
+
+
+class _OracleModule(torch.nn.Module):
+    def __init__(self, net):
+        super().__init__()
+        self._net = net
+
+    def forward(self, x):
+        return self._net.forward(x)
+
+
+def _reference_stepper(config, info, stepper, **kw):
+    """a Stepper with the same configuration whose module is the oracle network (CPU), weights of `stepper`"""
+    ref = ace_amd.Stepper.from_config(config, info, device="cpu", **kw)
+    ref._step_obj.module = Module(_OracleModule(_oracle_net(stepper, len(config.in_names), len(config.out_names))), None)
+    return ref
+
+
+@pytest.mark.parametrize("graph", [None, "step"])
+def test_engine_pointer_tables_and_forcing_indices_vs_the_oracle_loop(graph):
+    from oracle import stepper as ostep
+    in_names, out_names = ["f0", "p0", "p1", "f1"], ["p1", "d0", "p0"]
+    config, names, norm = _config(in_names, out_names, next_step_forcing_names=["f1"])
+    torch.manual_seed(0)
+    stepper = ace_amd.Stepper.from_config(config, ace_amd.DatasetInfo((H, W)), device="cpu")
+    B, T = 2, 4
+    g = torch.Generator().manual_seed(1)
+    ic = {k: torch.randn(B, 1, H, W, generator=g) for k in ["p0", "p1"]}
+    forcing = {k: torch.randn(B, T + 1, H, W, generator=g) for k in ["f0", "f1"]}
+    with fake_sfno() as fake:
+        eng = RolloutEngine(stepper, batch=B, n_forward_steps=T, graph=graph)
+        out, state = eng.predict(ic, forcing)
+        out = {k: v.clone() for k, v in out.items()}
+        again, _ = eng.predict(ic, forcing)
+        assert sum(n.forwards for n in fake._nets.values()) == 2 * T
+    means = {k: torch.tensor(norm.means[k]) for k in names}
+    stds = {k: torch.tensor(norm.stds[k]) for k in names}
+    ref = ostep.predict(_oracle_net(stepper, 4, 3), ic, forcing, T, in_names, out_names, means, stds, next_step_forcing_names=["f1"])
+    for k in out_names:
+        want = torch.stack([o[k] for o in ref], 1)
+        assert float((out[k] - want).abs().max()) <= 2e-6 * float(want.abs().max()), k
+        assert torch.equal(again[k], out[k])
+    for k in ["p0", "p1"]:
+        assert torch.equal(state[k], out[k][:, -1:])
+
+
+def test_engine_residual_prescribed_and_continue_from_last():
+    in_names, out_names = ["f0", "p0", "p1"], ["p0", "p1", "d0"]
+    config, names, norm = _config(in_names, out_names, residual_prediction=True, prescribed_prognostic_names=["p1"])
+    info = ace_amd.DatasetInfo((H, W))
+    torch.manual_seed(2)
+    stepper = ace_amd.Stepper.from_config(config, info, device="cpu")
+    ref = _reference_stepper(config, info, stepper)
+    B, T = 1, 3
+    g = torch.Generator().manual_seed(3)
+    ic = {k: torch.randn(B, 1, H, W, generator=g) for k in ["p0", "p1"]}
+    forcing = {k: torch.randn(B, 2 * T + 1, H, W, generator=g) for k in ["f0", "p1"]}       # p1 is prescribed from the data
+    want, want_state = ref.predict(ic, forcing, n_forward_steps=2 * T)
+    with fake_sfno():
+        eng = RolloutEngine(stepper, batch=B, n_forward_steps=T, graph="step")
+        first, s1 = eng.predict(ic, {k: v[:, : T + 1] for k, v in forcing.items()})
+        first = {k: v.clone() for k, v in first.items()}
+        second, s2 = eng.predict(s1, {k: v[:, T:] for k, v in forcing.items()})            # next window from the carried state
+    for k in out_names:
+        got = torch.cat([first[k], second[k]], dim=1)
+        assert float((got - want[k]).abs().max()) <= 5e-6 * float(want[k].abs().max()), k
+    assert torch.equal(second["p1"][:, -1], forcing["p1"][:, -1])                            # prescribed: overwritten from step s + 1
+
+
+def test_engine_with_slab_ocean_hooks_as_torch_ops():
+    """corrector (force-positive) + slab ocean through the engine's torch-op hook path vs Stepper.predict"""
+    in_names = ["sst", "ocean_fraction", "mld", "qflux", "p0"]
+    out_names = ["sst", "p0", "DLWRFsfc", "DSWRFsfc", "ULWRFsfc", "USWRFsfc", "LHTFLsfc", "SHTFLsfc"]
+    ocean = {"surface_temperature_name": "sst", "ocean_fraction_name": "ocean_fraction",
+             "slab": {"mixed_layer_depth_name": "mld", "q_flux_name": "qflux"}}
+    from ace_amd.corrector import AtmosphereCorrectorConfig
+    config, names, norm = _config(in_names, out_names, ocean=ocean, corrector=AtmosphereCorrectorConfig(force_positive_names=["p0"]))
+    info = ace_amd.DatasetInfo((H, W), timestep=datetime.timedelta(hours=6))
+    torch.manual_seed(4)
+    stepper = ace_amd.Stepper.from_config(config, info, device="cpu")
+    ref = _reference_stepper(config, info, stepper)
+    B, T = 2, 3
+    g = torch.Generator().manual_seed(5)
+    ic = {"sst": 290.0 + torch.randn(B, 1, H, W, generator=g), "p0": torch.randn(B, 1, H, W, generator=g)}
+    forcing = {"ocean_fraction": torch.rand(B, T + 1, H, W, generator=g), "mld": 20.0 + 30.0 * torch.rand(B, T + 1, H, W, generator=g),
+               "qflux": 10.0 * torch.randn(B, T + 1, H, W, generator=g)}
+    want, _ = ref.predict(ic, forcing)
+    with fake_sfno():
+        out, _ = RolloutEngine(stepper, batch=B, n_forward_steps=T, graph=None).predict(ic, forcing)
+    for k in out_names:
+        assert float((out[k] - want[k]).abs().max()) <= 5e-6 * max(float(want[k].abs().max()), 1.0), k
+    assert float(out["p0"].min()) >= 0.0
+
+
+def test_derived_insolation_through_engine_windows_and_run_inference(tmp_path):
+    """A stepper whose configuration derives the insolation: RolloutEngine.predict(time=), EnginePredict on ForcingWindows that carry
+    their time slices, run_inference over uneven windows - all equal to handing the precomputed field in."""
+    from ace_amd.inference import EnginePredict, ForcingWindows, InferenceData, TensorFileWriter, run_inference
+    from ace_amd.timeaxis import TimeAxis
+    in_names, out_names = ["sun", "p0", "f1"], ["p0", "d0"]
+    names = sorted(set(in_names) | set(out_names))
+    norm = NormalizationConfig(means={k: (300.0 if k == "sun" else 0.2) for k in names}, stds={k: (400.0 if k == "sun" else 1.5) for k in names})
+    config = ace_amd.SingleModuleStepConfig(
+        builder=ace_amd.ModuleSelector(type="SphericalFourierNeuralOperatorNet", config={"embed_dim": 8, "num_layers": 2, "operator_type": "dhconv"}),
+        in_names=in_names, out_names=out_names, normalization=norm, next_step_forcing_names=["sun"])
+    info = ace_amd.DatasetInfo((H, W), lat=torch.linspace(-78.75, 78.75, H), lon=torch.arange(W) * 22.5)
+    derived = {"insolation": {"insolation_name": "sun", "solar_constant": {"value": 1360.0}}}
+    torch.manual_seed(6)
+    stepper = ace_amd.Stepper.from_config(config, info, device="cpu", derived_forcings=derived)
+    plain = ace_amd.Stepper.from_config(config, info, device="cpu")
+    plain._step_obj.module.torch_module.load_state_dict(stepper.modules[0].state_dict())
+    B, total, T = 2, 5, 2
+    g = torch.Generator().manual_seed(7)
+    ic = {"p0": torch.randn(B, 1, H, W, generator=g)}
+    record = {"f1": torch.randn(B, total + 1, H, W, generator=g)}
+    time = TimeAxis.regular((2022, 3, 20, 12), datetime.timedelta(hours=6), total + 1, B)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sun = stepper.forcing_deriver(record, time)["sun"]
+        assert float(sun.max()) > 800 and sun.shape == (B, total + 1, H, W)
+        with fake_sfno():
+            eng = RolloutEngine(stepper, batch=B, n_forward_steps=total, graph="step")
+            out, _ = eng.predict(ic, record, time=time)
+            out = {k: v.clone() for k, v in out.items()}
+            with pytest.raises(ValueError, match="time axis"):
+                eng.predict(ic, record)
+            explicit, _ = RolloutEngine(plain, batch=B, n_forward_steps=total, graph="step").predict(ic, {**record, "sun": sun})
+            for k in out_names:
+                assert torch.equal(out[k], explicit[k]), k
+            # the windowed driver: windows of 2, 2 and 1 steps, each with its own slice of the time axis
+            windows = ForcingWindows(record, total, T, device="cpu", time=time)
+            writer = TensorFileWriter(str(tmp_path))
+            final = run_inference(EnginePredict(stepper, batch=B, graph="step"), InferenceData(ic, windows), writer=writer)
+    series = torch.load(tmp_path / "autoregressive_predictions.pt")
+    for k in out_names:
+        assert float((series[k] - out[k]).abs().max()) <= 2e-6 * float(out[k].abs().max()), k
+    assert torch.equal(final["p0"].cpu(), series["p0"][:, -1:])
+    assert (float((out["p0"][:, 0] - ic["p0"][:, 0]).abs().max())) > 0
