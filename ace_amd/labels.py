@@ -24,23 +24,22 @@ class BatchLabels:
         return f"BatchLabels(names={self.names}, tensor={self.tensor})"
 
     def conform_to_encoding(self, encoding: "LabelEncoding") -> "BatchLabels":
-        """Columns re-ordered to the encoding's names; names the batch does not have become zero columns, names the encoding
-        does not have are dropped (with a warning)."""
-        if len(self.names) == 0:
-            return BatchLabels(torch.zeros((self.tensor.shape[0], len(encoding.names)), device=self.tensor.device), names=encoding.names)
-        old_index = {name: i for i, name in enumerate(self.names)}
-        new_names = encoding.names
-        idx = torch.tensor([old_index.get(name, -1) for name in new_names], dtype=torch.long, device=self.tensor.device)
-        new_mask = idx == -1
-        safe_idx = idx.clone()
-        safe_idx[new_mask] = 0
-        gathered = self.tensor[:, safe_idx]
-        if bool(new_mask.any()):
-            gathered[:, new_mask] = 0
-        dropped = self._names_set.difference(new_names)
-        if dropped:
-            logging.warning(f"Dropping labels not present in new encoding: {dropped}")
-        return BatchLabels(gathered, new_names)
+        """A new BatchLabels in the encoding's column order: a column this batch holds is copied, a name it does not hold becomes a
+        zero column, a name the encoding does not know is dropped (logged) - labels.py:35-89."""
+        target = encoding.names
+        n = self.tensor.shape[0]
+        if not self.names:
+            return BatchLabels(torch.zeros((n, len(target)), device=self.tensor.device), names=target)
+        column = {name: j for j, name in enumerate(self.names)}
+        out = self.tensor.new_zeros((n, len(target)))
+        held = [(j, column[name]) for j, name in enumerate(target) if name in column]
+        if held:
+            dst, src = zip(*held)
+            out[:, list(dst)] = self.tensor[:, list(src)]
+        unknown = self._names_set.difference(target)
+        if unknown:
+            logging.warning(f"Dropping labels not present in new encoding: {unknown}")
+        return BatchLabels(out, target)
 
     def __eq__(self, other: Any) -> bool:
         return isinstance(other, BatchLabels) and self.names == other.names and torch.equal(self.tensor, other.tensor)
@@ -64,12 +63,13 @@ class LabelEncoding:
         self.names = labels.copy()
 
     def encode(self, labels: List[Set[str]], device) -> BatchLabels:
-        rows = []
-        for batch_labels in labels:
-            if not batch_labels.issubset(self.names):
-                raise InvalidLabelError(f"Invalid labels: at least one of {batch_labels} is not in {self.names}")
-            rows.append([1 if label in batch_labels else 0 for label in self.names])
-        return BatchLabels(tensor=torch.tensor(rows, dtype=torch.float32, device=device), names=self.names)
+        """one row per batch member: 1 where the member carries the encoding's label (labels.py:131-160)"""
+        known = set(self.names)
+        for member in labels:
+            if not member <= known:
+                raise InvalidLabelError(f"Invalid labels: at least one of {member} is not in {self.names}")
+        onehot = torch.tensor([[float(name in member) for name in self.names] for member in labels], dtype=torch.float32, device=device)
+        return BatchLabels(tensor=onehot.reshape(len(labels), len(self.names)), names=self.names)
 
     def get_state(self) -> Dict[str, Any]:
         return {"labels": self.names}
