@@ -31,17 +31,20 @@ class Registry(Generic[T]):
     def __init__(self):
         self._types: Dict[str, Type[T]] = {}
 
+    def _base(self):
+        """the T of Registry[T] (set by typing on the instance), or None for an unparametrised registry"""
+        orig = getattr(self, "__orig_class__", None)
+        return orig.__args__[0] if orig is not None else None
+
     def register(self, type_name: str) -> Callable[[Type[T]], Type[T]]:
-        def register_func(cls: Type[T]) -> Type[T]:
-            base_type = None
-            if hasattr(self, "__orig_class__"):
-                base_type = self.__orig_class__.__args__[0]
-            if base_type and not issubclass(cls, base_type):
-                raise TypeError(f"{cls} must be a subclass of {base_type}")
+        """decorator: file the class under `type_name`; a class that is not a T is a TypeError"""
+        def add(cls: Type[T]) -> Type[T]:
+            base = self._base()
+            if base is not None and not issubclass(cls, base):
+                raise TypeError(f"{cls} must be a subclass of {base}")
             self._types[type_name] = cls
             return cls
-
-        return register_func
+        return add
 
     def get(self, type_name: str, config: Mapping[str, Any]) -> T:
         cls = self._types[type_name]  # KeyError for an unknown type, as the reference
@@ -89,15 +92,17 @@ class Module:
         return {**self._module.state_dict(), "label_encoding": enc}
 
     def load_state(self, state: Dict[str, Any]) -> None:
+        """module.py:102-112: the label encoding travels with the weights (its order is the order the weights were trained in);
+        the rest is a strict load_state_dict"""
         from .labels import LabelEncoding
-        state = dict(state)
-        if state.get("label_encoding") is not None:
-            if self._label_encoding is None:
-                self._label_encoding = LabelEncoding.from_state(state.pop("label_encoding"))
+        weights = {k: v for k, v in state.items() if k != "label_encoding"}
+        stored = state.get("label_encoding")
+        if stored is not None:
+            if self._label_encoding is not None:
+                self._label_encoding.conform_to_state(stored)
             else:
-                self._label_encoding.conform_to_state(state.pop("label_encoding"))
-        state.pop("label_encoding", None)
-        self._module.load_state_dict(state)
+                self._label_encoding = LabelEncoding.from_state(stored)
+        self._module.load_state_dict(weights)
 
     def wrap_module(self, callable: Callable[[nn.Module], nn.Module]) -> "Module":
         return Module(callable(self._module), self._label_encoding)
