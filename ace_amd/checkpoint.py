@@ -144,7 +144,7 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
     step_cfg.pop("normalization", None)
     builder = step_cfg.pop("builder")
     unsupported = []
-    for k in ("secondary_decoder", "global_mean_removal", "input_dropout"):
+    for k in ("global_mean_removal", "input_dropout"):
         if step_cfg.get(k) is not None:
             unsupported.append(k)
     if step_cfg.get("include_channel_mask_inputs"):

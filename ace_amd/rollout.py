@@ -27,6 +27,8 @@ class RolloutEngine:
             raise ValueError("graph must be None, 'step' or 'window'")
         step = stepper._step_obj
         cfg = step.config
+        if getattr(step, "secondary_decoder", None) is not None:
+            raise NotImplementedError("RolloutEngine: the secondary decoder's diagnostics are produced by Stepper.predict")
         if getattr(stepper, "_multi_call", None) is not None:
             raise NotImplementedError("RolloutEngine: multi-call diagnostics (extra evaluations of the step with a scaled forcing) are "
                                       "produced by Stepper.predict; use it, or load with StepperOverrideConfig(multi_call=None)")

@@ -67,6 +67,64 @@ class StepOutput:
 
 
 @dataclasses.dataclass
+class SecondaryDecoderConfig:
+    """fme/core/step/secondary_decoder.py:16-42: additional diagnostics computed column-locally from the network's (normalised)
+    output tensor by a second registry network (normally the "MLP")."""
+    secondary_diagnostic_names: List[str]
+    network: Any
+
+    def __post_init__(self):
+        self.secondary_diagnostic_names = list(self.secondary_diagnostic_names)
+        if isinstance(self.network, Mapping):
+            self.network = ModuleSelector(**{k: (dict(v) if k == "config" else v) for k, v in self.network.items()})
+
+    @classmethod
+    def from_state(cls, state) -> Optional["SecondaryDecoderConfig"]:
+        if state is None or isinstance(state, cls):
+            return state
+        extra = set(state) - {"secondary_diagnostic_names", "network"}
+        if extra:
+            raise ValueError(f'can not match {sorted(extra)} to any data class field of "SecondaryDecoderConfig"')
+        return cls(**state)
+
+    def build(self, n_in_channels: int, dataset_info) -> "SecondaryDecoder":
+        return SecondaryDecoder(n_in_channels, self.secondary_diagnostic_names, self.network, dataset_info)
+
+
+class SecondaryDecoder:
+    """secondary_decoder.py:45-112."""
+    CHANNEL_DIM = -3
+
+    def __init__(self, in_dim: int, out_names: List[str], network: ModuleSelector, dataset_info):
+        self._module = network.build(n_in_channels=in_dim, n_out_channels=len(out_names), dataset_info=dataset_info)
+        self._packer = Packer(list(out_names))
+
+    @property
+    def torch_modules(self) -> nn.ModuleList:
+        return nn.ModuleList([self._module.torch_module])
+
+    def to(self, device) -> "SecondaryDecoder":
+        self._module = self._module.to(device)
+        return self
+
+    def wrap_module(self, wrapper) -> "SecondaryDecoder":
+        self._module = self._module.wrap_module(wrapper)
+        return self
+
+    def __call__(self, x: torch.Tensor) -> TensorDict:
+        return self._packer.unpack(self._module(x), axis=self.CHANNEL_DIM)
+
+    def get_module_state(self) -> dict:
+        return self._module.get_state()
+
+    def load_module_state(self, state: dict) -> None:
+        state = dict(state)
+        if state and all(k.startswith("module.") or k == "label_encoding" for k in state):      # DummyWrapper / DDP prefix
+            state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state.items()}
+        self._module.load_state(state)
+
+
+@dataclasses.dataclass
 class SingleModuleStepConfig:
     """single_module.py:48-259, restricted to the options on the hot path."""
 
@@ -87,9 +145,10 @@ class SingleModuleStepConfig:
     def __post_init__(self):
         from .corrector import AtmosphereCorrectorConfig
         from .ocean import OceanConfig
-        for field in ("secondary_decoder", "global_mean_removal", "input_dropout"):
+        for field in ("global_mean_removal", "input_dropout"):
             if getattr(self, field) is not None:
                 raise NotImplementedError(f"SingleModuleStepConfig.{field} is outside the accelerated hot path")
+        self.secondary_decoder = SecondaryDecoderConfig.from_state(self.secondary_decoder)
         # ocean / corrector: dataclass instances or their state dicts (as found in a checkpoint's step config)
         if isinstance(self.ocean, dict):
             self.ocean = OceanConfig.from_state(self.ocean)
@@ -109,6 +168,12 @@ class SingleModuleStepConfig:
                 raise ValueError(f"next_step_forcing_name '{name}' not in in_names: {self.in_names}")
             if name in self.out_names:
                 raise ValueError(f"next_step_forcing_name is an output variable: '{name}'")
+        if self.secondary_decoder is not None:
+            for name in self.secondary_decoder.secondary_diagnostic_names:
+                if name in self.in_names:
+                    raise ValueError(f"secondary_diagnostic_name is an input variable: '{name}'")
+                if name in self.out_names:
+                    raise ValueError(f"secondary_diagnostic_name is an output variable: '{name}'")
 
     @property
     def n_ic_timesteps(self) -> int:
@@ -116,7 +181,7 @@ class SingleModuleStepConfig:
 
     @property
     def _normalize_names(self):
-        return list(set(self.in_names).union(self.out_names))
+        return list(set(self.in_names).union(self.output_names))
 
     @property
     def input_names(self) -> List[str]:
@@ -126,7 +191,9 @@ class SingleModuleStepConfig:
 
     @property
     def output_names(self) -> List[str]:
-        return list(self.out_names)
+        """the network's outputs, then the secondary decoder's diagnostics (single_module.py:179-188)"""
+        extra = self.secondary_decoder.secondary_diagnostic_names if self.secondary_decoder is not None else []
+        return list(self.out_names) + [n for n in extra if n not in self.out_names]
 
     @property
     def prognostic_names(self) -> List[str]:
@@ -195,6 +262,8 @@ class SingleModuleStep:
                                       dataset_info=dataset_info)
         dev = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
         self.module = module.to(dev)
+        self.secondary_decoder = (config.secondary_decoder.build(n_in_channels=n_out_channels, dataset_info=dataset_info).to(dev)
+                                  if config.secondary_decoder is not None else None)
         init_weights(self.modules)
         self._img_shape = dataset_info.img_shape
         self._config = config
@@ -237,7 +306,10 @@ class SingleModuleStep:
 
     @property
     def modules(self) -> nn.ModuleList:
-        return nn.ModuleList([self.module.torch_module])
+        mods = [self.module.torch_module]
+        if self.secondary_decoder is not None:
+            mods.extend(self.secondary_decoder.torch_modules)
+        return nn.ModuleList(mods)
 
     def step(self, args: StepArgs, wrapper: Callable[[nn.Module], nn.Module] = lambda x: x) -> StepOutput:
         def network_call(input_norm: TensorDict) -> TensorDict:
@@ -245,7 +317,10 @@ class SingleModuleStep:
                 raise NotImplementedError("data masks are outside the accelerated hot path")
             input_tensor = self.in_packer.pack(input_norm, axis=self.CHANNEL_DIM)
             output_tensor = self.module.wrap_module(wrapper)(input_tensor, labels=args.labels)
-            return self.out_packer.unpack(output_tensor, axis=self.CHANNEL_DIM)
+            output = self.out_packer.unpack(output_tensor, axis=self.CHANNEL_DIM)
+            if self.secondary_decoder is not None:      # column-local diagnostics from the same normalised tensor (single_module.py:430-434)
+                output.update(self.secondary_decoder(output_tensor))
+            return output
 
         return step_with_adjustments(
             input=args.input, next_step_input_data=args.next_step_input_data, network_calls=network_call,
@@ -256,7 +331,8 @@ class SingleModuleStep:
         )
 
     def get_state(self):
-        return {"module": self.module.get_state()}
+        return {"module": self.module.get_state(),
+                "secondary_decoder": self.secondary_decoder.get_module_state() if self.secondary_decoder is not None else None}
 
     def load_state(self, state: Dict[str, Any]) -> None:
         module = dict(state["module"])
@@ -266,3 +342,5 @@ class SingleModuleStep:
         if module and all(k.startswith("module.") or k == "label_encoding" for k in module):
             module = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in module.items()}
         self.module.load_state(module)
+        if self.secondary_decoder is not None and state.get("secondary_decoder") is not None:
+            self.secondary_decoder.load_module_state(state["secondary_decoder"])

@@ -1,6 +1,7 @@
 """TEST INFRASTRUCTURE: an emulation of the ``ace_hpx_*`` C-ABI operators (include/ace_sfno.h, csrc/healpix.hip) on host memory,
 in plain torch fp32 / fp64 arithmetic, so that the HOST logic of ace_amd/healpix.py - layouts, pitches, padding tables, row-offset
-tables, weight preparation order, block composition, skip handling - can be checked against the reference's golden outputs in
+tables, weight preparation order, block composition, skip handling - and of ace_amd/mlp.py (the "MLP" registry network on the
+k = 1 operator) can be checked against the reference's golden outputs in
 the ``-m "not gpu"`` suite.  It restates what each entry point is documented to compute (the comments above each function in
 healpix.hip); it is NOT a fallback: nothing in the product imports it, ``HEALPixUNet.forward`` still refuses host tensors, and the
 GPU tests run the real kernels.  Use: ``with fake_hpx(): net._run(x)``."""
@@ -164,15 +165,17 @@ class FakeHpx:
 def fake_hpx():
     """ace_amd.healpix bound to the emulation for the duration of the block (its runtime caches are reset on both sides)."""
     import ace_amd.healpix as hp
+    import ace_amd.mlp as mlp
     from ace_amd import _lib as real
     fake = FakeHpx(real.lib())
-    saved = hp._lib
-    hp._lib = fake
+    saved = (hp._lib, mlp._lib, mlp.ColumnMLP.forward)
+    hp._lib = mlp._lib = fake
+    mlp.ColumnMLP.forward = mlp.ColumnMLP._run          # the body without the "must be on the GPU" guard
     hp._RT.__init__()
     hp._IDENTITY.clear()
     try:
         yield fake
     finally:
-        hp._lib = saved
+        hp._lib, mlp._lib, mlp.ColumnMLP.forward = saved
         hp._RT.__init__()
         hp._IDENTITY.clear()

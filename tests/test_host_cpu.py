@@ -201,9 +201,12 @@ def test_step_config_validation_and_names():
                                        prescribed_prognostic_names=["zz"])
     with pytest.raises(NotImplementedError):
         ace_amd.SingleModuleStepConfig(builder=b, in_names=["a"], out_names=["a"], normalization=norm, ocean=object())
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):           # built since round 3 (tests/test_step_options.py): a malformed state is a ValueError
         ace_amd.SingleModuleStepConfig(builder=b, in_names=["a"], out_names=["a"], normalization=norm,
                                        secondary_decoder={"x": 1})
+    with pytest.raises(NotImplementedError):
+        ace_amd.SingleModuleStepConfig(builder=b, in_names=["a"], out_names=["a"], normalization=norm,
+                                       global_mean_removal={"x": 1})
 
 
 def test_stepper_loop_bookkeeping_with_a_stub_module():
