@@ -27,8 +27,11 @@ class RolloutEngine:
             raise ValueError("graph must be None, 'step' or 'window'")
         step = stepper._step_obj
         cfg = step.config
-        if getattr(step, "secondary_decoder", None) is not None:
-            raise NotImplementedError("RolloutEngine: the secondary decoder's diagnostics are produced by Stepper.predict")
+        # secondary decoder (fme/core/step/secondary_decoder.py): column-local diagnostics decoded from the network's normalised
+        # output tensor - one more native module call on the static y buffer per step and a second fused unpack
+        self._secondary = getattr(step, "secondary_decoder", None)
+        if self._secondary is not None and graph == "window":
+            raise NotImplementedError("graph='window' with a secondary decoder: its module call is not captured; use graph='step'")
         if getattr(stepper, "_multi_call", None) is not None:
             raise NotImplementedError("RolloutEngine: multi-call diagnostics (extra evaluations of the step with a scaled forcing) are "
                                       "produced by Stepper.predict; use it, or load with StepperOverrideConfig(multi_call=None)")
@@ -72,6 +75,9 @@ class RolloutEngine:
         self.target_names = sorted(extra - set(self.forcing_names))
         self.target = {n: torch.zeros(B, T + 1, H, W, **f32) for n in self.target_names}
         self.out = {n: torch.zeros(B, T, H, W, **f32) for n in self.out_names}
+        self.sec_names = list(cfg.secondary_decoder.secondary_diagnostic_names) if self._secondary is not None else []
+        for n in self.sec_names:
+            self.out[n] = torch.zeros(B, T, H, W, **f32)
         norm = step.normalizer
         if norm.fill_nans_on_normalize or norm.fill_nans_on_denormalize:
             # normalizer.py:212-242: the fused pack/unpack kernels do not replace NaNs
@@ -106,6 +112,12 @@ class RolloutEngine:
         self._src_ptr_addr = [self._src_ptrs.data_ptr() + 8 * s * nin for s in range(T)]
         self._src_stride_addr = [self._src_strides.data_ptr() + 8 * s * nin for s in range(T)]
         self._dst_ptr_addr = [self._dst_ptrs.data_ptr() + 8 * s * nout for s in range(T)]
+        if self.sec_names:
+            self.sec_mean = torch.stack([norm.means[n].to(dev) for n in self.sec_names]).contiguous()
+            self.sec_std = torch.stack([norm.stds[n].to(dev) for n in self.sec_names]).contiguous()
+            self._sec_dst_ptrs = torch.tensor([[self.out[n].data_ptr() + 4 * s * self.HW for n in self.sec_names] for s in range(T)], **i64)
+            self._sec_dst_strides = torch.full((len(self.sec_names),), T * self.HW, **i64)
+            self._sec_dst_ptr_addr = [self._sec_dst_ptrs.data_ptr() + 8 * s * len(self.sec_names) for s in range(T)]
         # residual prediction (single_module.py:663-664): normalised prognostic inputs are added to the network output
         self._res_in = self._res_out = None
         if cfg.residual_prediction:
@@ -163,6 +175,11 @@ class RolloutEngine:
         else:
             fwd = L.ace_sfno_forward_graph if use_library_graph else L.ace_sfno_forward
             _lib.check(fwd(self.net._native, self.x.data_ptr(), self.y.data_ptr(), self.B, stream))
+        if self._secondary is not None:      # decoded from the raw network output, before the residual is added (single_module.py:430-434)
+            sec = self._secondary._module(self.y).contiguous()
+            _lib.check(L.ace_unpack_denormalize(sec.data_ptr(), self.sec_mean.data_ptr(), self.sec_std.data_ptr(),
+                                                self._sec_dst_ptr_addr[s], self._sec_dst_strides.data_ptr(),
+                                                self.B, len(self.sec_names), self.HW, stream))
         if self._res_in is not None:
             self.y.index_add_(1, self._res_out, self.x.index_select(1, self._res_in))
         _lib.check(L.ace_unpack_denormalize(self.y.data_ptr(), self.out_mean.data_ptr(), self.out_std.data_ptr(),

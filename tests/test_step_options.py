@@ -77,9 +77,29 @@ def test_stepper_with_multi_call_and_secondary_decoder_vs_reference_rollout():
     assert set(out2) == {k for k in g["steps"][0] if "co2" not in k}
     for k in out2:
         assert torch.equal(out2[k], out[k]), k
-    with pytest.raises(NotImplementedError, match="secondary decoder"):
-        from ace_amd.rollout import RolloutEngine
-        RolloutEngine(off, batch=2, n_forward_steps=3)
+
+
+def test_rollout_engine_with_secondary_decoder_host_logic():
+    """the engine calls the decoder's module on its static network-output buffer and unpacks the result with a second pointer
+    table - against Stepper.predict, on the emulations of both halves of the C ABI"""
+    from ace_amd.rollout import RolloutEngine
+    from _fake_sfno import fake_sfno
+    g = load_golden("gen_step_options.pt")["stepper"]
+    eng_st = load_stepper(g["state"], StepperOverrideConfig(multi_call=None), device="cpu").stepper
+    ref_st = _with_oracle_network(load_stepper(g["state"], StepperOverrideConfig(multi_call=None), device="cpu").stepper, 4, 4, (8, 16), 12)
+    with fake_hpx(), torch.no_grad():
+        want, _ = _rollout(ref_st, g)
+        with fake_sfno():
+            eng = RolloutEngine(eng_st, batch=2, n_forward_steps=3, graph="step")
+            out, state = eng.predict(g["ic"], g["forcing"])
+            with pytest.raises(NotImplementedError, match="window"):
+                RolloutEngine(eng_st, batch=2, n_forward_steps=3, graph="window")
+    assert set(out) == set(want) and {"s0", "s1"} <= set(out)
+    for k in out:
+        assert rel_max(out[k], want[k]) <= 5e-6, (k, rel_max(out[k], want[k]))
+    multi = load_stepper(g["state"], device="cpu").stepper
+    with pytest.raises(NotImplementedError, match="multi-call"):
+        RolloutEngine(multi, batch=2, n_forward_steps=3)
 
 
 def test_secondary_decoder_configuration_errors():
@@ -129,3 +149,10 @@ def test_stepper_with_multi_call_and_secondary_decoder_on_the_device():
         batched, _ = st.predict(ic, forcing)
     for k in out:
         assert rel_max(batched[k], out[k]) <= 2e-6, k
+    # the static-buffer engine produces the decoder's diagnostics too (not the multi-call ones)
+    from ace_amd.rollout import RolloutEngine
+    st.replace_multi_call(None)
+    eng_out, _ = RolloutEngine(st, batch=2, n_forward_steps=3, graph="step").predict(ic, forcing)
+    assert {"s0", "s1"} <= set(eng_out)
+    for k in eng_out:
+        assert rel_max(eng_out[k], out[k]) <= 5e-6, k
