@@ -50,7 +50,11 @@ def _img_shape_from_dataset_state(ds: Mapping[str, Any]) -> Tuple[int, int]:
     if hc is not None:
         if "lat" in hc and "lon" in hc:                      # LatLonCoordinates.get_state (coordinates.py:708-709)
             return (int(len(hc["lat"])), int(len(hc["lon"])))
-        raise NotImplementedError("HEALPix coordinates are outside the accelerated hot path")
+        if "face" in hc and "height" in hc and "width" in hc:    # HEALPixCoordinates (coordinates.py:716-799): the face's (height, width)
+            if len(hc["face"]) != 12:
+                raise ValueError("HEALPixCoordinates must have 12 faces.")
+            return (int(len(hc["height"])), int(len(hc["width"])))
+        raise ValueError(f"unknown horizontal coordinates in the checkpoint's dataset_info: {sorted(hc)}")
     go = ds.get("gridded_operations")
     if go is not None and "state" in go and "area_weights" in go["state"]:
         aw = go["state"]["area_weights"]

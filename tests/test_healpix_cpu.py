@@ -170,3 +170,34 @@ def test_symmetric_convnext_blocks_mirror_the_reference_parameters():
     blocks = [m for m in net.modules() if isinstance(m, SymmetricConvNeXtBlock)]
     assert any(b.skip_module is None for b in blocks) and any(b.skip_module is not None for b in blocks)
     assert any(isinstance(m, Multi_SymmetricConvNeXtBlock) and len(m.blocks) == 2 for m in net.modules())
+
+
+def test_checkpoint_of_a_healpix_stepper_loads(gold):
+    """load_stepper of a stepper state whose network is the HEALPixUNet and whose dataset_info carries HEALPixCoordinates
+    (fme/core/coordinates.py:716-799: face / height / width): the face size is the image shape, the weights load strictly."""
+    import datetime
+
+    from ace_amd.checkpoint import load_stepper
+    g = gold["unet"]["basic_maxpool"]
+    case = g["case"]
+    names = [f"v{i}" for i in range(max(case["n_in"], case["n_out"]))]
+    state = {"stepper": {
+        "config": {"step": {"type": "single_module", "config": {
+            "builder": {"type": "HEALPixUNet", "config": case["config"]}, "in_names": names[: case["n_in"]],
+            "out_names": names[: case["n_out"]],
+            "normalization": {"network": {"means": {n: 0.0 for n in names}, "stds": {n: 1.0 for n in names}}},
+            "ocean": None, "corrector": {"type": "atmosphere_corrector", "config": {}}}}},
+        "dataset_info": {"horizontal_coordinates": {"face": torch.arange(12.0), "height": torch.arange(float(case["nside"])),
+                                                    "width": torch.arange(float(case["nside"]))},
+                         "timestep": datetime.timedelta(hours=6) // datetime.timedelta(microseconds=1)},
+        "step": {"module": {**{f"module.{k}": v for k, v in g["state_dict"].items()}, "label_encoding": None}}}}
+    loaded = load_stepper(state, device="cpu")
+    assert loaded.dataset_info.img_shape == (case["nside"], case["nside"])
+    net = loaded.stepper.modules[0]
+    assert type(net).__name__ == "HEALPixUNet"
+    for k, v in g["state_dict"].items():
+        assert torch.equal(net.state_dict()[k], v)
+    bad = {"stepper": {**state["stepper"], "dataset_info": {"horizontal_coordinates": {"face": torch.arange(11.0), "height": torch.arange(8.0),
+                                                                                         "width": torch.arange(8.0)}}}}
+    with pytest.raises(ValueError, match="12 faces"):
+        load_stepper(bad, device="cpu")
