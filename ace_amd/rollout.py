@@ -79,10 +79,9 @@ class RolloutEngine:
         for n in self.sec_names:
             self.out[n] = torch.zeros(B, T, H, W, **f32)
         norm = step.normalizer
-        if norm.fill_nans_on_normalize or norm.fill_nans_on_denormalize:
-            # normalizer.py:212-242: the fused pack/unpack kernels do not replace NaNs
-            raise NotImplementedError("RolloutEngine: fill_nans_on_normalize / fill_nans_on_denormalize are not implemented "
-                                      "in the fused pack/unpack kernels; use Stepper.predict")
+        # normalizer.py:212-242: NaNs become 0 in normalised space (inputs) / the variable's mean (outputs).  The fused pack / unpack
+        # kernels do not replace NaNs: one in-place pass over the packed tensor on either side when the normaliser asks for it
+        self._fill_in, self._fill_out = bool(norm.fill_nans_on_normalize), bool(norm.fill_nans_on_denormalize)
         self.in_mean = torch.stack([norm.means[n].to(dev) for n in self.in_names]).contiguous()
         self.in_std = torch.stack([norm.stds[n].to(dev) for n in self.in_names]).contiguous()
         self.out_mean = torch.stack([norm.means[n].to(dev) for n in self.out_names]).contiguous()
@@ -168,6 +167,8 @@ class RolloutEngine:
         _lib.check(L.ace_pack_normalize(self._src_ptr_addr[s], self._src_stride_addr[s],
                                         self.in_mean.data_ptr(), self.in_std.data_ptr(), self.x.data_ptr(),
                                         self.B, nin, self.HW, stream))
+        if self._fill_in:
+            torch.nan_to_num_(self.x, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
         if self._conditioned:   # NoiseConditionedSFNO: fresh conditioning noise every step (stochastic_sfno.py:128-146), merged
             noise = self.net.conditioning_field(self.B, self.device, labels=self._labels)   # with the label / positional context
             _lib.check(L.ace_sfno_forward_conditioned(self.net._native, self.x.data_ptr(), noise.data_ptr(), self.y.data_ptr(),
@@ -182,6 +183,8 @@ class RolloutEngine:
                                                 self.B, len(self.sec_names), self.HW, stream))
         if self._res_in is not None:
             self.y.index_add_(1, self._res_out, self.x.index_select(1, self._res_in))
+        if self._fill_out:      # 0 in normalised space denormalises to the mean
+            torch.nan_to_num_(self.y, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
         _lib.check(L.ace_unpack_denormalize(self.y.data_ptr(), self.out_mean.data_ptr(), self.out_std.data_ptr(),
                                             self._dst_ptr_addr[s], self._dst_strides.data_ptr(),
                                             self.B, nout, self.HW, stream))

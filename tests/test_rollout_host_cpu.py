@@ -169,3 +169,30 @@ def test_derived_insolation_through_engine_windows_and_run_inference(tmp_path):
         assert float((series[k] - out[k]).abs().max()) <= 2e-6 * float(out[k].abs().max()), k
     assert torch.equal(final["p0"].cpu(), series["p0"][:, -1:])
     assert (float((out["p0"][:, 0] - ic["p0"][:, 0]).abs().max())) > 0
+
+
+def test_engine_fills_nans_as_the_normaliser_does():
+    """fill_nans_on_normalize / fill_nans_on_denormalize (fme/core/normalizer.py:212-242): a masked (NaN) region of a forcing enters
+    the network as 0 in normalised space - same rollout as Stepper.predict."""
+    in_names, out_names = ["f0", "p0"], ["p0", "d0"]
+    names = sorted(set(in_names) | set(out_names))
+    norm = NormalizationConfig(means={k: 0.3 * (i + 1) for i, k in enumerate(names)}, stds={k: 1.0 + 0.2 * i for i, k in enumerate(names)},
+                               fill_nans_on_normalize=True, fill_nans_on_denormalize=True)
+    config = ace_amd.SingleModuleStepConfig(
+        builder=ace_amd.ModuleSelector(type="SphericalFourierNeuralOperatorNet", config={"embed_dim": 8, "num_layers": 2, "operator_type": "dhconv"}),
+        in_names=in_names, out_names=out_names, normalization=norm)
+    info = ace_amd.DatasetInfo((H, W))
+    torch.manual_seed(8)
+    stepper = ace_amd.Stepper.from_config(config, info, device="cpu")
+    ref = _reference_stepper(config, info, stepper)
+    B, T = 2, 3
+    g = torch.Generator().manual_seed(9)
+    ic = {"p0": torch.randn(B, 1, H, W, generator=g)}
+    forcing = {"f0": torch.randn(B, T + 1, H, W, generator=g)}
+    forcing["f0"][:, :, :2, :5] = float("nan")                      # a "land" patch the data does not cover
+    want, _ = ref.predict(ic, forcing)
+    with fake_sfno():
+        out, _ = RolloutEngine(stepper, batch=B, n_forward_steps=T, graph="step").predict(ic, forcing)
+    for k in out_names:
+        assert bool(torch.isfinite(out[k]).all()), k
+        assert float((out[k] - want[k]).abs().max()) <= 5e-6 * float(want[k].abs().max()), k
