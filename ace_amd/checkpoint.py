@@ -13,8 +13,7 @@ Module weights are loaded with the strict ``load_state_dict`` the reference uses
 the "module." prefix of wrapped modules is accepted (fme/core/distributed/non_distributed.py:15-28).
 
 What is NOT carried over (and why) is returned in ``LoadedStepper.ignored``: training history, loss configuration,
-parameter-init configuration, an empty mask provider; input masking and a mask provider with masks
-raise unless ``ignore_unsupported=True``.  ``derived_forcings`` (the insolation computed from the time axis) is built
+parameter-init configuration.  Input masking and the dataset's mask provider are carried in (ace_amd/masking.py).  ``derived_forcings`` (the insolation computed from the time axis) is built
 (ace_amd/derived_forcings.py): the stepper then wants the times of every forcing window.  Latitudes / area weights and the hybrid-sigma
 coefficients are kept for the conservation correctors (ace_amd/corrector.py).  Features that change the rollout and are not
 implemented raise ``NotImplementedError`` unless ``ignore_unsupported=True``.
@@ -95,6 +94,7 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
     from .multi_call import MultiCallConfig
     ignored: List[str] = []
     multi_call = None
+    input_masking = None
     cfg = state["config"]
     derived_forcings = DerivedForcingsConfig.from_state(cfg.get("derived_forcings") if "step" in cfg else None)
     if "step" in cfg:                                         # ---- new format
@@ -108,15 +108,8 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
             step_state = step_state["wrapped_step"]
         if step_type not in _STEP_TYPES:
             raise NotImplementedError(f"step type '{step_type}' is outside the accelerated hot path")
-        # changes the rollout in the reference (input_process_func on every step, single_module.py:615-632): never dropped
-        # silently.  (derived_forcings - the insolation computed from the time axis - is built: ace_amd/derived_forcings.py.)
-        for k in ("input_masking",):
-            v = cfg.get(k)
-            if v not in (None, {}):
-                if not ignore_unsupported:
-                    raise NotImplementedError(f"StepperConfig.{k} is configured in this checkpoint and is outside the "
-                                              "accelerated hot path (pass ignore_unsupported=True to drop it)")
-                ignored.append(k)
+        # static input masking (input_process_func on every step, single_module.py:615-632): ace_amd/masking.py
+        input_masking = cfg.get("input_masking")
         ds_state = state["dataset_info"]
         normalization = _normalization_from_state(step_cfg["normalization"])
     else:                                                     # ---- legacy single-module stepper
@@ -164,13 +157,9 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
         raise ValueError(f"unknown step config fields: {sorted(unknown)}")
     config = SingleModuleStepConfig(builder=ModuleSelector(type=builder["type"], config=dict(builder["config"])),
                                     normalization=normalization, **step_cfg)
+    from .masking import SpatialMaskProvider
     mp = ds_state.get("mask_provider")
-    if mp is not None:
-        # a provider with masks drives the reference's output masking (single_module.py _output_masking): results differ
-        if isinstance(mp, Mapping) and mp.get("masks") and not ignore_unsupported:
-            raise NotImplementedError("dataset_info.mask_provider carries masks (output masking) - outside the accelerated "
-                                      "hot path (pass ignore_unsupported=True to drop it)")
-        ignored.append("dataset_info.mask_provider")
+    provider = SpatialMaskProvider.from_state(mp) if isinstance(mp, Mapping) else None      # drives the output masking (and input_masking)
     if ds_state.get("variable_metadata") is not None:
         ignored.append("dataset_info.variable_metadata")
     labels = ds_state.get("all_labels") or None
@@ -181,7 +170,7 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
     area = go.get("state", {}).get("area_weights") if isinstance(go, Mapping) else None
     dataset_info = DatasetInfo(_img_shape_from_dataset_state(ds_state), all_labels=set(labels) if labels else None,
                                timestep=_timestep_from_dataset_state(ds_state), lat=hc.get("lat"), lon=hc.get("lon"),
-                               ak=vc.get("ak"), bk=vc.get("bk"), area_weights=area)
+                               ak=vc.get("ak"), bk=vc.get("bk"), area_weights=area, mask_provider=provider)
     missing = config.corrector.unsupported(dataset_info)
     if missing:
         if not ignore_unsupported:
@@ -199,6 +188,7 @@ def stepper_config_from_state(state: Mapping[str, Any], ignore_unsupported: bool
         derived_forcings = DerivedForcingsConfig()
     config._derived_forcings = derived_forcings
     config._multi_call = multi_call
+    config._input_masking = input_masking
     return config, dataset_info, step_state, ignored
 
 
@@ -238,7 +228,7 @@ def load_stepper(checkpoint: Union[str, pathlib.Path, Mapping[str, Any]],
     state = checkpoint["stepper"] if "stepper" in checkpoint else checkpoint
     config, dataset_info, step_state, ignored = stepper_config_from_state(state, ignore_unsupported)
     stepper = Stepper.from_config(config, dataset_info, device=device, derived_forcings=getattr(config, "_derived_forcings", None),
-                                  multi_call=getattr(config, "_multi_call", None))
+                                  multi_call=getattr(config, "_multi_call", None), input_masking=getattr(config, "_input_masking", None))
     stepper.load_state({"step": step_state})
     apply_stepper_override(stepper, override_config)
     stepper.set_eval()

@@ -9,7 +9,7 @@ from typing import Optional, Set, Tuple
 class DatasetInfo:
     def __init__(self, img_shape: Tuple[int, int], all_labels: Optional[Set[str]] = None,
                  timestep: datetime.timedelta = datetime.timedelta(hours=6), lat=None, lon=None, ak=None, bk=None,
-                 area_weights=None):
+                 area_weights=None, mask_provider=None):
         """``lat``/``lon`` (degrees; LatLonCoordinates, fme/core/coordinates.py:608-709) give the area weights of the
         conservation correctors, ``ak``/``bk`` the hybrid sigma-pressure interfaces
         (HybridSigmaPressureCoordinate, coordinates.py:150-280); all optional."""
@@ -19,6 +19,7 @@ class DatasetInfo:
         self._area_weights = None
         self._vertical_coordinate = None
         self._horizontal_coordinates = None
+        self._mask_provider = mask_provider          # ace_amd.masking.SpatialMaskProvider or None
         if lat is not None and lon is not None:
             from .insolation import LatLonGrid
             import torch
@@ -49,6 +50,11 @@ class DatasetInfo:
     def horizontal_coordinates(self):
         """1-D lat / lon in degrees with a ``meshgrid`` (what the derived insolation reads), or None."""
         return self._horizontal_coordinates
+
+    @property
+    def mask_provider(self):
+        """the dataset's static masks (fme/core/spatial_mask_provider.py), or None"""
+        return self._mask_provider
 
     @property
     def vertical_coordinate(self):

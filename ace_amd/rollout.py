@@ -32,6 +32,9 @@ class RolloutEngine:
         self._secondary = getattr(step, "secondary_decoder", None)
         if self._secondary is not None and graph == "window":
             raise NotImplementedError("graph='window' with a secondary decoder: its module call is not captured; use graph='step'")
+        if getattr(stepper, "_masks", False):
+            raise NotImplementedError("RolloutEngine: static spatial masking of the step inputs / outputs (input_masking, the dataset's "
+                                      "mask provider) is applied by Stepper.predict")
         if getattr(stepper, "_multi_call", None) is not None:
             raise NotImplementedError("RolloutEngine: multi-call diagnostics (extra evaluations of the step with a scaled forcing) are "
                                       "produced by Stepper.predict; use it, or load with StepperOverrideConfig(multi_call=None)")

@@ -44,7 +44,7 @@ class Stepper:
     TIME_DIM = 1
     CHANNEL_DIM = -3
 
-    def __init__(self, step_obj: SingleModuleStep, derived_forcings=None, dataset_info=None, multi_call=None):
+    def __init__(self, step_obj: SingleModuleStep, derived_forcings=None, dataset_info=None, multi_call=None, input_masking=None):
         from .derived_forcings import DerivedForcingsConfig
         self._step_obj = step_obj
         # multi-call diagnostics (the reference's MultiCallStep wrapper, fme/core/step/multi_call.py): held beside the step
@@ -55,15 +55,29 @@ class Stepper:
         # forcings computed from the time axis (StepperConfig.derived_forcings, single_module.py:532-539, 870)
         self._derived_forcings = DerivedForcingsConfig.from_state(derived_forcings)
         self.forcing_deriver = self._derived_forcings.build(dataset_info)
+        # static spatial masking (StepperConfig.input_masking + the dataset's mask provider, single_module.py:615-632): inputs of every
+        # step get a fill value in masked regions, outputs NaN where the data has no valid points
+        from .masking import StaticSpatialMaskingConfig
+        self._input_masking_config = StaticSpatialMaskingConfig.from_state(input_masking)
+        provider = getattr(dataset_info, "mask_provider", None)
         self._input_process_func: Callable[[TensorMapping], TensorMapping] = lambda x: x
         self._output_masking: Callable[[TensorMapping], TensorDict] = lambda x: dict(x)
+        self._masks = False
+        if self._input_masking_config is not None:
+            if provider is None:
+                raise ValueError("input_masking needs the dataset's masks (dataset_info.mask_provider)")
+            self._input_process_func = self._input_masking_config.build(mask=provider, means=step_obj.normalizer.means)
+            self._masks = True
+        if provider is not None and provider:
+            self._output_masking = provider.build_output_spatial_masker()
+            self._masks = True
 
     @classmethod
     def from_config(cls, config: SingleModuleStepConfig, dataset_info, device=None, derived_forcings=None,
-                    multi_call=None) -> "Stepper":
+                    multi_call=None, input_masking=None) -> "Stepper":
         normalizer = config.normalization.build(config._normalize_names, device=device)
         return cls(SingleModuleStep(config, dataset_info, normalizer, device=device), derived_forcings=derived_forcings,
-                   dataset_info=dataset_info, multi_call=multi_call)
+                   dataset_info=dataset_info, multi_call=multi_call, input_masking=input_masking)
 
     # -- properties (single_module.py:960-1043)
     @property
