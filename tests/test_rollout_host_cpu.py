@@ -196,3 +196,49 @@ def test_engine_fills_nans_as_the_normaliser_does():
     for k in out_names:
         assert bool(torch.isfinite(out[k]).all()), k
         assert float((out[k] - want[k]).abs().max()) <= 5e-6 * float(want[k].abs().max()), k
+
+
+@pytest.mark.parametrize("case,graph", [("ace2_like", None), ("ace2_like", "step"), ("residual_prescribed", "step"),
+                                        ("ace2_like_override", None)])
+def test_engine_host_logic_vs_the_real_reference_stepper_rollout(case, graph):
+    """The CPU counterpart of the GPU suite's drop-in check: a state written by the REAL reference stepper
+    (tests/golden/gen_checkpoint.pt) loaded by ace_amd.load_stepper and rolled by the RolloutEngine on the emulated C ABI (oracle
+    network, torch-op hooks: ACE2-style corrector with its dry-air state, prescribed-SST ocean, next-step forcing; residual
+    prediction with a prescribed prognostic; the inference-time override) against the reference's own per-step outputs - same
+    tolerance rule as on the GPU (1e-5 of the field maximum per step, or 3 x the reference's own fp32 distance from exact arithmetic)."""
+    from _util import checkpoint_case, checkpoint_override, conditioning_floor, load_golden
+    g = checkpoint_case(load_golden("gen_checkpoint.pt"), case)
+    loaded = ace_amd.load_stepper(g["state"], override_config=checkpoint_override(g), device="cpu")
+    T = len(g["steps"])
+    with fake_sfno():
+        out, state = RolloutEngine(loaded.stepper, batch=2, n_forward_steps=T, graph=graph).predict(g["ic"], g["forcing"])
+    assert set(out) == set(g["steps"][0])
+    floor = conditioning_floor(g)
+    for s, want_all in enumerate(g["steps"]):
+        for k, want in want_all.items():
+            err = float((out[k][:, s] - want).abs().max()) / float(want.abs().max())
+            assert err <= max(1e-5 * (s + 1), 3.0 * floor[s][k]), (k, s, err)
+    if case == "ace2_like":
+        assert state.stepper_state.corrector_state.global_dry_air_mass is not None
+
+
+def test_windowed_engine_inference_vs_the_reference_continuous_rollout(tmp_path):
+    """run_inference over windows of 2 + 1 steps through EnginePredict == the reference stepper's continuous 3-step rollout: the
+    corrector's dry-air reference rides on the prognostic state from window to window (CPU counterpart of the GPU test)."""
+    from ace_amd.inference import EnginePredict, ForcingWindows, InferenceData, TensorFileWriter, run_inference
+    from _util import conditioning_floor, load_golden
+    g = load_golden("gen_checkpoint.pt")["ace2_like"]
+    stepper = ace_amd.load_stepper(g["state"], device="cpu").stepper
+    T = len(g["steps"])
+    with fake_sfno():
+        loader = ForcingWindows(g["forcing"], total_forward_steps=T, forward_steps_in_memory=2, device="cpu")
+        state = run_inference(EnginePredict(stepper, batch=2, graph="step"), InferenceData(g["ic"], loader), writer=TensorFileWriter(str(tmp_path)))
+        first = run_inference(EnginePredict(stepper, batch=2, graph="step"), InferenceData(g["ic"], ForcingWindows(g["forcing"], 1, 1, device="cpu")))
+    series = torch.load(tmp_path / "autoregressive_predictions.pt", weights_only=True)
+    floor = conditioning_floor(g)
+    for s, want_all in enumerate(g["steps"]):
+        for k, want in want_all.items():
+            err = float((series[k][:, s] - want).abs().max()) / float(want.abs().max())
+            assert err <= max(1e-5 * (s + 1), 3.0 * floor[s][k]), (k, s, err)
+    cs = state.stepper_state.corrector_state
+    assert cs is not None and torch.equal(cs.global_dry_air_mass, first.stepper_state.corrector_state.global_dry_air_mass)
