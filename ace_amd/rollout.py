@@ -35,9 +35,11 @@ class RolloutEngine:
         if getattr(stepper, "_masks", False):
             raise NotImplementedError("RolloutEngine: static spatial masking of the step inputs / outputs (input_masking, the dataset's "
                                       "mask provider) is applied by Stepper.predict")
-        if getattr(stepper, "_multi_call", None) is not None:
-            raise NotImplementedError("RolloutEngine: multi-call diagnostics (extra evaluations of the step with a scaled forcing) are "
-                                      "produced by Stepper.predict; use it, or load with StepperOverrideConfig(multi_call=None)")
+        # multi-call diagnostics (fme/core/step/multi_call.py): per multiplier one more pack (the scaled forcing) / forward / unpack
+        # into scratch planes / hooks per step, selected outputs copied under their suffixed names
+        self._mc = getattr(stepper, "_multi_call_config", None)
+        if self._mc is not None and graph == "window":
+            raise NotImplementedError("graph='window' with multi-call diagnostics is not captured; use graph='step'")
         # post-step hooks (corrector, prescribed-SST ocean): torch ops on the static buffers between the fused unpack of
         # step s and the pack of step s + 1 - stream ordered, no host synchronisation.  The corrector state (dry-air
         # reference mass) is seeded by the first step after load() and survives continue_from_last().
@@ -120,6 +122,32 @@ class RolloutEngine:
             self._sec_dst_ptrs = torch.tensor([[self.out[n].data_ptr() + 4 * s * self.HW for n in self.sec_names] for s in range(T)], **i64)
             self._sec_dst_strides = torch.full((len(self.sec_names),), T * self.HW, **i64)
             self._sec_dst_ptr_addr = [self._sec_dst_ptrs.data_ptr() + 8 * s * len(self.sec_names) for s in range(T)]
+        self._mc_state = None
+        if self._mc is not None:
+            from .multi_call import get_multi_call_name
+            mc = self._mc
+            if mc.forcing_name not in self.forcing_names:
+                raise NotImplementedError(f"RolloutEngine: the multi-call forcing '{mc.forcing_name}' must be an input-only network input")
+            if any(n not in self.out_names for n in mc.output_names):
+                raise NotImplementedError("RolloutEngine: multi-call outputs must be network outputs (not secondary-decoder diagnostics)")
+            self._mc_factors = list(mc.forcing_multipliers.items())
+            self._mc_copy = [[(n, get_multi_call_name(n, suffix)) for n in mc.output_names] for suffix, _ in self._mc_factors]
+            for pairs in self._mc_copy:
+                for _, new in pairs:
+                    self.out[new] = torch.zeros(B, T, H, W, **f32)
+            self.forcing_mc = [torch.zeros(B, T + 1, H, W, **f32) for _ in self._mc_factors]     # the scaled forcing, per multiplier
+            self.mc_scratch = {n: torch.zeros(B, 1, H, W, **f32) for n in self.out_names}        # one step's outputs of a re-evaluation
+            fi = self.in_names.index(mc.forcing_name)
+            self._mc_src_ptrs = []
+            for k in range(len(self._mc_factors)):
+                tab = self._src_ptrs.clone()
+                for st in range(T):
+                    t = st + 1 if mc.forcing_name in self.next_step_forcing else st
+                    tab[st, fi] = self.forcing_mc[k].data_ptr() + 4 * t * self.HW
+                self._mc_src_ptrs.append(tab)
+            self._mc_src_ptr_addr = [[tab.data_ptr() + 8 * st * nin for st in range(T)] for tab in self._mc_src_ptrs]
+            self._mc_dst_ptrs = torch.tensor([self.mc_scratch[n].data_ptr() for n in self.out_names], **i64)
+            self._mc_dst_strides = torch.full((len(self.out_names),), self.HW, **i64)
         # residual prediction (single_module.py:663-664): normalised prognostic inputs are added to the network output
         self._res_in = self._res_out = None
         if cfg.residual_prediction:
@@ -193,11 +221,60 @@ class RolloutEngine:
                                             self.B, nout, self.HW, stream))
         if self._physics is not None:   # corrector -> ocean -> prescribed prognostics (single_module.py:669-716), four launches
             self._physics.apply(s, stream)
-            return
-        if self._corrector is not None or self._ocean is not None:
-            self._apply_hooks(s)
-        for n in self.prescribed:     # after the ocean (single_module.py:700-716): overwritten from the data of step s + 1
-            self.out[n][:, s].copy_(self.target[n][:, s + 1] if n in self.target else self.forcing[n][:, s + 1])
+        else:
+            if self._corrector is not None or self._ocean is not None:
+                self._apply_hooks(s)
+            for n in self.prescribed:     # after the ocean (single_module.py:700-716): overwritten from the data of step s + 1
+                self.out[n][:, s].copy_(self.target[n][:, s + 1] if n in self.target else self.forcing[n][:, s + 1])
+        if self._mc is not None:
+            self._multi_call_step(s, use_library_graph)
+
+    def _multi_call_step(self, s: int, use_library_graph: bool):
+        """_multi_call.py:164-188 on the static buffers: the step of window position s evaluated again with the scaled forcing - same
+        x / y buffers as the plain evaluation (whose outputs are already unpacked), outputs into scratch planes, the post-step hooks
+        as torch ops on them (their corrector state is seeded like the plain path's and never fed back), selected fields copied."""
+        L = _lib.lib()
+        stream = _lib.current_stream()
+        nin, nout = len(self.in_names), len(self.out_names)
+        name = self._mc.forcing_name
+        for k, (suffix, factor) in enumerate(self._mc_factors):
+            _lib.check(L.ace_pack_normalize(self._mc_src_ptr_addr[k][s], self._src_stride_addr[s], self.in_mean.data_ptr(),
+                                            self.in_std.data_ptr(), self.x.data_ptr(), self.B, nin, self.HW, stream))
+            if self._fill_in:
+                torch.nan_to_num_(self.x, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
+            if self._conditioned:
+                noise = self.net.conditioning_field(self.B, self.device, labels=self._labels)
+                _lib.check(L.ace_sfno_forward_conditioned(self.net._native, self.x.data_ptr(), noise.data_ptr(), self.y.data_ptr(),
+                                                          self.B, stream))
+            else:
+                fwd = L.ace_sfno_forward_graph if use_library_graph else L.ace_sfno_forward
+                _lib.check(fwd(self.net._native, self.x.data_ptr(), self.y.data_ptr(), self.B, stream))
+            if self._res_in is not None:
+                self.y.index_add_(1, self._res_out, self.x.index_select(1, self._res_in))
+            if self._fill_out:
+                torch.nan_to_num_(self.y, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
+            _lib.check(L.ace_unpack_denormalize(self.y.data_ptr(), self.out_mean.data_ptr(), self.out_std.data_ptr(),
+                                                self._mc_dst_ptrs.data_ptr(), self._mc_dst_strides.data_ptr(), self.B, nout, self.HW, stream))
+            gen = {n: self.mc_scratch[n][:, 0] for n in self.out_names}
+            if self._corrector is not None or self._ocean is not None or self.prescribed:
+                inp = {n: (self.ic[n][:, 0] if s == 0 else self.out[n][:, s - 1]) for n in self.prognostic}
+                for n in self.forcing_names:
+                    src = self.forcing_mc[k] if n == name else self.forcing[n]
+                    inp[n] = src[:, s + 1 if n in self.next_step_forcing else s]
+                nxt = {n: (self.forcing_mc[k] if n == name else self.forcing[n])[:, s + 1] for n in self.forcing_names}
+                nxt.update({n: self.target[n][:, s + 1] for n in self.target_names})
+                new = gen
+                if self._corrector is not None:
+                    new, state = self._corrector(inp, new, nxt, self._mc_state)
+                    if self._mc_state is None:
+                        self._mc_state = state
+                if self._ocean is not None:
+                    new = self._ocean(inp, new, nxt)
+                for n in self.prescribed:
+                    new = {**new, n: nxt[n]}
+                gen = new
+            for src_name, dst_name in self._mc_copy[k]:
+                self.out[dst_name][:, s].copy_(gen[src_name])
 
     def _apply_hooks(self, s: int):
         """step_with_adjustments' tail (fme/core/step/single_module.py:669-716) on the window buffers of step s."""
@@ -252,6 +329,10 @@ class RolloutEngine:
         for n in self.target_names:
             self.target[n].copy_(forcing[n][:, : self.T + 1])
         self._corrector_state = None        # a new initial condition re-seeds the corrector
+        self._mc_state = None
+        if self._mc is not None:
+            for k, (_, factor) in enumerate(self._mc_factors):
+                torch.mul(self.forcing[self._mc.forcing_name], factor, out=self.forcing_mc[k])
         if self._have_ref is not None:
             self._have_ref.fill_(False)
         if self._physics is not None and self._physics.tracks_dry_air:
@@ -311,6 +392,7 @@ class RolloutEngine:
             self.load(initial_condition, forcing)
             carried = getattr(initial_condition, "stepper_state", None)
             if carried is not None:
+                self._mc_state = carried.corrector_state
                 self._corrector_state = carried.corrector_state
                 cs = carried.corrector_state
                 if self._have_ref is not None and cs is not None and cs.global_dry_air_mass is not None:

@@ -140,8 +140,8 @@ def test_checkpoint_with_multi_call_loads_and_overrides():
         load_stepper(bad, device="cpu")
 
 
-def test_rollout_engine_refuses_multi_call():
+def test_rollout_engine_multi_call_needs_the_step_graph_mode():
     from ace_amd.rollout import RolloutEngine
     st = _stub_stepper({"forcing_name": "co2", "forcing_multipliers": {"_x2": 2.0}, "output_names": ["ULWRFtoa"]})
-    with pytest.raises(NotImplementedError, match="multi-call"):
-        RolloutEngine(st, batch=1, n_forward_steps=2)
+    with pytest.raises(NotImplementedError, match="window"):
+        RolloutEngine(st, batch=1, n_forward_steps=2, graph="window")

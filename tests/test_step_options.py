@@ -99,9 +99,57 @@ def test_rollout_engine_with_secondary_decoder_host_logic():
     assert set(out) == set(want) and {"s0", "s1"} <= set(out)
     for k in out:
         assert rel_max(out[k], want[k]) <= 5e-6, (k, rel_max(out[k], want[k]))
-    multi = load_stepper(g["state"], device="cpu").stepper
-    with pytest.raises(NotImplementedError, match="multi-call"):
-        RolloutEngine(multi, batch=2, n_forward_steps=3)
+
+
+@pytest.mark.parametrize("graph", [None, "step"])
+def test_rollout_engine_with_multi_call_vs_reference_rollout(graph):
+    """the engine's multi-call re-evaluations (scaled-forcing pointer tables, scratch planes, suffixed outputs) together with the
+    secondary decoder, against the REAL reference stepper's rollout, on the emulations of both halves of the C ABI"""
+    from ace_amd.rollout import RolloutEngine
+    from _fake_sfno import fake_sfno
+    g = load_golden("gen_step_options.pt")["stepper"]
+    st = load_stepper(g["state"], device="cpu").stepper
+    with fake_hpx(), fake_sfno(), torch.no_grad():
+        eng = RolloutEngine(st, batch=2, n_forward_steps=3, graph=graph)
+        out, state = eng.predict(g["ic"], g["forcing"])
+        with pytest.raises(NotImplementedError, match="window"):
+            RolloutEngine(st, batch=2, n_forward_steps=3, graph="window")
+    assert set(out) == set(g["steps"][0])
+    for k in out:
+        want = torch.stack([s[k] for s in g["steps"]], dim=1)
+        assert rel_max(out[k], want) <= 1e-5, (k, rel_max(out[k], want))
+
+
+def test_rollout_engine_multi_call_with_corrector_and_ocean_hooks():
+    """multi-call on an ACE2-like stepper (reference-written state: dry-air / moisture / energy corrector, prescribed-SST ocean,
+    next-step forcing) with the scaled forcing being one the corrector itself reads: engine == Stepper.predict, over two windows
+    (the re-evaluations' corrector state is seeded like the plain path's and carried)."""
+    from ace_amd.rollout import RolloutEngine
+    from _fake_sfno import fake_sfno
+    g = load_golden("gen_checkpoint.pt")["ace2_like"]
+    mc = {"forcing_name": "DSWRFtoa", "forcing_multipliers": {"_dim": 0.9, "_bright": 1.1}, "output_names": ["ULWRFtoa", "USWRFtoa"]}
+    over = StepperOverrideConfig(multi_call=mc)
+    eng_st = load_stepper(g["state"], over, device="cpu").stepper
+    ref_st = load_stepper(g["state"], over, device="cpu").stepper
+    cfg = ref_st._step_obj.config
+    from oracle.sfno import SFNOConfig, SFNOOracle
+    ocfg = SFNOConfig(in_chans=len(cfg.in_names), out_chans=len(cfg.out_names), img_shape=(8, 16), embed_dim=16, num_layers=2,
+                      operator_type="dhconv")
+    ref_st._step_obj.module = Module(_OracleModule(SFNOOracle(ocfg, ref_st.modules[0].state_dict(), dtype=torch.float32)), None)
+    with torch.no_grad():
+        want, _ = ref_st.predict(g["ic"], g["forcing"])
+        with fake_sfno():
+            eng = RolloutEngine(eng_st, batch=2, n_forward_steps=2, graph="step")
+            first, s1 = eng.predict(g["ic"], {k: v[:, :3] for k, v in g["forcing"].items()})
+            first = {k: v.clone() for k, v in first.items()}
+            one = RolloutEngine(eng_st, batch=2, n_forward_steps=1, graph="step")
+            second, _ = one.predict(s1, {k: v[:, 2:] for k, v in g["forcing"].items()})
+    assert {"ULWRFtoa_dim", "ULWRFtoa_bright", "USWRFtoa_dim", "USWRFtoa_bright"} <= set(first)
+    for k in want:
+        got = torch.cat([first[k], second[k]], dim=1)
+        scale = max(float(want[k].abs().max()), 1e-30)
+        assert float((got - want[k]).abs().max()) <= 2e-5 * scale, (k, float((got - want[k]).abs().max()) / scale)
+    assert float((want["ULWRFtoa_bright"] - want["ULWRFtoa"]).abs().max()) > 0           # the scaled forcing was seen
 
 
 def test_secondary_decoder_configuration_errors():
@@ -159,10 +207,10 @@ def test_stepper_with_multi_call_and_secondary_decoder_on_the_device():
         batched, _ = st.predict(ic, forcing)
     for k in out:
         assert rel_max(batched[k], out[k]) <= 2e-6, k
-    # the static-buffer engine produces the decoder's diagnostics too (not the multi-call ones)
+    # the static-buffer engine produces both kinds of diagnostics too
     from ace_amd.rollout import RolloutEngine
-    st.replace_multi_call(None)
+    st.replace_multi_call(st.multi_call)
     eng_out, _ = RolloutEngine(st, batch=2, n_forward_steps=3, graph="step").predict(ic, forcing)
-    assert {"s0", "s1"} <= set(eng_out)
+    assert set(eng_out) == set(out)
     for k in eng_out:
         assert rel_max(eng_out[k], out[k]) <= 5e-6, k
