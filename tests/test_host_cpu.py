@@ -90,6 +90,8 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+                # ... nor the C-ABI emulations of the test suite (tests/_fake_sfno.py, tests/_fake_hpx.py), nor anything under tests/
+                assert "_fake_" not in src and "import tests" not in src and "from tests" not in src, f
 
 
 # ----------------------------------------------------------------------------- registry / builder
