@@ -187,7 +187,7 @@ class NoiseConditionedSFNO(nn.Module):
     def _release_native(self):
         if self._native is not None:
             try:
-                _lib.lib().ace_sfno_destroy(self._native)
+                self.__dict__.get("_native_destroy", _lib.lib().ace_sfno_destroy)(self._native)
             except Exception:
                 pass
         self._native, self._native_key, self._uploaded = None, None, {}
@@ -196,7 +196,7 @@ class NoiseConditionedSFNO(nn.Module):
         try:
             native = self.__dict__.get("_native")
             if native is not None:
-                _lib.lib().ace_sfno_destroy(native)
+                self.__dict__.get("_native_destroy", _lib.lib().ace_sfno_destroy)(native)
                 self.__dict__["_native"] = None
         except Exception:  # interpreter shutdown
             pass
@@ -209,6 +209,7 @@ class NoiseConditionedSFNO(nn.Module):
             with torch.cuda.device(device):
                 _lib.check(_lib.lib().ace_sfno_create(ctypes.byref(cfg), ctypes.byref(handle)))
             self._native, self._native_key = handle, (device.index, batch)
+            self.__dict__["_native_destroy"] = _lib.lib().ace_sfno_destroy      # freed by the library that made it
 
     def sync_weights(self, force: bool = False):
         L = _lib.lib()

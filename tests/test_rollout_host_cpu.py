@@ -242,3 +242,55 @@ def test_windowed_engine_inference_vs_the_reference_continuous_rollout(tmp_path)
             assert err <= max(1e-5 * (s + 1), 3.0 * floor[s][k]), (k, s, err)
     cs = state.stepper_state.corrector_state
     assert cs is not None and torch.equal(cs.global_dry_air_mass, first.stepper_state.corrector_state.global_dry_air_mass)
+
+
+def test_conditional_engine_with_labels_and_positional_context_vs_the_oracle():
+    """NoiseConditionedSFNO behind the engine on the emulated C ABI: the host forms ONE conditioning field
+    cat(noise, positional context + labels . label_pos_embed, label planes, ones) and uploads merged per-norm weights; the emulation's
+    forward is the CPU oracle with exactly that single field.  Reference for the comparison: the oracle of the FULL model (noise,
+    labels and positional context as the reference has them - bit for bit with the reference in fp32, tests/test_csfno_oracle.py)
+    stepped by hand with the same noise draws."""
+    from ace_amd.labels import BatchLabels
+    from oracle.csfno import CSFNOConfig, CSFNOOracle
+    in_names, out_names = ["f0", "p0"], ["p0", "d0"]
+    names = sorted(set(in_names) | set(out_names))
+    kw = {"embed_dim": 8, "noise_embed_dim": 3, "num_layers": 2, "pos_embed": False, "context_pos_embed_dim": 2, "label_embed_dim": 4,
+          "affine_norms": True, "normalize_big_skip": True}
+    cfg = ace_amd.SingleModuleStepConfig(
+        builder=ace_amd.ModuleSelector(type="NoiseConditionedSFNO", conditional=True, config=kw), in_names=in_names, out_names=out_names,
+        normalization=NormalizationConfig(means={k: 0.1 for k in names}, stds={k: 1.2 for k in names}))
+    torch.manual_seed(0)
+    stepper = ace_amd.Stepper.from_config(cfg, ace_amd.DatasetInfo((H, W), all_labels={"era5", "shield", "cm4"}), device="cpu")
+    net = stepper.modules[0]
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if ".W_scale_" in k or ".W_bias_" in k or k in ("label_pos_embed",):
+                p.copy_(0.3 * torch.randn(p.shape, generator=g))
+    B, T = 2, 3
+    ic = {"p0": torch.randn(B, 1, H, W, generator=g)}
+    forcing = {"f0": torch.randn(B, T + 1, H, W, generator=g)}
+    enc = stepper._step_obj.module._label_encoding
+    assert enc.names == ["cm4", "era5", "shield"]
+    labels = enc.encode([{"era5"}, {"shield", "cm4"}], "cpu")
+    with fake_sfno():
+        eng = RolloutEngine(stepper, batch=B, n_forward_steps=T, graph=None)
+        eng.set_labels(BatchLabels(labels.tensor[:, [2, 0, 1]], ["shield", "cm4", "era5"]))     # another column order: conformed
+        torch.manual_seed(5)
+        out, _ = eng.predict(ic, forcing)
+        out = {k: v.clone() for k, v in out.items()}
+        eng.set_labels(None)
+        with pytest.raises(ValueError, match="labels must be provided"):
+            eng.predict(ic, forcing)
+    ocfg = CSFNOConfig(in_chans=2, out_chans=2, img_shape=(H, W), noise_type="gaussian", **kw)
+    oracle = CSFNOOracle(ocfg, net.state_dict(), dtype=torch.float32)
+    torch.manual_seed(5)
+    state = ic["p0"][:, 0]
+    for s in range(T):
+        x = torch.stack([(forcing["f0"][:, s] - 0.1) / 1.2, (state - 0.1) / 1.2], dim=1)
+        noise = torch.randn(B, 3, H, W)                                   # the engine's draw of this step (gaussian)
+        y = oracle.forward(x, noise=noise, labels=labels.tensor) * 1.2 + 0.1
+        for i, k in enumerate(out_names):
+            # (fp32 both ways; the merged single-field sum and the reference's three separate sums round differently, free-running)
+            assert float((out[k][:, s] - y[:, i]).abs().max()) <= 1e-5 * (s + 1) * float(y[:, i].abs().max()), (k, s)
+        state = y[:, 0]
