@@ -2,6 +2,9 @@
 fme/ace/stepper/insolation/config.py:59-175, cm4.py:216-509 - GFDL CM4 / FMS astronomy): the mean over the model timestep ENDING
 at each time level of  S0 * (a / r)^2 * max(cos zenith, 0), per grid cell.
 
+The algorithm is that of the astronomy / time_manager modules of GFDL's Flexible Modeling System (FMS, Apache License 2.0), which the
+reference's cm4.py is derived from; nothing of either is copied here - the formulas are re-derived from the geometry below.
+
 Where it sits: once per forcing window, in front of the rollout (``Stepper.predict`` / ``EnginePredict`` / ``ForcingWindows``), on
 the device the forcings live on - (samples, T + 1, lat, lon) cells of elementwise arithmetic, a few ATen launches per window, never
 inside the per-step graphs.  Times come as an ``ace_amd.timeaxis.TimeAxis`` (no cftime / xarray on the path).
