@@ -242,7 +242,7 @@ class RolloutEngine:
                                             self.in_std.data_ptr(), self.x.data_ptr(), self.B, nin, self.HW, stream))
             if self._fill_in:
                 torch.nan_to_num_(self.x, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
-            if self._conditioned:
+            if self._conditioned:   # a fresh noise draw per evaluation, as the reference's repeated module call makes
                 noise = self.net.conditioning_field(self.B, self.device, labels=self._labels)
                 _lib.check(L.ace_sfno_forward_conditioned(self.net._native, self.x.data_ptr(), noise.data_ptr(), self.y.data_ptr(),
                                                           self.B, stream))
