@@ -47,6 +47,11 @@ constexpr int WS_OOBV = 0x7fffff00;   // buffer offset beyond every resource of 
 #define ACE_WS_VSPAN 8    // interleaved epilogue: its eight values are spread over the first VSPAN twelfths of the stage
 #endif
 
+
+// v_min_f32 / v_max_f32 as single instructions: hipcc puts a canonicalising `v_max x, x` in front of fminf / fmaxf on a computed value
+__device__ __forceinline__ float raw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float raw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 template <int KSW, int NSTG, int MODE>
 struct WsGeom {
     static constexpr int KH = KSW * NSTG;          // k16-steps per wave: its half of the contraction
@@ -267,8 +272,9 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
                 const bool ok = c.vo_p != WS_OOBV;   // a stored pixel of a live tile
                 rsm[e] += ok ? val : 0.f;
                 rsq[e] = ok ? fmaf(val, val, rsq[e]) : rsq[e];
-                rmn[e] = ok ? fminf(rmn[e], val) : rmn[e];
-                rmx[e] = ok ? fmaxf(rmx[e], val) : rmx[e];
+                const float lo_ = raw_min(rmn[e], val), hi_ = raw_max(rmx[e], val);
+                rmn[e] = ok ? lo_ : rmn[e];
+                rmx[e] = ok ? hi_ : rmx[e];
             }
             if (PK) {
                 const float xs = val * cscale;
@@ -291,23 +297,24 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
                 for (int cc = 0; cc < 8; ++cc) {
                     const float x = cc < 4 ? a[cc & 3] : b[cc & 3];
                     const bool ok = 8 * cq + cc < c.ncols_ok;
-                    sm += ok ? x : 0.f;
-                    sq = ok ? fmaf(x, x, sq) : sq;
-                    mn = ok ? fminf(mn, x) : mn;
-                    mx = ok ? fmaxf(mx, x) : mx;
+                    const float xs_ = ok ? x : 0.f, xm_ = ok ? x : __builtin_nanf("");      // two selects: 0 for the sums, NaN for min / max
+                    sm += xs_;
+                    sq = fmaf(xs_, xs_, sq);
+                    mn = raw_min(mn, xm_);
+                    mx = raw_max(mx, xm_);
                 }
 #pragma unroll
                 for (int off = 16; off <= 32; off <<= 1) {
                     sm += __shfl_xor(sm, off, 64);
                     sq += __shfl_xor(sq, off, 64);
-                    mn = fminf(mn, __shfl_xor(mn, off, 64));
-                    mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+                    mn = raw_min(mn, __shfl_xor(mn, off, 64));
+                    mx = raw_max(mx, __shfl_xor(mx, off, 64));
                 }
                 // ONE partial per workgroup and row instead of one per 32-pixel tile (r03: the norm finaliser read 2025 partials per
                 // channel, 6 KiB apart, and took 10 us): the row's running statistics live in LDS, always updated by the same lane
                 if (c.vo_s != WS_OOBV) {
                     f32x4 acc = Lacc[ln];
-                    acc[0] += sm; acc[1] += sq; acc[2] = fminf(acc[2], mn); acc[3] = fmaxf(acc[3], mx);
+                    acc[0] += sm; acc[1] += sq; acc[2] = raw_min(acc[2], mn); acc[3] = raw_max(acc[3], mx);
                     Lacc[ln] = acc;
                 }
             }
@@ -335,10 +342,12 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
             gst.val = val;
             if (RSTATS) {
                 const bool ok = c.vo_p != WS_OOBV;   // a stored pixel of a live tile
-                rsm[e] += ok ? val : 0.f;
-                rsq[e] = ok ? fmaf(val, val, rsq[e]) : rsq[e];
-                rmn[e] = ok ? fminf(rmn[e], val) : rmn[e];
-                rmx[e] = ok ? fmaxf(rmx[e], val) : rmx[e];
+                // two selects instead of four: 0 is neutral for the sums, a NaN for v_min_f32 / v_max_f32 (they return the other operand)
+                const float vs = ok ? val : 0.f, vm = ok ? val : __builtin_nanf("");
+                rsm[e] += vs;
+                rsq[e] = fmaf(vs, vs, rsq[e]);
+                rmn[e] = raw_min(rmn[e], vm);
+                rmx[e] = raw_max(rmx[e], vm);
                 asm volatile("" : "+v"(rsm[e]), "+v"(rsq[e]), "+v"(rmn[e]), "+v"(rmx[e]));
             }
             asm volatile("" : "+v"(gst.val));

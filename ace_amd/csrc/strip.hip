@@ -60,12 +60,13 @@ SDEV float wave_max_bits(unsigned raw) {
 }
 // one 1-KiB LDS-DMA piece: lane L's 16 bytes at gsrc land at lds_dst + 16 L (see kernels.hip glds16)
 SDEV void glds16(const void* gsrc, const char* lds_dst_uniform) {
-    unsigned keep;
+    // m0 = LDS base of the copy; declared clobbered instead of saved and restored around every piece (two scalar instructions
+    // per piece: the compiler keeps nothing in m0 across these kernels' loops)
     const unsigned addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cptr)lds_dst_uniform);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :
                  : "v"(gsrc), "s"(addr)
-                 : "memory");
+                 : "memory", "m0");
 }
 SDEV int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -116,28 +117,33 @@ SDEV void strip_body(const LegStripArgs& p, char* smem, const int m, const int g
     // l < m, never written by the producer - possibly stale bits of another layout) only occur in the first resident k-step.
     half8 bh[NK], bl[NK];
     {
-        const int klast16 = (K + 15) / 16 - 1;                // last k16-step with real data
-        const float* Bl = Bm + (long)(8 * g) * ks;
+        // Through a range-checked buffer descriptor over the K rows of THIS batch: a row at or beyond K (the tail of the last real
+        // k-step, every padded k-step) is out of range and reads as an exact zero - no clamp, no per-element mask, no stale data
+        // of an earlier, larger call (the reason the mask existed), and 32-bit offsets: per lane one offset per row e of its
+        // k-group plus the k-step's (uniform) offset, one 32-bit add per load.
+        const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B + (long)m * p.b_moff), 0,
+                                                           (unsigned)((long)K * ks * 4 < 0xFFFFFFFFl ? (long)K * ks * 4 : 0xFFFFFFFFl), 0x00020000);
+        unsigned vo[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vo[e] = (unsigned)(((long)(8 * g + e) * ks + nc) * 4);
         float raw[NK][8];
 #pragma unroll
         for (int jj = 0; jj < NK; ++jj) {
-            const int kstep = gm.j0 + jj < klast16 ? gm.j0 + jj : klast16;
-            const long rowoff = (long)(16 * kstep) * ks;       // wave-uniform
+            // the k-step's offset goes into the VECTOR offset: the hardware range check of a raw buffer covers the instruction and
+            // vector offsets only, not the scalar one
+            const unsigned so = (unsigned)((long)(16 * (gm.j0 + jj)) * ks * 4);     // wave-uniform
 #pragma unroll
-            for (int e = 0; e < 8; ++e) raw[jj][e] = Bl[rowoff + (long)e * ks];
+            for (int e = 0; e < 8; ++e) raw[jj][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsB, vo[e] + so, 0, 0));
         }
 #pragma unroll
         for (int jj = 0; jj < NK; ++jj)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float x = raw[jj][e] * bscale;
-                const int kk = 16 * (gm.j0 + jj) + 8 * g + e;   // un-clamped contraction index of this element
-                if (jj == 0) x = kk >= gm.klo ? x : 0.f;
-                // rows at and beyond K (the tail of the last real k-step, every padded k-step) are ZERO here, not "any finite
-                // value against a zero table fragment": with a batch smaller than the one the buffers were sized for they are
-                // stale data of an earlier, larger call at another magnitude, and (stale * bscale) can overflow fp16 to inf
-                // (0 * inf = NaN in the MFMA)
-                x = kk < K ? x : 0.f;
+                if (jj == 0) {   // indices below klo (inverse: l < m, never written by the producer) only occur in the first resident k-step
+                    const int kk = 16 * gm.j0 + 8 * g + e;
+                    x = kk >= gm.klo ? x : 0.f;
+                }
                 const _Float16 h = (_Float16)x;
                 bh[jj][e] = h;
                 bl[jj][e] = (_Float16)(x - (float)h);

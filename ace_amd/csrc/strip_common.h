@@ -37,12 +37,13 @@ MDEV float wave_max_bits(unsigned raw) {
     return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mx)));
 }
 MDEV void glds16(const void* gsrc, const char* lds_dst_uniform) {
-    unsigned keep;
+    // m0 = LDS base of the copy; declared clobbered instead of saved and restored around every piece (two scalar instructions
+    // per piece: the compiler keeps nothing in m0 across these kernels' loops)
     const unsigned addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cptr)lds_dst_uniform);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :
                  : "v"(gsrc), "s"(addr)
-                 : "memory");
+                 : "memory", "m0");
 }
 MDEV float fast_erf(float x) {   // kernels.hip: max abs error 1.1e-7
     const float t = fminf(fabsf(x), 4.0f);
@@ -63,7 +64,7 @@ MDEV float fast_erf(float x) {   // kernels.hip: max abs error 1.1e-7
 // instruction stream, about 6 VALU per MFMA (profiles/r03_mfma_valu_overlap_probe.txt)
 struct GeluStage { float val, u, t, q; };
 MDEV void gelu_stage0(GeluStage& g, float val) {
-    g.val = val;
+    g.val = val * 0.5f;                          // h = x / 2: the result is fma(h, erf, h)
     g.u = val * 0.70710678118654752440f;
     g.t = fminf(fabsf(g.u), 4.0f);
 }
@@ -82,12 +83,12 @@ MDEV void gelu_stage1(GeluStage& g) {
 MDEV float gelu_stage2(const GeluStage& g) {
     const float q = g.q * g.t;
     const float erf = copysignf(1.0f - __builtin_amdgcn_exp2f(-q), g.u);
-    return 0.5f * g.val * (1.0f + erf);
+    return fmaf(g.val, erf, g.val);              // x / 2 (1 + erf): one instruction and one rounding less than 0.5 x (1 + erf)
 }
 
 template <int ACT>
 MDEV float act_fn(float v) {
-    if (ACT == ACT_GELU_FAST || ACT == ACT_GELU) return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
+    if (ACT == ACT_GELU_FAST || ACT == ACT_GELU) { const float h = 0.5f * v; return fmaf(h, fast_erf(v * 0.70710678118654752440f), h); }
     if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
     if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
     return v;
