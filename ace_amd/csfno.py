@@ -83,6 +83,22 @@ class _Filter(nn.Module):
         scale[0, :] *= math.sqrt(2.0)
         self.filter.weight = nn.Parameter(scale * torch.randn(G, L, C // G, C // G, 2))
         self.filter.bias = nn.Parameter(torch.zeros(1, C, 1, 1))
+        self._shape = (G, L, C // G)
+        # checkpoints written before the grouped layout load as the reference loads them (s2convolutions.py:276-365)
+        self.filter._register_load_state_dict_pre_hook(self._legacy_weight_layouts)
+
+    def _legacy_weight_layouts(self, state_dict, prefix, *_):
+        """ungrouped (C, C, L, 2) -> a singleton group; then the old (G, in / G, out / G, L, 2) order -> (G, L, out / G, in / G, 2)"""
+        key = prefix + "weight"
+        w = state_dict.get(key)
+        if w is None:
+            return
+        G, L, Cg = self._shape
+        if tuple(w.shape) == (G * Cg, G * Cg, L, 2):
+            w = w.view(1, *w.shape)
+        if w.ndim == 5 and tuple(w.shape) == (G, Cg, Cg, L, 2):
+            w = w.permute(0, 3, 2, 1, 4)
+        state_dict[key] = w
 
 
 class _Block(nn.Module):

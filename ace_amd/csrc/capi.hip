@@ -49,6 +49,7 @@ Switches read_switches() {
     Switches sw;
     sw.no_fft = on("ACE_NO_FFT");
     sw.no_strip = on("ACE_NO_STRIP");
+    sw.no_fold = on("ACE_NO_FOLD");
     sw.no_dhconv_strip = on("ACE_NO_DHCONV_STRIP");
     sw.no_pk = on("ACE_NO_PK");
     sw.no_pk_sht = on("ACE_NO_PK_SHT");
@@ -116,6 +117,9 @@ struct ace_sht_plan {
     // strip kernels (strip.hip): wt / pt as pre-packed MFMA A fragments + per-m block offsets (nlat, lmax <= 192)
     DevBuf wt_frag, pt_frag, wt_off, pt_off;
     bool strip = false;
+    // ... and in the equatorially folded form (strip_fold.hip) when the tables are mirror-symmetric about the equator
+    DevBuf wt_ffrag, pt_ffrag, wt_foff, pt_foff;
+    bool fold = false;
     DevBuf slots;   // standalone transforms in f16x3 mode: dynamic-range slots (max|X|, max|coefficients|)
     Switches sw;    // measurement switches, read when the plan was built
 };
@@ -174,6 +178,16 @@ static int plan_build(int nlat, int nlon, int lmax, int mmax, Grid g, std::uniqu
             pack_legendre_strip(t.pt.data(), t.mmax, t.nlat, t.lmax, t.Lp, 1, p->pt_scale, sp);
             HIP_TRY(up(sp, p->pt_frag, p->pt_off));
             p->strip = true;
+            // P_l^m(-x) = (-1)^(l+m) P_l^m(x) on a grid that is symmetric about the equator (all three quadratures are): checked
+            // on the fp32 tables themselves - mirror entries agree to the rounding of the fp64 recursion
+            if (fold_symmetry_error(t.wt.data(), t.mmax, t.nlat, t.lmax, t.Hp, 0) < 2e-6 &&
+                fold_symmetry_error(t.pt.data(), t.mmax, t.nlat, t.lmax, t.Lp, 1) < 2e-6) {
+                pack_legendre_fold(t.wt.data(), t.mmax, t.nlat, t.lmax, t.Hp, 0, p->wt_scale, sp);
+                HIP_TRY(up(sp, p->wt_ffrag, p->wt_foff));
+                pack_legendre_fold(t.pt.data(), t.mmax, t.nlat, t.lmax, t.Lp, 1, p->pt_scale, sp);
+                HIP_TRY(up(sp, p->pt_ffrag, p->pt_foff));
+                p->fold = true;
+            }
         }
     }
     out = std::move(p);
@@ -225,6 +239,14 @@ static int run_legendre_forward(const ace_sht_plan& pl, const float* X, float* D
         } else {
             a.C = D; a.omax = dmax;
         }
+        if (pl.fold && !pl.sw.no_fold) {   // half the contraction: sums / differences of mirror latitudes (strip_fold.hip)
+            LegStripArgs f = a;
+            f.A = reinterpret_cast<const _Float16*>(pl.wt_ffrag.p); f.tile_off = reinterpret_cast<const int*>(pl.wt_foff.p);
+            if (legendre_fold_eligible(f)) {
+                HIP_TRY(launch_legendre_fold(f, s));
+                return ACE_OK;
+            }
+        }
         if (legendre_strip_eligible(a)) {
             HIP_TRY(launch_legendre_strip(a, s));
             return ACE_OK;
@@ -262,6 +284,14 @@ static int run_legendre_inverse(const ace_sht_plan& pl, const float* E, float* X
         a.ascale = pl.pt_scale; a.bmax = emax;
         a.C = X; a.c_rstride = N2; a.c_moff = (long)pl.nlat * N2;
         a.N = (int)N2; a.K = pl.lmax; a.R = pl.nlat; a.nbatch = pl.mmax; a.mode = 1;
+        if (pl.fold && !pl.sw.no_fold) {   // even / odd degrees separately, rows and mirror rows from their sum and difference
+            LegStripArgs f = a;
+            f.A = reinterpret_cast<const _Float16*>(pl.pt_ffrag.p); f.tile_off = reinterpret_cast<const int*>(pl.pt_foff.p);
+            if (legendre_fold_eligible(f)) {
+                HIP_TRY(launch_legendre_fold(f, s));
+                return ACE_OK;
+            }
+        }
         if (legendre_strip_eligible(a)) {
             HIP_TRY(launch_legendre_strip(a, s));
             return ACE_OK;

@@ -129,7 +129,9 @@ FDEV void fft_unit(int& cblk, int& lat) {
 #ifndef ACE_FFT_INV_WAVES
 #define ACE_FFT_INV_WAVES 7   // three 9-wave workgroups per CU (LDS allows three) need <= 72 registers
 #endif
-template <int N1, int N2, int R, bool PLN>
+// FULLM: Mm == W / 2 + 1 (every wavenumber kept).  Then every output of a column is either stored or has the magnitude of a
+// stored entry (its Hermitian mirror), so the range maximum is the plain maximum over the column - no per-store selects.
+template <int N1, int N2, int R, bool PLN, bool FULLM>
 __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? 7 : ACE_FFT_FWD_WAVES) : (N1 * N2 == 1440 && R == 8 ? 4 : 0)) void dft_forward_fft_kernel(DftArgs p) {
     constexpr int W = N1 * N2, H1 = N1 / 2 + 1, NT = R * N2;
     constexpr int PITCH = W + 4;     // 16-byte aligned rows; PITCH = 4 (mod 8): the 16 rows x 4 b of a wave's level-1 read hit 64 banks
@@ -156,7 +158,8 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? 7 : ACE_FFT_FWD_WAV
     // fused instance-norm affine of this thread's row in level 1 (one load pair per thread, applied in registers)
     const int r1 = tid % R, b1 = tid / R;
     const int cr = c0 + (r1 < rlast ? r1 : rlast);
-    const float sc = p.sc ? p.sc[(long)b * p.C + cr] : 1.f, sh = p.sc ? p.sh[(long)b * p.C + cr] : 0.f;
+    float sc = p.sc ? p.sc[(long)b * p.C + cr] : 1.f;
+    const float sh = p.sc ? p.sh[(long)b * p.C + cr] : 0.f;
     if constexpr (PLN) {
         // the field arrives as P-format planes [C/8][H W][8] (hi | lo): an entry = 8 channels of one pixel, 16 bytes per plane;
         // this workgroup's R rows are R / 8 k-groups.  (hi + lo) / scale is the producer's 22-bit value, exactly.
@@ -165,7 +168,8 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? 7 : ACE_FFT_FWD_WAV
         const int kgmax = p.C / 8 - 1;
         const auto rsh = wide_rsrc(p.xhi + (long)b * p.sxp + (long)k * W * 8);
         const auto rsl = wide_rsrc(p.xlo + (long)b * p.sxp + (long)k * W * 8);
-        const float inv = ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(slot_load(p.xslot + (tid & 63)))));
+        // the producer's power-of-two scale comes off in the level-1 affine (an exact scaling: same values as dividing here)
+        sc *= ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(slot_load(p.xslot + (tid & 63)))));
         u32x4 eh[NPE], el[NPE];
 #pragma unroll
         for (int q = 0; q < NPE; ++q) {
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? 7 : ACE_FFT_FWD_WAV
                 const half8 h8 = __builtin_bit_cast(half8, eh[q]), l8 = __builtin_bit_cast(half8, el[q]);
                 float* d = xs + (8 * (idx / W)) * PITCH + idx % W;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) d[e * PITCH] = ((float)h8[e] + (float)l8[e]) * inv;
+                for (int e = 0; e < 8; ++e) d[e * PITCH] = (float)h8[e] + (float)l8[e];
             }
         }
     } else {
@@ -253,14 +257,15 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? 7 : ACE_FFT_FWD_WAV
             const bool has_mirror = k1 > 0 && k1 < N1 / 2;
             const v2f* zcol = Zs + k1 * ZP + r;
             sfft::CFft<N2, false, v2f>::run([&](int bb) { return zcol[bb * R]; }, [&](int q, v2f out) {
-                const float mag = fmaxf(fabsf(out.x), fabsf(out.y));
+                const float mag = FULLM ? 0.f : fmaxf(fabsf(out.x), fabsf(out.y));
+                if (FULLM) vmax = fmaxf(vmax, fmaxf(fabsf(out.x), fabsf(out.y)));   // v_max3_f32
                 if (q < K2N) {
                     const bool ok = k1 + N1 * q < p.Mm && (ACE_FFT_ABL != 1 || out.x == 1.2345e-30f);
                     const auto rs = wide_rsrc(obase + (long)q * N1 * ms * 4);
                     const int off = (int)(ok ? od : kDrop);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out.x), rs, off, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out.y), rs, off, imoff, 0);
-                    vmax = fmaxf(vmax, ok ? mag : 0.f);
+                    if (!FULLM) vmax = fmaxf(vmax, ok ? mag : 0.f);
                 }
                 if (q >= N2 / 2) {   // k2 = N2 - 1 - q <= N2 / 2 - 1 (k2 = N2 / 2 would be beyond W / 2 for every mirrored column)
                     const bool ok = has_mirror && (N1 - k1) + N1 * (N2 - 1 - q) < p.Mm && (ACE_FFT_ABL != 1 || out.x == 1.2345e-30f);
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? 7 : ACE_FFT_FWD_WAV
                     const int off = (int)(ok ? om : kDrop);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out.x), rs, off, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(-out.y), rs, off, imoff, 0);
-                    vmax = fmaxf(vmax, ok ? mag : 0.f);
+                    if (!FULLM) vmax = fmaxf(vmax, ok ? mag : 0.f);
                 }
             });
         }
@@ -290,11 +295,14 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? 7 : ACE_FFT_FWD_WAV
 template <int N1, int N2, int R = FFT_ROWS>
 hipError_t launch_fwd(const DftArgs& a, hipStream_t s) {
     dim3 grid((unsigned)((a.C + R - 1) / R), (unsigned)a.H, (unsigned)a.Bt), block(R * N2);
+    const bool full = a.Mm == a.W / 2 + 1;
     if (a.xhi) {
         if (!a.xlo || !a.xslot || a.C % 8 != 0) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((dft_forward_fft_kernel<N1, N2, R, true>), grid, block, 0, s, a);
+        if (full) hipLaunchKernelGGL((dft_forward_fft_kernel<N1, N2, R, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((dft_forward_fft_kernel<N1, N2, R, true, false>), grid, block, 0, s, a);
     } else {
-        hipLaunchKernelGGL((dft_forward_fft_kernel<N1, N2, R, false>), grid, block, 0, s, a);
+        if (full) hipLaunchKernelGGL((dft_forward_fft_kernel<N1, N2, R, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((dft_forward_fft_kernel<N1, N2, R, false, false>), grid, block, 0, s, a);
     }
     return hipGetLastError();
 }
@@ -311,10 +319,14 @@ hipError_t launch_fwd(const DftArgs& a, hipStream_t s) {
 template <int N1, int N2, int R, bool XCD>
 __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_INV_WAVES : (N1 * N2 == 1440 && R == 8 ? 4 : 0)) void dft_inverse_fft_kernel(DftArgs p) {
     constexpr int W = N1 * N2, H1 = N1 / 2 + 1, NT = R * N2;
-    constexpr int PITCH = W + 4;   // 16-byte aligned rows
-    static_assert(N1 % 2 == 0 && N2 % 2 == 0 && N1 >= 4 && N2 >= H1 && W % 4 == 0, "even factors");
+    // The output rows are staged COLUMN-major, element (row r, longitude c) at c * RP + r with RP = R + 1: step B's threads (b1, r)
+    // write one longitude of R consecutive rows per instruction - consecutive banks (r03: row-major rows of W + 4 floats put the
+    // 32 rows of a write on 8 banks, 41 % of the kernel's LDS cycles were bank conflicts); the copy-out reads four longitudes
+    // of a row with four 4-byte reads, lanes = 8 row pieces x 8 rows, RP = 1 (mod 8): 32 distinct banks per half wave.
+    constexpr int RP = R + 1;
+    static_assert(N1 % 2 == 0 && N2 % 2 == 0 && N1 >= 4 && N2 >= H1 && W % 4 == 0 && R % 8 == 0, "even factors, whole row groups");
     constexpr int ZP = ZPitch<N2, R>::value;   // U[k1][b][r], as Z of the forward kernel
-    constexpr int YS = R * PITCH, US = 2 * H1 * ZP;
+    constexpr int YS = W * RP, US = 2 * H1 * ZP;
     __shared__ __attribute__((aligned(16))) float smem[YS > US ? YS : US];
     float* ys = smem;
     v2f* Us = reinterpret_cast<v2f*>(smem);
@@ -385,7 +397,7 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_INV_WAVES : (N1 * 
         constexpr RootTab<N1> T1{};
         const int cr = c0 + (r < rlast ? r : rlast);
         const float bias = p.bias ? p.bias[cr] : 0.f;
-        float* yr = ys + r * PITCH + b1;
+        float* yr = ys + b1 * RP + r;                 // longitude N2 a + b1 of row r at yr[N2 a RP]
         float s0 = u[0].x + u[N1 / 2].x + bias, sh = u[0].x + ((N1 / 2) % 2 ? -u[N1 / 2].x : u[N1 / 2].x) + bias;
 #pragma unroll
         for (int k1 = 1; k1 < N1 / 2; ++k1) {
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_INV_WAVES : (N1 * 
             sh += (k1 % 2 ? -2.f : 2.f) * u[k1].x;
         }
         yr[0] = s0;
-        yr[N2 * (N1 / 2)] = sh;
+        yr[N2 * (N1 / 2) * RP] = sh;
 #pragma unroll
         for (int a = 1; a < N1 / 2; ++a) {
             // (P, Q) = sum_k1 (Ur, Ui) * (2 cos, -2 sin)(2 pi k1 a / N1);  w_N1^j = (cos, -sin)
@@ -403,8 +415,8 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_INV_WAVES : (N1 * 
                 const int j = (k1 * a) % N1;
                 pq += u[k1] * v2f{2.f * T1.re[j], 2.f * T1.im[j]};
             }
-            yr[N2 * a] = pq.x + pq.y;
-            yr[N2 * (N1 - a)] = pq.x - pq.y;
+            yr[N2 * a * RP] = pq.x + pq.y;
+            yr[N2 * (N1 - a) * RP] = pq.x - pq.y;
         }
     }
     __syncthreads();
@@ -412,10 +424,12 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_INV_WAVES : (N1 * 
     // ---- rows -> memory, 16 B per lane both ways
     float vmax = 0.f;
     const auto rsy = wide_rsrc(p.y + ((long)b * p.C + c0) * HW + (long)k * W);
-    for (int idx = tid; idx < R * (W / 4); idx += NT) {
-        const int r = idx / (W / 4), j = idx % (W / 4);
-        if (r <= rlast) {
-            const float4 v = *reinterpret_cast<const float4*>(ys + r * PITCH + 4 * j);
+    constexpr int JG = (W / 4 + 7) / 8;            // groups of eight 16-byte pieces per row
+    for (int idx = tid; idx < JG * 8 * R; idx += NT) {
+        const int j = (idx / (8 * R)) * 8 + (idx & 7), r = (idx >> 3) % R;
+        if (r <= rlast && j < W / 4) {
+            const float* src = ys + (4 * j) * RP + r;
+            const float4 v = make_float4(src[0], src[RP], src[2 * RP], src[3 * RP]);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsy, (int)(((unsigned)r * (unsigned)HW + 4u * j) * 4u), 0, 0);
             vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         }

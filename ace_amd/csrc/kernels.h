@@ -10,6 +10,7 @@ namespace ace {
 struct Switches {
     bool no_fft = false;           // ACE_NO_FFT: longitude DFT on the matrix kernels
     bool no_strip = false;         // ACE_NO_STRIP: Legendre stages on the tile engine
+    bool no_fold = false;          // ACE_NO_FOLD: Legendre stages on strip.hip (all latitudes) instead of the equatorially folded strip_fold.hip
     bool no_dhconv_strip = false;  // ACE_NO_DHCONV_STRIP: spectral filter contraction on the tile engine
     bool no_pk = false;            // ACE_NO_PK: 1x1 convolutions on the on-the-fly-split engine (v3)
     bool no_pk_sht = false;        // ACE_NO_PK_SHT: fp32 D, expanded filter operand
@@ -161,6 +162,9 @@ struct LegStripArgs {
 constexpr int LEG_STRIP_SLACK_ROWS = 16;
 bool legendre_strip_eligible(const LegStripArgs& a);
 hipError_t launch_legendre_strip(const LegStripArgs& a, hipStream_t s);
+// the equatorially folded form (strip_fold.hip): same arguments, A / tile_off from pack_legendre_fold (strip_pack.h); K, R <= 192
+bool legendre_fold_eligible(const LegStripArgs& a);
+hipError_t launch_legendre_fold(const LegStripArgs& a, hipStream_t s);
 
 // conv weight (O x I) -> packed MFMA A fragments (fp16 hi/lo), optionally W diag(a) per sample with the scale derived from
 // wmax * max|a| (published to wslot); order 0: blocks by 32-row tile then k16-step (what conv_ws.hip keeps resident), 1: by k16-step then tile

@@ -133,4 +133,104 @@ inline void pack_legendre_strip(const float* tab, int mmax, int nrows, int ncols
     }
 }
 
+// ---- equatorially folded form (strip_fold.hip) ------------------------------------------------------------------------------
+// For grids whose nodes and weights are symmetric about the equator (legendre-gauss, lobatto, equiangular - checked on the host
+// table, fold_symmetry_error), P_l^m(-x) = (-1)^(l+m) P_l^m(x) halves the latitude contraction:
+//     forward  c[l][m] = sum_{kf < Hh} wt[m][l][kf] (X[kf] + s X[H-1-kf]),  s = +1 for (l - m) even, -1 for (l - m) odd
+//     inverse  X[kf] = E[kf] + O[kf],  X[H-1-kf] = E[kf] - O[kf],  E / O = sum over l of even / odd (l - m) of pt[m][kf][l] c[l]
+// with Hh = ceil(H / 2) (an odd H has a middle row that is its own mirror image: it enters once).  The wave keeps BOTH folded
+// data operands resident (even: the sums / the even-degree coefficient rows, odd: the differences / the odd-degree rows) and the
+// table streams as "units": unit u = 2 tp + p is the 32-row tile tp of parity p over nkp2 k16-steps.  Forward: unit (tp, p)
+// yields the output rows l = m + p + 2 (32 tp + r); inverse: the pair of units tp yields rows kf = 32 tp + r (E + O) and their
+// mirror images H - 1 - kf (E - O).  Contraction indices start AT the triangle (l = m + p + 2 j), so there is no l < m masking.
+struct FoldGeom {
+    int Hh;      // folded latitude count ceil(H / 2)
+    int nkp;     // k16-steps per parity that carry data
+    int nkp2;    // ... rounded up to an even count, at least 2 (a unit is nkp2 2-KiB blocks = nkp2 / 2 pieces per wave)
+    int npairs;  // pairs of units (32-row tiles per parity)
+};
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline FoldGeom fold_geom(int mode, int m, int R, int K) {
+    FoldGeom g;
+    int n16;
+    if (mode == 0) {            // R = lmax rows, K = nlat
+        g.Hh = (K + 1) / 2;
+        n16 = g.Hh;
+        const int nr0 = (R - m + 1) / 2;          // rows of even parity l = m, m + 2, ... < R
+        g.npairs = nr0 > 0 ? (nr0 + 31) / 32 : 0;
+    } else {                    // R = nlat rows, K = lmax
+        g.Hh = (R + 1) / 2;
+        n16 = (K - m + 1) / 2;                    // even-parity degrees l = m, m + 2, ... < K
+        if (n16 < 0) n16 = 0;
+        g.npairs = (g.Hh + 31) / 32;
+    }
+    g.nkp = (n16 + 15) / 16;
+    g.nkp2 = g.nkp > 0 ? (g.nkp + 1) & ~1 : 2;    // at least one (all-zero) group: the inverse still writes its zeros
+    return g;
+}
+
+// max |tab[..][H-1-k] - s tab[..][k]| / max |tab| over the table (forward layout wt[m][l][pitch] or inverse pt[m][k][pitch]):
+// the fold is used when this is at rounding level
+inline double fold_symmetry_error(const float* tab, int mmax, int nlat, int lmax, int pitch, int mode) {
+    double worst = 0.0, mx = 0.0;
+    for (int m = 0; m < mmax; ++m)
+        for (int l = m; l < lmax; ++l) {
+            const double s = ((l - m) & 1) ? -1.0 : 1.0;
+            for (int k = 0; k < nlat; ++k) {
+                const double a = mode == 0 ? tab[((size_t)m * lmax + l) * pitch + k] : tab[((size_t)m * nlat + k) * pitch + l];
+                const double b = mode == 0 ? tab[((size_t)m * lmax + l) * pitch + (nlat - 1 - k)] : tab[((size_t)m * nlat + (nlat - 1 - k)) * pitch + l];
+                worst = std::fmax(worst, std::fabs(b - s * a));
+                mx = std::fmax(mx, std::fabs(a));
+            }
+        }
+    return mx > 0.0 ? worst / mx : 0.0;
+}
+
+// tab as for pack_legendre_strip.  nlat / lmax: logical extents.  The folded entry is the mean of the two mirror entries (they
+// differ by fp32 rounding of the fp64 recursion at most); the middle row of an odd nlat keeps its own value.
+inline void pack_legendre_fold(const float* tab, int mmax, int nlat, int lmax, int pitch, int mode, float scale, StripPack& out) {
+    const int R = mode == 0 ? lmax : nlat, K = mode == 0 ? nlat : lmax;
+    out.tile_off.assign((size_t)mmax, 0);
+    long blocks = 0;
+    for (int m = 0; m < mmax; ++m) {
+        const FoldGeom g = fold_geom(mode, m, R, K);
+        out.tile_off[m] = (int)blocks;
+        blocks += (long)g.npairs * 2 * g.nkp2;
+    }
+    out.blocks = blocks;
+    out.frags.assign((size_t)blocks * 1024, 0);
+    for (int m = 0; m < mmax; ++m) {
+        const FoldGeom g = fold_geom(mode, m, R, K);
+        for (int u = 0; u < 2 * g.npairs; ++u) {
+            const int tp = u >> 1, p = u & 1;
+            for (int jj = 0; jj < g.nkp; ++jj) {
+                uint16_t* blk = out.frags.data() + ((size_t)out.tile_off[m] + (size_t)u * g.nkp2 + jj) * 1024;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, gg = lane >> 5;
+                    for (int e = 0; e < 8; ++e) {
+                        const int c = 16 * jj + 8 * gg + e;
+                        // forward: row = degree index, column = folded latitude; inverse: row = folded latitude, column = degree index
+                        const int kf = mode == 0 ? c : 32 * tp + i;
+                        const int l = m + p + 2 * (mode == 0 ? 32 * tp + i : c);
+                        float v = 0.f;
+                        if (kf < g.Hh && l < lmax) {
+                            const int km = nlat - 1 - kf;
+                            const double s = p ? -1.0 : 1.0;
+                            const double a = mode == 0 ? tab[((size_t)m * lmax + l) * pitch + kf] : tab[((size_t)m * nlat + kf) * pitch + l];
+                            const double b = mode == 0 ? tab[((size_t)m * lmax + l) * pitch + km] : tab[((size_t)m * nlat + km) * pitch + l];
+                            v = (float)((km == kf ? a : 0.5 * (a + s * b)) * (double)scale);
+                        }
+                        const uint16_t hi = f32_to_f16_bits(v);
+                        const uint16_t lo = f32_to_f16_bits(v - f16_bits_to_f32(hi));
+                        blk[lane * 8 + e] = hi;
+                        blk[512 + lane * 8 + e] = lo;
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace ace

@@ -113,6 +113,67 @@ class Distributed:
         self._owns_group = False
 
 
+class AsyncEnsembleMean:
+    """The ensemble-mean diagnostic OFF the step stream ("on a side stream, at diagnostic cadence").
+
+    `submit(fields)` records an event on the caller's stream, and on a side stream - after that event - stacks the fields into a
+    reduction buffer owned by this object, all-reduces it over RCCL (the process group's collective is ordered after the side
+    stream, not after the step stream) and divides by the number of ranks.  The step stream never waits: the next step's
+    kernels are enqueued while the reduce is in flight; the producer may overwrite its fields only after `wait()` /
+    `result()` (or after its own stream has waited on `done`).  On CPU tensors (gloo) the same calls run synchronously.
+    Semantics: gen.mean(dim=members) then reduce_mean (fme/ace/aggregator/one_step/ensemble.py:93-112,299;
+    fme/core/distributed/torch_distributed.py:130-132)."""
+
+    def __init__(self, shape, device, distributed: Optional[Distributed] = None):
+        self.dist = distributed or Distributed.get_instance()
+        self.device = torch.device(device)
+        self.buf = torch.zeros(tuple(shape), device=self.device)
+        self.cuda = self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self.done = torch.cuda.Event(enable_timing=True) if self.cuda else None
+        self.begin = torch.cuda.Event(enable_timing=True) if self.cuda else None
+        self._pending = False
+
+    def submit(self, fields) -> None:
+        """fields: a sequence of equally shaped tensors (one per output name) or one tensor of the buffer's shape, produced on the
+        CURRENT stream"""
+        if not self.cuda:
+            self.buf.copy_(fields if torch.is_tensor(fields) else torch.stack(list(fields)))
+            self.dist.reduce_mean(self.buf)
+            self._pending = True
+            return
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            if torch.is_tensor(fields):
+                self.buf.copy_(fields)
+            else:
+                torch.stack(list(fields), out=self.buf)
+            self.begin.record(self.stream)
+            self.dist.reduce_mean(self.buf)
+            self.done.record(self.stream)
+        self._pending = True
+
+    def wait(self) -> None:
+        """make the CURRENT stream wait for the last submitted reduction (no host synchronisation)"""
+        if self.cuda and self._pending:
+            torch.cuda.current_stream(self.device).wait_event(self.done)
+
+    def result(self) -> torch.Tensor:
+        """the reduced mean, after a host synchronisation on the side stream"""
+        if self.cuda and self._pending:
+            self.done.synchronize()
+        return self.buf
+
+    def last_allreduce_ms(self) -> Optional[float]:
+        """device time of the last all-reduce + scale on the side stream (None before the first one / on CPU)"""
+        if not (self.cuda and self._pending):
+            return None
+        self.done.synchronize()
+        return float(self.begin.elapsed_time(self.done))
+
+
 class EnsembleMean:
     """Running ensemble-mean diagnostic over members that live on different ranks
     (fme/ace/aggregator/one_step/ensemble.py:93-112,299): mean over local members, then reduce_mean."""

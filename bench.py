@@ -185,19 +185,24 @@ def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, 
     if "ocean_fraction" in fc:
         fc["ocean_fraction"] = torch.rand(1, T + 1, *IMG, generator=g).to(dev)
     eng.load(ic, fc)
-    ens_mean = torch.zeros(len(eng.out_names), *IMG, device=dev)
+    from ace_amd.distributed import AsyncEnsembleMean
+    ens = AsyncEnsembleMean((len(eng.out_names), *IMG), dev, dist)   # side stream + events: the step stream never waits for RCCL
 
     def window(n_steps):
         for s in range(n_steps):
             eng._enqueue_step(s % T, eng.graph_mode == "step")
 
+    allreduce_ms = None
     with torch.no_grad():
         if eng.graph_mode == "window":
             eng.run_window()                                      # untimed: captures the K-step window and replays it
         else:
             window(max(Wm, 1))                                    # untimed warm-up (graph capture happens here)
         if world > 1:                                             # ... and of the one collective: RCCL sets its channels / buffers
-            dist.reduce_mean(ens_mean)                            # up on the first all-reduce of a size
+            ens.submit([eng.out[n][0, 0] for n in eng.out_names])  # up on the first all-reduce of a size
+            ens.result()
+            ens.submit([eng.out[n][0, 0] for n in eng.out_names])  # second one: the steady-state time of the collective
+            allreduce_ms = ens.last_allreduce_ms()
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
@@ -206,9 +211,9 @@ def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, 
             eng.run_window()
         else:
             window(K)
-        if world > 1:  # ensemble-mean diagnostic of the final state, once per window (reference cadence)
-            ens_mean.copy_(torch.stack([eng.out[n][0, K - 1] for n in eng.out_names]))
-            dist.reduce_mean(ens_mean)
+        if world > 1:  # ensemble-mean diagnostic of the final state, once per window (reference cadence), on the side stream
+            ens.submit([eng.out[n][0, K - 1] for n in eng.out_names])
+            ens.result()
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
@@ -245,7 +250,7 @@ def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, 
     y_gpu = eng.y.detach().cpu() if rank == 0 else None
     del eng
     torch.cuda.empty_cache()
-    return dict(dt=dt, stages=stages, x_cpu=x_cpu, y_gpu=y_gpu)
+    return dict(dt=dt, stages=stages, x_cpu=x_cpu, y_gpu=y_gpu, allreduce_ms=allreduce_ms, allreduce_bytes=ens.buf.numel() * 4)
 
 
 # HBM bytes per launch and MFMA-busy from separate rocprofv3 --pmc passes (tools/pmc_collect.sh -> tools/pmc_to_profile.py ->
@@ -321,6 +326,16 @@ def main():
         modes = [args.precision]
     runs = {m: time_mode(stepper, m, forcing, prog, dist, dev, K, Wm, args.graph, world, rank) for m in modes}
 
+    # who ran what: one record per rank (device, its member's wall time and its all-reduce time), gathered on every rank
+    ranks_info = [None] * world
+    mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(dev),
+            "backend": (torch.distributed.get_backend() if dist.is_distributed() else "none"),
+            "allreduce_ms": runs[modes[0]]["allreduce_ms"]}
+    if dist.is_distributed():
+        torch.distributed.all_gather_object(ranks_info, mine)
+    else:
+        ranks_info = [mine]
+
     result = None
     if rank == 0:
         main_mode = modes[0]
@@ -382,6 +397,9 @@ def main():
                        "collective": "RCCL all-reduce mean of the (50,180,360) output state once per window" if world > 1 else "none"},
             "roofline": roofline, "roofline_sht": roofline_sht, "stages": stages, "cpu_baseline": cpu,
             "lib_sha256": lib_sha256(),
+            "multi_gpu": {"world_size": world, "ranks": ranks_info, "allreduce_bytes": r["allreduce_bytes"],
+                          "allreduce_stream": "side stream, event-ordered after the step stream (ace_amd/distributed.py AsyncEnsembleMean)",
+                          "timing": "max over ranks of [barrier; K steps; one ensemble-mean all-reduce; sync; barrier]"},
         }
         for m in modes[1:]:
             result[f"mode_{m}"] = {"value": round(world * K / runs[m]["dt"], 3), "unit": "steps/s",

@@ -9,7 +9,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def load_golden(name):
-    return torch.load(os.path.join(GOLDEN, name), weights_only=False)
+    return torch.load(os.path.join(GOLDEN, name), weights_only=False, map_location="cpu")   # (the reference-held csfno checkpoint was saved from a GPU)
 
 
 def rel_max(a: torch.Tensor, b: torch.Tensor) -> float:
@@ -121,3 +121,38 @@ def conditioning_floor(case: dict):
     exact = oracle_checkpoint_rollout(case, torch.float64)
     return [{k: float((want.double() - exact[s][k]).abs().max() / want.double().abs().max()) for k, want in st.items()}
             for s, st in enumerate(case["steps"])]
+
+
+def csfno_reference_checkpoint_case():
+    """The reference-HELD, RNG-free golden of the conditional SFNO (fme/core/models/conditional_sfno/test_sfnonet.py:162-191,
+    testdata/test_sfnonet_checkpoint_{input,output}.pt, copied as tests/golden/ref_csfno_checkpoint_*.pt): a raw conditional
+    SphericalFourierNeuralOperatorNet (embed 16, 2 layers, 9 x 18 equiangular, big skip, pos_embed) with a SCALAR context embedding
+    (8), labels (4) and a 16-channel 2-D noise context, the spectral filter stored in the pre-grouping layout (1, in, out, L, 2).
+
+    The accelerated family (NoiseConditionedSFNO, stochastic_sfno.py) has no scalar embedding, so the case is mapped onto it
+    exactly: the scalar embedding and the labels are both per-sample vectors entering every norm through a Linear layer
+    (layers.py:262-318), i.e. ONE 12-dimensional label vector with the concatenated weights; with a scalar embedding the
+    reference's scale has no leading 1 (scale = W_scale(e) + ..., layers.py:270-281), which goes into the merged bias.
+    Returns dict(kwargs, labels (12 names), state (ace_amd NoiseConditionedSFNO names), x, label_vector, noise, y)."""
+    d = load_golden("ref_csfno_checkpoint_input.pt")
+    y = load_golden("ref_csfno_checkpoint_output.pt")
+    x = d.pop("x")
+    ctx = d.pop("context")
+    state = {}
+    for k, v in d.items():
+        if ".W_scale." in k or ".W_bias." in k or "_labels." in k:
+            continue
+        state["conditional_model." + k] = v.clone()
+    for k in list(d):
+        if k.endswith(".W_scale.weight") or k.endswith(".W_bias.weight"):
+            which = "scale" if k.endswith(".W_scale.weight") else "bias"
+            pre = k[: -len(f"W_{which}.weight")]
+            w = torch.cat([d[pre + f"W_{which}.weight"], d[pre + f"W_{which}_labels.weight"]], dim=1)
+            b = d[pre + f"W_{which}.bias"] + d[pre + f"W_{which}_labels.bias"] - (1.0 if which == "scale" else 0.0)
+            state["conditional_model." + pre + f"W_{which}_labels.weight"] = w
+            state["conditional_model." + pre + f"W_{which}_labels.bias"] = b
+    kwargs = dict(embed_dim=16, num_layers=2, noise_embed_dim=16, noise_type="gaussian", data_grid="equiangular",
+                  filter_type="linear", pos_embed=True, big_skip=True, encoder_layers=1, use_mlp=True)
+    labels = [f"context_{i:02d}" for i in range(12)]
+    return dict(kwargs=kwargs, labels=labels, state=state, x=x, label_vector=torch.cat([ctx["embedding_scalar"], ctx["labels"]], dim=1),
+                noise=ctx["noise"], y=y)

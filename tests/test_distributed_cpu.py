@@ -14,7 +14,7 @@ WORKER = textwrap.dedent(
     import os, sys, torch
     sys.path.insert(0, os.environ["ACE_ROOT"])
     os.environ["FME_FORCE_CPU"] = "1"
-    from ace_amd.distributed import Distributed, EnsembleMean
+    from ace_amd.distributed import AsyncEnsembleMean, Distributed, EnsembleMean
     d = Distributed.get_instance()
     assert d.world_size == 2 and d.is_distributed()
     # member g lives on rank g % world (fme/ace/data_loading/inference.py:296-298)
@@ -26,6 +26,14 @@ WORKER = textwrap.dedent(
     ref = (torch.randn(3, 4, 8, generator=torch.Generator().manual_seed(100))
            + torch.randn(3, 4, 8, generator=torch.Generator().manual_seed(101))) / 2
     torch.testing.assert_close(mean, ref)
+    # the side-stream form bench.py and the rollout use (synchronous on CPU tensors): a list of per-name fields, then a tensor
+    am = AsyncEnsembleMean((3, 4, 8), "cpu", d)
+    am.submit([state[i] for i in range(3)])
+    am.wait()
+    torch.testing.assert_close(am.result(), ref)
+    am.submit(2.0 * state)
+    torch.testing.assert_close(am.result(), 2.0 * ref)
+    assert am.last_allreduce_ms() is None
     t = torch.tensor([float(d.rank + 1)])
     assert d.reduce_max(t.clone()).item() == 2.0
     assert d.reduce_sum(t.clone()).item() == 3.0

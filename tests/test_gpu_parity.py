@@ -128,10 +128,15 @@ def test_sht_golden_regression(dev):
     (8, 16, None, None, "equiangular", 3), (24, 48, 20, 17, "legendre-gauss", 33), (180, 360, 120, 100, "legendre-gauss", 17),
     (30, 720, 24, 15, "equiangular", 9), (20, 1440, 16, 12, "legendre-gauss", 5),
 ])
-@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
-def test_sht_vs_oracle(dev, nlat, nlon, lmax, mmax, grid, n, precision):
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16x3-nofold"])
+def test_sht_vs_oracle(dev, nlat, nlon, lmax, mmax, grid, n, precision, monkeypatch):
+    """f16x3: the Legendre stages run the equatorially folded strip kernel (csrc/strip_fold.hip) wherever the tables are
+    mirror-symmetric (all three quadratures; odd nlat has a self-mirrored middle row); f16x3-nofold: csrc/strip.hip, all latitudes."""
     import ace_amd
     import oracle
+    if precision == "f16x3-nofold":
+        monkeypatch.setenv("ACE_NO_FOLD", "1")   # read when the plan is built
+        precision = "f16x3"
     x = torch.randn(n, nlat, nlon, generator=torch.Generator().manual_seed(nlat))
     o_f = oracle.RealSHT(nlat, nlon, lmax, mmax, grid, dtype=torch.float64)
     o_i = oracle.InverseRealSHT(nlat, nlon, lmax, mmax, grid, dtype=torch.float64)
@@ -162,10 +167,13 @@ def test_sht_leading_dims_and_empty(dev):
         ace_amd.RealSHT(12, 24, grid="healpix")
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
-def test_sht_180x360_vs_reference(dev, precision):
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16x3-nofold"])
+def test_sht_180x360_vs_reference(dev, precision, monkeypatch):
     """coefficients and round trip emitted by the reference itself (tests/golden/make_golden.py)."""
     import ace_amd
+    if precision == "f16x3-nofold":
+        monkeypatch.setenv("ACE_NO_FOLD", "1")
+        precision = "f16x3"
     d = load_golden("gen_sht_180x360.pt")
     x = torch.randn(3, 180, 360, generator=torch.Generator().manual_seed(d["seed"]))
     sht = ace_amd.RealSHT(180, 360, lmax=180, mmax=181, grid="legendre-gauss", precision=precision)

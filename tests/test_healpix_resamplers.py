@@ -96,15 +96,7 @@ def test_resampler_configuration_surface():
         SmoothedInterpolateConv(in_channels=2, out_channels=2, mode="bilinear")
 
 
-# ---------------------------------------------------------------------------------------------------------------------
-# Written after round 3's GPU budget was spent: these have run on the CPU emulations of the C ABI only.  They are skipped unless
-# ACE_RUN_UNVERIFIED=1 (tools/r4_first.sh sets it - the first GPU call of the next round); once green there, the gate goes.
-_unverified = pytest.mark.skipif(not os.environ.get("ACE_RUN_UNVERIFIED"), reason="not yet run on an MI355X (written after the round's "
-                                 "GPU budget was spent); set ACE_RUN_UNVERIFIED=1 - tools/r4_first.sh does")
-
-
 @pytest.mark.gpu
-@_unverified
 @pytest.mark.parametrize("name", ["dealiased_smoothed", "dealiased_smoothed_isolatitude"])
 def test_resampler_unets_vs_reference(name):
     g = load_golden("gen_healpix_resamplers.pt")["unet"][name]
@@ -116,7 +108,6 @@ def test_resampler_unets_vs_reference(name):
 
 
 @pytest.mark.gpu
-@_unverified
 def test_resampler_blocks_vs_reference():
     gold = load_golden("gen_healpix_resamplers.pt")["blocks"]
     for name, g in gold.items():

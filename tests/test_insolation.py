@@ -236,16 +236,7 @@ def test_forcing_deriver_on_a_window():
     assert passthrough(forcing) is forcing
 
 
-# ---------------------------------------------------------------------------------------------------------------------
-# on the device (the derived forcing is computed where the forcing window lives)
-# Written after round 3's GPU budget was spent: these have run on the CPU emulations of the C ABI only.  They are skipped unless
-# ACE_RUN_UNVERIFIED=1 (tools/r4_first.sh sets it - the first GPU call of the next round); once green there, the gate goes.
-_unverified = pytest.mark.skipif(not os.environ.get("ACE_RUN_UNVERIFIED"), reason="not yet run on an MI355X (written after the round's "
-                                 "GPU budget was spent); set ACE_RUN_UNVERIFIED=1 - tools/r4_first.sh does")
-
-
 @pytest.mark.gpu
-@_unverified
 def test_insolation_on_the_device_matches_the_reference_cases():
     """Same cases, computed on the MI355X (ATen elementwise kernels; sin / cos differ from the host's by an ulp): the same
     absolute bound as on the host."""
@@ -263,7 +254,6 @@ def test_insolation_on_the_device_matches_the_reference_cases():
 
 
 @pytest.mark.gpu
-@_unverified
 @pytest.mark.parametrize("graph", [None, "step"])
 def test_rollout_engine_with_derived_insolation(graph):
     """RolloutEngine / EnginePredict of a stepper whose checkpoint derives the insolation: the engine computes it once per window

@@ -168,15 +168,7 @@ def test_secondary_decoder_configuration_errors():
         ace_amd.SingleModuleStepConfig(**base, secondary_decoder={**sd(["d"]), "surprise": 1})
 
 
-# ---------------------------------------------------------------------------------------------------------------------
-# Written after round 3's GPU budget was spent: these have run on the CPU emulations of the C ABI only.  They are skipped unless
-# ACE_RUN_UNVERIFIED=1 (tools/r4_first.sh sets it - the first GPU call of the next round); once green there, the gate goes.
-_unverified = pytest.mark.skipif(not os.environ.get("ACE_RUN_UNVERIFIED"), reason="not yet run on an MI355X (written after the round's "
-                                 "GPU budget was spent); set ACE_RUN_UNVERIFIED=1 - tools/r4_first.sh does")
-
-
 @pytest.mark.gpu
-@_unverified
 def test_mlp_vs_reference_on_the_device():
     for name, g in load_golden("gen_step_options.pt")["mlp"].items():
         net = ace_amd.ModuleSelector(type="MLP", config=g["config"]).build(g["n_in"], g["n_out"], ace_amd.DatasetInfo((4, 8))).torch_module
@@ -189,7 +181,6 @@ def test_mlp_vs_reference_on_the_device():
 
 
 @pytest.mark.gpu
-@_unverified
 def test_stepper_with_multi_call_and_secondary_decoder_on_the_device():
     """the same reference rollout through the real kernels (network, decoder MLP, the multi-call re-evaluations), per multiplier
     and as one batched step"""

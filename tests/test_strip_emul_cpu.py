@@ -20,6 +20,18 @@ def test_strip_kernel_index_algebra(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_folded_strip_kernel_index_algebra(tmp_path):
+    """ace_amd/csrc/strip_fold.hip (equatorially folded Legendre stages): geometry, packer, the two range-checked strip
+    descriptors, unit / pair loop, row maps and store masks against UNFOLDED direct sums - even and odd nlat, ragged shapes,
+    every output element written exactly once."""
+    exe = str(tmp_path / "strip_fold_emul")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "emul", "strip_fold_emul.cpp")], check=True)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "worst" in res.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
 def test_conv_ws_work_decomposition(tmp_path):
     """ace_amd/csrc/ws_plan.h (shared by the kernel and its launcher): every (channel slice, pixel tile) unit exactly once,
     every (statistics slot, row) exactly one partial, over a sweep of channel counts and field sizes."""
