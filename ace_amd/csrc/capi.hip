@@ -51,9 +51,12 @@ Switches read_switches() {
     sw.no_strip = on("ACE_NO_STRIP");
     sw.no_fold = on("ACE_NO_FOLD");
     sw.no_dhconv_strip = on("ACE_NO_DHCONV_STRIP");
+#ifdef ACE_MEASUREMENT_SWITCHES   // historical routings: measurement builds only (tools/mkvar.sh NAME -DACE_MEASUREMENT_SWITCHES)
     sw.no_pk = on("ACE_NO_PK");
     sw.no_pk_sht = on("ACE_NO_PK_SHT");
+#endif
     sw.no_enc_ws = on("ACE_NO_ENC_WS");
+    sw.no_enc_pk = on("ACE_NO_ENC_PK");
     if (const char* e = std::getenv("ACE_CONV_WL")) sw.conv_wl = !(e[0] == '0' && !e[1]);
     if (const char* e = std::getenv("ACE_PLANES_STREAM")) sw.planes_stream = !(e[0] == '0' && !e[1]);
     if (const char* e = std::getenv("ACE_CONV_WS")) {
@@ -162,32 +165,35 @@ static int plan_build(int nlat, int nlon, int lmax, int mmax, Grid g, std::uniqu
         HIP_TRY(launch_split_f16(p->wt.p, t.Hp, p->wt_hi.p, p->wt_lo.p, t.Hp, (long)t.mmax * t.lmax, t.Hp, p->wt_scale, nullptr));
         HIP_TRY(launch_split_f16(p->pt.p, t.Lp, p->pt_hi.p, p->pt_lo.p, t.Lp, (long)t.mmax * t.nlat, t.Lp, p->pt_scale, nullptr));
         HIP_TRY(hipDeviceSynchronize());
+        auto up = [](const StripPack& sp, DevBuf& frag, DevBuf& off) -> hipError_t {
+            hipError_t e = frag.alloc((sp.frags.size() + 1) / 2, false);   // halves -> floats
+            if (e != hipSuccess) return e;
+            e = hipMemcpy(frag.p, sp.frags.data(), sp.frags.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return e;
+            e = off.alloc(sp.tile_off.size(), false);
+            if (e != hipSuccess) return e;
+            return hipMemcpy(off.p, sp.tile_off.data(), sp.tile_off.size() * sizeof(int), hipMemcpyHostToDevice);
+        };
         if (t.nlat <= 192 && t.lmax <= 192) {
-            auto up = [](const StripPack& sp, DevBuf& frag, DevBuf& off) -> hipError_t {
-                hipError_t e = frag.alloc((sp.frags.size() + 1) / 2, false);   // halves -> floats
-                if (e != hipSuccess) return e;
-                e = hipMemcpy(frag.p, sp.frags.data(), sp.frags.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
-                if (e != hipSuccess) return e;
-                e = off.alloc(sp.tile_off.size(), false);
-                if (e != hipSuccess) return e;
-                return hipMemcpy(off.p, sp.tile_off.data(), sp.tile_off.size() * sizeof(int), hipMemcpyHostToDevice);
-            };
             StripPack sp;
             pack_legendre_strip(t.wt.data(), t.mmax, t.lmax, t.nlat, t.Hp, 0, p->wt_scale, sp);
             HIP_TRY(up(sp, p->wt_frag, p->wt_off));
             pack_legendre_strip(t.pt.data(), t.mmax, t.nlat, t.lmax, t.Lp, 1, p->pt_scale, sp);
             HIP_TRY(up(sp, p->pt_frag, p->pt_off));
             p->strip = true;
-            // P_l^m(-x) = (-1)^(l+m) P_l^m(x) on a grid that is symmetric about the equator (all three quadratures are): checked
-            // on the fp32 tables themselves - mirror entries agree to the rounding of the fp64 recursion
-            if (fold_symmetry_error(t.wt.data(), t.mmax, t.nlat, t.lmax, t.Hp, 0) < 2e-6 &&
-                fold_symmetry_error(t.pt.data(), t.mmax, t.nlat, t.lmax, t.Lp, 1) < 2e-6) {
-                pack_legendre_fold(t.wt.data(), t.mmax, t.nlat, t.lmax, t.Hp, 0, p->wt_scale, sp);
-                HIP_TRY(up(sp, p->wt_ffrag, p->wt_foff));
-                pack_legendre_fold(t.pt.data(), t.mmax, t.nlat, t.lmax, t.Lp, 1, p->pt_scale, sp);
-                HIP_TRY(up(sp, p->pt_ffrag, p->pt_foff));
-                p->fold = true;
-            }
+        }
+        // P_l^m(-x) = (-1)^(l+m) P_l^m(x) on a grid that is symmetric about the equator (all three quadratures are): checked
+        // on the fp32 tables themselves - mirror entries agree to the rounding of the fp64 recursion.  Folded, a parity's contraction
+        // fits the strip kernels' resident operand up to 768 latitudes / degrees (strip_fold.hip: 0.25-degree grid included).
+        if ((t.nlat + 1) / 2 <= 16 * FOLD_NKP_BIG && (t.lmax + 1) / 2 <= 16 * FOLD_NKP_BIG && !p->sw.no_fold &&
+            fold_symmetry_error(t.wt.data(), t.mmax, t.nlat, t.lmax, t.Hp, 0) < 2e-6 &&
+            fold_symmetry_error(t.pt.data(), t.mmax, t.nlat, t.lmax, t.Lp, 1) < 2e-6) {
+            StripPack sp;
+            pack_legendre_fold(t.wt.data(), t.mmax, t.nlat, t.lmax, t.Hp, 0, p->wt_scale, sp);
+            HIP_TRY(up(sp, p->wt_ffrag, p->wt_foff));
+            pack_legendre_fold(t.pt.data(), t.mmax, t.nlat, t.lmax, t.Lp, 1, p->pt_scale, sp);
+            HIP_TRY(up(sp, p->pt_ffrag, p->pt_foff));
+            p->fold = true;
         }
     }
     out = std::move(p);
@@ -225,7 +231,7 @@ static int run_legendre_forward(const ace_sht_plan& pl, const float* X, float* D
     g.C = D; g.ldc = (long)pl.mmax * N2; g.sC = N2;
     g.M = pl.lmax; g.N = (int)N2; g.K = pl.nlat; g.nbatch = pl.mmax; g.a_kpad = pl.Hp;
     g.tri = TRI_ROWS_GE_BATCH;
-    if (pl.strip && !pl.sw.no_strip && xmax) {   // register-resident strip kernel (strip.hip)
+    if ((pl.strip || pl.fold) && !pl.sw.no_strip && xmax) {   // register-resident strip kernels (strip_fold.hip, strip.hip)
         LegStripArgs a;
         a.B = X; a.b_kstride = N2; a.b_moff = (long)pl.nlat * N2;
         a.A = reinterpret_cast<const _Float16*>(pl.wt_frag.p); a.tile_off = reinterpret_cast<const int*>(pl.wt_off.p);
@@ -247,7 +253,7 @@ static int run_legendre_forward(const ace_sht_plan& pl, const float* X, float* D
                 return ACE_OK;
             }
         }
-        if (legendre_strip_eligible(a)) {
+        if (pl.strip && legendre_strip_eligible(a)) {
             HIP_TRY(launch_legendre_strip(a, s));
             return ACE_OK;
         }
@@ -277,7 +283,7 @@ static int run_legendre_inverse(const ace_sht_plan& pl, const float* E, float* X
     g.C = X; g.ldc = N2; g.sC = (long)pl.nlat * N2;
     g.M = pl.nlat; g.N = (int)N2; g.K = pl.lmax; g.nbatch = pl.mmax; g.a_kpad = pl.Lp;
     g.tri = TRI_K_GE_BATCH;
-    if (pl.strip && !pl.sw.no_strip && emax) {   // register-resident strip kernel (strip.hip)
+    if ((pl.strip || pl.fold) && !pl.sw.no_strip && emax) {   // register-resident strip kernels (strip_fold.hip, strip.hip)
         LegStripArgs a;
         a.B = E; a.b_kstride = (long)pl.mmax * N2; a.b_moff = N2;
         a.A = reinterpret_cast<const _Float16*>(pl.pt_frag.p); a.tile_off = reinterpret_cast<const int*>(pl.pt_off.p);
@@ -292,7 +298,7 @@ static int run_legendre_inverse(const ace_sht_plan& pl, const float* E, float* X
                 return ACE_OK;
             }
         }
-        if (legendre_strip_eligible(a)) {
+        if (pl.strip && legendre_strip_eligible(a)) {
             HIP_TRY(launch_legendre_strip(a, s));
             return ACE_OK;
         }
@@ -588,7 +594,6 @@ extern "C" int ace_conditional_layer_norm(const float* x, const float* noise, co
                                           int noise_dim, long hw, void* stream) {
     if (!x || !y || n <= 0 || c <= 0 || hw <= 0 || (w_scale && (!w_bias || !noise || noise_dim <= 0)))
         return fail(ACE_ERR_INVALID, "ace_conditional_layer_norm: bad argument");
-    if (hw % 4 != 0) return fail(ACE_ERR_INVALID, "ace_conditional_layer_norm: needs hw % 4 == 0");
     hipStream_t s = static_cast<hipStream_t>(stream);
     DevBuf stats;
     HIP_TRY(stats.alloc((size_t)2 * n * hw, false));
@@ -660,6 +665,7 @@ struct ace_sfno {
     DevBuf Wq1;          // folded (norm affine) fc1 weights as packed MFMA A fragments, per sample (conv_ws.hip)
     DevBuf Wq0;          // folded inner-skip weights likewise
     DevBuf zero_c;       // C zeros (bias of the bias-free last encoder convolution on conv_ws.hip)
+    DevBuf inP;          // the network input as P-format planes (in_chans rounded up to 8 channels): operand of the first encoder convolution
     DevBuf pe_slot;      // dynamic-range slot (64 words) holding max|pos_embed|: the residual bound of that convolution
     DevBuf phys;         // fused post-step physics (ace_step_physics): fp64 global sums, parameters
     int nstrips = 0;
@@ -708,13 +714,14 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
         if (c.noise_embed_dim < 0 || c.noise_embed_dim > 512) return fail(ACE_ERR_INVALID, "noise_embed_dim must be in [0, 512]");
         if (c.filter_num_groups < 1 || c.embed_dim % c.filter_num_groups != 0)
             return fail(ACE_ERR_INVALID, "embed_dim must be divisible by filter_num_groups");
-        if (((long)c.nlat * c.nlon) % 4 != 0) return fail(ACE_ERR_INVALID, "conditional layer norm needs nlat * nlon % 4 == 0");
     }
     if (c.activation_function < 1 || c.activation_function > 3)
         return fail(ACE_ERR_INVALID, "Unknown activation function");
-    if (c.data_grid != GRID_LEGENDRE_GAUSS && c.data_grid != GRID_EQUIANGULAR)
-        return fail(ACE_ERR_INVALID, "data_grid must be 'legendre-gauss' or 'equiangular'");
-    if (c.encoder_layers < 1) return fail(ACE_ERR_INVALID, "encoder_layers must be >= 1");
+    // 'lobatto' is what fme.sht_fix.RealSHT defaults to and what the reference's block-level goldens were made on
+    // (conditional_sfno/benchmark.py:85-86); the registered builders only ever pass the other two
+    if (c.data_grid != GRID_LEGENDRE_GAUSS && c.data_grid != GRID_EQUIANGULAR && c.data_grid != GRID_LOBATTO)
+        return fail(ACE_ERR_INVALID, "data_grid must be 'legendre-gauss', 'equiangular' or 'lobatto'");
+    if (c.encoder_layers < 0) return fail(ACE_ERR_INVALID, "encoder_layers must be >= 0");   // 0: one bias-free convolution each side (sfnonet.py:566-577, 660-671)
     if (c.precision != 0 && c.precision != 1) return fail(ACE_ERR_INVALID, "precision must be 0 (fp32) or 1 (f16x3)");
 
     auto n = std::make_unique<ace_sfno>();
@@ -818,6 +825,7 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
                 HIP_TRY(n->Wq1.alloc((size_t)n->Bmax * n->hid * C, true));   // hi + lo halves = one float per element
             if (conv_ws_eligible((int)C, (int)C, HW, 0, n->sw.conv_ws_roles)) HIP_TRY(n->Wq0.alloc((size_t)n->Bmax * C * C, true));
             HIP_TRY(n->zero_c.alloc((size_t)C, true));
+            HIP_TRY(n->inP.alloc((size_t)n->Bmax * ((c.in_chans + 7) / 8 * 8) * n->HW, true));   // two planes of halves = one float per element
             HIP_TRY(n->pe_slot.alloc(64, true));
             HIP_TRY(n->part.alloc((size_t)2 * n->Bmax * n->nstrips * C * 4, true));
             const size_t cp = (size_t)((C + 31) & ~31);
@@ -867,7 +875,7 @@ extern "C" long ace_sfno_workspace_size(const ace_sfno* n, int batch) {
     size_t fl = 0;
     auto add = [&](const DevBuf& b) { fl += b.n; };
     for (const DevBuf* b : {&n->h0, &n->h1, &n->Y, &n->T, &n->R, &n->U, &n->X, &n->D, &n->E, &n->stats, &n->P, &n->cln_stats, &n->inN,
-                            &n->P2, &n->part, &n->Wp0, &n->Wp1, &n->Wq1, &n->Wq0, &n->zero_c, &n->pe_slot, &n->Wf0, &n->bf0, &n->Wf1,
+                            &n->P2, &n->part, &n->Wp0, &n->Wp1, &n->Wq1, &n->Wq0, &n->zero_c, &n->inP, &n->pe_slot, &n->Wf0, &n->bf0, &n->Wf1,
                             &n->bf1, &n->amax, &n->phys})
         add(*b);
     for (const auto& t : n->taps) add(t);
@@ -1197,7 +1205,35 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     long cur_bs = (long)Cin * HW;
     int curC = Cin;
     float* ping[2] = {n->Y.p, n->T.p};
-    for (int j = 0; j < c.encoder_layers; ++j) {
+    // Will the last encoder convolution run on conv_ws.hip (below)?  Then a ONE-hidden-layer encoder (the ACE2 shape) never
+    // materialises its hidden activation as fp32: the network input is packed to P-format planes (in_chans rounded up to a k-group,
+    // 11 MB) and the first convolution runs on the packed-operand engine, whose epilogue writes GELU(W x + b) straight as the
+    // planes that convolution reads (r03: fp32 write + pack pass = 55 + 41 us per step).
+    const bool enc_ws_ok = [&] {
+        const Weight& we = *n->weights[n->index.at("encoder." + std::to_string(2 * c.encoder_layers) + ".weight")];
+        const bool block0_fused = f16 && c.normalization_layer == 1 && c.use_mlp && n->P2.p && packed_ok(n, C) && n->hid % 8 == 0 &&
+                                  (n->plan_data == n->plan_lg.get() || c.num_layers == 1);
+        return !n->sw.no_enc_ws && block0_fused && c.encoder_layers >= 1 && c.pos_embed && we.frag0.p && n->zero_c.p &&
+               n->pe_slot.p && n->part.p && conv_ws_eligible(C, C, HW, 2, n->sw.conv_ws_roles);
+    }();
+    bool enc_hidden_planes = false;   // n->P holds the last hidden activation of the encoder as planes scaled from slot(encoder_layers)
+    if (enc_ws_ok && c.encoder_layers == 1 && n->inP.p && !n->sw.no_enc_pk) {
+        const Weight& w0 = *n->weights[n->index.at("encoder.0.weight")];
+        const Weight& b0 = *n->weights[n->index.at("encoder.0.bias")];
+        const int cin8 = (Cin + 7) / 8 * 8;
+        if (w0.thi.p && w0.pitch >= cin8) {
+            _Float16* Ih = reinterpret_cast<_Float16*>(n->inP.p);
+            _Float16* Il = Ih + (size_t)n->Bmax * cin8 * HW;
+            HIP_TRY(launch_pack_pformat(in, HW, (long)Cin * HW, Cin, (int)HW, B, nullptr, nullptr, 0, slot(0), Ih, Il, HW, (long)cin8 * HW, s));
+            _Float16* Th = reinterpret_cast<_Float16*>(n->P.p);
+            _Float16* Tl = Th + (size_t)n->Bmax * C * HW;
+            ACE_TRY(conv_pk(n, w0, b0.buf.p, Ih, Il, cin8, slot(0), nullptr, C, nullptr, 0, nullptr, nullptr, act, B, s, nullptr, Th, Tl,
+                            b0.absmax, slot(1)));
+            enc_hidden_planes = true;
+            curC = C;
+        }
+    }
+    for (int j = 0; j < c.encoder_layers && !enc_hidden_planes; ++j) {
         const std::string p = "encoder." + std::to_string(2 * j);
         ACE_TRY(conv(n, conv_weight(n, p + ".weight", p + ".bias"), cur, cur_bs, curC, nullptr, 0, -1, ping[j & 1], C,
                      nullptr, 0, nullptr, nullptr, act, B, s, nullptr, nullptr, slot(j == 0 ? 0 : j), nullptr,
@@ -1222,7 +1258,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             _Float16* Tl = Th + (size_t)n->Bmax * C * HW;
             _Float16* Hh = reinterpret_cast<_Float16*>(n->P2.p);
             _Float16* Hl = Hh + (size_t)n->Bmax * C * HW;
-            ACE_TRY(pack_act(n, cur, cur_bs, C, nullptr, nullptr, slot(c.encoder_layers), Th, Tl, B, s));
+            if (!enc_hidden_planes) ACE_TRY(pack_act(n, cur, cur_bs, C, nullptr, nullptr, slot(c.encoder_layers), Th, Tl, B, s));
             ConvStripArgs k;
             k.Xhi = Th; k.Xlo = Tl; k.ldn = HW; k.sX = (long)C * HW; k.xslot = slot(c.encoder_layers);
             k.A = reinterpret_cast<const _Float16*>(we.frag0.p); k.sA = 0; k.ascale = we.ascale;
@@ -1304,6 +1340,9 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             a0 = sc0; b0 = sh0;
             MARK(ST_NORM0);
         }
+        // (Round 4 tried packing the inner skip's folded weights on a side stream beside the SHT chain - they depend on norm0's
+        // statistics only.  Same box, whole step in a hipGraph: 5.76 -> 5.86 ms; the fork / join edges cost more than the 7 us
+        // kernel they hide.  profiles/r04_s3_kdur_side_pack_*.txt)
         // spectral filter (s2convolutions.py:162-197): SHT -> contraction -> inverse SHT + bias
         unsigned *xmax = slot(sb + 0), *dmax = slot(sb + 1), *emax = slot(sb + 2);
         if (h_planes_only)   // the block input exists as planes only (written by the previous block's fc2, mode 4)
@@ -1614,9 +1653,14 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                      nullptr, j == 0 ? (c.use_mlp ? hslot(c.num_layers) : nullptr) : slot(3 + j), skip_in_slot, slot(4 + j)));
         cur = ping[j & 1]; cur_bs = actB; curC = C;
     }
-    ACE_TRY(conv(n, conv_weight(n, "decoder." + std::to_string(2 * c.encoder_layers) + ".weight", ""), cur, cur_bs, curC,
-                 nullptr, 0, -1, out, c.out_chans, nullptr, 0, nullptr, nullptr, ACT_NONE, B, s, nullptr, nullptr,
-                 slot(3 + c.encoder_layers), nullptr, nullptr));
+    {
+        // without hidden decoder layers the last convolution is the one that sees cat(x, input) and the last block's range slot
+        const bool first = c.encoder_layers == 0, cat = first && c.big_skip;
+        ACE_TRY(conv(n, conv_weight(n, "decoder." + std::to_string(2 * c.encoder_layers) + ".weight", ""), cur, cur_bs,
+                     cat ? C + Cin : curC, cat ? skip_in : nullptr, (long)Cin * HW, cat ? C : -1, out, c.out_chans, nullptr, 0, nullptr,
+                     nullptr, ACT_NONE, B, s, nullptr, nullptr,
+                     first ? (c.use_mlp ? hslot(c.num_layers) : nullptr) : slot(3 + c.encoder_layers), cat ? skip_in_slot : nullptr, nullptr));
+    }
     MARK(ST_DECODER);
     return ACE_OK;
 }

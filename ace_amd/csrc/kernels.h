@@ -12,9 +12,10 @@ struct Switches {
     bool no_strip = false;         // ACE_NO_STRIP: Legendre stages on the tile engine
     bool no_fold = false;          // ACE_NO_FOLD: Legendre stages on strip.hip (all latitudes) instead of the equatorially folded strip_fold.hip
     bool no_dhconv_strip = false;  // ACE_NO_DHCONV_STRIP: spectral filter contraction on the tile engine
-    bool no_pk = false;            // ACE_NO_PK: 1x1 convolutions on the on-the-fly-split engine (v3)
-    bool no_pk_sht = false;        // ACE_NO_PK_SHT: fp32 D, expanded filter operand
+    bool no_pk = false;            // measurement builds only (-DACE_MEASUREMENT_SWITCHES) ACE_NO_PK: 1x1 convolutions on the on-the-fly-split engine (v3)
+    bool no_pk_sht = false;        // measurement builds only: ACE_NO_PK_SHT: fp32 D, expanded filter operand
     bool no_enc_ws = false;        // ACE_NO_ENC_WS: last encoder convolution on the v3 engine
+    bool no_enc_pk = false;        // ACE_NO_ENC_PK: first encoder convolution writes fp32 + a pack pass (r03) instead of planes from the packed engine
     int conv_ws_roles = 7;         // ACE_CONV_WS=skip,fc1,fc2|all|none: roles on conv_ws.hip (bit 0 inner skip, 1 fc1, 2 fc2)
     bool conv_wl = true;           // ACE_CONV_WL=0: fc1 on conv_ws.hip instead of conv_wl.hip (weights in LDS, unsynchronised waves)
     bool planes_stream = true;     // ACE_PLANES_STREAM=0: fc2 also writes the block output as fp32 (the residual stream round-trips twice)
@@ -60,7 +61,6 @@ struct GemmArgs {
     unsigned* omax = nullptr;
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
-void set_force_v1(bool v);
 
 // Compensated-fp16 engine (f16x3): same contract as launch_gemm, but the A operand is given pre-split into two
 // fp16 planes (hi, lo; pitch g.lda HALVES, rows zero-padded to a multiple of 32 columns: g.a_kpad), scaled by the

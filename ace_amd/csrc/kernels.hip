@@ -1261,8 +1261,13 @@ hipError_t launch_split_f16_tiled(const float* src, long lds_, void* hi, void* l
 }
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-static bool g_force_v1 = (getenv("ACE_FORCE_V1") != nullptr);  // A/B switch for measurements
-void set_force_v1(bool v) { g_force_v1 = v; }
+// Historical engine switches (ACE_FORCE_V1, ACE_G4_TILE, ACE_NO_PK, ACE_NO_PK_SHT) only exist in measurement builds
+// (-DACE_MEASUREMENT_SWITCHES, tools/mkvar.sh): the shipped library has one routing per shape.
+#ifdef ACE_MEASUREMENT_SWITCHES
+static const bool g_force_v1 = (getenv("ACE_FORCE_V1") != nullptr);
+#else
+static constexpr bool g_force_v1 = false;
+#endif
 
 template <int WM, int WN, bool VEC>
 static hipError_t launch_gemm_vec(const GemmArgs& a, hipStream_t s, int tilesM, int tilesN, dim3 grid, dim3 block) {
@@ -2168,7 +2173,11 @@ hipError_t launch_gemm_f16x3_packed(const Gemm4Args& a, hipStream_t s) {
     if (a.N % 4 != 0 || (a.C && (!al16(a.C) || a.ldc % 4 != 0 || a.sC % 4 != 0))) return hipErrorInvalidValue;
     if (a.R && (!al16(a.R) || a.ldr % 4 != 0 || a.sR % 4 != 0)) return hipErrorInvalidValue;
     const long waste128 = (long)((a.M + 127) / 128) * 128, waste64 = (long)((a.M + 63) / 64) * 64;
+#ifdef ACE_MEASUREMENT_SWITCHES
     static const int env_force = getenv("ACE_G4_TILE") ? atoi(getenv("ACE_G4_TILE")) : 0;   // A/B switch: 1 = 128x128, 2 = 64x256
+#else
+    constexpr int env_force = 0;
+#endif
     const int force = a.tile ? a.tile : env_force;
     if (a.cplx && (a.cplx % 128 != 0 || a.K != 2 * a.cplx || a.N != 2 * a.cplx || a.ldn != a.cplx || force != 1)) return hipErrorInvalidValue;
     if (force == 1 || (force == 0 && a.M >= 128 && waste128 <= waste64)) return launch_gemm4_cfg<2, 2>(a, s);
@@ -3069,41 +3078,59 @@ hipError_t launch_fold_affine(const float* W, long ldw, const float* a, const fl
 //   cln_apply_kernel : thread = 8 channels x 4 pixels; the two 1x1 "noise" convolutions are computed on the fly
 //                      (2 J FMAs per element; their weights for the 8 channels sit in LDS), fp32 output + max|y|
 // ---------------------------------------------------------------------------------------------
+// V pixels per lane: 4 (16-byte accesses, H W % 4 == 0) or 1 (any field size, e.g. the 9 x 18 grids of the reference's own goldens)
+template <int V>
+struct PixVec {
+    float v[V];
+    __device__ __forceinline__ void load(const float* p) {
+        if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+        else v[0] = *p;
+    }
+    __device__ __forceinline__ void store(float* p) const {
+        if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        else *p = v[0];
+    }
+};
+
+template <int V>
 __global__ __launch_bounds__(512) void cln_stats_kernel(const float* __restrict__ x, int C, long HW, float eps,
                                                         float* __restrict__ mean, float* __restrict__ rstd) {
     const int b = blockIdx.y;
-    const int q = threadIdx.x & 63, cg = threadIdx.x >> 6;      // pixel quad, channel group (0..7)
-    const long p = ((long)blockIdx.x * 64 + q) * 4;
-    const bool ok = p < HW;                                     // HW % 4 == 0
+    const int q = threadIdx.x & 63, cg = threadIdx.x >> 6;      // pixel group, channel group (0..7)
+    const long p = ((long)blockIdx.x * 64 + q) * V;
+    const bool ok = p < HW;                                     // HW % V == 0
     const float* xb = x + (long)b * C * HW + (ok ? p : 0);
-    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    double s[V], ss[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { s[e] = 0.0; ss[e] = 0.0; }
     for (int c = cg; c < C; c += 8) {
-        const float4 v = *reinterpret_cast<const float4*>(xb + (long)c * HW);
-        const float xs[4] = {v.x, v.y, v.z, v.w};
+        PixVec<V> xv;
+        xv.load(xb + (long)c * HW);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { s[e] += (double)xs[e]; ss[e] += (double)xs[e] * (double)xs[e]; }
+        for (int e = 0; e < V; ++e) { s[e] += (double)xv.v[e]; ss[e] += (double)xv.v[e] * (double)xv.v[e]; }
     }
-    __shared__ double rs[8][64][4], rss[8][64][4];
+    __shared__ double rs[8][64][V], rss[8][64][V];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { rs[cg][q][e] = s[e]; rss[cg][q][e] = ss[e]; }
+    for (int e = 0; e < V; ++e) { rs[cg][q][e] = s[e]; rss[cg][q][e] = ss[e]; }
     __syncthreads();
     if (cg == 0 && ok) {
-        float m4[4], r4[4];
+        PixVec<V> m4, r4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < V; ++e) {
             double a = 0.0, bq = 0.0;
             for (int k = 0; k < 8; ++k) { a += rs[k][q][e]; bq += rss[k][q][e]; }
             const double mu = a / C;
             double var = bq / C - mu * mu;
             if (var < 0.0) var = 0.0;
-            m4[e] = (float)mu;
-            r4[e] = (float)(1.0 / sqrt(var + (double)eps));
+            m4.v[e] = (float)mu;
+            r4.v[e] = (float)(1.0 / sqrt(var + (double)eps));
         }
-        *reinterpret_cast<float4*>(mean + (long)b * HW + p) = make_float4(m4[0], m4[1], m4[2], m4[3]);
-        *reinterpret_cast<float4*>(rstd + (long)b * HW + p) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        m4.store(mean + (long)b * HW + p);
+        r4.store(rstd + (long)b * HW + p);
     }
 }
 
+template <int V>
 __global__ __launch_bounds__(256) void cln_apply_kernel(const float* x, const float* __restrict__ noise,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -3119,46 +3146,45 @@ __global__ __launch_bounds__(256) void cln_apply_kernel(const float* x, const fl
         wsm[t] = (src != nullptr && c < C) ? src[(long)c * J + j] : 0.f;
     }
     __syncthreads();
-    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * V;
     float vmax = 0.f;
     if (p < HW) {
-        float sc[8][4], bi[8][4];
+        float sc[8][V], bi[8][V];
 #pragma unroll
         for (int r = 0; r < 8; ++r)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { sc[r][e] = 1.f; bi[r][e] = 0.f; }
+            for (int e = 0; e < V; ++e) { sc[r][e] = 1.f; bi[r][e] = 0.f; }
         if (ws != nullptr) {
             const float* nb = noise + (long)b * J * HW + p;
             for (int j = 0; j < J; ++j) {
-                const float4 n4 = *reinterpret_cast<const float4*>(nb + (long)j * HW);
-                const float ns[4] = {n4.x, n4.y, n4.z, n4.w};
+                PixVec<V> nv;
+                nv.load(nb + (long)j * HW);
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const float a = wsm[r * J + j], bq = wsm[8 * J + r * J + j];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { sc[r][e] = fmaf(a, ns[e], sc[r][e]); bi[r][e] = fmaf(bq, ns[e], bi[r][e]); }
+                    for (int e = 0; e < V; ++e) { sc[r][e] = fmaf(a, nv.v[e], sc[r][e]); bi[r][e] = fmaf(bq, nv.v[e], bi[r][e]); }
                 }
             }
         }
-        const float4 m4 = *reinterpret_cast<const float4*>(mean + (long)b * HW + p);
-        const float4 r4 = *reinterpret_cast<const float4*>(rstd + (long)b * HW + p);
-        const float mu[4] = {m4.x, m4.y, m4.z, m4.w}, rs[4] = {r4.x, r4.y, r4.z, r4.w};
+        PixVec<V> mu, rs;
+        mu.load(mean + (long)b * HW + p);
+        rs.load(rstd + (long)b * HW + p);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int c = c0 + r;
             if (c >= C) break;
-            const float4 v = *reinterpret_cast<const float4*>(x + ((long)b * C + c) * HW + p);
-            const float xs[4] = {v.x, v.y, v.z, v.w};
+            PixVec<V> xv, o;
+            xv.load(x + ((long)b * C + c) * HW + p);
             const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
-            float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = (xs[e] - mu[e]) * rs[e];
+            for (int e = 0; e < V; ++e) {
+                float t = (xv.v[e] - mu.v[e]) * rs.v[e];
                 if (gamma) t = t * g + bt;
-                o[e] = t * sc[r][e] + bi[r][e];
-                vmax = fmaxf(vmax, fabsf(o[e]));
+                o.v[e] = t * sc[r][e] + bi[r][e];
+                vmax = fmaxf(vmax, fabsf(o.v[e]));
             }
-            *reinterpret_cast<float4*>(y + ((long)b * C + c) * HW + p) = make_float4(o[0], o[1], o[2], o[3]);
+            o.store(y + ((long)b * C + c) * HW + p);
         }
     }
     if (omax) {
@@ -3168,19 +3194,25 @@ __global__ __launch_bounds__(256) void cln_apply_kernel(const float* x, const fl
     }
 }
 
+template <int V>
+static void launch_cln(const float* x, const float* noise, const float* gamma, const float* beta, const float* ws, const float* wb,
+                       float eps, float* mean, float* rstd, float* y, int Bt, int C, int Jm, long HW, hipStream_t s, unsigned* omax) {
+    const long nv = HW / V;
+    hipLaunchKernelGGL(cln_stats_kernel<V>, dim3((unsigned)((nv + 63) / 64), (unsigned)Bt), dim3(512), 0, s, x, C, HW, eps, mean, rstd);
+    hipLaunchKernelGGL(cln_apply_kernel<V>, dim3((unsigned)((nv + 255) / 256), (unsigned)((C + 7) / 8), (unsigned)Bt), dim3(256),
+                       (size_t)2 * 8 * Jm * sizeof(float), s, x, noise, mean, rstd, gamma, beta, ws, wb, y, C, Jm, HW, omax);
+}
+
 hipError_t launch_cond_layer_norm(const float* x, const float* noise, const float* gamma, const float* beta,
                                   const float* ws, const float* wb, float eps, float* stats, float* y, int Bt, int C,
                                   int J, long HW, hipStream_t s, unsigned* omax) {
-    if (HW % 4 != 0 || !al16(x) || !al16(y) || !al16(stats) || (ws && (!noise || !al16(noise) || J <= 0 || J > 512)))
-        return hipErrorInvalidValue;
+    if (ws && (!noise || J <= 0 || J > 512)) return hipErrorInvalidValue;
     float* mean = stats;
     float* rstd = stats + (long)Bt * HW;
-    hipLaunchKernelGGL(cln_stats_kernel, dim3((unsigned)((HW / 4 + 63) / 64), (unsigned)Bt), dim3(512), 0, s, x, C, HW, eps,
-                       mean, rstd);
     const int Jm = ws ? J : 1;
-    hipLaunchKernelGGL(cln_apply_kernel, dim3((unsigned)((HW / 4 + 255) / 256), (unsigned)((C + 7) / 8), (unsigned)Bt),
-                       dim3(256), (size_t)2 * 8 * Jm * sizeof(float), s, x, noise, mean, rstd, gamma, beta, ws, wb, y, C, Jm,
-                       HW, omax);
+    const bool vec = HW % 4 == 0 && al16(x) && al16(y) && al16(stats) && (!ws || al16(noise));
+    if (vec) launch_cln<4>(x, noise, gamma, beta, ws, wb, eps, mean, rstd, y, Bt, C, Jm, HW, s, omax);
+    else launch_cln<1>(x, noise, gamma, beta, ws, wb, eps, mean, rstd, y, Bt, C, Jm, HW, s, omax);
     return hipGetLastError();
 }
 

@@ -37,11 +37,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) char* lds_cptr;
 
-constexpr int NH_MAX = 3;                          // nkp2 <= 6: Hh <= 96 (forward), ceil(lmax / 2) <= 96 (inverse)
-constexpr int FSLOT_BYTES = 2 * NH_MAX * 2048;     // one unit of A fragments (hi + lo)
+constexpr int NH_MAX = FOLD_NKP_SMALL / 2;         // small form: nkp2 <= 6: Hh <= 96 (forward), ceil(lmax / 2) <= 96 (inverse)
+constexpr int NH_BIG = FOLD_NKP_BIG / 2;           // big form: nkp2 = 12, 18, 24 (one workgroup per CU, 512 registers per lane)
 constexpr int FNSLOT = 3;                          // unit u + 2 is in flight while unit u is consumed
 constexpr int FTS_BYTES = 2048;                    // per-wave transpose buffer: 16 rows x 32 dwords
-constexpr int FLDS_BYTES = FNSLOT * FSLOT_BYTES + 4 * FTS_BYTES;   // 44 KiB
+constexpr int fold_lds_bytes(int nh) { return FNSLOT * 2 * nh * 2048 + 4 * FTS_BYTES; }   // NH 3: 44 KiB; NH 12: 152 KiB
+constexpr int FLDS_BYTES = fold_lds_bytes(NH_MAX);
 
 FDEV unsigned slot_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 FDEV int pow2_exponent_for(float mx) {
@@ -72,6 +73,8 @@ struct RowMap { int rbase, rstep, vlo, vhi; };
 template <int NH, int OUT, bool FULLN, int MODE>
 FDEV void fold_body(const LegStripArgs& p, char* smem, const int m, const int grp, const FoldGeom gm) {
     constexpr int NKP = 2 * NH;       // k16-steps per unit; a unit = 4 NH pieces, NH per wave
+    constexpr int FSLOT_BYTES = NKP * 2048;   // one unit of A fragments (hi + lo)
+    constexpr bool BIG = NH > NH_MAX; // 0.25-degree form: one wave per SIMD, both operands (2 x NKP x 8 registers) still resident
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,24 +127,31 @@ FDEV void fold_body(const LegStripArgs& p, char* smem, const int m, const int gr
             vd[e] = (unsigned)(((long)(8 * g + e) * ks + nc) * 4);
             vm[e] = (unsigned)(((long)(H - 1 - gm.Hh - (8 * g + e)) * ks + nc) * 4);   // row (H - 1 - kf) - Hh of the mirror descriptor
         }
-        float ra[NKP][8], rb[NKP][8];
+        // small form: every row of the strip in flight at once; big form: in chunks of CHK k-steps (the raw fp32 values of a whole
+        // 0.25-degree strip would not fit beside the fragments they become)
+        constexpr int CHK = BIG ? 4 : NKP;
 #pragma unroll
-        for (int jj = 0; jj < NKP; ++jj) {
-            const unsigned so = (unsigned)((long)(16 * jj) * rowb);     // wave-uniform; in the VECTOR offset (range-checked)
+        for (int j0 = 0; j0 < NKP; j0 += CHK) {
+            float ra[CHK][8], rb[CHK][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                ra[jj][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsD, vd[e] + so, 0, 0));
-                rb[jj][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsM, vm[e] - so, 0, 0));
+            for (int jc = 0; jc < CHK; ++jc) {
+                const unsigned so = (unsigned)((long)(16 * (j0 + jc)) * rowb);     // wave-uniform; in the VECTOR offset (range-checked)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    ra[jc][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsD, vd[e] + so, 0, 0));
+                    rb[jc][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsM, vm[e] - so, 0, 0));
+                }
             }
+#pragma unroll
+            for (int jc = 0; jc < CHK; ++jc)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = ra[jc][e] * bscale, b = rb[jc][e] * bscale;
+                    ACE_FOLD_SPLIT(a + b, bh[0][j0 + jc][e], bl[0][j0 + jc][e]);
+                    ACE_FOLD_SPLIT(a - b, bh[1][j0 + jc][e], bl[1][j0 + jc][e]);
+                }
+            if (BIG) __builtin_amdgcn_sched_barrier(0);   // keep the chunks in order: hoisting every load to the top is what overflows
         }
-#pragma unroll
-        for (int jj = 0; jj < NKP; ++jj)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float a = ra[jj][e] * bscale, b = rb[jj][e] * bscale;
-                ACE_FOLD_SPLIT(a + b, bh[0][jj][e], bl[0][jj][e]);
-                ACE_FOLD_SPLIT(a - b, bh[1][jj][e], bl[1][jj][e]);
-            }
     } else {
         // coefficient rows l = m + p + 2 (16 jj + 8 g + e) of this wavenumber; rows at or beyond lmax are outside the descriptor
         const float* Em = p.B + (long)m * p.b_moff;
@@ -151,23 +161,28 @@ FDEV void fold_body(const LegStripArgs& p, char* smem, const int m, const int gr
         unsigned ve[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) ve[e] = (unsigned)(((long)(m + 2 * (8 * g + e)) * ks + nc) * 4);
-        float r0[NKP][8], r1[NKP][8];
+        constexpr int CHK = BIG ? 2 : NKP;
 #pragma unroll
-        for (int jj = 0; jj < NKP; ++jj) {
-            const unsigned so = (unsigned)((long)(32 * jj) * rowb);
+        for (int j0 = 0; j0 < NKP; j0 += CHK) {
+            float r0[CHK][8], r1[CHK][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                r0[jj][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsE, ve[e] + so, 0, 0));
-                r1[jj][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsE, ve[e] + so + (unsigned)rowb, 0, 0));
+            for (int jc = 0; jc < CHK; ++jc) {
+                const unsigned so = (unsigned)((long)(32 * (j0 + jc)) * rowb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    r0[jc][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsE, ve[e] + so, 0, 0));
+                    r1[jc][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsE, ve[e] + so + (unsigned)rowb, 0, 0));
+                }
             }
+#pragma unroll
+            for (int jc = 0; jc < CHK; ++jc)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    ACE_FOLD_SPLIT(r0[jc][e] * bscale, bh[0][j0 + jc][e], bl[0][j0 + jc][e]);
+                    ACE_FOLD_SPLIT(r1[jc][e] * bscale, bh[1][j0 + jc][e], bl[1][j0 + jc][e]);
+                }
+            if (BIG) __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int jj = 0; jj < NKP; ++jj)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                ACE_FOLD_SPLIT(r0[jj][e] * bscale, bh[0][jj][e], bl[0][jj][e]);
-                ACE_FOLD_SPLIT(r1[jj][e] * bscale, bh[1][jj][e], bl[1][jj][e]);
-            }
     }
 
     // ---- scales
@@ -271,19 +286,42 @@ FDEV void fold_body(const LegStripArgs& p, char* smem, const int m, const int gr
         f32x16 a0, a1, a2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; }
-        half8 fh[NKP], fl[NKP];
+        (void)a1;
+        // table fragments: the whole unit up front (small form: 48 registers at most) or in groups of FG k-steps, the next group
+        // requested before the MFMAs of the current one (big form)
+        constexpr int FG = BIG ? (MODE == 1 ? 1 : 2) : NKP;   // (the big inverse form also holds the even parity's tile: one k-step of read-ahead)
+        half8 fh[2][FG], fl[2][FG];
 #pragma unroll
-        for (int jj = 0; jj < NKP; ++jj) {
-            fh[jj] = *reinterpret_cast<const half8*>(slot + jj * 2048);
-            fl[jj] = *reinterpret_cast<const half8*>(slot + jj * 2048 + 1024);
+        for (int q = 0; q < FG; ++q) {
+            fh[0][q] = *reinterpret_cast<const half8*>(slot + q * 2048);
+            fl[0][q] = *reinterpret_cast<const half8*>(slot + q * 2048 + 1024);
         }
 #pragma unroll
-        for (int jj = 0; jj < NKP; ++jj) {
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[jj], bh[PAR][jj], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[jj], bl[PAR][jj], a1, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[jj], bh[PAR][jj], a2, 0, 0, 0);
+        for (int g0 = 0; g0 < NKP; g0 += FG) {
+            constexpr int dummy = 0; (void)dummy;
+            const int cur = (g0 / FG) & 1;
+            if (g0 + FG < NKP) {
+#pragma unroll
+                for (int q = 0; q < FG; ++q) {
+                    fh[cur ^ 1][q] = *reinterpret_cast<const half8*>(slot + (g0 + FG + q) * 2048);
+                    fl[cur ^ 1][q] = *reinterpret_cast<const half8*>(slot + (g0 + FG + q) * 2048 + 1024);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < FG; ++q) {
+                if constexpr (BIG) {   // two accumulators (both small terms in one): 16 registers the big form needs; the chains still alternate
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[cur][q], bh[PAR][g0 + q], a0, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[cur][q], bh[PAR][g0 + q], a2, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[cur][q], bl[PAR][g0 + q], a0, 0, 0, 0);
+                } else {
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[cur][q], bh[PAR][g0 + q], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[cur][q], bl[PAR][g0 + q], a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[cur][q], bh[PAR][g0 + q], a2, 0, 0, 0);
+                }
+            }
         }
-        return (a0 + a1) + a2;
+        if constexpr (BIG) return a0 + a2;
+        else return (a0 + a1) + a2;
     };
     using T0 = std::integral_constant<int, 0>;
     using T1 = std::integral_constant<int, 1>;
@@ -308,6 +346,22 @@ FDEV void fold_body(const LegStripArgs& p, char* smem, const int m, const int gr
             });
             if (last) pa = ev;
         }
+    } else if constexpr (BIG) {
+        // big form: no deferred epilogue (its two held tiles are 32 registers the 384-register operands leave no room for); the rows
+        // of a pair are stored as soon as both parities are in - the stores themselves still retire under the next pair's MFMAs
+        for (int tp = 0; tp < gm.npairs; ++tp) {
+            const f32x16 ev = unit(2 * tp, T0{}, [] {});
+            const f32x16 od = unit(2 * tp + 1, T1{}, [] {});
+            f32x16 t = ev + od;
+            const bool inner = tp + 1 < gm.npairs;
+            if (inner) { tile_max(north_map(tp), t, std::true_type{}); store_tile(north_map(tp), t, std::true_type{}); }
+            else { tile_max(north_map(tp), t, std::false_type{}); store_tile(north_map(tp), t, std::false_type{}); }
+            __builtin_amdgcn_sched_barrier(0);   // one 16-register tile at a time through the transpose buffer
+            t = ev - od;
+            if (inner) { tile_max(south_map(tp), t, std::true_type{}); store_tile(south_map(tp), t, std::true_type{}); }
+            else { tile_max(south_map(tp), t, std::false_type{}); store_tile(south_map(tp), t, std::false_type{}); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     } else {
         for (int tp = 0; tp < gm.npairs; ++tp) {
             const f32x16 ev = unit(2 * tp, T0{}, [&] {
@@ -329,9 +383,10 @@ FDEV void fold_body(const LegStripArgs& p, char* smem, const int m, const int gr
     // the dummy pieces issued past the end land in the ring: retire them before its first slot doubles as the reduction scratch
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // last pair: masked.  The range reduction (shuffles, an LDS round trip) runs before the last stores (strip.hip)
+    constexpr bool STORED_IN_LOOP = BIG && MODE == 1;   // (the big inverse form has stored every pair already)
     const int tl = gm.npairs - 1;
     const RowMap ma = MODE == 0 ? fwd_map(tl, 0) : north_map(tl), mb = MODE == 0 ? fwd_map(tl, 1) : south_map(tl);
-    if (OUT != 1 && gm.npairs > 0) {
+    if (OUT != 1 && gm.npairs > 0 && !STORED_IN_LOOP) {
         tile_max(ma, pa, std::false_type{});
         tile_max(mb, pb, std::false_type{});
     }
@@ -345,7 +400,7 @@ FDEV void fold_body(const LegStripArgs& p, char* smem, const int m, const int gr
         if (tid == 0) atomicMax(p.omax + (blockIdx.x & 63), __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
         __syncthreads();        // ... before the transpose buffer of the last tiles re-uses the LDS
     }
-    if (gm.npairs > 0) {
+    if (gm.npairs > 0 && !STORED_IN_LOOP) {
         store_tile(ma, pa, std::false_type{});
         store_tile(mb, pb, std::false_type{});
     }
@@ -369,16 +424,49 @@ __global__ __launch_bounds__(256, 2) void legendre_fold_kernel(LegStripArgs p, i
     }
 }
 
+// The 0.25-degree form: one workgroup per CU (dynamic LDS: three units of up to 48 KiB), one wave per SIMD with the whole register
+// file - both folded operands of a 721-latitude strip are 384 registers.  Whole 128-column groups and 16-byte stores only.
+template <int OUT, int MODE>
+__global__ __launch_bounds__(256, 1) void legendre_fold_big_kernel(LegStripArgs p, int G) {
+    extern __shared__ __attribute__((aligned(16))) char smem_big[];
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int m = (idx / G) * 8 + xcd;
+    const int grp = idx % G;
+    if (m >= p.nbatch) return;
+    const FoldGeom gm = fold_geom(MODE, m, p.R, p.K);
+    switch (gm.nkp2) {
+        case 12: fold_body<6, OUT, true, MODE>(p, smem_big, m, grp, gm); break;
+        case 18: fold_body<9, OUT, true, MODE>(p, smem_big, m, grp, gm); break;
+        case 24: fold_body<12, OUT, true, MODE>(p, smem_big, m, grp, gm); break;
+        default:
+            if constexpr (MODE == 1) {   // the inverse's contraction shrinks with m: the high wavenumbers need the small unit sizes too
+                switch (gm.nkp2) {
+                    case 2: fold_body<1, OUT, true, MODE>(p, smem_big, m, grp, gm); break;
+                    case 4: fold_body<2, OUT, true, MODE>(p, smem_big, m, grp, gm); break;
+                    case 6: fold_body<3, OUT, true, MODE>(p, smem_big, m, grp, gm); break;
+                    default: break;
+                }
+            }
+            break;
+    }
+}
+
 }  // namespace
 
 bool legendre_fold_eligible(const LegStripArgs& a) {
     if (a.K < 1 || a.R < 1 || a.N < 1 || a.nbatch < 1 || (a.mode != 0 && a.mode != 1)) return false;
     const FoldGeom g0 = fold_geom(a.mode, 0, a.R, a.K);
-    if (g0.nkp2 > 2 * NH_MAX) return false;
+    if (g0.nkp2 > 2 * NH_BIG) return false;
     if (!a.A || !a.tile_off || !a.B || !a.bmax) return false;
-    // 32-bit byte offsets from the wavenumber's base (and the wrap of the out-of-range mirror offsets well above them)
-    const double span = ((double)(a.mode == 0 ? a.K : a.K + 32 * 2 * NH_MAX) + 64.0) * (double)a.b_kstride * 4.0;
-    if (span >= 2147483647.0) return false;
+    if (g0.nkp2 > 2 * NH_MAX) {   // big form: whole column groups, 16-byte stores
+        const bool vec = a.N % 4 == 0 && a.c_rstride % 4 == 0 && a.c_moff % 4 == 0;
+        if (a.N % 128 != 0 || !vec || (!a.Chi && (reinterpret_cast<uintptr_t>(a.C) & 15) != 0)) return false;
+    }
+    // 32-bit UNSIGNED byte offsets from the wavenumber's base.  Forward: rows up to 16 nkp2 (<= nlat / 2 + 96 + 15), and the
+    // out-of-range mirror offsets wrap to within that many rows below 2^32 - they must stay above the descriptor's num_records.
+    // Inverse: rows up to m + 32 nkp2 <= lmax + 192 (the rounding of the unit size), all of them plain positive offsets.
+    const double rowb = (double)a.b_kstride * 4.0;
+    if (a.mode == 0 ? ((double)a.K + 2.0 * (16.0 * FOLD_NKP_BIG + 64.0)) * rowb >= 4.0e9 : ((double)a.K + 256.0) * rowb >= 4.0e9) return false;
     if (a.Chi) return a.mode == 0 && a.N % 4 == 0 && a.c_rstride % 4 == 0 && a.c_moff % 4 == 0 && a.cslot &&
                       (reinterpret_cast<uintptr_t>(a.Chi) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.Clo) & 7) == 0;
     return a.C != nullptr;
@@ -402,7 +490,29 @@ static hipError_t launch_fold_mode(const LegStripArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <int OUT, int MODE>
+static hipError_t launch_fold_big(const LegStripArgs& a, int nh, hipStream_t s) {
+    const int G = a.N / 128;
+    const int mgroups = (a.nbatch + 7) / 8;
+    const int lds = fold_lds_bytes(nh);
+    static bool configured = false;   // per instantiation: the dynamic LDS ceiling is a property of the function
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(legendre_fold_big_kernel<OUT, MODE>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, fold_lds_bytes(NH_BIG));
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((legendre_fold_big_kernel<OUT, MODE>), dim3((unsigned)(mgroups * 8 * G)), dim3(256), (size_t)lds, s, a, G);
+    return hipGetLastError();
+}
+
 hipError_t launch_legendre_fold(const LegStripArgs& a, hipStream_t s) {
+    const FoldGeom g0 = fold_geom(a.mode, 0, a.R, a.K);
+    if (g0.nkp2 > 2 * NH_MAX) {
+        const int nh = g0.nkp2 / 2;
+        if (a.mode == 0) return a.Chi ? launch_fold_big<1, 0>(a, nh, s) : launch_fold_big<0, 0>(a, nh, s);
+        return launch_fold_big<0, 1>(a, nh, s);
+    }
     return a.mode == 0 ? launch_fold_mode<0>(a, s) : launch_fold_mode<1>(a, s);
 }
 

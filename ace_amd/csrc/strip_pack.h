@@ -146,9 +146,21 @@ inline void pack_legendre_strip(const float* tab, int mmax, int nrows, int ncols
 struct FoldGeom {
     int Hh;      // folded latitude count ceil(H / 2)
     int nkp;     // k16-steps per parity that carry data
-    int nkp2;    // ... rounded up to an even count, at least 2 (a unit is nkp2 2-KiB blocks = nkp2 / 2 pieces per wave)
+    int nkp2;    // ... rounded up to an instantiated count (fold_round_nkp; a unit is nkp2 2-KiB blocks = nkp2 / 2 pieces per wave)
     int npairs;  // pairs of units (32-row tiles per parity)
 };
+// k16-steps per unit the kernels are instantiated for: 2, 4, 6 (two workgroups per CU: 1-degree grids) and 12, 18, 24 (one
+// workgroup per CU with all 512 registers per lane: up to 384 folded latitudes / degrees per parity - the 0.25-degree grid).  At
+// least one (all-zero) group: an inverse wavenumber with nothing to contract still writes its zeros.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int fold_round_nkp(int nkp) {
+    if (nkp <= 6) return nkp > 0 ? (nkp + 1) & ~1 : 2;
+    return ((nkp + 5) / 6) * 6;
+}
+constexpr int FOLD_NKP_SMALL = 6, FOLD_NKP_BIG = 24;
+
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
@@ -167,7 +179,7 @@ inline FoldGeom fold_geom(int mode, int m, int R, int K) {
         g.npairs = (g.Hh + 31) / 32;
     }
     g.nkp = (n16 + 15) / 16;
-    g.nkp2 = g.nkp > 0 ? (g.nkp + 1) & ~1 : 2;    // at least one (all-zero) group: the inverse still writes its zeros
+    g.nkp2 = fold_round_nkp(g.nkp);
     return g;
 }
 

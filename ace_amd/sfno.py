@@ -31,7 +31,7 @@ _OPERATOR = {"diagonal": 0, "dhconv": 1}
 _NORM = {"none": 0, "instance_norm": 1}
 _ACT = {"gelu": 1, "relu": 2, "silu": 3}
 _ACT_LAYER = {"gelu": nn.GELU, "relu": nn.ReLU, "silu": nn.SiLU}
-_GRID = {"legendre-gauss": 0, "equiangular": 2}
+_GRID = {"legendre-gauss": 0, "lobatto": 1, "equiangular": 2}
 _PRECISION = {"fp32": 0, "f16x3": 1}
 # "f16x3": contractions with K >= 32 on error-compensated fp16 MFMA (fp32-class accuracy: measured error against an fp64
 # oracle is BELOW the fp32 CPU reference's own); "fp32": every contraction on exact-fp32 MFMA (bitwise k-ordered fma chains)

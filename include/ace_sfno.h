@@ -99,7 +99,7 @@ int ace_instance_norm(const float* x, const float* gamma, const float* beta, flo
 /* ConditionalLayerNorm.forward restricted to noise conditioning (fme/core/models/conditional_sfno/layers.py:95-141,
  * 245-318): per-PIXEL layer norm over the c channels (biased variance, eps inside the sqrt, optional elementwise
  * gamma/beta (c)), then y = y_norm * (1 + W_scale noise) + W_bias noise with the 1x1 convolutions W_scale, W_bias
- * (c, noise_dim), noise (n, noise_dim, hw).  w_scale = w_bias = NULL: plain ChannelLayerNorm.  Needs hw % 4 == 0.
+ * (c, noise_dim), noise (n, noise_dim, hw).  w_scale = w_bias = NULL: plain ChannelLayerNorm.  Any hw (16-byte accesses when hw % 4 == 0).
  * Test / building-block entry: allocates its statistics workspace and synchronises. */
 int ace_conditional_layer_norm(const float* x, const float* noise, const float* gamma, const float* beta,
                                const float* w_scale, const float* w_bias, float eps, float* y, int n, int c,

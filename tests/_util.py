@@ -156,3 +156,45 @@ def csfno_reference_checkpoint_case():
     labels = [f"context_{i:02d}" for i in range(12)]
     return dict(kwargs=kwargs, labels=labels, state=state, x=x, label_vector=torch.cat([ctx["embedding_scalar"], ctx["labels"]], dim=1),
                 noise=ctx["noise"], y=y)
+
+
+def csfno_block_case(name):
+    """The reference's block-level regression golden `name` (csfno_block / csfno_block_8_groups; output held by the reference,
+    parameters and inputs re-drawn by tests/golden/make_golden_csfno_block.py) mapped onto a ONE-block NoiseConditionedSFNO the
+    C ABI can run: identity encoder / decoder convolutions (encoder_layers 0, no big skip, no pos_embed), the given positional
+    context as the wrapper's learned one, lobatto data grid, and the filter padded by a zero row from the benchmark's lmax = 8 to
+    the network's lmax = nlat = 9 (coefficients are computed per degree, so the first 8 are unchanged and the 9th is filtered to
+    zero).  The network adds the identity outer skip the stand-alone block does not have (conditional_sfno/sfnonet.py:429-435 with
+    outer_skip=None vs 'identity' at :653): block output = network output - norm0(x), see `csfno_block_norm0`."""
+    g = load_golden("gen_csfno_block.pt")[name]
+    C, G = 16, g["groups"]
+    kwargs = dict(embed_dim=C, num_layers=1, encoder_layers=0, big_skip=False, pos_embed=False, noise_embed_dim=4,
+                  noise_type="gaussian", context_pos_embed_dim=2, filter_num_groups=G, data_grid="lobatto", mlp_ratio=2.0,
+                  use_mlp=True, affine_norms=False)
+    labels = ["l0", "l1", "l2"]
+    state = {}
+    for k, v in g["state"].items():
+        if k == "filter.filter.weight":          # (G, L = 8, C/G, C/G, 2) -> L = 9
+            v = torch.cat([v, torch.zeros(G, 1, *v.shape[2:])], dim=1)
+        state["conditional_model.blocks.0." + k] = v.clone()
+    eye = torch.eye(C)[:, :, None, None]
+    state["conditional_model.encoder.0.weight"] = eye.clone()
+    state["conditional_model.decoder.0.weight"] = eye.clone()
+    state["pos_embed"] = g["embedding_pos"].clone()                       # (1, 2, 9, 18): the wrapper's learned positional context
+    state["label_pos_embed"] = torch.zeros(len(labels), 2, 9, 18)         # ... without its label interaction
+    return dict(kwargs=kwargs, labels=labels, state=state, x=g["x"], noise=g["noise"], label_vector=g["labels"],
+                embedding_pos=g["embedding_pos"], y=g["held_output"], block_state=g["state"])
+
+
+def csfno_block_norm0(case, dtype=torch.float64):
+    """norm0(x, context) of the block case: the reference formula (conditional_sfno/layers.py:262-318) in torch, fp64"""
+    s = {k: v.to(dtype) for k, v in case["block_state"].items()}
+    x, noise, lab, pos = (case[k].to(dtype) for k in ("x", "noise", "label_vector", "embedding_pos"))
+    F = torch.nn.functional
+    scale = 1.0 + F.conv2d(noise, s["norm0.W_scale_2d.weight"]) + F.linear(lab, s["norm0.W_scale_labels.weight"], s["norm0.W_scale_labels.bias"])[:, :, None, None] \
+        + F.conv2d(pos, s["norm0.W_scale_pos.weight"])
+    bias = F.conv2d(noise, s["norm0.W_bias_2d.weight"]) + F.linear(lab, s["norm0.W_bias_labels.weight"], s["norm0.W_bias_labels.bias"])[:, :, None, None] \
+        + F.conv2d(pos, s["norm0.W_bias_pos.weight"])
+    mean = x.mean(dim=1, keepdim=True)
+    var = x.var(dim=1, keepdim=True, unbiased=False)
+    return (x - mean) * torch.rsqrt(var + 1e-5) * scale + bias

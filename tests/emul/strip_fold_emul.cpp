@@ -65,7 +65,11 @@ static double run_case(int mode, int H, int L, int M, int N, unsigned seed) {
     const int G = (N + 127) / 128;
     for (int m = 0; m < M; ++m) {
         const FoldGeom gm = fold_geom(mode, m, R, K);
-        if (gm.nkp2 > 6 || gm.nkp2 % 2 || gm.nkp2 < 2) { std::printf("bad nkp2 %d\n", gm.nkp2); return 1e9; }
+        // instantiated unit sizes: 2, 4, 6 (small form) and 12, 18, 24 (big form, one workgroup per CU)
+        if (!(gm.nkp2 == 2 || gm.nkp2 == 4 || gm.nkp2 == 6 || gm.nkp2 == 12 || gm.nkp2 == 18 || gm.nkp2 == 24) || gm.nkp2 < gm.nkp) {
+            std::printf("bad nkp2 %d (nkp %d)\n", gm.nkp2, gm.nkp);
+            return 1e9;
+        }
         const int NKP = gm.nkp2;
         const uint16_t* Am = sp.frags.data() + (size_t)sp.tile_off[m] * 1024;
         const int nunits = 2 * gm.npairs;
@@ -218,6 +222,9 @@ int main() {
         {0, 100, 90, 51, 256}, {1, 100, 90, 51, 256}, {0, 16, 16, 17, 48},     {1, 16, 16, 17, 48},     {0, 65, 48, 60, 32},
         {1, 65, 48, 60, 32},   {0, 192, 192, 97, 128}, {1, 192, 192, 97, 128}, {0, 181, 180, 91, 64},   {1, 181, 180, 91, 64},
         {0, 24, 24, 13, 12},   {1, 24, 24, 13, 12},   {0, 12, 12, 13, 20},     {1, 12, 12, 13, 20},     {0, 33, 32, 17, 36}, {1, 33, 32, 17, 36},
+        // big form (more than 96 folded latitudes / degrees per parity): unit sizes 12, 18, 24, and the inverse's descent through every
+        // size as the wavenumber grows; whole 128-column groups only (the big form's eligibility)
+        {0, 400, 390, 12, 128}, {1, 400, 390, 12, 128}, {0, 721, 721, 3, 128}, {1, 721, 721, 3, 128}, {1, 230, 225, 226, 128}, {0, 201, 200, 9, 128},
     };
     double worst = 0.0;
     for (auto& c : cases) {

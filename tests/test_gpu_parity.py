@@ -72,7 +72,8 @@ def test_instance_norm(dev, n, c, hw):
 
 # ---------------------------------------------------------------------------------- SHT
 @pytest.mark.parametrize("n,c,j,hw,affine,cond", [(2, 16, 8, 288, True, True), (1, 384, 32, 4132, True, True),
-                                                   (3, 5, 4, 64, False, True), (2, 24, 0, 100, True, False)])
+                                                   (3, 5, 4, 64, False, True), (2, 24, 0, 100, True, False),
+                                                   (4, 16, 12, 162, False, True), (1, 7, 3, 13, True, True)])   # H W % 4 != 0: 4-byte path
 def test_conditional_layer_norm(dev, n, c, j, hw, affine, cond):
     """ConditionalLayerNorm with noise conditioning (conditional_sfno/layers.py:95-141, 245-318) against the reference's
     torch formula in fp64."""
@@ -537,6 +538,52 @@ def test_conditional_stepper_rollout_with_labels(dev):
     eng.set_labels(None)
     with pytest.raises(ValueError):
         eng.predict(ic, forcing)                                   # labels must be provided
+
+
+def test_noise_conditioned_sfno_reference_held_checkpoint_golden(dev, precision):
+    """The reference-HELD, RNG-free golden of the conditional family (conditional_sfno/test_sfnonet.py:162-191,
+    testdata/test_sfnonet_checkpoint_{input,output}.pt) through the registry and the C ABI: legacy spectral-filter layout on load,
+    scalar embedding + labels as one label vector (tests/_util.py), 16-channel noise context, equiangular 9 x 18, big skip - at the
+    reference's own assert_close bar (rtol 1.3e-6, atol 1e-5)."""
+    import ace_amd
+    from _util import csfno_reference_checkpoint_case
+    c = csfno_reference_checkpoint_case()
+
+    class Info:
+        img_shape = (9, 18)
+        all_labels = set(c["labels"])
+
+    net = ace_amd.ModuleSelector(type="NoiseConditionedSFNO", config=dict(c["kwargs"]), conditional=True).build(2, 3, Info()).torch_module
+    net.load_state_dict(c["state"], strict=True)
+    net.to(dev).set_precision(precision)
+    with torch.no_grad():
+        y = net(c["x"].to(dev), labels=c["label_vector"].to(dev), noise=c["noise"].to(dev))
+    torch.testing.assert_close(y.cpu(), c["y"])
+    assert rel_max(y, c["y"]) <= NET_TOL
+
+
+@pytest.mark.parametrize("name", ["csfno_block", "csfno_block_8_groups"])
+def test_noise_conditioned_sfno_reference_held_block_goldens(dev, name, precision):
+    """The reference's block-level regression goldens (fme/core/benchmark/testdata/csfno_block{,_8_groups}-regression.pt,
+    conditional_sfno/benchmark.py:100-119: dense and 8-group spectral filter, lobatto 9 x 18, noise + label + positional context)
+    through the C ABI: a one-block network with identity encoder / decoder (tests/_util.py: csfno_block_case) minus norm0(x) - the
+    identity outer skip the stand-alone block does not have - at the reference's own assert_close bar."""
+    import ace_amd
+    from _util import csfno_block_case, csfno_block_norm0
+    c = csfno_block_case(name)
+
+    class Info:
+        img_shape = (9, 18)
+        all_labels = set(c["labels"])
+
+    net = ace_amd.ModuleSelector(type="NoiseConditionedSFNO", config=dict(c["kwargs"]), conditional=True).build(16, 16, Info()).torch_module
+    net.load_state_dict(c["state"], strict=True)
+    net.to(dev).set_precision(precision)
+    with torch.no_grad():
+        y = net(c["x"].to(dev), labels=c["label_vector"].to(dev), noise=c["noise"].to(dev))
+    block = (y.cpu().double() - csfno_block_norm0(c)).float()
+    torch.testing.assert_close(block, c["y"])
+    assert rel_max(block, c["y"]) <= NET_TOL
 
 
 def test_noise_conditioned_sfno_errors(dev):
