@@ -254,10 +254,11 @@ def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, 
 
 
 # HBM bytes per launch and MFMA-busy from separate rocprofv3 --pmc passes (tools/pmc_collect.sh -> tools/pmc_to_profile.py ->
-# profiles/r03_pmc_traffic.json).  FETCH_SIZE / WRITE_SIZE in KB; gfx950 correction: 16-byte-per-lane streaming reads are
+# profiles/r04_pmc_traffic.json).  FETCH_SIZE / WRITE_SIZE in KB; gfx950 correction: 16-byte-per-lane streaming reads are
 # counted at half size (MI355X_MICROARCH.md "HBM").  The file carries the sha256 of the library the counters were taken on:
 # figures are attached to the bench line ONLY when that is the library being timed now (otherwise null + the reason).
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_FILE = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json")) if os.path.exists(f)),
+                os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"))   # newest counter file; its build stamp decides whether it is used
 
 
 def lib_sha256():
@@ -274,7 +275,7 @@ def measured_counters():
         with open(PMC_FILE) as f:
             d = json.load(f)
     except (OSError, ValueError):
-        return {}, "no counter file (profiles/r03_pmc_traffic.json)"
+        return {}, "no counter file (profiles/r04_pmc_traffic.json)"
     from ace_amd import build as _build
     if d.get("_lib_sha256") != lib_sha256() and d.get("_src_sha256") != _build.source_sha256():
         # neither the binary nor (hipcc output is not bit-reproducible: a rebuilt library differs) the kernel sources match
@@ -286,9 +287,9 @@ def measured_counters():
 # the kernel that runs each stage in the default (f16x3) mode
 KERNEL_OF_STAGE = {
     "mlp.fc1": "conv_wl_kernel", "mlp.fc2+outer_skip": "conv_ws_kernel", "inner_skip+activation": "conv_ws_kernel",
-    "dhconv": "dhconv_strip_kernel", "forward_transform.legendre": "legendre_strip_kernel",
-    "inverse_transform.legendre": "legendre_strip_kernel", "forward_transform.dft": "dft_forward_fft_kernel",
-    "inverse_transform.dft": "dft_inverse_fft_kernel", "encoder": "gemm3_f16x3_kernel", "decoder": "gemm3_f16x3_kernel",
+    "dhconv": "dhconv_strip_kernel", "forward_transform.legendre": "legendre_fold_kernel",
+    "inverse_transform.legendre": "legendre_fold_kernel", "forward_transform.dft": "dft_forward_fft_kernel",
+    "inverse_transform.dft": "dft_inverse_fft_kernel", "encoder": "gemm4_f16x3_kernel + conv_ws_kernel", "decoder": "gemm3_f16x3_kernel",
 }
 
 
@@ -370,7 +371,7 @@ def main():
                             mfma_busy_frac=round(3 * fl / t_launch / 1e12 / 2500.0, 4), mfma_busy_pmc=ent.get("mfma_busy"))
         sht_us = stages["forward_transform.dft"]["us_per_launch"] + stages["forward_transform.legendre"]["us_per_launch"]
         sht_bytes = 384 * 180 * 360 * 4 + 181 * 180 * 180 * 4 + 384 * 180 * 181 * 8     # 223.1 MB
-        roofline_sht = dict(kernel="forward SHT (dft_forward_fft_kernel + legendre_strip_kernel)", bound="hbm",
+        roofline_sht = dict(kernel="forward SHT (dft_forward_fft_kernel + legendre_fold_kernel)", bound="hbm",
                             achieved=round(sht_bytes / (sht_us * 1e-6) / 1e9, 1), peak=PEAK_HBM, unit="GB/s",
                             frac=round(sht_bytes / (sht_us * 1e-6) / 1e9 / PEAK_HBM, 4),
                             traffic=(pmc[(main_mode, "forward_transform.dft")]["bytes"] +

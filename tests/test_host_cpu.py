@@ -285,7 +285,7 @@ def test_stepper_derives_the_insolation_from_the_window_times():
 
 
 def test_counter_file_is_tied_to_a_build():
-    """bench.py takes `roofline.traffic` / `mfma_busy_pmc` from profiles/r03_pmc_traffic.json only when that file was collected on
+    """bench.py takes `roofline.traffic` / `mfma_busy_pmc` from the newest profiles/rNN_pmc_traffic.json only when that file was collected on
     the library that is loaded now or on one built from the same kernel sources and flags (tools/pmc_collect.sh stamps both
     hashes); otherwise it says why it reports null.  The stamps must be present and well-formed."""
     import json

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 counter passes over tools/pmc_run.py (one pass per counter group; --pmc is never combined with sys/hip/hsa traces)
 # usage: pmc_collect.sh TAG   -> gpurun_out/pmc_TAG.json (+ raw per-pass summaries)
-tag=${1:-r03}
+tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc_$tag
 pass() {  # name, counters...

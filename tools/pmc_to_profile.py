@@ -1,10 +1,10 @@
 #!/usr/bin/env python
-"""gpurun_out/pmc_<tag>.json (tools/pmc_collect.sh) -> profiles/r03_pmc_traffic.json keyed "mode|stage" for bench.py's
+"""gpurun_out/pmc_<tag>.json (tools/pmc_collect.sh) -> profiles/r04_pmc_traffic.json keyed "mode|stage" for bench.py's
 roofline.traffic, plus a readable table.  HBM bytes per launch = 2 x FETCH_SIZE KB (gfx950: 16-byte-per-lane reads are counted
 at half size, MI355X_MICROARCH.md) + WRITE_SIZE KB; kernels whose reads are 4-byte-per-lane get the uncorrected figure too."""
 import json, re, sys
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_r03.json"
-dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03_pmc_traffic.json"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_r04.json"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r04_pmc_traffic.json"
 sha = sys.argv[3] if len(sys.argv) > 3 else None   # sha256 of the library the passes ran on (bench.py compares it)
 src_sha = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] else None   # ... and of its kernel sources + flags (ace_amd/build.py)
 d = json.load(open(src))
@@ -14,6 +14,9 @@ RULES = [  # (regex on kernel key, stage, reads are wide (x2 correction applies)
     (r"^dft_inverse_fft_kernel", "inverse_transform.dft", False),   # spectral side: 4-byte loads in 64-byte runs
     (r"^legendre_strip_kernel<0", "forward_transform.legendre", True),
     (r"^legendre_strip_kernel<1", "inverse_transform.legendre", True),
+    # round 4: the folded kernels legendre_fold_kernel<OUT, FULLN, MODE> (strip_fold.hip); the strip is read with 4-byte loads
+    (r"^legendre_fold_kernel<\d, (true|false), 0>", "forward_transform.legendre", False),
+    (r"^legendre_fold_kernel<\d, (true|false), 1>", "inverse_transform.legendre", False),
     (r"^dhconv_strip_kernel", "dhconv", True),
     (r"^conv_ws_kernel<12, 1, 0>", "inner_skip+activation", True),
     (r"^conv_ws_kernel<12, 1, 1>", "mlp.fc1", True),
@@ -22,6 +25,7 @@ RULES = [  # (regex on kernel key, stage, reads are wide (x2 correction applies)
     (r"^conv_ws_kernel<12, 2, [35]>", "mlp.fc2+outer_skip(last block)", True),
     (r"^gemm3_f16x3_kernel<2, 2, false, true, false>", "decoder", True),
     (r"^gemm3_f16x3_kernel<2, 2, false, false, false>", "encoder", True),
+    (r"^conv_ws_kernel<12, 1, 2>", "encoder", True),                              # round 4: last encoder convolution (the first one: gemm4 <2,2>)
 ]
 out = {"_source": src, "_lib_sha256": sha, "_src_sha256": src_sha, "_note": "per-launch means over the dispatches of 2 eager forwards; separate rocprofv3 --pmc passes "
        "(FETCH_SIZE | WRITE_SIZE TCC_HIT TCC_MISS | SQ busy | SQ insts), never combined with API traces"}
