@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """In-kernel timeline of the longitude FFT kernels (csrc/fft.hip): s_memtime stamps of wave 0 of EVERY workgroup (phases of the
-forward and of the inverse kernel) at the network's size (384 fields, 180 x 360).  Needs a library built with -DACE_FFT_TRACE:
-  tools/mkvar.sh ffttrace -DACE_FFT_TRACE; ACE_SFNO_LIB=exp/libexp_ffttrace.so python tools/trace_fft.py
+forward and of the inverse kernel) at the network's size (384 fields, 180 x 360).  The stamps live in the measurement version of
+fft.hip (tools/patches/r4_persistent_fft_kernels.patch: persistent kernels + trace macros; the shipped fft.hip has neither):
+  git apply tools/patches/r4_persistent_fft_kernels.patch; tools/mkvar.sh ffttrace -DACE_FFT_TRACE; git checkout ace_amd/csrc/fft.hip
+  ACE_SFNO_LIB=exp/libexp_ffttrace.so python tools/trace_fft.py
 Prints per-phase medians (cycles of the stamp counter), workgroup lifetimes, and how many workgroups were alive at once per XCC."""
 import collections
 import ctypes
