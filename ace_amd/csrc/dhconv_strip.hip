@@ -230,10 +230,16 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
 
 __global__ __launch_bounds__(256, 1) void dhconv_strip_kernel(DhconvStripArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 6 * 8192];
-    // heavy degrees first: blocks in dispatch order take l = L - 1, L - 1, L - 1 (its C / 128 column groups), L - 2, ...
+    // Workgroup b runs on XCD b % 8 (each XCD has its own L2).  The C / 128 column groups of one degree all read the degree's
+    // coefficient rows D[l] (the A operand: up to 181 rows x 768 values as hi / lo planes): deal whole DEGREES to XCDs so that the
+    // groups of a degree follow each other on ONE XCD and the later ones find D[l] in its L2 (round 3 dealt consecutive blocks -
+    // the groups of a degree - to three different XCDs: 176 MB of D traffic for 100 MB of D, profiles/r04_pmc_table.txt).
+    // Heavy degrees first within every XCD: XCD x takes l = L - 1 - x, L - 9 - x, ...
     const int ncg = p.C / 128;
-    const int l = p.L - 1 - (int)(blockIdx.x / ncg);
-    const int j = blockIdx.x % ncg;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int l = p.L - 1 - ((idx / ncg) * 8 + xcd);
+    const int j = idx % ncg;
+    if (l < 0) return;
     const int rows_l = (l + 1) * p.trimul < p.Mrows ? (l + 1) * p.trimul : p.Mrows;
     // degrees with more than 192 rows (a batch of 2 at the 1-degree grid: 362; the 0.25-degree grid: 721) are cut into chunks
     // of 192 rows, one workgroup each (blockIdx.y); the filter slice of a (degree, column group) is then streamed once per
@@ -259,7 +265,7 @@ bool dhconv_strip_eligible(const DhconvStripArgs& a) {
 
 hipError_t launch_dhconv_strip(const DhconvStripArgs& a, hipStream_t s) {
     if (!dhconv_strip_eligible(a)) return hipErrorInvalidValue;
-    dim3 grid((unsigned)(a.L * (a.C / 128)), (unsigned)((a.Mrows + 191) / 192)), block(256);
+    dim3 grid((unsigned)(((a.L + 7) / 8) * 8 * (a.C / 128)), (unsigned)((a.Mrows + 191) / 192)), block(256);   // whole degrees per XCD (see the kernel)
     hipLaunchKernelGGL(dhconv_strip_kernel, grid, block, 0, s, a);
     return hipGetLastError();
 }

@@ -77,6 +77,51 @@ def test_engine_pointer_tables_and_forcing_indices_vs_the_oracle_loop(graph):
         assert torch.equal(state[k], out[k][:, -1:])
 
 
+def test_configs0_s80_plumbing_at_180x360_four_steps():
+    """BASELINE.json configs[0] / SURVEY 8(d) "S80" on the CPU: 80 distinct variables (8 forcing-only + 36 prognostic in = 44; 36
+    prognostic + 36 diagnostic out = 72) on the full 1-degree grid, mu = 0.1 / sigma = 1.1 for every name (test_single_module.py:
+    2331-2333), 4 six-hourly steps - names -> channels, normalise, network, denormalise, state feedback, forcing index - through the
+    engine (emulated C ABI) and through Stepper.predict, against the oracle's stepper loop.  The network is a small SFNO (embed 16 x
+    2 layers) so that the 180 x 360 plumbing runs in seconds; the full-width arithmetic is the GPU suite's business."""
+    from oracle import stepper as ostep
+    from oracle.sfno import SFNOConfig, SFNOOracle
+    HH, WW, T, B = 180, 360, 4, 1
+    forcing_names = [f"forcing_{i}" for i in range(8)]
+    prog = [f"prog_{i}" for i in range(36)]
+    diag = [f"diag_{i}" for i in range(36)]
+    in_names, out_names = forcing_names + prog, prog + diag
+    names = forcing_names + prog + diag
+    assert len(set(names)) == 80 and len(in_names) == 44 and len(out_names) == 72
+    norm = NormalizationConfig(means={k: 0.1 for k in names}, stds={k: 1.1 for k in names})
+    config = ace_amd.SingleModuleStepConfig(
+        builder=ace_amd.ModuleSelector(type="SphericalFourierNeuralOperatorNet", config={"embed_dim": 16, "num_layers": 2, "operator_type": "dhconv"}),
+        in_names=in_names, out_names=out_names, normalization=norm)
+    torch.manual_seed(0)
+    stepper = ace_amd.Stepper.from_config(config, ace_amd.DatasetInfo((HH, WW)), device="cpu")
+    g = torch.Generator().manual_seed(1)
+    ic = {k: torch.randn(B, 1, HH, WW, generator=g) for k in prog}
+    forcing = {k: torch.randn(B, T + 1, HH, WW, generator=g) for k in forcing_names}
+    net = SFNOOracle(SFNOConfig(in_chans=44, out_chans=72, img_shape=(HH, WW), embed_dim=16, num_layers=2, operator_type="dhconv"),
+                     stepper.modules[0].state_dict(), dtype=torch.float32)
+    means = {k: torch.tensor(0.1) for k in names}
+    stds = {k: torch.tensor(1.1) for k in names}
+    ref = ostep.predict(net, ic, forcing, T, in_names, out_names, means, stds)
+    with fake_sfno():
+        out, state = RolloutEngine(stepper, batch=B, n_forward_steps=T, graph="step").predict(ic, forcing)
+    for k in out_names:
+        want = torch.stack([o[k] for o in ref], 1)
+        assert out[k].shape == (B, T, HH, WW)
+        assert float((out[k] - want).abs().max()) <= 2e-6 * float(want.abs().max()), k
+    for k in prog:
+        assert torch.equal(state[k], out[k][:, -1:])
+    # the same through Stepper.predict with the oracle network as its module
+    cpu = _reference_stepper(config, ace_amd.DatasetInfo((HH, WW)), stepper)
+    cpu._step_obj.module = Module(_OracleModule(net), None)
+    got, _ = cpu.predict(ic, forcing)
+    for k in out_names:
+        assert float((got[k] - out[k]).abs().max()) <= 2e-6 * float(out[k].abs().max()), k
+
+
 def test_engine_residual_prescribed_and_continue_from_last():
     in_names, out_names = ["f0", "p0", "p1"], ["p0", "p1", "d0"]
     config, names, norm = _config(in_names, out_names, residual_prediction=True, prescribed_prognostic_names=["p1"])

@@ -5,7 +5,7 @@
 tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-if [ -f exp/libexp_fftold.so ]; then bash tools/kdur2.sh ${tag}_fftold $GRAFT_REPO_ROOT/exp/libexp_fftold.so; grep "steps/s" gpurun_out/kdur_${tag}_fftold.txt; fi
+
 bash tools/kdur2.sh ${tag}; grep "steps/s" gpurun_out/kdur_${tag}.txt
 timeout 1100 python -m pytest tests -m gpu -q 2>&1 | tail -8 > gpurun_out/${tag}_pytest.txt; tail -3 gpurun_out/${tag}_pytest.txt
 timeout 400 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; head -c 400 gpurun_out/${tag}_bench.json; echo
