@@ -1294,3 +1294,27 @@ def test_healpix_stepper_rollout(dev):
                 state[n] = y[:, :, j] * float(norm.stds[n]) + float(norm.means[n])
                 assert rel_max(out[n][:, s], state[n]) <= 2e-6, (s, n)
     assert all(out[n].shape == (B, T, 12, ns, ns) for n in out_names)
+
+
+def test_async_ensemble_mean_side_stream_on_the_device(dev):
+    """ace_amd/distributed.py AsyncEnsembleMean on CUDA tensors (one process: the all-reduce itself is the identity, the stream and
+    event choreography is what runs): fields produced on the step stream are stacked and reduced on the side stream after an event,
+    the step stream keeps running, result() synchronises on the reduction only, last_allreduce_ms() times it."""
+    from ace_amd.distributed import AsyncEnsembleMean, Distributed
+    Distributed.reset()
+    d = Distributed.get_instance()
+    ens = AsyncEnsembleMean((5, 18, 36), dev, d)
+    g = torch.Generator().manual_seed(2)
+    base = torch.randn(5, 18, 36, generator=g).to(dev)
+    fields = [(base[i] * 2.0 + 1.0) for i in range(5)]          # produced by kernels on the current (step) stream
+    ens.submit(fields)
+    busy = torch.randn(2048, 2048, device=dev) @ torch.randn(2048, 2048, device=dev)   # the step stream goes on meanwhile
+    out = ens.result()
+    assert torch.equal(out, torch.stack(fields))
+    ms = ens.last_allreduce_ms()
+    assert ms is not None and ms >= 0.0
+    ens.submit(3.0 * base)                                       # a tensor of the buffer's shape
+    ens.wait()                                                   # the CURRENT stream waits (no host synchronisation)
+    assert torch.equal(ens.buf.clone(), 3.0 * base)
+    assert bool(torch.isfinite(busy).all())
+    Distributed.reset()
