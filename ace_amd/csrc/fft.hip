@@ -451,7 +451,12 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_INV_WAVES : (N1 * 
 template <int N1, int N2, int R = FFT_ROWS>
 hipError_t launch_inv(const DftArgs& a, hipStream_t s) {
     dim3 grid((unsigned)((a.C + R - 1) / R), (unsigned)a.H, (unsigned)a.Bt), block(R * N2);
-    hipLaunchKernelGGL((dft_inverse_fft_kernel<N1, N2, R, ACE_FFT_XCD_INV != 0>), grid, block, 0, s, a);
+    // The spectral side is read in runs of R floats per wavenumber.  With R = 32 a run is a whole 128-byte line and launch order is
+    // the faster mapping (r03).  With fewer rows per workgroup (the 0.25-degree grid: R = 8, 32-byte runs) FOUR neighbouring channel
+    // blocks share every line: dealt round-robin they sit on four XCDs and each fetches the whole line; the XCD-contiguous unit
+    // ranges of the forward kernel put them on one L2.
+    constexpr bool XCD = ACE_FFT_XCD_INV != 0 || R * 4 < 128;
+    hipLaunchKernelGGL((dft_inverse_fft_kernel<N1, N2, R, XCD>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 
