@@ -9,8 +9,9 @@ sha = sys.argv[3] if len(sys.argv) > 3 else None   # sha256 of the library the p
 src_sha = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] else None   # ... and of its kernel sources + flags (ace_amd/build.py)
 d = json.load(open(src))
 RULES = [  # (regex on kernel key, stage, reads are wide (x2 correction applies))
-    (r"^dft_forward_fft_kernel<.*, true>", "forward_transform.dft", True),                 # planes input (every block but the first)
-    (r"^dft_forward_fft_kernel<.*, false>", "forward_transform.dft(first block)", True),   # fp32 rows
+    # dft_forward_fft_kernel<N1, N2, R, PLN, FULLM> (round 4 added FULLM)
+    (r"^dft_forward_fft_kernel<\d+, \d+, \d+, true(, (true|false))?>", "forward_transform.dft", True),                 # planes input (every block but the first)
+    (r"^dft_forward_fft_kernel<\d+, \d+, \d+, false(, (true|false))?>", "forward_transform.dft(first block)", True),   # fp32 rows
     (r"^dft_inverse_fft_kernel", "inverse_transform.dft", False),   # spectral side: 4-byte loads in 64-byte runs
     (r"^legendre_strip_kernel<0", "forward_transform.legendre", True),
     (r"^legendre_strip_kernel<1", "inverse_transform.legendre", True),
@@ -24,7 +25,8 @@ RULES = [  # (regex on kernel key, stage, reads are wide (x2 correction applies)
     (r"^conv_ws_kernel<12, 2, [24]>", "mlp.fc2+outer_skip", True),               # mode 4: residual from planes, h' as planes only
     (r"^conv_ws_kernel<12, 2, [35]>", "mlp.fc2+outer_skip(last block)", True),
     (r"^gemm3_f16x3_kernel<2, 2, false, true, false>", "decoder", True),
-    (r"^gemm3_f16x3_kernel<2, 2, false, false, false>", "encoder", True),
+    (r"^gemm3_f16x3_kernel<2, 2, false, false, false>", "decoder", True),        # round 4: the decoder's first convolution only (the encoder's runs on gemm4)
+    (r"^gemm4_f16x3_kernel<2, 2, false, true>", "encoder(first convolution)", True),
     (r"^conv_ws_kernel<12, 1, 2>", "encoder", True),                              # round 4: last encoder convolution (the first one: gemm4 <2,2>)
 ]
 out = {"_source": src, "_lib_sha256": sha, "_src_sha256": src_sha, "_note": "per-launch means over the dispatches of 2 eager forwards; separate rocprofv3 --pmc passes "
