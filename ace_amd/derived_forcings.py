@@ -18,10 +18,12 @@ class ForcingWindow(dict):
     """name -> tensor forcing window that carries its time axis (the reference's BatchData.time)."""
 
     time: Optional[TimeAxis] = None
+    derived: bool = False     # set by ForcingDeriver: the derived forcings (the insolation) of this window have been computed from its times
 
-    def __init__(self, data: Mapping[str, torch.Tensor], time=None):
+    def __init__(self, data: Mapping[str, torch.Tensor], time=None, derived: bool = False):
         super().__init__(data)
         self.time = as_time_axis(time)
+        self.derived = bool(derived)
 
 
 @dataclasses.dataclass
@@ -83,4 +85,4 @@ class ForcingDeriver:
         example = next((v for v in forcing.values() if isinstance(v, torch.Tensor)), None)
         if example is not None and tuple(time.shape) != tuple(example.shape[:2]):
             raise ValueError(f"time axis of shape {tuple(time.shape)} for forcings of (samples, time levels) = {tuple(example.shape[:2])}")
-        return ForcingWindow(self.insolation.compute(time, forcing, device=device), time)
+        return ForcingWindow(self.insolation.compute(time, forcing, device=device), time, derived=True)

@@ -207,11 +207,20 @@ class EnginePredict:
     """``PredictFunction`` on the static-buffer ``RolloutEngine``: one engine per window length (the last window of a
     rollout may be shorter), built on first use.  Outputs are copied out of the engine's buffers (the next window reuses them)."""
 
-    def __init__(self, stepper, batch: int, graph: Optional[str] = "step"):
+    def __init__(self, stepper, batch: int, graph: Optional[str] = "step", labels=None):
+        """``labels``: the batch's labels for a label-conditioned stepper (BatchLabels, or a (batch, n_labels) tensor in the module's
+        encoding) - the reference takes them from the forcing batch (fme/core/generics/inference.py); every engine of this predict
+        function gets them before its first window."""
         self._stepper = stepper
         self._batch = batch
         self._graph = graph
+        self._labels = labels
         self._engines: Dict[int, Any] = {}
+
+    def set_labels(self, labels) -> None:
+        self._labels = labels
+        for eng in self._engines.values():
+            eng.set_labels(labels)
 
     def __call__(self, initial_condition: TensorDict, forcing: TensorDict,
                  compute_derived_variables: bool = False) -> Tuple[TensorDict, TensorDict]:
@@ -222,6 +231,8 @@ class EnginePredict:
         if eng is None:
             eng = self._engines[n_steps] = RolloutEngine(self._stepper, batch=self._batch, n_forward_steps=n_steps,
                                                          graph=self._graph)
+            if self._labels is not None:
+                eng.set_labels(self._labels)
         out, state = eng.predict(initial_condition, forcing)
         kept = type(state)({k: v.clone() for k, v in state.items()})
         kept.stepper_state = getattr(state, "stepper_state", None)

@@ -83,6 +83,16 @@ class RolloutEngine:
         self.sec_names = list(cfg.secondary_decoder.secondary_diagnostic_names) if self._secondary is not None else []
         for n in self.sec_names:
             self.out[n] = torch.zeros(B, T, H, W, **f32)
+        # The secondary decoder's diagnostics are unpacked straight into their output planes: they do not pass through the post-step
+        # hooks here (the reference and Stepper.predict put them in the dict the corrector and the ocean see).  Refuse the
+        # configurations where that difference would show instead of raising KeyError mid-rollout.
+        hooked = set(getattr(self._corrector, "force_positive_names", []) or [])
+        if self._ocean is not None:
+            hooked |= {getattr(getattr(self._ocean, "config", None), "surface_temperature_name", None)}
+        clash = sorted(hooked.intersection(self.sec_names))
+        if clash:
+            raise NotImplementedError(f"secondary-decoder diagnostics {clash} are also touched by the post-step hooks (force_positive / "
+                                      "ocean): use Stepper.predict for this configuration")
         norm = step.normalizer
         # normalizer.py:212-242: NaNs become 0 in normalised space (inputs) / the variable's mean (outputs).  The fused pack / unpack
         # kernels do not replace NaNs: one in-place pass over the packed tensor on either side when the normaliser asks for it
@@ -351,6 +361,17 @@ class RolloutEngine:
             self._window_graph = None
         step = self.stepper._step_obj   # Stepper.replace_ocean / overrides after construction take effect here
         if step._ocean is not self._ocean or step._corrector is not self._corrector:
+            # The engine's forcing / target name sets and static buffers were laid out for the ocean it was built with: a
+            # replacement that reads other fields (a slab ocean's q_flux / mixed-layer depth, an SST the old configuration did not
+            # prescribe) or that the fused kernels do not know cannot be swapped in - ask for a new engine instead of failing
+            # mid-run on a missing buffer.
+            new_ocean = step._ocean
+            needed = set(getattr(getattr(new_ocean, "config", None) or getattr(step._config, "ocean", None) or object(), "forcing_names", []) or [])
+            missing = sorted(needed - set(self.forcing_names) - set(self.target_names))
+            if missing or (self._physics is not None and new_ocean is not None and getattr(new_ocean, "is_slab", False)):
+                raise RuntimeError("the stepper's ocean was replaced after this RolloutEngine was built and the new one needs fields / "
+                                   f"a path the engine's static buffers were not laid out for ({missing or 'slab ocean with fused physics'}): "
+                                   "build a new RolloutEngine for the modified stepper")
             self._ocean, self._corrector = step._ocean, step._corrector
             self._window_graph = None
             if self._physics is not None:
@@ -386,7 +407,10 @@ class RolloutEngine:
         from .step import StepperState
         from .stepper import PrognosticState
         deriver = self.stepper.forcing_deriver
-        if deriver.needs_time and deriver.insolation.config.insolation_name not in forcing:
+        # ALWAYS computed - a data field of the same name in the forcing record is overwritten, as Insolation.compute and
+        # Stepper.predict do (fme/core/step/derived_forcings: the derived field wins) - unless this very window has been through
+        # the deriver already (EnginePredict derives in front of the engine and marks the window)
+        if deriver.needs_time and not getattr(forcing, "derived", False):
             forcing = deriver(forcing, time, device=self.device)      # once per window, in front of the captured steps
         with torch.no_grad():
             self.load(initial_condition, forcing)

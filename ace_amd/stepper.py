@@ -102,6 +102,7 @@ class Stepper:
             cfg.validate(self._step_obj.input_names, self._step_obj.output_names)
         self._multi_call_config = cfg
         self._multi_call = cfg.build(self._step_obj.step, batched=batched) if cfg is not None else None
+        self._extended_normalizer = None      # rebuilt on first use (see `normalizer`)
 
     @property
     def n_ic_timesteps(self) -> int:
@@ -114,7 +115,13 @@ class Stepper:
     @property
     def normalizer(self):
         if self._multi_call_config is not None:
-            return self._multi_call_config.extend_normalizer(self._step_obj.normalizer)
+            # extended once per multi-call configuration and per underlying normaliser, not on every access
+            base = self._step_obj.normalizer
+            cached = getattr(self, "_extended_normalizer", None)
+            if cached is None or cached[0] is not base:
+                cached = (base, self._multi_call_config.extend_normalizer(base))
+                self._extended_normalizer = cached
+            return cached[1]
         return self._step_obj.normalizer
 
     @property
@@ -171,7 +178,10 @@ class Stepper:
         output = result.output
         if self._multi_call is not None:     # multi_call.py:296-312: its own state and diagnostics are discarded
             output = {**self._multi_call.step(args=args, wrapper=wrapper).output, **output}
-        return StepOutput(output=self._output_masking(output), stepper_state=result.stepper_state)
+        # the wrapped step's corrector diagnostics travel with the output, masked the same way (single_module.py:1063-1075)
+        diags = result.corrector_diagnostics
+        return StepOutput(output=self._output_masking(output), stepper_state=result.stepper_state,
+                          corrector_diagnostics=self._output_masking(dict(diags)) if diags else {})
 
     def predict_generator(self, ic_dict: TensorMapping, forcing_dict: TensorMapping, n_forward_steps: int,
                           labels=None, data_mask=None, stepper_state=None) -> Generator[StepOutput, None, None]:
