@@ -74,6 +74,8 @@ SIGNATURES = {
     "ace_instance_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_long, c_void_p]),
     "ace_conditional_layer_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                                            c_int, c_int, c_int, c_long, c_void_p]),
+    "ace_conditional_layer_norm_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                                 c_int, c_int, c_int, c_long, c_void_p]),
     "ace_sfno_create": (c_int, [POINTER(AceSfnoConfig), POINTER(c_void_p)]),
     "ace_sfno_destroy": (None, [c_void_p]),
     "ace_sfno_set_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_long, c_void_p]),

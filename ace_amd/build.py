@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libace_sfno.so")
-SOURCES = ["kernels.hip", "fft.hip", "strip.hip", "strip_fold.hip", "conv_ws.hip", "conv_wl.hip", "dhconv_strip.hip", "physics.hip", "healpix.hip", "capi.hip", "tables.cpp"]
+SOURCES = ["kernels.hip", "fft.hip", "strip.hip", "strip_fold.hip", "conv_ws.hip", "conv_wl.hip", "dhconv_strip.hip", "cln_mfma.hip", "physics.hip", "healpix.hip", "capi.hip", "tables.cpp"]
 HEADERS = ["kernels.h", "strip_common.h", "strip_pack.h", "ws_plan.h", "small_fft.h", "tables.h", os.path.join("..", "..", "include", "ace_sfno.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 

@@ -57,6 +57,8 @@ Switches read_switches() {
 #endif
     sw.no_enc_ws = on("ACE_NO_ENC_WS");
     sw.no_enc_pk = on("ACE_NO_ENC_PK");
+    sw.no_cln_mfma = on("ACE_NO_CLN_MFMA");
+    sw.no_cln_planes = on("ACE_NO_CLN_PLANES");
     if (const char* e = std::getenv("ACE_CONV_WL")) sw.conv_wl = !(e[0] == '0' && !e[1]);
     if (const char* e = std::getenv("ACE_PLANES_STREAM")) sw.planes_stream = !(e[0] == '0' && !e[1]);
     if (const char* e = std::getenv("ACE_CONV_WS")) {
@@ -602,6 +604,45 @@ extern "C" int ace_conditional_layer_norm(const float* x, const float* noise, co
     return ACE_OK;
 }
 
+extern "C" int ace_conditional_layer_norm_f16x3(const float* x, const float* noise, const float* gamma, const float* beta,
+                                                const float* w_scale, const float* w_bias, float eps, float* y, int n, int c,
+                                                int noise_dim, long hw, void* stream) {
+    if (!x || !y || n <= 0 || c <= 0 || hw <= 0 || (w_scale && (!w_bias || !noise || noise_dim <= 0)))
+        return fail(ACE_ERR_INVALID, "ace_conditional_layer_norm_f16x3: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ClnMfmaArgs a;
+    a.x = x; a.y = y; a.sx = (long)c * hw; a.C = c; a.HW = hw; a.nbatch = n; a.eps = eps; a.gamma = gamma; a.beta = beta;
+    DevBuf fs, fb, cslot;
+    if (w_scale) {   // one-off weight preparation (what ace_sfno_set_weight does once per parameter) + the conditioning field's bound
+        if (c % 32 != 0 || noise_dim > 128) return fail(ACE_ERR_INVALID, "ace_conditional_layer_norm_f16x3: needs c % 256 == 0, noise_dim <= 128");
+        const size_t halves = cln_frag_halves(c, noise_dim);
+        std::vector<float> host((size_t)c * noise_dim);
+        std::vector<uint16_t> frags(halves);
+        int k = 0;
+        for (const float* wsrc : {w_scale, w_bias}) {
+            HIP_TRY(hipMemcpy(host.data(), wsrc, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+            float mx = 0.f;
+            for (float v : host) mx = std::max(mx, std::fabs(v));
+            const float sc = cln_frag_scale(mx);
+            pack_cln_frags(host.data(), c, noise_dim, sc, frags.data());
+            DevBuf& dst = k == 0 ? fs : fb;
+            HIP_TRY(dst.alloc((halves + 1) / 2, false));
+            HIP_TRY(hipMemcpy(dst.p, frags.data(), halves * sizeof(uint16_t), hipMemcpyHostToDevice));
+            (k == 0 ? a.ascale_s : a.ascale_b) = sc;
+            ++k;
+        }
+        HIP_TRY(cslot.alloc(AMAX_SHARDS));
+        HIP_TRY(launch_absmax(noise, (long)n * noise_dim * hw, reinterpret_cast<unsigned*>(cslot.p), s));
+        a.cond = noise; a.scond = (long)noise_dim * hw; a.J = noise_dim; a.cslot = reinterpret_cast<const unsigned*>(cslot.p);
+        a.As = reinterpret_cast<const _Float16*>(fs.p); a.Ab = reinterpret_cast<const _Float16*>(fb.p);
+    }
+    if (!cln_mfma_eligible(a))
+        return fail(ACE_ERR_INVALID, "ace_conditional_layer_norm_f16x3: needs c % 256 == 0 (c <= 1024), hw % 4 == 0 (c > 512: hw % 32 == 0), noise_dim <= 128");
+    HIP_TRY(launch_cln_mfma(a, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return ACE_OK;
+}
+
 extern "C" int ace_pack_normalize(const float* const* srcs, const long* strides, const float* mean, const float* std_,
                                   float* dst, int batch, int nch, long hw, void* stream) {
     if (!srcs || !strides || !mean || !std_ || !dst) return fail(ACE_ERR_INVALID, "ace_pack_normalize: null argument");
@@ -682,6 +723,10 @@ struct ace_sfno {
     const float* w(const std::string& name) const {
         auto it = index.find(name);
         return it == index.end() ? nullptr : weights[it->second]->buf.p;
+    }
+    const Weight* find(const std::string& name) const {
+        auto it = index.find(name);
+        return it == index.end() ? nullptr : weights[it->second].get();
     }
 };
 
@@ -841,7 +886,7 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
         HIP_TRY(n->cln_stats.alloc((size_t)2 * n->Bmax * HW));
         if (c.normalize_big_skip && c.big_skip) HIP_TRY(n->inN.alloc((size_t)n->Bmax * c.in_chans * HW));
     }
-    HIP_TRY(n->amax.alloc((size_t)(16 + 12 * c.num_layers) * AMAX_SHARDS));
+    HIP_TRY(n->amax.alloc((size_t)(16 + 12 * c.num_layers + 1) * AMAX_SHARDS));   // + the conditioning field's slot
     if (c.normalization_layer == 1) {
         const size_t cp = (size_t)((C + 31) & ~31);
         HIP_TRY(n->Wf0.alloc((size_t)n->Bmax * C * cp));
@@ -1009,6 +1054,30 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
         for (float v : host) mx = std::max(mx, std::fabs(v));
         std::vector<float> rep(64, mx);
         HIP_TRY(hipMemcpy(n->pe_slot.p, rep.data(), rep.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    {   // conditioning convolutions of a conditional layer norm: MFMA A fragments for cln_mfma.hip (f16x3 networks, C % 256 == 0)
+        const std::string& wn = w.name;
+        const bool is_cln_w = (wn.size() > 17 && wn.compare(wn.size() - 17, 17, "W_scale_2d.weight") == 0) ||
+                              (wn.size() > 16 && wn.compare(wn.size() - 16, 16, "W_bias_2d.weight") == 0);
+        const int J = n->cfg.noise_embed_dim;
+        if (is_cln_w && n->cfg.precision == 1 && J >= 1 && J <= 128 && numel == (long)n->C * J && n->C % 256 == 0 && n->C <= 1024) {
+            std::vector<float> host((size_t)numel);
+            HIP_TRY(hipMemcpy(host.data(), w.buf.p, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+            float mx = 0.f;
+            for (float v : host) mx = std::max(mx, std::fabs(v));
+            w.wabs = mx;
+            w.winf = 0.f;   // max row sum of |w|: bounds the convolution's output by winf * max |cond|
+            for (int r = 0; r < n->C; ++r) {
+                double rs = 0.0;
+                for (int j = 0; j < J; ++j) rs += std::fabs((double)host[(size_t)r * J + j]);
+                w.winf = std::max(w.winf, (float)(rs * (1.0 + 1e-6)));
+            }
+            w.ascale = cln_frag_scale(mx);
+            std::vector<uint16_t> frags(cln_frag_halves(n->C, J));
+            pack_cln_frags(host.data(), n->C, J, w.ascale, frags.data());
+            if (!w.frag0.p) HIP_TRY(w.frag0.alloc((frags.size() + 1) / 2, false));
+            HIP_TRY(hipMemcpy(w.frag0.p, frags.data(), frags.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
     }
     if (w.pitch == 0 && !w.is_filter && numel <= (1 << 16)) {  // biases: bound used by the P-format producers
         std::vector<float> host((size_t)numel);
@@ -1290,10 +1359,46 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     const bool cln = c.normalization_layer == 2;
     const float* skip_in = in;               // second source of the big-skip concat
     const unsigned* skip_in_slot = slot(0);
+    // one conditional layer norm (layers.py:245-318): a single MFMA pass (cln_mfma.hip) where the shape allows it and the
+    // conditioning weights were packed at upload, else statistics + apply (kernels.hip)
+    unsigned* noise_slot = slot(16 + 12 * c.num_layers);
+    if (cln && f16 && noise) HIP_TRY(launch_absmax(noise, (long)B * c.noise_embed_dim * HW, noise_slot, s));
+    // planes (optional): where the single-pass kernel can, it also writes y as the P-format operand of the packed convolutions
+    // (scaled by a bound it publishes to omax) - *planes_done says so, the caller then skips its pack pass; with
+    // fp32_needed = false that is the ONLY output (y untouched).
+    auto cond_norm = [&](const float* x, float* y, const std::string& q, int Cc, unsigned* omax, _Float16* phi = nullptr,
+                         _Float16* plo = nullptr, bool fp32_needed = true, bool* planes_done = nullptr) -> int {
+        const Weight* wsc = n->find(q + "W_scale_2d.weight");
+        const Weight* wbi = n->find(q + "W_bias_2d.weight");
+        const Weight* wga = n->find(q + "norm.weight");
+        const Weight* wbe = n->find(q + "norm.bias");
+        if (planes_done) *planes_done = false;
+        ClnMfmaArgs a;
+        a.x = x; a.y = y; a.sx = (long)Cc * HW; a.C = Cc; a.HW = HW; a.nbatch = B; a.eps = 1e-5f; a.omax = omax;
+        a.gamma = W(q + "norm.weight"); a.beta = W(q + "norm.bias");
+        if (f16 && noise && wsc && wbi && wsc->frag0.p && wbi->frag0.p && !n->sw.no_cln_mfma) {
+            a.cond = noise; a.scond = (long)c.noise_embed_dim * HW; a.J = c.noise_embed_dim; a.cslot = noise_slot;
+            a.As = reinterpret_cast<const _Float16*>(wsc->frag0.p); a.Ab = reinterpret_cast<const _Float16*>(wbi->frag0.p);
+            a.ascale_s = wsc->ascale; a.ascale_b = wbi->ascale;
+            if (phi && plo && omax && !n->sw.no_cln_planes && cln_mfma_planes_ok(a) && (!a.gamma || (wga && wbe))) {
+                a.Phi = phi; a.Plo = plo; a.sP = (long)Cc * HW;
+                a.gmax = a.gamma ? wga->absmax : 1.f; a.bmax = a.gamma ? wbe->absmax : 0.f;
+                a.ws_inf = wsc->winf; a.wb_inf = wbi->winf;
+                if (!fp32_needed) a.y = nullptr;
+            }
+            if (cln_mfma_eligible(a)) {
+                HIP_TRY(launch_cln_mfma(a, s));
+                if (planes_done) *planes_done = a.Phi != nullptr;
+                return ACE_OK;
+            }
+            a.Phi = a.Plo = nullptr; a.y = y;
+        }
+        HIP_TRY(launch_cond_layer_norm(x, noise, a.gamma, a.beta, W(q + "W_scale_2d.weight"), W(q + "W_bias_2d.weight"), 1e-5f,
+                                       n->cln_stats.p, y, B, Cc, c.noise_embed_dim, HW, s, omax));
+        return ACE_OK;
+    };
     if (cln && c.big_skip && c.normalize_big_skip) {
-        HIP_TRY(launch_cond_layer_norm(in, noise, W("norm_big_skip.norm.weight"), W("norm_big_skip.norm.bias"),
-                                       W("norm_big_skip.W_scale_2d.weight"), W("norm_big_skip.W_bias_2d.weight"), 1e-5f,
-                                       n->cln_stats.p, n->inN.p, B, Cin, c.noise_embed_dim, HW, s, slot(7)));
+        ACE_TRY(cond_norm(in, n->inN.p, "norm_big_skip.", Cin, slot(7)));
         skip_in = n->inN.p;
         skip_in_slot = slot(7);
     }
@@ -1324,10 +1429,12 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         const int sb = 16 + 12 * i;  // slot base of this block
         if (f16 && i + 1 >= 8) HIP_TRY(launch_zero_u32(hslot(i + 1), AMAX_SHARDS, s));
         const float *a0 = nullptr, *b0 = nullptr;
+        bool n0_planes = false, n1_planes = false;   // the conditional norms wrote their output as the packed convolutions' operand
         if (cln) {   // x_norm = CLN0(h; noise), in place: the block never needs the un-normalised h again (sfnonet.py:388-437)
-            HIP_TRY(launch_cond_layer_norm(h, noise, W(p + "norm0.norm.weight"), W(p + "norm0.norm.bias"),
-                                           W(p + "norm0.W_scale_2d.weight"), W(p + "norm0.W_bias_2d.weight"), 1e-5f,
-                                           n->cln_stats.p, h, B, C, c.noise_embed_dim, HW, s, slot(sb + 3)));
+            const bool pk_ahead = f16 && !scale_residual && packed_ok(n, C) && (!c.use_mlp || n->hid % 8 == 0);   // = `pk` below
+            _Float16* P0 = reinterpret_cast<_Float16*>(n->P.p);
+            ACE_TRY(cond_norm(h, h, p + "norm0.", C, slot(sb + 3), pk_ahead ? P0 : nullptr,
+                              pk_ahead ? P0 + (size_t)n->Bmax * C * HW : nullptr, true, &n0_planes));
             MARK(ST_NORM0);
         }
         if (norm) {
@@ -1571,7 +1678,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         } else if (pk) {
             have_ph = have_hstats = false;
             const Weight& ws = *n->weights[n->index.at(p + "inner_skip.weight")];
-            ACE_TRY(pack_act(n, res, actB, C, ra, rb, skip_max, Ph, Pl, B, s));
+            if (!n0_planes) ACE_TRY(pack_act(n, res, actB, C, ra, rb, skip_max, Ph, Pl, B, s));
             ACE_TRY(conv_pk(n, ws, W(p + "inner_skip.bias"), Ph, Pl, C, skip_max, n->T.p, C, n->Y.p, actB, nullptr, nullptr,
                             act, B, s, slot(sb + 4)));
         } else {
@@ -1582,10 +1689,9 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         if (!fused) MARK(ST_INNER_SKIP);
         // norm1 -> MLP -> + residual   (sfnonet.py:234-250)
         const float *a1 = nullptr, *b1 = nullptr;
-        if (cln) {
-            HIP_TRY(launch_cond_layer_norm(n->T.p, noise, W(p + "norm1.norm.weight"), W(p + "norm1.norm.bias"),
-                                           W(p + "norm1.W_scale_2d.weight"), W(p + "norm1.W_bias_2d.weight"), 1e-5f,
-                                           n->cln_stats.p, n->T.p, B, C, c.noise_embed_dim, HW, s, slot(sb + 5)));
+        if (cln) {   // followed by the packed MLP, norm1's output exists as planes only
+            const bool to_mlp = c.use_mlp && pk && !n->taps_on;
+            ACE_TRY(cond_norm(n->T.p, n->T.p, p + "norm1.", C, slot(sb + 5), to_mlp ? Ph : nullptr, to_mlp ? Pl : nullptr, false, &n1_planes));
             MARK(ST_NORM1);
         }
         if (norm && !fused) {
@@ -1605,7 +1711,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             const unsigned* tmax = (norm || cln) ? slot(sb + 5) : slot(sb + 4);
             _Float16* Uh = reinterpret_cast<_Float16*>(n->U.p);
             _Float16* Ul = Uh + (size_t)n->Bmax * n->hid * HW;
-            ACE_TRY(pack_act(n, n->T.p, actB, C, a1, b1, tmax, Ph, Pl, B, s));
+            if (!n1_planes) ACE_TRY(pack_act(n, n->T.p, actB, C, a1, b1, tmax, Ph, Pl, B, s));
             const bool gelu1 = act == ACT_GELU || act == ACT_GELU_FAST;
             if (w1.frag0.p && !a1 && gelu1 && n->sw.conv_wl && conv_wl_eligible(C, n->hid, HW)) {
                 // weights in LDS, unsynchronised waves (conv_wl.hip): the noise-conditioned nets' fc1 (no norm affine to fold)

@@ -16,6 +16,8 @@ struct Switches {
     bool no_pk_sht = false;        // measurement builds only: ACE_NO_PK_SHT: fp32 D, expanded filter operand
     bool no_enc_ws = false;        // ACE_NO_ENC_WS: last encoder convolution on the v3 engine
     bool no_enc_pk = false;        // ACE_NO_ENC_PK: first encoder convolution writes fp32 + a pack pass (r03) instead of planes from the packed engine
+    bool no_cln_mfma = false;      // ACE_NO_CLN_MFMA: conditional layer norms as statistics + apply passes (kernels.hip) instead of cln_mfma.hip
+    bool no_cln_planes = false;    // ACE_NO_CLN_PLANES: ... which write fp32 only, followed by a pack pass (instead of P-format planes from the norm kernel)
     int conv_ws_roles = 7;         // ACE_CONV_WS=skip,fc1,fc2|all|none: roles on conv_ws.hip (bit 0 inner skip, 1 fc1, 2 fc2)
     bool conv_wl = true;           // ACE_CONV_WL=0: fc1 on conv_ws.hip instead of conv_wl.hip (weights in LDS, unsynchronised waves)
     bool planes_stream = true;     // ACE_PLANES_STREAM=0: fc2 also writes the block output as fp32 (the residual stream round-trips twice)
@@ -242,6 +244,29 @@ hipError_t launch_dft_inverse(const DftArgs& a, hipStream_t s);
 bool launch_dft_forward_fft(const DftArgs& a, hipStream_t s, hipError_t* err);
 bool launch_dft_inverse_fft(const DftArgs& a, hipStream_t s, hipError_t* err);
 bool dft_fft_has_width(int W);   // widths with an instantiated two-level FFT
+
+// Conditional layer norm in one pass (cln_mfma.hip): statistics + the two conditioning 1x1 convolutions on MFMA + apply, for
+// C % 256 == 0 and H W % 32 == 0.  As / Ab: W_scale / W_bias as packed MFMA A fragments [C / 32][ceil(J / 16)][hi 512 | lo 512] halves
+// scaled by the powers of two ascale_s / ascale_b (pack_cln_frags, host); NULL: plain channel layer norm.  cslot: range slot of cond.
+struct ClnMfmaArgs {
+    const float* x = nullptr; float* y = nullptr; long sx = 0;       // (nbatch, C, HW); y may alias x
+    const float* cond = nullptr; long scond = 0; int J = 0;          // conditioning field (nbatch, J, HW)
+    const unsigned* cslot = nullptr;
+    const _Float16* As = nullptr; const _Float16* Ab = nullptr; float ascale_s = 1.f, ascale_b = 1.f;
+    const float* gamma = nullptr; const float* beta = nullptr;       // optional elementwise affine (C)
+    float eps = 1e-5f; int C = 0; long HW = 0; int nbatch = 1;
+    unsigned* omax = nullptr;                                        // atomicMax of bits(max|y|); with planes: the BOUND they are scaled by
+    // optional P-format output (fp16 hi / lo planes [C / 8][HW][8], the B operand of the packed convolutions), 128-pixel form only
+    // (cln_mfma_planes_ok).  y may then be null.  The planes' scale cannot be the true max |y| (unknown until every tile is done):
+    // it is the bound (sqrt(C) gmax + bmax)(1 + ws_inf max|cond|) + wb_inf max|cond| - fp16 hi + lo keep full precision as
+    // long as the bound is within 2^14 of the true max (it is ~20x) - published to omax, from which consumers derive the scale.
+    _Float16* Phi = nullptr; _Float16* Plo = nullptr; long sP = 0;   // per-sample stride in halves
+    float gmax = 1.f, bmax = 0.f;                                    // max |gamma|, max |beta| (1, 0 without the affine)
+    float ws_inf = 0.f, wb_inf = 0.f;                                // max row sums of |W_scale|, |W_bias|
+};
+bool cln_mfma_eligible(const ClnMfmaArgs& a);
+bool cln_mfma_planes_ok(const ClnMfmaArgs& a);
+hipError_t launch_cln_mfma(const ClnMfmaArgs& a, hipStream_t s);
 
 // per-(b,c) instance-norm statistics over H*W -> affine (scale, shift):
 //   scale = gamma[c] * rsqrt(var + eps),  shift = beta[c] - mean * scale   (biased var, fp64 accumulation)

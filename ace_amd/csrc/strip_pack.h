@@ -245,4 +245,29 @@ inline void pack_legendre_fold(const float* tab, int mmax, int nlat, int lmax, i
     }
 }
 
+// ---- conditional layer norm on MFMA (cln_mfma.hip): a (C x J) 1x1-convolution weight as error-compensated A fragments of
+// v_mfma_f32_32x32x16_f16, [C / 32 row tiles][ceil(J / 16) k-steps][hi 512 | lo 512] halves; lane (i, g) element e of a block is
+// W[32 rt + i][16 ks + 8 g + e] * scale (zero beyond J).  `scale` = cln_frag_scale(max |W|): max |W| scale in [2^9, 2^10).
+inline float cln_frag_scale(float wabs) {
+    int e = 0;
+    if (wabs > 0.f && std::isfinite(wabs)) { (void)std::frexp(wabs, &e); e = 10 - e; }
+    return std::ldexp(1.0f, e);
+}
+inline size_t cln_frag_halves(int C, int J) { return (size_t)(C / 32) * (size_t)((J + 15) / 16) * 1024; }
+inline void pack_cln_frags(const float* W, int C, int J, float scale, uint16_t* out) {
+    const int nk = (J + 15) / 16;
+    for (int rt = 0; rt < C / 32; ++rt)
+        for (int ks = 0; ks < nk; ++ks) {
+            uint16_t* blk = out + ((size_t)rt * nk + ks) * 1024;
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int row = 32 * rt + (lane & 31), j = 16 * ks + 8 * (lane >> 5) + e;
+                    const float v = j < J ? W[(size_t)row * J + j] * scale : 0.f;
+                    const uint16_t hi = f32_to_f16_bits(v);
+                    blk[lane * 8 + e] = hi;
+                    blk[512 + lane * 8 + e] = f32_to_f16_bits(v - f16_bits_to_f32(hi));
+                }
+        }
+}
+
 }  // namespace ace

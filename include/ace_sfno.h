@@ -105,6 +105,14 @@ int ace_conditional_layer_norm(const float* x, const float* noise, const float* 
                                const float* w_scale, const float* w_bias, float eps, float* y, int n, int c,
                                int noise_dim, long hw, void* stream);
 
+/* The same operator as the f16x3 NoiseConditionedSFNO runs it: ONE pass per 32-pixel tile - fp64 statistics, the two
+ * conditioning convolutions on the matrix cores with error-compensated fp16 operands, apply - instead of a statistics and an
+ * apply pass.  Needs c % 256 == 0 (c <= 1024), hw % 4 == 0 (c > 512: hw % 32 == 0), noise_dim <= 128; any other shape is ACE_ERR_INVALID (no fallback:
+ * the network routes such shapes to the two-pass form itself).  Test / building-block entry: packs the weights, synchronises. */
+int ace_conditional_layer_norm_f16x3(const float* x, const float* noise, const float* gamma, const float* beta,
+                                     const float* w_scale, const float* w_bias, float eps, float* y, int n, int c,
+                                     int noise_dim, long hw, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * The network.  Replaces SphericalFourierNeuralOperatorNet.__init__/forward
  * (fme/ace/models/modulus/sfnonet.py:341-685, 713-749) as built by

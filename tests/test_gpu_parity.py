@@ -106,6 +106,59 @@ def test_conditional_layer_norm(dev, n, c, j, hw, affine, cond):
     assert rel_max(y, ref) <= OP_TOL
 
 
+@pytest.mark.parametrize("n,c,j,hw,affine,cond", [(2, 256, 33, 64, True, True), (1, 512, 33, 4096, True, True),
+                                                   (1, 512, 16, 32, True, True), (3, 256, 5, 160, False, True),
+                                                   (1, 768, 33, 96, True, True), (1, 1024, 40, 64, True, True),
+                                                   (2, 256, 128, 32, True, True), (2, 512, 0, 96, True, False),
+                                                   (1, 512, 33, 4100, True, True), (2, 256, 8, 36, True, True),     # ragged last 128-pixel tile
+                                                   (1, 512, 33, 516, False, True), (1, 768, 8, 64, False, False)])
+def test_conditional_layer_norm_single_pass_mfma(dev, n, c, j, hw, affine, cond):
+    """The single-pass form of the same operator (csrc/cln_mfma.hip: the two conditioning convolutions on the matrix cores with
+    error-compensated fp16 operands), which the f16x3 NoiseConditionedSFNO uses when C % 256 == 0: same fp64 formula, same bar."""
+    from ace_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(c + hw + j)
+    x = torch.randn(n, c, hw, generator=g) * 3.0 + 1.5
+    noise = torch.randn(n, max(j, 1), hw, generator=g) * 1.7
+    gamma = 1.0 + 0.3 * torch.randn(c, generator=g)
+    beta = 0.2 * torch.randn(c, generator=g)
+    ws = 0.3 * torch.randn(c, max(j, 1), generator=g)
+    wb = 0.02 * torch.randn(c, max(j, 1), generator=g)       # different magnitudes: each weight has its own power-of-two scale
+    xd = x.double()
+    ref = (xd - xd.mean(dim=1, keepdim=True)) * torch.rsqrt(xd.var(dim=1, keepdim=True, unbiased=False) + 1e-5)
+    if affine:
+        ref = ref * gamma.double()[None, :, None] + beta.double()[None, :, None]
+    if cond:
+        ref = ref * (1.0 + torch.einsum("cj,njp->ncp", ws.double(), noise.double())) + torch.einsum("cj,njp->ncp", wb.double(), noise.double())
+    t = [v.to(dev) for v in (x, noise, gamma, beta, ws, wb)]
+    null = ctypes.c_void_p(0)
+    args = lambda y: (_lib.ptr(t[0]), _lib.ptr(t[1]) if cond else null, _lib.ptr(t[2]) if affine else null,
+                      _lib.ptr(t[3]) if affine else null, _lib.ptr(t[4]) if cond else null, _lib.ptr(t[5]) if cond else null,
+                      1e-5, _lib.ptr(y))
+    y = torch.empty(n, c, hw, device=dev)
+    _lib.check(L.ace_conditional_layer_norm_f16x3(*args(y), n, c, j, hw, _lib.current_stream()))
+    assert rel_max(y, ref) <= OP_TOL, rel_max(y, ref)
+    two_pass = torch.empty(n, c, hw, device=dev)
+    _lib.check(L.ace_conditional_layer_norm(*args(two_pass), n, c, j, hw, _lib.current_stream()))
+    assert rel_max(y, two_pass) <= OP_TOL
+    inplace = t[0].clone()                                   # the network normalises in place
+    _lib.check(L.ace_conditional_layer_norm_f16x3(_lib.ptr(inplace), *args(inplace)[1:], n, c, j, hw, _lib.current_stream()))
+    assert torch.equal(inplace, y)
+
+
+def test_conditional_layer_norm_single_pass_refuses_other_shapes(dev):
+    """No silent fallback at the op level: shapes outside the single-pass kernel's reach are an error naming the constraint."""
+    from ace_amd import _lib
+    L = _lib.lib()
+    x = torch.randn(1, 40, 64, device=dev)
+    y = torch.empty_like(x)
+    null = ctypes.c_void_p(0)
+    for c, hw in ((40, 64), (256, 10)):
+        with pytest.raises(ValueError, match="c % 256"):
+            _lib.check(L.ace_conditional_layer_norm_f16x3(_lib.ptr(x), null, null, null, null, null, 1e-5, _lib.ptr(y), 1, c, 0, hw,
+                                                          _lib.current_stream()))
+
+
 def test_sht_golden_regression(dev):
     """fme/core/benchmark/testdata/{sht,inverse_sht}-regression.pt (lobatto 9x18)."""
     import ace_amd
@@ -416,14 +469,15 @@ def test_noise_conditioned_sfno_vs_reference(dev, name, precision):
     assert torch.isfinite(a).all() and not torch.equal(a, b)
 
 
-@pytest.mark.parametrize("embed", [128, 256])
-def test_noise_conditioned_sfno_wide_vs_oracle(dev, embed):
+@pytest.mark.parametrize("embed,noise_dim", [(128, 8), (256, 8), (512, 33)])
+def test_noise_conditioned_sfno_wide_vs_oracle(dev, embed, noise_dim):
     """Channel widths at which the noise-conditioned net's fc1 runs on csrc/conv_wl.hip (weights in LDS; K = 128 / 256 here,
-    512 at the ERA5 configuration) and the other convolutions on the packed-operand engine: against the fp64 oracle with the
-    module's own (reference-order) initial weights.  The small reference-emitted goldens stay on the tile engines."""
+    512 at the ERA5 configuration), the other convolutions on the packed-operand engine and - C % 256 == 0 - the conditional
+    layer norms on the single-pass MFMA kernel (csrc/cln_mfma.hip): against the fp64 oracle with the module's own
+    (reference-order) initial weights.  The small reference-emitted goldens stay on the tile engines."""
     import ace_amd
     from oracle.csfno import CSFNOConfig, CSFNOOracle
-    kwargs = dict(embed_dim=embed, noise_embed_dim=8, noise_type="gaussian", num_layers=2, use_mlp=True, mlp_ratio=2.0,
+    kwargs = dict(embed_dim=embed, noise_embed_dim=noise_dim, noise_type="gaussian", num_layers=2, use_mlp=True, mlp_ratio=2.0,
                   affine_norms=True, normalize_big_skip=True)
     cfg = CSFNOConfig(in_chans=5, out_chans=4, img_shape=(16, 32), **kwargs)
     torch.manual_seed(11)

@@ -51,3 +51,15 @@ def test_small_fft_templates(tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "small ffts ok" in res.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_conditional_layer_norm_mfma_decomposition(tmp_path):
+    """ace_amd/csrc/cln_mfma.hip (single-pass conditional layer norm): waves x row tiles, the A fragments pack_cln_frags builds at
+    weight upload, the B fragments built from the conditioning field, the MFMA lane layout and the apply, against the direct
+    fp64 formula for C in {256, 512, 768, 1024} and ragged J."""
+    exe = str(tmp_path / "cln_mfma_emul")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "emul", "cln_mfma_emul.cpp")], check=True)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "worst" in res.stdout
