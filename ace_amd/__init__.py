@@ -17,7 +17,7 @@ from .step import SecondaryDecoderConfig, SingleModuleStep, SingleModuleStepConf
 from .mlp import ColumnMLP, MLPConfig  # noqa: F401
 from .checkpoint import LoadedStepper, StepperOverrideConfig, apply_stepper_override, load_stepper  # noqa: F401
 from .csfno import NoiseConditionedSFNO, NoiseConditionedSFNOBuilder  # noqa: F401
-from .healpix import HEALPixUNet, HEALPixUNetBuilder  # noqa: F401
+from .healpix import CapturedHEALPixForward, HEALPixUNet, HEALPixUNetBuilder  # noqa: F401
 from .corrector import AtmosphereCorrectorConfig  # noqa: F401
 from .ocean import OceanConfig  # noqa: F401
 from .derived_variables import AtmosphericDeriveFn, compute_derived_quantities  # noqa: F401

@@ -28,6 +28,7 @@
 
 #include "../../include/ace_sfno.h"
 #include "kernels.h"
+#include "strip_common.h"
 
 using namespace ace;
 
@@ -242,6 +243,70 @@ __global__ __launch_bounds__(256) void hpx_pad_kernel(const float* __restrict__ 
     if (amax) block_amax(vmax, amax);
 }
 
+// The same gather, written as the PACKED convolution engine's operand: fp16 hi / lo "P-format" planes [item * 12 + face][cg][cell][8]
+// (cell = padded row * mp + column; entry = channels 8 cg .. 8 cg + 7 of one cell: the MFMA B fragment of a lane), scaled by
+// 2^(12 - exponent(bound)) with bound = max(bound of x, bound of x2) - padding copies / averages cells, it cannot exceed its sources -
+// published to pmax.  Channels [0, cin) come from x, [cin, cin + cin2) from x2 (the skip concatenation), the rest of the last
+// group is zero.  `slack` zero entries behind every plane pair (the last taps of the last row read past the end).
+__global__ __launch_bounds__(256) void hpx_pad_planes_kernel(const float* __restrict__ x, long x_img_stride, long x_chan_stride, int x_pitch,
+                                                             const float* __restrict__ x2, long x2_img_stride, long x2_chan_stride, int x2_pitch,
+                                                             int cin, int cin2, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int m, int mp,
+                                                             const int* __restrict__ ia, const int* __restrict__ ib, int items,
+                                                             const unsigned* __restrict__ xmax, const unsigned* __restrict__ x2max,
+                                                             unsigned* __restrict__ pmax, int slack) {
+    const int lane = threadIdx.x & 63;
+    float bound = wave_max_bits(slot_load(xmax + lane));
+    if (x2max) bound = fmaxf(bound, wave_max_bits(slot_load(x2max + lane)));
+    const float scale = ldexpf(1.0f, pow2_exponent_for(bound));
+    if (blockIdx.x == 0 && threadIdx.x < 64) pmax[threadIdx.x] = __float_as_uint(bound);
+    const int ctot = cin + cin2, cg8 = (ctot + 7) / 8;
+    const long cells = (long)m * mp;
+    const long total = (long)items * 12 * cg8 * cells;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int cellp = (int)(t % cells);
+        const int row = cellp / mp, col = cellp % mp;
+        long q = t / cells;
+        const int cg = (int)(q % cg8);
+        q /= cg8;
+        const int face = (int)(q % 12), item = (int)(q / 12);
+        half8 hh, ll;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hh[e] = (_Float16)0.f; ll[e] = (_Float16)0.f; }
+        if (col < m) {
+            const long cell = (long)row * m + col;
+            const int a = ia[(long)face * m * m + cell], b = ib[(long)face * m * m + cell];
+            const int af = a >> 24, ay = (a >> 12) & 4095, ax = a & 4095, bf = b >> 24, by = (b >> 12) & 4095, bx = b & 4095;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = 8 * cg + e;
+                if (ch >= ctot) break;
+                const bool second = ch >= cin;
+                const float* src = second ? x2 : x;
+                const long is = second ? x2_img_stride : x_img_stride, cs = second ? x2_chan_stride : x_chan_stride;
+                const int pt = second ? x2_pitch : x_pitch, cc = second ? ch - cin : ch;
+                const float va = src[(long)(item * 12 + af) * is + (long)cc * cs + (long)ay * pt + ax];
+                float v = va;
+                if (a != b) v = 0.5f * va + 0.5f * src[(long)(item * 12 + bf) * is + (long)cc * cs + (long)by * pt + bx];
+                v = __builtin_amdgcn_fmed3f(v * scale, -65504.f, 65504.f);
+                const _Float16 h = (_Float16)v;
+                hh[e] = h;
+                ll[e] = (_Float16)(v - (float)h);
+            }
+        }
+        const long eo = (((long)(item * 12 + face) * cg8 + cg) * cells + cellp) * 8;
+        *reinterpret_cast<half8*>(hi + eo) = hh;
+        *reinterpret_cast<half8*>(lo + eo) = ll;
+    }
+    if (slack > 0 && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < slack) {
+        half8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
+        const long eo = ((long)items * 12 * cg8 * cells + threadIdx.x) * 8;
+        *reinterpret_cast<half8*>(hi + eo) = z;
+        *reinterpret_cast<half8*>(lo + eo) = z;
+    }
+}
+
 // 2 x 2 pooling, stride 2: x [imgs * c][H][px] -> y [imgs * c][H / 2][py]
 template <bool MAX>
 __global__ __launch_bounds__(256) void hpx_pool2_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int H, int W,
@@ -314,6 +379,7 @@ extern "C" int ace_hpx_absmax(const float* x, long n, unsigned* amax, void* stre
 // ---- prepared weights: fp16 hi/lo planes [rows16][pitch] scaled by a power of two (what ace_sfno_set_weight does per parameter)
 struct ace_hpx_weight {
     _Float16* hi = nullptr; _Float16* lo = nullptr;
+    _Float16* thi = nullptr; _Float16* tlo = nullptr;   // the same planes in the packed engine's A-tile order (ace_hpx_conv_packed)
     int rows = 0, cols = 0, pitch = 0;
     float ascale = 1.f;
 };
@@ -321,6 +387,8 @@ extern "C" void ace_hpx_weight_destroy(ace_hpx_weight* w) {
     if (!w) return;
     if (w->hi) (void)hipFree(w->hi);
     if (w->lo) (void)hipFree(w->lo);
+    if (w->thi) (void)hipFree(w->thi);
+    if (w->tlo) (void)hipFree(w->tlo);
     delete w;
 }
 extern "C" int ace_hpx_weight_create(const float* w_dev, int rows, int cols, void* stream, ace_hpx_weight** out) {
@@ -347,6 +415,15 @@ extern "C" int ace_hpx_weight_create(const float* w_dev, int rows, int cols, voi
     hipError_t er = hipMemsetAsync(w->hi, 0, halves * 2, s);
     if (er == hipSuccess) er = hipMemsetAsync(w->lo, 0, halves * 2, s);
     if (er == hipSuccess) er = launch_split_f16(w_dev, cols, w->hi, w->lo, w->pitch, rows, cols, w->ascale, s);
+    if (er == hipSuccess && cols % 8 == 0) {   // a (tap, padded channel) ordered matrix: also as tiles for the packed engine
+        if (hipMalloc(reinterpret_cast<void**>(&w->thi), halves * 2) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&w->tlo), halves * 2) != hipSuccess) {
+            ace_hpx_weight_destroy(w);
+            return hfail(ACE_ERR_RUNTIME, "ace_hpx_weight_create: out of device memory");
+        }
+        er = hipMemsetAsync(w->thi, 0, halves * 2, s);
+        if (er == hipSuccess) er = hipMemsetAsync(w->tlo, 0, halves * 2, s);
+        if (er == hipSuccess) er = launch_split_f16_tiled(w_dev, cols, w->thi, w->tlo, w->pitch, rows, cols, w->ascale, s);
+    }
     if (er == hipSuccess) er = hipStreamSynchronize(s);
     if (er != hipSuccess) { ace_hpx_weight_destroy(w); return hfail(ACE_ERR_RUNTIME, std::string("ace_hpx_weight_create: ") + hipGetErrorString(er)); }
     *out = w;
@@ -382,6 +459,55 @@ extern "C" int ace_hpx_conv(const float* x, const float* x2, int cin, int cin2, 
     g.act = act; g.cap = cap;
     if (!gemm_f16x3_eligible(g)) return hfail(ACE_ERR_INVALID, "ace_hpx_conv: operands must be 16-byte aligned");
     HPX_TRY(launch_gemm_f16x3(g, w->hi, w->lo, w->ascale, 1.0f, s, xmax, ymax, cin2 > 0 ? x2max : nullptr));
+    return ACE_OK;
+}
+
+// The k x k convolution on the packed-operand engine (kernels.hip gemm4, implicit-GEMM form): the padded input comes as P-format
+// planes from ace_hpx_pad_planes (cpad = 8 ceil(channels / 8) channels per image, `pitch` entries per padded row, H + (k - 1) dil rows),
+// the weight as a prepared (cout x k k cpad) matrix in (tap, padded channel) order (zero columns for the padding channels).
+// Both operands stream by LDS-DMA; no fp32 activation is split in the kernel (gemm3 spends its loader waves on that).
+extern "C" int ace_hpx_conv_packed(const void* xhi, const void* xlo, int cpad, const ace_hpx_weight* w, const float* bias, float* y,
+                                   int imgs, int cout, int H, int W, int pitch, int k, int dil, int act, float cap, const unsigned* pmax,
+                                   unsigned* ymax, void* stream) {
+    if (!xhi || !xlo || !w || !y || !pmax || imgs < 1 || cpad < 8 || (cpad & 7) || cout < 1 || H < 1 || W < 1 || pitch < W + (k - 1) * dil ||
+        (pitch & 3) || k < 2 || dil < 1 || (k - 1) * dil > ACE_HPX_SLACK)
+        return hfail(ACE_ERR_INVALID, "ace_hpx_conv_packed: bad argument (k >= 2, channels padded to 8, pitch % 4 == 0)");
+    if (!(act == ACT_NONE || act == ACT_GELU || act == ACT_RELU)) return hfail(ACE_ERR_INVALID, "ace_hpx_conv_packed: activation must be none, gelu or relu");
+    const int K = cpad * k * k;
+    if (w->rows != cout || w->cols != K || !w->thi)
+        return hfail(ACE_ERR_INVALID, "ace_hpx_conv_packed: prepared weight is " + std::to_string(w->rows) + " x " + std::to_string(w->cols) +
+                                          ", expected " + std::to_string(cout) + " x " + std::to_string(K) + " (tap, padded channel) columns");
+    const int rows_in = H + (k - 1) * dil;
+    const long cells = (long)rows_in * pitch;
+    Gemm4Args a;
+    a.Ahi = w->thi; a.Alo = w->tlo; a.lda = w->pitch; a.sA = 0; a.ascale = w->ascale; a.a_tiled = 1;
+    a.Bhi = static_cast<const _Float16*>(xhi); a.Blo = static_cast<const _Float16*>(xlo);
+    a.ldn = cells; a.sB = (long)(cpad / 8) * cells * 8; a.bmax = pmax;
+    a.C = y; a.ldc = (long)H * pitch; a.sC = (long)cout * H * pitch; a.omax = ymax;
+    a.bias = bias; a.sbias = 0;
+    a.M = cout; a.N = H * pitch; a.K = K; a.nbatch = imgs;
+    a.act = act; a.cap = cap;
+    a.impl_k = k; a.impl_cg8 = cpad / 8; a.impl_pitch = pitch; a.impl_dil = dil;
+    // 128 x 128 tiles unless they waste over 20 % more rows than 64 x 256 ones: the launcher's own rule (least padding) picks 64-row
+    // tiles for cout = 544 (576 against 640 rows), the 128-row tile is the faster engine (same box, nside 64: 4.47 -> 4.08 ms per forward)
+    if (5 * ((cout + 127) / 128 * 128) <= 6 * ((cout + 63) / 64 * 64)) a.tile = 1;
+    HPX_TRY(launch_gemm_f16x3_packed(a, static_cast<hipStream_t>(stream)));
+    return ACE_OK;
+}
+
+extern "C" int ace_hpx_pad_planes(const float* x, long x_img_stride, long x_chan_stride, int x_pitch, const float* x2, long x2_img_stride,
+                                  long x2_chan_stride, int x2_pitch, int cin, int cin2, void* hi, void* lo, const int* idx_a_dev,
+                                  const int* idx_b_dev, int items, int nside, int p, int y_pitch, const unsigned* xmax, const unsigned* x2max,
+                                  unsigned* pmax, void* stream) {
+    const int m = nside + 2 * p;
+    if (!x || !hi || !lo || !idx_a_dev || !idx_b_dev || items < 1 || cin < 1 || cin2 < 0 || (cin2 > 0 && (!x2 || !x2max)) || nside < 1 || p < 1 ||
+        y_pitch < m || !xmax || !pmax)
+        return hfail(ACE_ERR_INVALID, "ace_hpx_pad_planes: bad argument");
+    const long total = (long)items * 12 * ((cin + cin2 + 7) / 8) * m * y_pitch;
+    hipLaunchKernelGGL(hpx_pad_planes_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, x_img_stride, x_chan_stride,
+                       x_pitch, cin2 > 0 ? x2 : x, x2_img_stride, x2_chan_stride, x2_pitch, cin, cin2, static_cast<_Float16*>(hi),
+                       static_cast<_Float16*>(lo), m, y_pitch, idx_a_dev, idx_b_dev, items, xmax, cin2 > 0 ? x2max : nullptr, pmax, ACE_HPX_SLACK);
+    HPX_TRY(hipGetLastError());
     return ACE_OK;
 }
 

@@ -129,6 +129,13 @@ struct Gemm4Args {
     int M = 0, N = 0, K = 0, nbatch = 1;
     int tri = TRI_NONE; int trimul = 1;
     int act = ACT_NONE;
+    // implicit-GEMM B (impl_k > 0; the HEALPix k x k convolutions on padded faces): the contraction runs over (tap, channel group)
+    // - k group kg = tap * impl_cg8 + cg - and reads the P-format planes of the PADDED tensor, plane group cg, at the pixel offset
+    // ((tap / impl_k) * impl_pitch + tap % impl_k) * impl_dil from the output pixel: a shifted window per tap, no im2col tensor.
+    // ldn = entries per plane group (the caller keeps (impl_k - 1) * impl_dil entries of slack behind the last one); the result is
+    // clamped from above by `cap` (capped GELU).  fp32 output only (no P-format output, residual or triangular form).
+    int impl_k = 0, impl_cg8 = 0, impl_pitch = 0, impl_dil = 1;
+    float cap = 3.0e38f;
 };
 hipError_t launch_gemm_f16x3_packed(const Gemm4Args& a, hipStream_t s);
 int gemm4_strips(int M, int N);

@@ -1596,8 +1596,9 @@ extern "C" int ace_debug_g4_trace(void* dst) { return (int)hipMemcpyFromSymbol(d
 #endif                    // validated on the GPU (round 2: tools/ab.sh with -DACE_G4_REGEPI=1)
 struct Frags4 { half8 ah[2], al[2], bh[2], bl[2]; };  // one 16-deep k half: [tile]
 
-template <int WM, int WN, bool RES, bool PK>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args q, int tilesM, int tilesN) {
+template <int WM, int WN, bool RES, bool PK, bool IMPL>
+DEVINL void gemm4_body(const Gemm4Args& q, const int tilesM, const int tilesN) {
+    static_assert(!IMPL || (!RES && !PK), "implicit-GEMM form: fp32 output only");
     constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
     static_assert(NW == 4, "piece distribution assumes 4 waves");
     constexpr int BKT = 32;
@@ -1682,6 +1683,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
         if (cplx) nn -= nhalf * cplx;
         bcol[c] = (long)nn * 8;
     }
+    // implicit-GEMM B: (plane group, tap row, tap column) of the k group each of this wave's pieces fetches NEXT; issue() is called
+    // once per stage, in stage order, and steps them by the stage's four k groups (wave-uniform scalars, no table in memory)
+    int icg[BCW], ity[BCW], itx[BCW];
+    if constexpr (IMPL) {
+#pragma unroll
+        for (int c = 0; c < BCW; ++c) {
+            const int tap = bkg[c] / q.impl_cg8;
+            icg[c] = bkg[c] % q.impl_cg8; ity[c] = tap / q.impl_k; itx[c] = tap % q.impl_k;
+        }
+    }
     auto issue = [&](int k0, int buf) {
         _Float16* Ab = As + buf * 2 * APL;
         _Float16* Bb = Bs + buf * 2 * BPL;
@@ -1701,6 +1712,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
             if (cplx) {                     // block (k half == n half ? Wr : Wi), k group inside the block
                 const int khalf = k0 >= cplx;
                 off = (long)(khalf != nhalf) * cplx * cplx + (long)(kg - khalf * (cplx / 8)) * ldn * 8 + bcol[c];
+            }
+            if constexpr (IMPL) {           // plane group at the tap's pixel shift; k groups past K: the last one (zero A columns)
+                const bool past = ity[c] >= q.impl_k;
+                const int cgq = past ? q.impl_cg8 - 1 : icg[c], ty = past ? q.impl_k - 1 : ity[c], tx = past ? q.impl_k - 1 : itx[c];
+                off = ((long)cgq * ldn + (long)(ty * q.impl_pitch + tx) * q.impl_dil) * 8 + bcol[c];
+                icg[c] += 4;
+                while (icg[c] >= q.impl_cg8) {
+                    icg[c] -= q.impl_cg8;
+                    if (++itx[c] == q.impl_k) { itx[c] = 0; ++ity[c]; }
+                }
             }
             glds16(reinterpret_cast<const float*>(Bhi + off), reinterpret_cast<float*>(Bb + cb * 512));
             glds16(reinterpret_cast<const float*>(Blo + off), reinterpret_cast<float*>(Bb + BPL + cb * 512));
@@ -2008,6 +2029,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
                     float v = fmaf(o[e] * inv_a, inv_b, bvv[jj]);
                     if (RES) v += fmaf(r4[e], rsv[jj], rtv[jj]);
                     o[e] = act_const<AC>(v, actk);
+                    if constexpr (IMPL) o[e] = fminf(o[e], q.cap);
                 }
                 const bool ok = row < M && cok;
                 if (C && ok) *reinterpret_cast<float4*>(C + (long)row * ldc + colb) = make_float4(o[0], o[1], o[2], o[3]);
@@ -2073,6 +2095,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G4T(54);
 #endif
+}
+
+template <int WM, int WN, bool RES, bool PK>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args q, int tilesM, int tilesN) {
+    gemm4_body<WM, WN, RES, PK, false>(q, tilesM, tilesN);
+}
+// the same engine with the implicit-GEMM B operand (Gemm4Args::impl_k): HEALPix k x k convolutions
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_implicit_kernel(Gemm4Args q, int tilesM, int tilesN) {
+    gemm4_body<WM, WN, false, false, true>(q, tilesM, tilesN);
 }
 
 // fp32 [K][N] (row pitch ldb) -> P-format fp16 hi/lo planes [ceil(K/8)][ldn][8], optional per-row affine (fused
@@ -2152,6 +2184,16 @@ static hipError_t launch_gemm4_cfg(const Gemm4Args& a, hipStream_t s) {
         configured[ci] = true;
     }
     dim3 grid((unsigned)nblk), block(64 * WM * WN);
+    if (a.impl_k > 0) {
+        static bool configured_impl = false;
+        if (!configured_impl) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm4_implicit_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            configured_impl = true;
+        }
+        hipLaunchKernelGGL((gemm4_implicit_kernel<WM, WN>), grid, block, lds, s, a, tilesM, tilesN);
+        return hipGetLastError();
+    }
     if (pk && res) hipLaunchKernelGGL((gemm4_f16x3_kernel<WM, WN, true, true>), grid, block, lds, s, a, tilesM, tilesN);
     else if (pk) hipLaunchKernelGGL((gemm4_f16x3_kernel<WM, WN, false, true>), grid, block, lds, s, a, tilesM, tilesN);
     else if (res) hipLaunchKernelGGL((gemm4_f16x3_kernel<WM, WN, true, false>), grid, block, lds, s, a, tilesM, tilesN);
@@ -2172,6 +2214,9 @@ hipError_t launch_gemm_f16x3_packed(const Gemm4Args& a, hipStream_t s) {
     if (!a.Chi && !a.C) return hipErrorInvalidValue;
     if (a.N % 4 != 0 || (a.C && (!al16(a.C) || a.ldc % 4 != 0 || a.sC % 4 != 0))) return hipErrorInvalidValue;
     if (a.R && (!al16(a.R) || a.ldr % 4 != 0 || a.sR % 4 != 0)) return hipErrorInvalidValue;
+    if (a.impl_k > 0 && (a.R || a.Chi || a.cplx || a.tri != TRI_NONE || a.part || a.impl_cg8 < 1 || a.impl_dil < 1 || a.impl_pitch < 1 ||
+                         a.K != a.impl_k * a.impl_k * a.impl_cg8 * 8 || !a.a_tiled))
+        return hipErrorInvalidValue;
     const long waste128 = (long)((a.M + 127) / 128) * 128, waste64 = (long)((a.M + 63) / 64) * 64;
 #ifdef ACE_MEASUREMENT_SWITCHES
     static const int env_force = getenv("ACE_G4_TILE") ? atoi(getenv("ACE_G4_TILE")) : 0;   // A/B switch: 1 = 128x128, 2 = 64x256

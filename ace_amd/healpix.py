@@ -21,6 +21,7 @@ the SFNO path; every tensor carries a 64-word "bound slot" (max |x|, produced by
 consuming convolution derives its power-of-two scale.  There is no CPU path: tensors must live on an MI355X."""
 import ctypes
 import dataclasses
+import os
 from typing import Any, Callable, Dict, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
@@ -185,6 +186,7 @@ class _Runtime:
 
 _RT = _Runtime()
 _SLACK = 16   # ACE_HPX_SLACK_FLOATS
+_PACKED_CONV = os.environ.get("ACE_HPX_NO_PACKED", "0") in ("", "0")   # k x k convolutions on the packed engine (ACE_HPX_NO_PACKED=1: gemm3, fp32 operand)
 
 
 def _repitch(x: Hpx, pitch: int) -> Hpx:
@@ -231,7 +233,12 @@ class CappedGELU(nn.Module):
         self.register_buffer("cap", torch.tensor(cap_value, dtype=torch.float32))
 
     def code(self) -> Tuple[int, float]:
-        return ACT_GELU, float(self.cap.item())
+        # the buffer lives on the device: its value is read back once per change, not per call (a device -> host copy in every
+        # forward costs a synchronisation, and is not allowed inside a graph capture)
+        stamp = (self.cap.data_ptr(), self.cap._version)
+        if getattr(self, "_cap_host", None) is None or self._cap_host[0] != stamp:
+            self._cap_host = (stamp, float(self.cap.item()))
+        return ACT_GELU, self._cap_host[1]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -285,12 +292,14 @@ class HEALPixLayer(nn.Module):
         self._pad = padding
         self._k, self._dil = kernel_size, dilation
         self._prep: Optional[Tuple[Tuple[int, int], int, Any]] = None       # (weight stamp, native prepared-weight handle, its destroyer)
+        self._prep_pk: Optional[Tuple[Tuple[int, int, int], int, Any]] = None   # the same for the packed engine's (tap, padded channel) form
         self._rows: Dict[Tuple[int, int, int, str], torch.Tensor] = {}
 
     def __del__(self):
         try:
-            if self._prep is not None:
-                self._prep[2](ctypes.c_void_p(self._prep[1]))
+            for prep in (self._prep, self._prep_pk):
+                if prep is not None:
+                    prep[2](ctypes.c_void_p(prep[1]))
         except Exception:
             pass
 
@@ -315,6 +324,22 @@ class HEALPixLayer(nn.Module):
                 self._prep[2](ctypes.c_void_p(self._prep[1]))
             self._prep = (stamp, h.value, _lib.lib().ace_hpx_weight_destroy)      # freed by the library that made it
         return ctypes.c_void_p(self._prep[1])
+
+    def _weight_packed(self, cpad: int) -> ctypes.c_void_p:
+        """The k x k weight for the packed engine: columns = (tap, channel padded to `cpad`), zero columns for the padding."""
+        w = self.base.weight
+        stamp = (w.data_ptr(), w._version, cpad)
+        if self._prep_pk is None or self._prep_pk[0] != stamp:
+            cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+            t = torch.zeros(cout, k * k, cpad, dtype=torch.float32, device=w.device)
+            t[:, :, :cin] = w.detach().permute(0, 2, 3, 1).reshape(cout, k * k, cin).float()
+            t = t.reshape(cout, k * k * cpad).contiguous()
+            h = ctypes.c_void_p()
+            _check(_lib.lib().ace_hpx_weight_create(t.data_ptr(), t.shape[0], t.shape[1], _lib.current_stream(), ctypes.byref(h)))
+            if self._prep_pk is not None:
+                self._prep_pk[2](ctypes.c_void_p(self._prep_pk[1]))
+            self._prep_pk = (stamp, h.value, _lib.lib().ace_hpx_weight_destroy)
+        return ctypes.c_void_p(self._prep_pk[1])
 
     def _row_offsets(self, cin: int, rows_in: int, pitch: int, device) -> torch.Tensor:
         key = (cin, rows_in, pitch, str(device))
@@ -348,6 +373,23 @@ class HEALPixLayer(nn.Module):
                                  "Make sure that nside was set correctly in the model config.")
             ia, ib = _RT.table(W, p, dev, pad_layer.mode)
             ctot = cin + cin2
+            if _PACKED_CONV and (self._k - 1) * self._dil <= _SLACK:
+                # the packed engine: padding gather -> fp16 hi / lo planes (both sources at once), implicit-GEMM convolution
+                cpad = (ctot + 7) // 8 * 8
+                halves = imgs * cpad * m * mp + _SLACK * 8
+                planes = torch.empty(2, halves, dtype=torch.float16, device=dev)
+                pmax = _RT.slot(dev)
+                d, d2 = x.data, (x2.data if x2 is not None else None)
+                _check(L.ace_hpx_pad_planes(d.data_ptr(), d.stride(0), d.stride(1), x.pitch,
+                                            d2.data_ptr() if d2 is not None else None, d2.stride(0) if d2 is not None else 0,
+                                            d2.stride(1) if d2 is not None else 0, x2.pitch if x2 is not None else 0, cin, cin2,
+                                            planes[0].data_ptr(), planes[1].data_ptr(), ia.data_ptr(), ib.data_ptr(), imgs // 12, W, p, mp,
+                                            _bound(x).data_ptr(), _bound(x2).data_ptr() if x2 is not None else None, pmax.data_ptr(), st))
+                y = torch.empty(imgs, cout, H, mp, dtype=torch.float32, device=dev)
+                _check(L.ace_hpx_conv_packed(planes[0].data_ptr(), planes[1].data_ptr(), cpad, self._weight_packed(cpad),
+                                             _lib.ptr(bias) if bias is not None else None, y.data_ptr(), imgs, cout, H, W, mp, self._k, self._dil,
+                                             act[0], act[1], pmax.data_ptr(), ymax.data_ptr(), st))
+                return Hpx(y, W, ymax)
             flat = torch.empty(imgs * ctot * m * mp + _SLACK, dtype=torch.float32, device=dev)
             xmax = _RT.slot(dev)
             for src, c0 in ((x, 0), (x2, cin)):
@@ -1260,6 +1302,39 @@ class HEALPixUNet(nn.Module):
         out = self.decoder(self.encoder(x))
         y = out.data[..., : out.width]
         return y.reshape(B, 12, self.output_channels, h, w).contiguous()                     # unfold
+
+
+class CapturedHEALPixForward:
+    """One forward of a HEALPix network captured in a hipGraph with static input / output buffers.
+
+    At nside 64 the eager forward is ~150 launches of 5 - 40 us kernels driven from Python and is bound by the host; every
+    native call of the forward is asynchronous on the current stream (weight handles and padding tables are built once, in the
+    warm-up), so the whole forward captures, and a replay costs the device time only.  The result is the same kernels on the
+    same data: bit-identical to the eager forward.  Inference only; the input shape is fixed at capture.
+    """
+
+    def __init__(self, net: nn.Module, example: torch.Tensor, warmup: int = 2):
+        if not example.is_cuda:
+            raise RuntimeError("CapturedHEALPixForward needs a device tensor (MI355X); there is no CPU path")
+        self.net = net
+        self.x = example.detach().clone()
+        with torch.no_grad():
+            side = torch.cuda.Stream(device=example.device)
+            side.wait_stream(torch.cuda.current_stream(example.device))
+            with torch.cuda.stream(side):
+                for _ in range(max(warmup, 1)):
+                    net(self.x)
+            torch.cuda.current_stream(example.device).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.y = net(self.x)
+
+    def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
+        if inputs.shape != self.x.shape:
+            raise ValueError(f"captured for inputs of shape {tuple(self.x.shape)}, got {tuple(inputs.shape)}")
+        self.x.copy_(inputs)
+        self.graph.replay()
+        return self.y
 
 
 @ModuleSelector.register("HEALPixUNet")

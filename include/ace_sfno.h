@@ -322,6 +322,17 @@ void ace_hpx_weight_destroy(ace_hpx_weight* w);
 int ace_hpx_conv(const float* x, const float* x2, int cin, int cin2, const ace_hpx_weight* w, const long* row_off, const float* bias,
                  const float* R, float* y, int imgs, int cout, int H, int W, int pitch, int k, int dil, int act, float cap,
                  const unsigned* xmax, const unsigned* x2max, unsigned* ymax, void* stream);
+/* The k x k (k >= 2) convolutions on the packed-operand engine: ace_hpx_pad_planes does the face padding of x (and, for the skip
+ * concatenation, x2 behind it) straight into the engine's activation format - fp16 hi / lo planes [imgs][cpad / 8][(nside + 2 p) x
+ * y_pitch cells][8 channels], cpad = channels rounded up to 8, scaled by the bound it publishes to pmax (+ ACE_HPX_SLACK_FLOATS
+ * zero ENTRIES of 16 bytes behind each of hi, lo, kept allocated by the caller) - and ace_hpx_conv_packed contracts it with a weight
+ * prepared from [cout][(ky k + kx) cpad + i] (zero columns for i >= channels).  Same arithmetic as ace_hpx_conv (compensated fp16,
+ * fp32 accumulation), results equal to rounding; both operands stream by LDS-DMA. */
+int ace_hpx_pad_planes(const float* x, long x_img_stride, long x_chan_stride, int x_pitch, const float* x2, long x2_img_stride,
+                       long x2_chan_stride, int x2_pitch, int cin, int cin2, void* hi, void* lo, const int* idx_a_dev, const int* idx_b_dev,
+                       int items, int nside, int p, int y_pitch, const unsigned* xmax, const unsigned* x2max, unsigned* pmax, void* stream);
+int ace_hpx_conv_packed(const void* xhi, const void* xlo, int cpad, const ace_hpx_weight* w, const float* bias, float* y, int imgs, int cout,
+                        int H, int W, int pitch, int k, int dil, int act, float cap, const unsigned* pmax, unsigned* ymax, void* stream);
 /* nn.AvgPool2d(2) / nn.MaxPool2d(2) on `planes` = imgs * channels planes (the input's bound also bounds the result). */
 int ace_hpx_pool2(const float* x, float* y, long planes, int H, int W, int pitch_in, long plane_stride_in, int pitch_out,
                   long plane_stride_out, int is_max, void* stream);

@@ -130,6 +130,69 @@ class FakeHpx:
         _f32(y, imgs * cout * N).view(imgs, cout, N).copy_(_act(out, act, cap).float())
         return 0
 
+    def ace_hpx_pad_planes(self, x, x_img_stride, x_chan_stride, x_pitch, x2, x2_img_stride, x2_chan_stride, x2_pitch, cin, cin2, hi, lo, ia, ib,
+                           items, nside, p, y_pitch, xmax, x2max, pmax, stream):
+        """the gather of ace_hpx_pad for both sources, stored as documented: fp16 hi / lo planes [img][channel group][cell][8] (the
+        emulated bound slots are zero: scale 2^0)"""
+        self.calls.append("pad_planes")
+        m = nside + 2 * p
+        if y_pitch < m or p < 1 or (cin2 and not x2):
+            return 1
+        a = _view(ia, 12 * m * m, ctypes.c_int32, torch.int32).long().reshape(12, m, m)
+        b = _view(ib, 12 * m * m, ctypes.c_int32, torch.int32).long().reshape(12, m, m)
+        imgs, ctot = items * 12, cin + cin2
+        cg8, cells = (ctot + 7) // 8, m * y_pitch
+        ymax, xmax_ = int(max(((a >> 12) & 4095).max(), ((b >> 12) & 4095).max())), int(max((a & 4095).max(), (b & 4095).max()))
+        item = torch.arange(items).view(items, 1, 1, 1, 1)
+        same = (a == b).view(1, 12, 1, m, m)
+        full = torch.zeros(imgs, cg8 * 8, m, y_pitch, dtype=torch.float32)
+        for ptr, ist, cst, pt, c, c0 in ((x, x_img_stride, x_chan_stride, x_pitch, cin, 0), (x2, x2_img_stride, x2_chan_stride, x2_pitch, cin2, cin)):
+            if not c:
+                continue
+            src = _f32(ptr, (imgs - 1) * ist + (c - 1) * cst + ymax * pt + xmax_ + 1)
+            ch = torch.arange(c).view(1, 1, c, 1, 1)
+
+            def gather(s_):
+                s_ = s_.view(1, 12, 1, m, m)
+                return src[((item * 12 + (s_ >> 24)) * ist + ch * cst + ((s_ >> 12) & 4095) * pt + (s_ & 4095))]
+
+            va, vb = gather(a), gather(b)
+            full[:, c0:c0 + c, :, :m] = torch.where(same, va, 0.5 * va + 0.5 * vb).reshape(imgs, c, m, m)
+        ent = full.view(imgs, cg8, 8, cells).permute(0, 1, 3, 2).contiguous()        # [img][cg][cell][8]
+        h16 = ent.to(torch.float16)
+        l16 = (ent - h16.float()).to(torch.float16)
+        n = imgs * cg8 * cells * 8
+        for ptr, val in ((hi, h16), (lo, l16)):
+            dst = _view(ptr, n + 16 * 8, ctypes.c_uint16, torch.int16)
+            dst[:n] = val.reshape(-1).view(torch.int16)
+            dst[n:] = 0
+        return 0
+
+    def ace_hpx_conv_packed(self, xhi, xlo, cpad, w, bias, y, imgs, cout, H, W, pitch, k, dil, act, cap, pmax, ymax, stream):
+        self.calls.append(f"conv{k}")
+        Wm = self._w(w)
+        K = cpad * k * k
+        if Wm.shape != (cout, K) or pitch % 4 or pitch < W + (k - 1) * dil or cpad % 8 or k < 2:
+            return 1
+        rows_in, cg8 = H + (k - 1) * dil, cpad // 8
+        cells, N = rows_in * pitch, H * pitch
+        n = imgs * cg8 * cells * 8 + 16 * 8
+        xs = (_view(xhi, n, ctypes.c_uint16, torch.int16).view(torch.float16).double() + _view(xlo, n, ctypes.c_uint16, torch.int16).view(torch.float16).double())
+        ent = xs.view(-1, 8)                                                              # [entry][8 channels]
+        col = torch.arange(N)
+        out = torch.zeros(imgs, cout, N, dtype=torch.float64)
+        Wt = Wm.view(cout, k * k, cg8, 8)
+        for t in range(k * k):
+            toff = ((t // k) * pitch + (t % k)) * dil
+            for cg in range(cg8):
+                for i in range(imgs):
+                    Bt = ent[(i * cg8 + cg) * cells + toff + col]                         # [N][8]
+                    out[i] += Wt[:, t, cg, :] @ Bt.T
+        if bias:
+            out = out + _f32(bias, cout).double().view(1, cout, 1)
+        _f32(y, imgs * cout * N).view(imgs, cout, N).copy_(_act(out, act, cap).float())
+        return 0
+
     def ace_hpx_pool2(self, x, y, planes, H, W, pitch_in, plane_stride_in, pitch_out, plane_stride_out, is_max, stream):
         self.calls.append("pool")
         if H % 2 or W % 2:

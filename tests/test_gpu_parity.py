@@ -1290,6 +1290,28 @@ def test_healpix_symmetric_convnext_unet_vs_reference(dev):
     assert rel_max(y, g["y"]) <= NET_TOL, rel_max(y, g["y"])
 
 
+def test_healpix_forward_captured_in_a_graph(dev):
+    """ace_amd.CapturedHEALPixForward: the whole forward replayed from a hipGraph (no Python between the launches) gives the eager
+    forward's bits on the captured input and on fresh inputs, and stays within the bar of the reference's output."""
+    import ace_amd
+    g = load_golden("gen_healpix.pt")["unet"]["convnext_avgpool_tconv"]
+    case = g["case"]
+    net = ace_amd.ModuleSelector(type="HEALPixUNet", config=case["config"]).build(
+        case["n_in"], case["n_out"], ace_amd.DatasetInfo((case["nside"], case["nside"]))).torch_module.to(dev)
+    net.load_state_dict(g["state_dict"], strict=True)
+    x = g["x"].to(dev)
+    cap = ace_amd.CapturedHEALPixForward(net, x)
+    with torch.no_grad():
+        y = cap(x).clone()
+        assert torch.equal(y, net(x))
+        assert rel_max(y, g["y"]) <= NET_TOL
+        x2 = torch.randn_like(x) * 2.0 + 0.5                  # another range: the bound slots are recomputed inside the graph
+        assert torch.equal(cap(x2), net(x2))
+        assert torch.equal(cap(x), y)
+    with pytest.raises(ValueError, match="captured for inputs of shape"):
+        cap(x[:, :, :1])
+
+
 def test_healpix_weight_update_is_seen(dev):
     """The prepared (fp16 hi / lo) copy of a convolution weight is re-made when the parameter changes in place: doubling the
     output layer's weight and bias (a 1 x 1 convolution without activation) doubles the output."""

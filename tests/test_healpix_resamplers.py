@@ -44,15 +44,21 @@ def _run_block(blk, x, device):
     return out.data[..., : out.width]
 
 
+@pytest.mark.parametrize("packed", [True, False])
 @pytest.mark.parametrize("file,name", UNETS)
-def test_unet_host_logic_on_the_emulated_operators(file, name):
+def test_unet_host_logic_on_the_emulated_operators(file, name, packed, monkeypatch):
+    """packed: the k x k convolutions through ace_hpx_pad_planes + ace_hpx_conv_packed (channel groups of 8, (tap, padded channel)
+    weight columns); else through ace_hpx_pad + ace_hpx_conv (row-offset table) - the ACE_HPX_NO_PACKED=1 routing."""
+    import ace_amd.healpix as hp
+    monkeypatch.setattr(hp, "_PACKED_CONV", packed)
     g = load_golden(file)["unet"][name]
     net = _build(g["case"], g["state_dict"])
     with fake_hpx() as fake, torch.no_grad():
         y = net._run(g["x"])
     assert y.shape == g["y"].shape
     assert rel_max(y, g["y"]) <= NET_TOL, rel_max(y, g["y"])
-    assert "pad" in fake.calls and any(c.startswith("conv") for c in fake.calls)
+    assert ("pad_planes" in fake.calls) == packed and (packed or "pad" in fake.calls)     # (the resampler blocks keep their own ace_hpx_pad)
+    assert any(c.startswith("conv") for c in fake.calls)
     with pytest.raises(RuntimeError, match="MI355X"):       # the product path still refuses host tensors
         net(g["x"])
 
