@@ -382,6 +382,7 @@ struct ace_hpx_weight {
     _Float16* thi = nullptr; _Float16* tlo = nullptr;   // the same planes in the packed engine's A-tile order (ace_hpx_conv_packed)
     int rows = 0, cols = 0, pitch = 0;
     float ascale = 1.f;
+    float winf = 0.f;   // max row sum of |w|: |W x| <= winf max|x| (the bound a P-format output is scaled by)
 };
 extern "C" void ace_hpx_weight_destroy(ace_hpx_weight* w) {
     if (!w) return;
@@ -407,6 +408,11 @@ extern "C" int ace_hpx_weight_create(const float* w_dev, int rows, int cols, voi
     ace_hpx_weight* w = new ace_hpx_weight;
     w->rows = rows; w->cols = cols; w->pitch = (cols + 31) & ~31;
     w->ascale = std::ldexp(1.0f, e);
+    for (int r = 0; r < rows; ++r) {
+        double rs = 0.0;
+        for (int c = 0; c < cols; ++c) rs += std::fabs((double)host[(size_t)r * cols + c]);
+        w->winf = std::max(w->winf, (float)(rs * (1.0 + 1e-6)));
+    }
     const size_t halves = (size_t)((rows + 15) / 16 * 16) * w->pitch;
     if (hipMalloc(reinterpret_cast<void**>(&w->hi), halves * 2) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&w->lo), halves * 2) != hipSuccess) {
         ace_hpx_weight_destroy(w);
@@ -466,12 +472,12 @@ extern "C" int ace_hpx_conv(const float* x, const float* x2, int cin, int cin2, 
 // planes from ace_hpx_pad_planes (cpad = 8 ceil(channels / 8) channels per image, `pitch` entries per padded row, H + (k - 1) dil rows),
 // the weight as a prepared (cout x k k cpad) matrix in (tap, padded channel) order (zero columns for the padding channels).
 // Both operands stream by LDS-DMA; no fp32 activation is split in the kernel (gemm3 spends its loader waves on that).
-extern "C" int ace_hpx_conv_packed(const void* xhi, const void* xlo, int cpad, const ace_hpx_weight* w, const float* bias, float* y,
-                                   int imgs, int cout, int H, int W, int pitch, int k, int dil, int act, float cap, const unsigned* pmax,
-                                   unsigned* ymax, void* stream) {
-    if (!xhi || !xlo || !w || !y || !pmax || imgs < 1 || cpad < 8 || (cpad & 7) || cout < 1 || H < 1 || W < 1 || pitch < W + (k - 1) * dil ||
-        (pitch & 3) || k < 2 || dil < 1 || (k - 1) * dil > ACE_HPX_SLACK)
-        return hfail(ACE_ERR_INVALID, "ace_hpx_conv_packed: bad argument (k >= 2, channels padded to 8, pitch % 4 == 0)");
+extern "C" int ace_hpx_conv_packed(const void* xhi, const void* xlo, int cpad, const ace_hpx_weight* w, const float* bias, float bias_max,
+                                   float* y, void* yhi, void* ylo, int imgs, int cout, int H, int W, int pitch, int k, int dil, int act, float cap,
+                                   const unsigned* pmax, unsigned* ymax, void* stream) {
+    if (!xhi || !xlo || !w || (!y && !yhi) || (yhi && (!ylo || !ymax || (cout & 7))) || !pmax || imgs < 1 || cpad < 8 || (cpad & 7) || cout < 1 ||
+        H < 1 || W < 1 || pitch < W + (k - 1) * dil || (pitch & 3) || k < 2 || dil < 1 || (k - 1) * dil > ACE_HPX_SLACK || !(bias_max >= 0.f))
+        return hfail(ACE_ERR_INVALID, "ace_hpx_conv_packed: bad argument (k >= 2, channels padded to 8, pitch % 4 == 0; planes out: cout % 8 == 0 and a slot)");
     if (!(act == ACT_NONE || act == ACT_GELU || act == ACT_RELU)) return hfail(ACE_ERR_INVALID, "ace_hpx_conv_packed: activation must be none, gelu or relu");
     const int K = cpad * k * k;
     if (w->rows != cout || w->cols != K || !w->thi)
@@ -483,7 +489,11 @@ extern "C" int ace_hpx_conv_packed(const void* xhi, const void* xlo, int cpad, c
     a.Ahi = w->thi; a.Alo = w->tlo; a.lda = w->pitch; a.sA = 0; a.ascale = w->ascale; a.a_tiled = 1;
     a.Bhi = static_cast<const _Float16*>(xhi); a.Blo = static_cast<const _Float16*>(xlo);
     a.ldn = cells; a.sB = (long)(cpad / 8) * cells * 8; a.bmax = pmax;
-    a.C = y; a.ldc = (long)H * pitch; a.sC = (long)cout * H * pitch; a.omax = ymax;
+    if (yhi) {   // P-format output only: the operand of a following 1 x 1 convolution (ace_hpx_conv1_packed); its bound goes to ymax
+        a.Chi = static_cast<_Float16*>(yhi); a.Clo = static_cast<_Float16*>(ylo); a.ldnc = (long)H * pitch; a.sCp = (long)cout * H * pitch;
+        a.cw = w->winf; a.cb = bias_max; a.cslot = ymax;
+    }
+    if (y) { a.C = y; a.ldc = (long)H * pitch; a.sC = (long)cout * H * pitch; if (!yhi) a.omax = ymax; }
     a.bias = bias; a.sbias = 0;
     a.M = cout; a.N = H * pitch; a.K = K; a.nbatch = imgs;
     a.act = act; a.cap = cap;
@@ -491,6 +501,29 @@ extern "C" int ace_hpx_conv_packed(const void* xhi, const void* xlo, int cpad, c
     // 128 x 128 tiles unless they waste over 20 % more rows than 64 x 256 ones: the launcher's own rule (least padding) picks 64-row
     // tiles for cout = 544 (576 against 640 rows), the 128-row tile is the faster engine (same box, nside 64: 4.47 -> 4.08 ms per forward)
     if (5 * ((cout + 127) / 128 * 128) <= 6 * ((cout + 63) / 64 * 64)) a.tile = 1;
+    HPX_TRY(launch_gemm_f16x3_packed(a, static_cast<hipStream_t>(stream)));
+    return ACE_OK;
+}
+
+// 1 x 1 convolution (+ bias, + residual, activation none / GELU / ReLU without a cap) whose input is the P-format output of
+// ace_hpx_conv_packed: x planes [imgs][cin / 8][H pitch][8] with bound slot xslot; R / y: [imgs][cout][H][pitch] fp32.
+extern "C" int ace_hpx_conv1_packed(const void* xhi, const void* xlo, int cin, const ace_hpx_weight* w, const float* bias, const float* R, float* y,
+                                    int imgs, int cout, int H, int W, int pitch, int act, const unsigned* xslot, unsigned* ymax, void* stream) {
+    if (!xhi || !xlo || !w || !y || !xslot || imgs < 1 || cin < 8 || (cin & 7) || cout < 1 || H < 1 || W < 1 || pitch < W || (pitch & 3))
+        return hfail(ACE_ERR_INVALID, "ace_hpx_conv1_packed: bad argument (cin % 8 == 0, pitch % 4 == 0)");
+    if (!(act == ACT_NONE || act == ACT_GELU || act == ACT_RELU)) return hfail(ACE_ERR_INVALID, "ace_hpx_conv1_packed: activation must be none, gelu or relu");
+    if (w->rows != cout || w->cols != cin || !w->thi)
+        return hfail(ACE_ERR_INVALID, "ace_hpx_conv1_packed: prepared weight is " + std::to_string(w->rows) + " x " + std::to_string(w->cols) +
+                                          ", expected " + std::to_string(cout) + " x " + std::to_string(cin));
+    const long N = (long)H * pitch;
+    Gemm4Args a;
+    a.Ahi = w->thi; a.Alo = w->tlo; a.lda = w->pitch; a.sA = 0; a.ascale = w->ascale; a.a_tiled = 1;
+    a.Bhi = static_cast<const _Float16*>(xhi); a.Blo = static_cast<const _Float16*>(xlo); a.ldn = N; a.sB = (long)cin * N; a.bmax = xslot;
+    a.C = y; a.ldc = N; a.sC = (long)cout * N; a.omax = ymax;
+    a.bias = bias; a.sbias = 0;
+    if (R) { a.R = R; a.ldr = N; a.sR = (long)cout * N; }
+    a.M = cout; a.N = (int)N; a.K = cin; a.nbatch = imgs;
+    a.act = act;
     HPX_TRY(launch_gemm_f16x3_packed(a, static_cast<hipStream_t>(stream)));
     return ACE_OK;
 }

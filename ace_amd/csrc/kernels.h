@@ -133,7 +133,7 @@ struct Gemm4Args {
     // - k group kg = tap * impl_cg8 + cg - and reads the P-format planes of the PADDED tensor, plane group cg, at the pixel offset
     // ((tap / impl_k) * impl_pitch + tap % impl_k) * impl_dil from the output pixel: a shifted window per tap, no im2col tensor.
     // ldn = entries per plane group (the caller keeps (impl_k - 1) * impl_dil entries of slack behind the last one); the result is
-    // clamped from above by `cap` (capped GELU).  fp32 output only (no P-format output, residual or triangular form).
+    // clamped from above by `cap` (capped GELU).  fp32 and / or P-format output; no residual, no triangular form.
     int impl_k = 0, impl_cg8 = 0, impl_pitch = 0, impl_dil = 1;
     float cap = 3.0e38f;
 };

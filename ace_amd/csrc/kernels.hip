@@ -1598,7 +1598,7 @@ struct Frags4 { half8 ah[2], al[2], bh[2], bl[2]; };  // one 16-deep k half: [ti
 
 template <int WM, int WN, bool RES, bool PK, bool IMPL>
 DEVINL void gemm4_body(const Gemm4Args& q, const int tilesM, const int tilesN) {
-    static_assert(!IMPL || (!RES && !PK), "implicit-GEMM form: fp32 output only");
+    static_assert(!IMPL || !RES, "implicit-GEMM form: no residual");
     constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
     static_assert(NW == 4, "piece distribution assumes 4 waves");
     constexpr int BKT = 32;
@@ -1845,7 +1845,8 @@ DEVINL void gemm4_body(const Gemm4Args& q, const int tilesM, const int tilesN) {
     if (PK) {  // bound of this launch's output, identical in every workgroup; consumers read it from cslot
         const float inb = q.cinb ? wave_max(raw_c) : bbound;      // bound of the (normalised) conv input
         const float resb = q.rmax ? wave_max(raw_r) : 0.f;        // bound of the residual term
-        const float cbound = fmaf(q.cw, inb, q.cb) + resb;
+        float cbound = fmaf(q.cw, inb, q.cb) + resb;
+        if constexpr (IMPL) { if (q.act != ACT_NONE) cbound = fminf(cbound, fmaxf(q.cap, 0.25f)); }   // capped GELU / ReLU: -0.17 <= value <= cap
         cscale = ldexpf(1.0f, pow2_exponent_for(cbound));
         if (tid == 0) atomicMax(q.cslot + (blockIdx.x & 63), __float_as_uint(cbound));
     }
@@ -1972,7 +1973,9 @@ DEVINL void gemm4_body(const Gemm4Args& q, const int tilesM, const int tilesN) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float bvs = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bl), 8 * rg + e));
-                    const float x = act_const<AC>(fmaf(tv[e] * inv_a, inv_b, bvs), actk) * cscale;
+                    float v = act_const<AC>(fmaf(tv[e] * inv_a, inv_b, bvs), actk);
+                    if constexpr (IMPL) v = fminf(v, q.cap);
+                    const float x = v * cscale;
                     const _Float16 a = (_Float16)x;
                     hh[e] = a;
                     ll[e] = (_Float16)(x - (float)a);
@@ -2101,10 +2104,10 @@ template <int WM, int WN, bool RES, bool PK>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_f16x3_kernel(Gemm4Args q, int tilesM, int tilesN) {
     gemm4_body<WM, WN, RES, PK, false>(q, tilesM, tilesN);
 }
-// the same engine with the implicit-GEMM B operand (Gemm4Args::impl_k): HEALPix k x k convolutions
-template <int WM, int WN>
+// the same engine with the implicit-GEMM B operand (Gemm4Args::impl_k): HEALPix k x k convolutions (PK: P-format output)
+template <int WM, int WN, bool PK>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm4_implicit_kernel(Gemm4Args q, int tilesM, int tilesN) {
-    gemm4_body<WM, WN, false, false, true>(q, tilesM, tilesN);
+    gemm4_body<WM, WN, false, PK, true>(q, tilesM, tilesN);
 }
 
 // fp32 [K][N] (row pitch ldb) -> P-format fp16 hi/lo planes [ceil(K/8)][ldn][8], optional per-row affine (fused
@@ -2185,13 +2188,15 @@ static hipError_t launch_gemm4_cfg(const Gemm4Args& a, hipStream_t s) {
     }
     dim3 grid((unsigned)nblk), block(64 * WM * WN);
     if (a.impl_k > 0) {
-        static bool configured_impl = false;
-        if (!configured_impl) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm4_implicit_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static bool configured_impl[2] = {false, false};
+        const void* fi = pk ? (const void*)gemm4_implicit_kernel<WM, WN, true> : (const void*)gemm4_implicit_kernel<WM, WN, false>;
+        if (!configured_impl[pk]) {
+            hipError_t e = hipFuncSetAttribute(fi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            configured_impl = true;
+            configured_impl[pk] = true;
         }
-        hipLaunchKernelGGL((gemm4_implicit_kernel<WM, WN>), grid, block, lds, s, a, tilesM, tilesN);
+        if (pk) hipLaunchKernelGGL((gemm4_implicit_kernel<WM, WN, true>), grid, block, lds, s, a, tilesM, tilesN);
+        else hipLaunchKernelGGL((gemm4_implicit_kernel<WM, WN, false>), grid, block, lds, s, a, tilesM, tilesN);
         return hipGetLastError();
     }
     if (pk && res) hipLaunchKernelGGL((gemm4_f16x3_kernel<WM, WN, true, true>), grid, block, lds, s, a, tilesM, tilesN);
@@ -2214,7 +2219,7 @@ hipError_t launch_gemm_f16x3_packed(const Gemm4Args& a, hipStream_t s) {
     if (!a.Chi && !a.C) return hipErrorInvalidValue;
     if (a.N % 4 != 0 || (a.C && (!al16(a.C) || a.ldc % 4 != 0 || a.sC % 4 != 0))) return hipErrorInvalidValue;
     if (a.R && (!al16(a.R) || a.ldr % 4 != 0 || a.sR % 4 != 0)) return hipErrorInvalidValue;
-    if (a.impl_k > 0 && (a.R || a.Chi || a.cplx || a.tri != TRI_NONE || a.part || a.impl_cg8 < 1 || a.impl_dil < 1 || a.impl_pitch < 1 ||
+    if (a.impl_k > 0 && (a.R || a.cplx || a.tri != TRI_NONE || a.part || a.impl_cg8 < 1 || a.impl_dil < 1 || a.impl_pitch < 1 ||
                          a.K != a.impl_k * a.impl_k * a.impl_cg8 * 8 || !a.a_tiled))
         return hipErrorInvalidValue;
     const long waste128 = (long)((a.M + 127) / 128) * 128, waste64 = (long)((a.M + 63) / 64) * 64;

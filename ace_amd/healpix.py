@@ -58,6 +58,20 @@ class Hpx:
         return self.data.shape[-2]
 
 
+@dataclasses.dataclass
+class HpxPlanes:
+    """An activation that exists ONLY as the packed engine's operand: fp16 hi / lo planes (2, images * channels * rows * pitch halves),
+    entries [image][channel / 8][rows x pitch cells][8 channels], scaled by the bound in `amax`.  Produced by a k x k convolution whose
+    consumer is a 1 x 1 convolution (HEALPixLayer.conv(planes_out=True) -> HEALPixLayer.conv_planes)."""
+    planes: torch.Tensor
+    images: int
+    channels: int
+    rows: int
+    width: int
+    pitch: int
+    amax: torch.Tensor
+
+
 def _round4(n: int) -> int:
     return (n + 3) & ~3
 
@@ -350,7 +364,39 @@ class HEALPixLayer(nn.Module):
             self._rows[key] = (taps[:, None] + chan[None, :]).reshape(-1).contiguous().to(device)
         return self._rows[key]
 
-    def conv(self, x: Hpx, x2: Optional[Hpx] = None, residual: Optional[Hpx] = None, act: Tuple[int, float] = (ACT_NONE, _INF)) -> Hpx:
+    def _bias_max(self) -> float:
+        b = self.base.bias
+        if b is None:
+            return 0.0
+        stamp = (b.data_ptr(), b._version)
+        if getattr(self, "_bmax", None) is None or self._bmax[0] != stamp:
+            self._bmax = (stamp, float(b.detach().abs().max().item()))
+        return self._bmax[1]
+
+    def packs_planes(self) -> bool:
+        """can conv(planes_out=True) hand its result to a 1 x 1 convolution as planes?"""
+        return (_PACKED_CONV and isinstance(self.base, nn.Conv2d) and self._pad > 0 and (self._k - 1) * self._dil <= _SLACK
+                and self.base.out_channels % 8 == 0)
+
+    def conv_planes(self, x: HpxPlanes, residual: Optional[Hpx] = None, act: Tuple[int, float] = (ACT_NONE, _INF)) -> Hpx:
+        """this 1 x 1 convolution on an input that exists as planes (no cap on the activation: the engine's plain form has none)"""
+        base = self.base
+        if not isinstance(base, nn.Conv2d) or self._k != 1 or self._pad > 0 or act[1] != _INF:
+            raise TypeError("conv_planes(): a 1 x 1 convolution without a capped activation")
+        dev = x.planes.device
+        cout = base.out_channels
+        if residual is not None:
+            residual = _repitch(residual, x.pitch)
+        y = torch.empty(x.images, cout, x.rows, x.pitch, dtype=torch.float32, device=dev)
+        ymax = _RT.slot(dev)
+        _check(_lib.lib().ace_hpx_conv1_packed(x.planes[0].data_ptr(), x.planes[1].data_ptr(), x.channels, self._weight(),
+                                               _lib.ptr(base.bias) if base.bias is not None else None,
+                                               residual.data.data_ptr() if residual is not None else None, y.data_ptr(), x.images, cout, x.rows,
+                                               x.width, x.pitch, act[0], x.amax.data_ptr(), ymax.data_ptr(), _lib.current_stream()))
+        return Hpx(y, x.width, ymax)
+
+    def conv(self, x: Hpx, x2: Optional[Hpx] = None, residual: Optional[Hpx] = None, act: Tuple[int, float] = (ACT_NONE, _INF),
+             planes_out: bool = False):
         base = self.base
         if not isinstance(base, nn.Conv2d):
             raise TypeError("conv() on a non-convolution HEALPixLayer")
@@ -385,10 +431,17 @@ class HEALPixLayer(nn.Module):
                                             d2.stride(1) if d2 is not None else 0, x2.pitch if x2 is not None else 0, cin, cin2,
                                             planes[0].data_ptr(), planes[1].data_ptr(), ia.data_ptr(), ib.data_ptr(), imgs // 12, W, p, mp,
                                             _bound(x).data_ptr(), _bound(x2).data_ptr() if x2 is not None else None, pmax.data_ptr(), st))
+                if planes_out:       # the consumer is a 1 x 1 convolution: the result exists as its operand only
+                    out = torch.empty(2, imgs * cout * H * mp, dtype=torch.float16, device=dev)
+                    _check(L.ace_hpx_conv_packed(planes[0].data_ptr(), planes[1].data_ptr(), cpad, self._weight_packed(cpad),
+                                                 _lib.ptr(bias) if bias is not None else None, self._bias_max(), None, out[0].data_ptr(),
+                                                 out[1].data_ptr(), imgs, cout, H, W, mp, self._k, self._dil, act[0], act[1], pmax.data_ptr(),
+                                                 ymax.data_ptr(), st))
+                    return HpxPlanes(out, imgs, cout, H, W, mp, ymax)
                 y = torch.empty(imgs, cout, H, mp, dtype=torch.float32, device=dev)
                 _check(L.ace_hpx_conv_packed(planes[0].data_ptr(), planes[1].data_ptr(), cpad, self._weight_packed(cpad),
-                                             _lib.ptr(bias) if bias is not None else None, y.data_ptr(), imgs, cout, H, W, mp, self._k, self._dil,
-                                             act[0], act[1], pmax.data_ptr(), ymax.data_ptr(), st))
+                                             _lib.ptr(bias) if bias is not None else None, 0.0, y.data_ptr(), None, None, imgs, cout, H, W, mp,
+                                             self._k, self._dil, act[0], act[1], pmax.data_ptr(), ymax.data_ptr(), st))
                 return Hpx(y, W, ymax)
             flat = torch.empty(imgs * ctot * m * mp + _SLACK, dtype=torch.float32, device=dev)
             xmax = _RT.slot(dev)
@@ -464,10 +517,26 @@ def _run_convblock(convblock: nn.Sequential, x: Hpx, x2: Optional[Hpx] = None, r
     while i < len(mods):
         layer = mods[i]
         nxt = mods[i + 1] if i + 1 < len(mods) and not isinstance(mods[i + 1], HEALPixLayer) else None
-        last = (i + (2 if nxt is not None else 1)) >= len(mods)
+        step = 2 if nxt is not None else 1
+        last = (i + step) >= len(mods)
+        # k x k convolution followed by a 1 x 1 one (ConvNeXt: 3 x 3 -> GELU -> 1 x 1): the activation between them is handed over
+        # as the packed engine's planes, never written in fp32
+        j = i + step
+        follower = mods[j] if j < len(mods) and isinstance(mods[j], HEALPixLayer) else None
+        if (follower is not None and not last and layer.packs_planes() and isinstance(follower.base, nn.Conv2d) and follower._k == 1
+                and follower._pad == 0):
+            fact = mods[j + 1] if j + 1 < len(mods) and not isinstance(mods[j + 1], HEALPixLayer) else None
+            if _act_code(fact)[1] == _INF:
+                p = layer.conv(x, x2=x2, act=_act_code(nxt), planes_out=True)
+                fstep = 2 if fact is not None else 1
+                flast = (j + fstep) >= len(mods)
+                x = follower.conv_planes(p, residual=residual if flast else None, act=_act_code(fact))
+                x2 = None
+                i = j + fstep
+                continue
         x = layer.conv(x, x2=x2, residual=residual if last else None, act=_act_code(nxt))
         x2 = None
-        i += 2 if nxt is not None else 1
+        i += step
     return x
 
 

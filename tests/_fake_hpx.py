@@ -168,8 +168,8 @@ class FakeHpx:
             dst[n:] = 0
         return 0
 
-    def ace_hpx_conv_packed(self, xhi, xlo, cpad, w, bias, y, imgs, cout, H, W, pitch, k, dil, act, cap, pmax, ymax, stream):
-        self.calls.append(f"conv{k}")
+    def ace_hpx_conv_packed(self, xhi, xlo, cpad, w, bias, bias_max, y, yhi, ylo, imgs, cout, H, W, pitch, k, dil, act, cap, pmax, ymax, stream):
+        self.calls.append(f"conv{k}" + ("->planes" if yhi else ""))
         Wm = self._w(w)
         K = cpad * k * k
         if Wm.shape != (cout, K) or pitch % 4 or pitch < W + (k - 1) * dil or cpad % 8 or k < 2:
@@ -190,7 +190,34 @@ class FakeHpx:
                     out[i] += Wt[:, t, cg, :] @ Bt.T
         if bias:
             out = out + _f32(bias, cout).double().view(1, cout, 1)
-        _f32(y, imgs * cout * N).view(imgs, cout, N).copy_(_act(out, act, cap).float())
+        res = _act(out, act, cap).float()
+        if y:
+            _f32(y, imgs * cout * N).view(imgs, cout, N).copy_(res)
+        if yhi:                                                                           # [img][cout / 8][N][8], emulated scale 2^0
+            if cout % 8:
+                return 1
+            ent_o = res.view(imgs, cout // 8, 8, N).permute(0, 1, 3, 2).contiguous()
+            h16 = ent_o.to(torch.float16)
+            l16 = (ent_o - h16.float()).to(torch.float16)
+            for ptr, val in ((yhi, h16), (ylo, l16)):
+                _view(ptr, imgs * cout * N, ctypes.c_uint16, torch.int16).copy_(val.reshape(-1).view(torch.int16))
+        return 0
+
+    def ace_hpx_conv1_packed(self, xhi, xlo, cin, w, bias, R, y, imgs, cout, H, W, pitch, act, xslot, ymax, stream):
+        self.calls.append("conv1<-planes")
+        Wm = self._w(w)
+        if Wm.shape != (cout, cin) or pitch % 4 or cin % 8:
+            return 1
+        N = H * pitch
+        n = imgs * cin * N
+        xs = (_view(xhi, n, ctypes.c_uint16, torch.int16).view(torch.float16).double() + _view(xlo, n, ctypes.c_uint16, torch.int16).view(torch.float16).double())
+        B = xs.view(imgs, cin // 8, N, 8).permute(0, 1, 3, 2).reshape(imgs, cin, N)
+        out = torch.einsum("ok,ikn->ion", Wm, B)
+        if bias:
+            out = out + _f32(bias, cout).double().view(1, cout, 1)
+        if R:
+            out = out + _f32(R, imgs * cout * N).double().view(imgs, cout, N)
+        _f32(y, imgs * cout * N).view(imgs, cout, N).copy_(_act(out, act, float("inf")).float())
         return 0
 
     def ace_hpx_pool2(self, x, y, planes, H, W, pitch_in, plane_stride_in, pitch_out, plane_stride_out, is_max, stream):
