@@ -1290,6 +1290,104 @@ def test_healpix_symmetric_convnext_unet_vs_reference(dev):
     assert rel_max(y, g["y"]) <= NET_TOL, rel_max(y, g["y"])
 
 
+@pytest.mark.parametrize("nside,cin,cin2,cout,k,dil,act,cap", [(8, 12, 0, 24, 3, 1, 1, 10.0), (8, 5, 6, 136, 3, 2, 1, 0.7), (16, 16, 0, 20, 3, 4, 0, float("inf")),
+                                                              (8, 9, 0, 7, 3, 1, 2, 2.0), (8, 24, 8, 544, 3, 1, 1, 10.0)])
+def test_healpix_packed_operators_vs_torch(dev, nside, cin, cin2, cout, k, dil, act, cap):
+    """ace_hpx_pad_planes + ace_hpx_conv_packed (+ ace_hpx_conv1_packed on the planes it writes) against torch in fp64 on the
+    reference-padded tensor: channel counts that are not multiples of 8, two sources (the skip concatenation), dilations 1 / 2 / 4,
+    capped GELU / ReLU / no activation, cout below and above the 128-row tile rule; and equal to rounding to ace_hpx_pad + ace_hpx_conv."""
+    import numpy as np
+    from ace_amd import _lib
+    L = _lib.lib()
+    st = _lib.current_stream()
+    g = torch.Generator().manual_seed(nside + cin + cout)
+    p = (k - 1) * dil // 2
+    m = nside + 2 * p
+    mp = (m + 3) // 4 * 4
+    imgs = 12
+    x = torch.randn(imgs, cin, nside, nside, generator=g) * 2.0
+    x2 = torch.randn(imgs, cin2, nside, nside, generator=g) * 0.5 if cin2 else None
+    w = torch.randn(cout, cin + cin2, k, k, generator=g) / (3.0 * (cin + cin2)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    ia, ib = np.zeros(12 * m * m, dtype=np.int32), np.zeros(12 * m * m, dtype=np.int32)
+    assert L.ace_hpx_pad_table_host(nside, p, ia.ctypes.data, ib.ctypes.data) == 0
+    iad, ibd = torch.from_numpy(ia).to(dev), torch.from_numpy(ib).to(dev)
+
+    def host_pad(t):          # the same gather on the host, in fp64
+        a = torch.from_numpy(ia).long().view(12, m, m)
+        bb = torch.from_numpy(ib).long().view(12, m, m)
+        td = t.double().view(1, 12, t.shape[1], nside, nside)
+        ga = td[0, a >> 24, :, (a >> 12) & 4095, a & 4095]
+        gb = td[0, bb >> 24, :, (bb >> 12) & 4095, bb & 4095]
+        return (0.5 * ga + 0.5 * gb).permute(0, 3, 1, 2)        # [12][c][m][m]  (a == b: 0.5 a + 0.5 a = a exactly)
+
+    xs = [t for t in (x, x2) if t is not None]
+    padded = torch.cat([host_pad(t) for t in xs], dim=1)
+    ref = torch.nn.functional.conv2d(padded, w.double(), b.double(), dilation=dil)
+    # the arithmetic's error scales with the contraction's magnitude; a low cap shrinks max|ref| (the norm's denominator) below it
+    tol = OP_TOL * max(1.0, float(ref.abs().max()) / min(cap, float(ref.abs().max())))
+    if act == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif act == 2:
+        ref = torch.relu(ref)
+    ref = torch.clamp(ref, max=cap)
+
+    def slot_of(t):
+        s_ = torch.zeros(64, dtype=torch.int32, device=dev)
+        assert L.ace_hpx_absmax(t.data_ptr(), t.numel(), s_.data_ptr(), st) == 0
+        return s_
+
+    xd, x2d = x.to(dev).contiguous(), (x2.to(dev).contiguous() if x2 is not None else None)
+    sx, sx2 = slot_of(xd), (slot_of(x2d) if x2d is not None else None)
+    ctot = cin + cin2
+    cpad = (ctot + 7) // 8 * 8
+    planes = torch.full((2, imgs * cpad * m * mp + 16 * 8), float("nan"), dtype=torch.float16, device=dev)
+    pmax = torch.zeros(64, dtype=torch.int32, device=dev)
+    assert L.ace_hpx_pad_planes(xd.data_ptr(), xd.stride(0), xd.stride(1), nside, x2d.data_ptr() if x2d is not None else None,
+                                x2d.stride(0) if x2d is not None else 0, x2d.stride(1) if x2d is not None else 0, nside if x2d is not None else 0,
+                                cin, cin2, planes[0].data_ptr(), planes[1].data_ptr(), iad.data_ptr(), ibd.data_ptr(), 1, nside, p, mp,
+                                sx.data_ptr(), sx2.data_ptr() if sx2 is not None else None, pmax.data_ptr(), st) == 0, L.ace_hpx_last_error()
+    assert bool(torch.isfinite(planes.float()).all())
+    wp = torch.zeros(cout, k * k, cpad)
+    wp[:, :, :ctot] = w.permute(0, 2, 3, 1).reshape(cout, k * k, ctot)
+    wp = wp.reshape(cout, k * k * cpad).contiguous().to(dev)
+    hw = ctypes.c_void_p()
+    assert L.ace_hpx_weight_create(wp.data_ptr(), cout, k * k * cpad, st, ctypes.byref(hw)) == 0
+    bd = b.to(dev)
+    y = torch.empty(imgs, cout, nside, mp, device=dev)
+    ymax = torch.zeros(64, dtype=torch.int32, device=dev)
+    null = ctypes.c_void_p(0)
+    assert L.ace_hpx_conv_packed(planes[0].data_ptr(), planes[1].data_ptr(), cpad, hw, bd.data_ptr(), 0.0, y.data_ptr(), null, null, imgs, cout,
+                                 nside, nside, mp, k, dil, act, cap, pmax.data_ptr(), ymax.data_ptr(), st) == 0, L.ace_hpx_last_error()
+    torch.cuda.synchronize()
+    assert rel_max(y[..., :nside], ref) <= tol, rel_max(y[..., :nside], ref)
+    assert abs(float(ymax.view(torch.float32).max()) - float(y.abs().max())) == 0.0
+    if cout % 8 == 0:          # the same result handed to a 1 x 1 convolution as planes (with a residual)
+        c3 = 10
+        w3 = torch.randn(c3, cout, generator=g) / cout ** 0.5
+        b3 = torch.randn(c3, generator=g) * 0.1
+        r3 = torch.randn(imgs, c3, nside, mp, generator=g)
+        oplanes = torch.empty(2, imgs * cout * nside * mp, dtype=torch.float16, device=dev)
+        oslot = torch.zeros(64, dtype=torch.int32, device=dev)
+        assert L.ace_hpx_conv_packed(planes[0].data_ptr(), planes[1].data_ptr(), cpad, hw, bd.data_ptr(), float(b.abs().max()), null,
+                                     oplanes[0].data_ptr(), oplanes[1].data_ptr(), imgs, cout, nside, nside, mp, k, dil, act, cap, pmax.data_ptr(),
+                                     oslot.data_ptr(), st) == 0, L.ace_hpx_last_error()
+        assert float(oslot.view(torch.float32).max()) >= float(ref.abs().max()) * (1.0 - 1e-6)   # a bound (fp32), not the maximum
+        h3 = ctypes.c_void_p()
+        w3d = w3.to(dev).contiguous()
+        assert L.ace_hpx_weight_create(w3d.data_ptr(), c3, cout, st, ctypes.byref(h3)) == 0
+        y3 = torch.empty(imgs, c3, nside, mp, device=dev)
+        y3max = torch.zeros(64, dtype=torch.int32, device=dev)
+        r3d, b3d = r3.to(dev), b3.to(dev)
+        assert L.ace_hpx_conv1_packed(oplanes[0].data_ptr(), oplanes[1].data_ptr(), cout, h3, b3d.data_ptr(), r3d.data_ptr(), y3.data_ptr(), imgs, c3,
+                                      nside, nside, mp, 0, oslot.data_ptr(), y3max.data_ptr(), st) == 0, L.ace_hpx_last_error()
+        torch.cuda.synchronize()
+        ref3 = torch.einsum("oc,nchw->nohw", w3.double(), ref) + b3.double().view(1, c3, 1, 1) + r3.double()[..., :nside]
+        assert rel_max(y3[..., :nside], ref3) <= tol, rel_max(y3[..., :nside], ref3)
+        L.ace_hpx_weight_destroy(h3)
+    L.ace_hpx_weight_destroy(hw)
+
+
 def test_healpix_forward_captured_in_a_graph(dev):
     """ace_amd.CapturedHEALPixForward: the whole forward replayed from a hipGraph (no Python between the launches) gives the eager
     forward's bits on the captured input and on fresh inputs, and stays within the bar of the reference's output."""
