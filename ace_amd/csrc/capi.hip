@@ -1489,6 +1489,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 ds.sW = (long)2 * C * C; ds.bscale = n->wx_scale[i];
                 ds.E = n->E.p; ds.sE = (long)n->Mm * N2; ds.omax = emax;
                 ds.C = C; ds.L = n->L; ds.Mrows = n->Mm * B; ds.trimul = B;
+                ds.groups = cln ? c.filter_num_groups : 1;
             }
             if (dplanes && n->wx_compact[i] && !n->sw.no_dhconv_strip && dhconv_strip_eligible(ds)) {
                 HIP_TRY(launch_dhconv_strip(ds, s));

@@ -52,7 +52,14 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, g = lane >> 5;
     const int C = p.C, K2 = 2 * C;
-    const int nstages = C / 32;                   // stage t = k in [32 t, 32 t + 32) of BOTH halves of the row (D_re | D_im)
+    // Block-diagonal filter (G groups of C / G channels: output channel o sees input channels of its own group only, the dense
+    // form holds exact zeros elsewhere): this workgroup's 128 output channels need the input range [k_lo, k_lo + kspan) only -
+    // its group (C / G a multiple of 128) or the 128 / (C / G) whole groups under its outputs.  Skipping exact zeros changes no bit.
+    const int cg = C / p.groups;
+    const bool skip = p.groups > 1 && (cg % 128 == 0 || 128 % cg == 0);
+    const int kspan = skip ? (cg > 128 ? cg : 128) : C;
+    const int tb = skip ? ((128 * j) / kspan) * (kspan / 32) : 0;   // first stage
+    const int nstages = kspan / 32;               // stage t = k in [32 (tb + t), + 32) of BOTH halves of the row (D_re | D_im)
     const int oc = 128 * j + 32 * wave;           // this wave's 32 output channels (real and imaginary part)
 
     const unsigned raw_a = slot_load(p.amax + lane);
@@ -71,7 +78,7 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
         asrc[k] = (pl ? Dl : Dh) + (long)row * K2 + sl * C + 8 * ls;
     }
     auto issue_a = [&](int t) {   // stage t -> ring slot t % NSTG; stages past the end re-fetch the last (uniform count)
-        const int tt = t < nstages ? t : nstages - 1;
+        const int tt = tb + (t < nstages ? t : nstages - 1);
         char* dst = smem + (t % NSTG) * STAGE;
 #pragma unroll
         for (int k = 0; k < NA; ++k) glds16(asrc[k] + 32 * tt, dst + (wave + 4 * k) * 1024);
@@ -84,7 +91,7 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
     const _Float16* Wl = p.Wlo + (long)l * p.sW;
     struct BSet { half8 h[2][2], l[2][2]; };      // [k16 step][Wr | Wi]
     auto issue_b = [&](BSet& b, int t) {
-        const int tt = t < nstages ? t : nstages - 1;
+        const int tt = tb + (t < nstages ? t : nstages - 1);
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -170,7 +177,7 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
         });
         __builtin_amdgcn_s_barrier();             // every wave is done reading the slot of stage t (refilled by A(t + 3))
     };
-    for (int t0 = 0; t0 < nstages; t0 += 4)       // nstages = C / 32 is a multiple of 4
+    for (int t0 = 0; t0 < nstages; t0 += 4)       // nstages (C / 32, or the group span / 32) is a multiple of 4
         static_for<0, 4>([&](auto u) { stage(t0 + u, bs[u], bs[(u + PB) % 4]); });
     // The dummy tail fetches are still in flight into fragment sets that are dead as far as hipcc knows: the wait that retires
     // them NAMES their registers, or the allocator may hand those registers to the epilogue's values above the wait and the
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void dhconv_strip_kernel(DhconvStripArgs p)
 }  // namespace
 
 bool dhconv_strip_eligible(const DhconvStripArgs& a) {
-    return a.C % 128 == 0 && a.C >= 128 && a.Mrows >= 1 && (a.Mrows + 191) / 192 <= 65535 && a.L >= 1 && a.Dhi && a.Dlo && a.Whi && a.Wlo && a.E && a.amax;
+    return a.C % 128 == 0 && a.C >= 128 && a.groups >= 1 && a.C % a.groups == 0 && a.Mrows >= 1 && (a.Mrows + 191) / 192 <= 65535 && a.L >= 1 && a.Dhi && a.Dlo && a.Whi && a.Wlo && a.E && a.amax;
 }
 
 hipError_t launch_dhconv_strip(const DhconvStripArgs& a, hipStream_t s) {

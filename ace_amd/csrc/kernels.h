@@ -223,6 +223,7 @@ struct DhconvStripArgs {
     float* E = nullptr; long sE = 0;                                              // fp32 output [l][row][2C]
     unsigned* omax = nullptr;
     int C = 0, L = 0, Mrows = 0, trimul = 1;                                      // rows of degree l: min((l + 1) * trimul, Mrows)
+    int groups = 1;                                                               // block-diagonal filter (grouped csfno filter, s2convolutions.py:119-135): zero blocks are skipped
 };
 bool dhconv_strip_eligible(const DhconvStripArgs& a);
 hipError_t launch_dhconv_strip(const DhconvStripArgs& a, hipStream_t s);

@@ -469,16 +469,18 @@ def test_noise_conditioned_sfno_vs_reference(dev, name, precision):
     assert torch.isfinite(a).all() and not torch.equal(a, b)
 
 
-@pytest.mark.parametrize("embed,noise_dim", [(128, 8), (256, 8), (512, 33)])
-def test_noise_conditioned_sfno_wide_vs_oracle(dev, embed, noise_dim):
+@pytest.mark.parametrize("embed,noise_dim,groups", [(128, 8, 1), (256, 8, 1), (512, 33, 1), (256, 8, 4), (256, 8, 2), (512, 8, 2), (384, 8, 2)])
+def test_noise_conditioned_sfno_wide_vs_oracle(dev, embed, noise_dim, groups):
     """Channel widths at which the noise-conditioned net's fc1 runs on csrc/conv_wl.hip (weights in LDS; K = 128 / 256 here,
     512 at the ERA5 configuration), the other convolutions on the packed-operand engine and - C % 256 == 0 - the conditional
     layer norms on the single-pass MFMA kernel (csrc/cln_mfma.hip): against the fp64 oracle with the module's own
-    (reference-order) initial weights.  The small reference-emitted goldens stay on the tile engines."""
+    (reference-order) initial weights.  The small reference-emitted goldens stay on the tile engines.  groups > 1: the block-diagonal
+    spectral filter (s2convolutions.py:119-135) on csrc/dhconv_strip.hip, which skips the zero blocks where the group size divides or
+    is a multiple of its 128-channel column groups (64, 128, 256 here; 192 = the dense walk)."""
     import ace_amd
     from oracle.csfno import CSFNOConfig, CSFNOOracle
     kwargs = dict(embed_dim=embed, noise_embed_dim=noise_dim, noise_type="gaussian", num_layers=2, use_mlp=True, mlp_ratio=2.0,
-                  affine_norms=True, normalize_big_skip=True)
+                  affine_norms=True, normalize_big_skip=True, filter_num_groups=groups)
     cfg = CSFNOConfig(in_chans=5, out_chans=4, img_shape=(16, 32), **kwargs)
     torch.manual_seed(11)
     net = ace_amd.ModuleSelector(type="NoiseConditionedSFNO", config=dict(kwargs)).build(5, 4, ace_amd.DatasetInfo((16, 32))).torch_module
