@@ -107,8 +107,9 @@ SIGNATURES = {
                              c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ace_hpx_pad_planes": (c_int, [c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "ace_hpx_conv_packed": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                    c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "ace_hpx_conv_packed": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_long, c_int,
+                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "ace_hpx_halo_planes": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ace_hpx_conv1_packed": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p, c_void_p, c_void_p]),
     "ace_hpx_pool2": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_void_p]),

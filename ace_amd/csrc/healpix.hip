@@ -307,6 +307,60 @@ __global__ __launch_bounds__(256) void hpx_pad_planes_kernel(const float* __rest
     }
 }
 
+// Face padding IN PLACE on planes whose interior a convolution's epilogue has just written (ace_hpx_conv_packed with the padded
+// plane pitch and the interior's shift): every halo cell is gathered from interior cells of the neighbouring faces' planes (same
+// channel group, same scale: copies of 16-byte entries; the two-source corner cells are averaged and re-split), the gap columns
+// [m, mp) and the slack entries are zeroed (the epilogue's gap-column results spilled into them).  Reads interiors only, writes
+// everything else: no ordering between threads matters.
+__global__ __launch_bounds__(256) void hpx_halo_planes_kernel(_Float16* __restrict__ hi, _Float16* __restrict__ lo, int cg8, int nside, int p,
+                                                              int mp, const int* __restrict__ ia, const int* __restrict__ ib, int items, int slack) {
+    const int m = nside + 2 * p;
+    const long cells = (long)m * mp;
+    const long total = (long)items * 12 * cg8 * cells;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int cellp = (int)(t % cells);
+        const int row = cellp / mp, col = cellp % mp;
+        if (row >= p && row < p + nside && col >= p && col < p + nside) continue;   // interior: the convolution's own result
+        long q = t / cells;
+        const int cg = (int)(q % cg8);
+        q /= cg8;
+        const int face = (int)(q % 12), item = (int)(q / 12);
+        half8 hh, ll;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hh[e] = (_Float16)0.f; ll[e] = (_Float16)0.f; }
+        if (col < m) {
+            const long cell = (long)row * m + col;
+            const int a = ia[(long)face * m * m + cell], b = ib[(long)face * m * m + cell];
+            auto entry = [&](int s_) { return (((long)(item * 12 + (s_ >> 24)) * cg8 + cg) * cells + (long)(((s_ >> 12) & 4095) + p) * mp + (s_ & 4095) + p) * 8; };
+            const long ea = entry(a);
+            hh = *reinterpret_cast<const half8*>(hi + ea);
+            ll = *reinterpret_cast<const half8*>(lo + ea);
+            if (a != b) {
+                const long eb = entry(b);
+                const half8 h2 = *reinterpret_cast<const half8*>(hi + eb), l2 = *reinterpret_cast<const half8*>(lo + eb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = 0.5f * ((float)hh[e] + (float)ll[e]) + 0.5f * ((float)h2[e] + (float)l2[e]);
+                    const _Float16 h = (_Float16)v;
+                    hh[e] = h;
+                    ll[e] = (_Float16)(v - (float)h);
+                }
+            }
+        }
+        const long eo = (((long)(item * 12 + face) * cg8 + cg) * cells + cellp) * 8;
+        *reinterpret_cast<half8*>(hi + eo) = hh;
+        *reinterpret_cast<half8*>(lo + eo) = ll;
+    }
+    if (slack > 0 && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < slack) {
+        half8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
+        const long eo = ((long)items * 12 * cg8 * cells + threadIdx.x) * 8;
+        *reinterpret_cast<half8*>(hi + eo) = z;
+        *reinterpret_cast<half8*>(lo + eo) = z;
+    }
+}
+
 // 2 x 2 pooling, stride 2: x [imgs * c][H][px] -> y [imgs * c][H / 2][py]
 template <bool MAX>
 __global__ __launch_bounds__(256) void hpx_pool2_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int H, int W,
@@ -472,25 +526,32 @@ extern "C" int ace_hpx_conv(const float* x, const float* x2, int cin, int cin2, 
 // planes from ace_hpx_pad_planes (cpad = 8 ceil(channels / 8) channels per image, `pitch` entries per padded row, H + (k - 1) dil rows),
 // the weight as a prepared (cout x k k cpad) matrix in (tap, padded channel) order (zero columns for the padding channels).
 // Both operands stream by LDS-DMA; no fp32 activation is split in the kernel (gemm3 spends its loader waves on that).
-extern "C" int ace_hpx_conv_packed(const void* xhi, const void* xlo, int cpad, const ace_hpx_weight* w, const float* bias, float bias_max,
-                                   float* y, void* yhi, void* ylo, int imgs, int cout, int H, int W, int pitch, int k, int dil, int act, float cap,
-                                   const unsigned* pmax, unsigned* ymax, void* stream) {
+// x_plane_cells / y_plane_cells (0: the natural (H + (k - 1) dil) pitch / H pitch): entries per channel-group plane when the planes are
+// those of a LARGER padded tensor and xhi / yhi point at a shifted origin inside it - a 1 x 1 convolution reading the interior of
+// planes padded for a k x k one (k = 1, origin at (p, p)), or a result written into the interior of the next convolution's padded
+// planes (ace_hpx_halo_planes then fills the halo).
+extern "C" int ace_hpx_conv_packed(const void* xhi, const void* xlo, int cpad, long x_plane_cells, const ace_hpx_weight* w, const float* bias,
+                                   float bias_max, float* y, void* yhi, void* ylo, long y_plane_cells, int imgs, int cout, int H, int W, int pitch,
+                                   int k, int dil, int act, float cap, const unsigned* pmax, unsigned* ymax, void* stream) {
     if (!xhi || !xlo || !w || (!y && !yhi) || (yhi && (!ylo || !ymax || (cout & 7))) || !pmax || imgs < 1 || cpad < 8 || (cpad & 7) || cout < 1 ||
-        H < 1 || W < 1 || pitch < W + (k - 1) * dil || (pitch & 3) || k < 2 || dil < 1 || (k - 1) * dil > ACE_HPX_SLACK || !(bias_max >= 0.f))
-        return hfail(ACE_ERR_INVALID, "ace_hpx_conv_packed: bad argument (k >= 2, channels padded to 8, pitch % 4 == 0; planes out: cout % 8 == 0 and a slot)");
+        H < 1 || W < 1 || pitch < W + (k - 1) * dil || (pitch & 3) || k < 1 || dil < 1 || (k - 1) * dil > ACE_HPX_SLACK || !(bias_max >= 0.f) ||
+        x_plane_cells < 0 || y_plane_cells < 0 || (x_plane_cells > 0 && x_plane_cells < (long)(H + (k - 1) * dil) * pitch) ||
+        (y_plane_cells > 0 && y_plane_cells < (long)H * pitch))
+        return hfail(ACE_ERR_INVALID, "ace_hpx_conv_packed: bad argument (channels padded to 8, pitch % 4 == 0; planes out: cout % 8 == 0 and a slot)");
     if (!(act == ACT_NONE || act == ACT_GELU || act == ACT_RELU)) return hfail(ACE_ERR_INVALID, "ace_hpx_conv_packed: activation must be none, gelu or relu");
     const int K = cpad * k * k;
     if (w->rows != cout || w->cols != K || !w->thi)
         return hfail(ACE_ERR_INVALID, "ace_hpx_conv_packed: prepared weight is " + std::to_string(w->rows) + " x " + std::to_string(w->cols) +
                                           ", expected " + std::to_string(cout) + " x " + std::to_string(K) + " (tap, padded channel) columns");
     const int rows_in = H + (k - 1) * dil;
-    const long cells = (long)rows_in * pitch;
+    const long cells = x_plane_cells > 0 ? x_plane_cells : (long)rows_in * pitch;   // entries per channel-group plane of x
     Gemm4Args a;
     a.Ahi = w->thi; a.Alo = w->tlo; a.lda = w->pitch; a.sA = 0; a.ascale = w->ascale; a.a_tiled = 1;
     a.Bhi = static_cast<const _Float16*>(xhi); a.Blo = static_cast<const _Float16*>(xlo);
     a.ldn = cells; a.sB = (long)(cpad / 8) * cells * 8; a.bmax = pmax;
-    if (yhi) {   // P-format output only: the operand of a following 1 x 1 convolution (ace_hpx_conv1_packed); its bound goes to ymax
-        a.Chi = static_cast<_Float16*>(yhi); a.Clo = static_cast<_Float16*>(ylo); a.ldnc = (long)H * pitch; a.sCp = (long)cout * H * pitch;
+    if (yhi) {   // P-format output: the operand of a following convolution; its bound goes to ymax
+        const long ycells = y_plane_cells > 0 ? y_plane_cells : (long)H * pitch;
+        a.Chi = static_cast<_Float16*>(yhi); a.Clo = static_cast<_Float16*>(ylo); a.ldnc = ycells; a.sCp = (long)(cout / 8) * ycells * 8;
         a.cw = w->winf; a.cb = bias_max; a.cslot = ymax;
     }
     if (y) { a.C = y; a.ldc = (long)H * pitch; a.sC = (long)cout * H * pitch; if (!yhi) a.omax = ymax; }
@@ -540,6 +601,18 @@ extern "C" int ace_hpx_pad_planes(const float* x, long x_img_stride, long x_chan
     hipLaunchKernelGGL(hpx_pad_planes_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, x_img_stride, x_chan_stride,
                        x_pitch, cin2 > 0 ? x2 : x, x2_img_stride, x2_chan_stride, x2_pitch, cin, cin2, static_cast<_Float16*>(hi),
                        static_cast<_Float16*>(lo), m, y_pitch, idx_a_dev, idx_b_dev, items, xmax, cin2 > 0 ? x2max : nullptr, pmax, ACE_HPX_SLACK);
+    HPX_TRY(hipGetLastError());
+    return ACE_OK;
+}
+
+extern "C" int ace_hpx_halo_planes(void* hi, void* lo, int cpad, const int* idx_a_dev, const int* idx_b_dev, int items, int nside, int p, int y_pitch,
+                                   void* stream) {
+    const int m = nside + 2 * p;
+    if (!hi || !lo || !idx_a_dev || !idx_b_dev || items < 1 || cpad < 8 || (cpad & 7) || nside < 1 || p < 1 || y_pitch < m)
+        return hfail(ACE_ERR_INVALID, "ace_hpx_halo_planes: bad argument");
+    const long total = (long)items * 12 * (cpad / 8) * m * y_pitch;
+    hipLaunchKernelGGL(hpx_halo_planes_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<_Float16*>(hi),
+                       static_cast<_Float16*>(lo), cpad / 8, nside, p, y_pitch, idx_a_dev, idx_b_dev, items, ACE_HPX_SLACK);
     HPX_TRY(hipGetLastError());
     return ACE_OK;
 }

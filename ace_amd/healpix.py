@@ -62,7 +62,7 @@ class Hpx:
 class HpxPlanes:
     """An activation that exists ONLY as the packed engine's operand: fp16 hi / lo planes (2, images * channels * rows * pitch halves),
     entries [image][channel / 8][rows x pitch cells][8 channels], scaled by the bound in `amax`.  Produced by a k x k convolution whose
-    consumer is a 1 x 1 convolution (HEALPixLayer.conv(planes_out=True) -> HEALPixLayer.conv_planes)."""
+    consumer is a 1 x 1 convolution (HEALPixLayer.conv_padded(out="planes") -> HEALPixLayer.conv_planes)."""
     planes: torch.Tensor
     images: int
     channels: int
@@ -70,6 +70,37 @@ class HpxPlanes:
     width: int
     pitch: int
     amax: torch.Tensor
+
+
+@dataclasses.dataclass
+class PaddedPlanes:
+    """A face-PADDED activation as the packed engine's operand: fp16 hi / lo planes (2, images * cpad * m * pitch + slack halves),
+    entries [image][channel / 8][m x pitch cells][8], m = width + 2 p, scaled by the bound in `amax`; `channels` of the `cpad`
+    (a multiple of 8) are real.  Made by HEALPixLayer.pad_planes (a gather from fp32 tensors) or by a k x k convolution that
+    writes its result into the interior and lets ace_hpx_halo_planes gather the halo."""
+    planes: torch.Tensor
+    images: int
+    channels: int
+    cpad: int
+    rows: int        # unpadded rows (= width: faces are square)
+    width: int
+    p: int
+    pitch: int
+    amax: torch.Tensor
+    mode: str
+
+    @property
+    def m(self) -> int:
+        return self.width + 2 * self.p
+
+    @property
+    def cells(self) -> int:
+        return self.m * self.pitch
+
+    def origin(self, k: int, dil: int) -> int:
+        """entry offset of the window origin of a (k, dil) convolution whose own padding is (k - 1) dil / 2 <= p"""
+        q = self.p - (k - 1) * dil // 2
+        return q * self.pitch + q
 
 
 def _round4(n: int) -> int:
@@ -373,11 +404,6 @@ class HEALPixLayer(nn.Module):
             self._bmax = (stamp, float(b.detach().abs().max().item()))
         return self._bmax[1]
 
-    def packs_planes(self) -> bool:
-        """can conv(planes_out=True) hand its result to a 1 x 1 convolution as planes?"""
-        return (_PACKED_CONV and isinstance(self.base, nn.Conv2d) and self._pad > 0 and (self._k - 1) * self._dil <= _SLACK
-                and self.base.out_channels % 8 == 0)
-
     def conv_planes(self, x: HpxPlanes, residual: Optional[Hpx] = None, act: Tuple[int, float] = (ACT_NONE, _INF)) -> Hpx:
         """this 1 x 1 convolution on an input that exists as planes (no cap on the activation: the engine's plain form has none)"""
         base = self.base
@@ -394,6 +420,82 @@ class HEALPixLayer(nn.Module):
                                                residual.data.data_ptr() if residual is not None else None, y.data_ptr(), x.images, cout, x.rows,
                                                x.width, x.pitch, act[0], x.amax.data_ptr(), ymax.data_ptr(), _lib.current_stream()))
         return Hpx(y, x.width, ymax)
+
+    def pad_planes(self, x: Hpx, x2: Optional[Hpx] = None) -> PaddedPlanes:
+        """face padding of x (and x2 behind it: the skip concatenation) for THIS k x k convolution, written as the packed engine's planes"""
+        dev = x.data.device
+        imgs, W = x.data.shape[0], x.width
+        cin = x.data.shape[1]
+        cin2 = x2.data.shape[1] if x2 is not None else 0
+        p, m = self._pad, W + 2 * self._pad
+        mp = max(_RT.pitch_for(W), _round4(m))
+        pad_layer = self.layers[0]
+        if pad_layer.mode == "isolatitude" and W != pad_layer._nside:
+            raise ValueError(f"HEALPixPaddingIsolatitude expected face size H={pad_layer._nside} (from init), but input has H={W}. "
+                             "Make sure that nside was set correctly in the model config.")
+        ia, ib = _RT.table(W, p, dev, pad_layer.mode)
+        cpad = (cin + cin2 + 7) // 8 * 8
+        planes = torch.empty(2, imgs * cpad * m * mp + _SLACK * 8, dtype=torch.float16, device=dev)
+        pmax = _RT.slot(dev)
+        d, d2 = x.data, (x2.data if x2 is not None else None)
+        _check(_lib.lib().ace_hpx_pad_planes(d.data_ptr(), d.stride(0), d.stride(1), x.pitch,
+                                             d2.data_ptr() if d2 is not None else None, d2.stride(0) if d2 is not None else 0,
+                                             d2.stride(1) if d2 is not None else 0, x2.pitch if x2 is not None else 0, cin, cin2,
+                                             planes[0].data_ptr(), planes[1].data_ptr(), ia.data_ptr(), ib.data_ptr(), imgs // 12, W, p, mp,
+                                             _bound(x).data_ptr(), _bound(x2).data_ptr() if x2 is not None else None, pmax.data_ptr(),
+                                             _lib.current_stream()))
+        return PaddedPlanes(planes, imgs, cin + cin2, cpad, x.rows, W, p, mp, pmax, pad_layer.mode)
+
+    def accepts(self, pp: PaddedPlanes) -> bool:
+        """can this convolution read `pp` (padded for a convolution with at least its own reach, in its own padding mode)?"""
+        if not (_PACKED_CONV and isinstance(self.base, nn.Conv2d) and self.base.in_channels == pp.channels):
+            return False
+        reach = (self._k - 1) * self._dil
+        if reach % 2 or reach // 2 > pp.p or reach > _SLACK:
+            return False
+        return self._pad == 0 if self._k == 1 else (self._pad == reach // 2 and self.layers[0].mode == pp.mode)
+
+    def conv_padded(self, pp: PaddedPlanes, act: Tuple[int, float] = (ACT_NONE, _INF), out: str = "fp32",
+                    pad_for: Optional["HEALPixLayer"] = None):
+        """this convolution on an already padded input.  out: "fp32" -> Hpx; "planes" -> HpxPlanes (operand of a 1 x 1 convolution);
+        "padded" -> PaddedPlanes for the k x k convolution `pad_for` (result written into the interior, halo gathered in place)."""
+        base = self.base
+        L = _lib.lib()
+        st = _lib.current_stream()
+        dev = pp.planes.device
+        imgs, H, W, mp, cout, bias = pp.images, pp.rows, pp.width, pp.pitch, base.out_channels, base.bias
+        w = self._weight_packed(pp.cpad)
+        bptr = _lib.ptr(bias) if bias is not None else None
+        xo = pp.origin(self._k, self._dil) * 16                      # bytes: one entry = 8 halves
+        xhi, xlo = pp.planes[0].data_ptr() + xo, pp.planes[1].data_ptr() + xo
+        ymax = _RT.slot(dev)
+        if out == "fp32":
+            y = torch.empty(imgs, cout, H, mp, dtype=torch.float32, device=dev)
+            _check(L.ace_hpx_conv_packed(xhi, xlo, pp.cpad, pp.cells, w, bptr, 0.0, y.data_ptr(), None, None, 0, imgs, cout, H, W, mp, self._k,
+                                         self._dil, act[0], act[1], pp.amax.data_ptr(), ymax.data_ptr(), st))
+            return Hpx(y, W, ymax)
+        if cout % 8:
+            raise ValueError("a packed-planes result needs out_channels % 8 == 0")
+        if out == "planes":
+            o = torch.empty(2, imgs * cout * H * mp, dtype=torch.float16, device=dev)
+            _check(L.ace_hpx_conv_packed(xhi, xlo, pp.cpad, pp.cells, w, bptr, self._bias_max(), None, o[0].data_ptr(), o[1].data_ptr(), 0, imgs,
+                                         cout, H, W, mp, self._k, self._dil, act[0], act[1], pp.amax.data_ptr(), ymax.data_ptr(), st))
+            return HpxPlanes(o, imgs, cout, H, W, mp, ymax)
+        # "padded": the next convolution's padded planes - same face size and pitch rule, its own padding width
+        q = pad_for._pad
+        m2 = W + 2 * q
+        mp2 = max(_RT.pitch_for(W), _round4(m2))
+        if mp2 != mp:
+            raise ValueError("padded hand-over needs the same row pitch on both sides")
+        nxt = PaddedPlanes(torch.empty(2, imgs * cout * m2 * mp2 + _SLACK * 8, dtype=torch.float16, device=dev), imgs, cout, cout, H, W, q, mp2,
+                           ymax, pad_for.layers[0].mode)
+        yo = (q * mp2 + q) * 16
+        _check(L.ace_hpx_conv_packed(xhi, xlo, pp.cpad, pp.cells, w, bptr, self._bias_max(), None, nxt.planes[0].data_ptr() + yo,
+                                     nxt.planes[1].data_ptr() + yo, nxt.cells, imgs, cout, H, W, mp, self._k, self._dil, act[0], act[1],
+                                     pp.amax.data_ptr(), ymax.data_ptr(), st))
+        ia, ib = _RT.table(W, q, dev, nxt.mode)
+        _check(L.ace_hpx_halo_planes(nxt.planes[0].data_ptr(), nxt.planes[1].data_ptr(), cout, ia.data_ptr(), ib.data_ptr(), imgs // 12, W, q, mp2, st))
+        return nxt
 
     def conv(self, x: Hpx, x2: Optional[Hpx] = None, residual: Optional[Hpx] = None, act: Tuple[int, float] = (ACT_NONE, _INF),
              planes_out: bool = False):
@@ -420,29 +522,7 @@ class HEALPixLayer(nn.Module):
             ia, ib = _RT.table(W, p, dev, pad_layer.mode)
             ctot = cin + cin2
             if _PACKED_CONV and (self._k - 1) * self._dil <= _SLACK:
-                # the packed engine: padding gather -> fp16 hi / lo planes (both sources at once), implicit-GEMM convolution
-                cpad = (ctot + 7) // 8 * 8
-                halves = imgs * cpad * m * mp + _SLACK * 8
-                planes = torch.empty(2, halves, dtype=torch.float16, device=dev)
-                pmax = _RT.slot(dev)
-                d, d2 = x.data, (x2.data if x2 is not None else None)
-                _check(L.ace_hpx_pad_planes(d.data_ptr(), d.stride(0), d.stride(1), x.pitch,
-                                            d2.data_ptr() if d2 is not None else None, d2.stride(0) if d2 is not None else 0,
-                                            d2.stride(1) if d2 is not None else 0, x2.pitch if x2 is not None else 0, cin, cin2,
-                                            planes[0].data_ptr(), planes[1].data_ptr(), ia.data_ptr(), ib.data_ptr(), imgs // 12, W, p, mp,
-                                            _bound(x).data_ptr(), _bound(x2).data_ptr() if x2 is not None else None, pmax.data_ptr(), st))
-                if planes_out:       # the consumer is a 1 x 1 convolution: the result exists as its operand only
-                    out = torch.empty(2, imgs * cout * H * mp, dtype=torch.float16, device=dev)
-                    _check(L.ace_hpx_conv_packed(planes[0].data_ptr(), planes[1].data_ptr(), cpad, self._weight_packed(cpad),
-                                                 _lib.ptr(bias) if bias is not None else None, self._bias_max(), None, out[0].data_ptr(),
-                                                 out[1].data_ptr(), imgs, cout, H, W, mp, self._k, self._dil, act[0], act[1], pmax.data_ptr(),
-                                                 ymax.data_ptr(), st))
-                    return HpxPlanes(out, imgs, cout, H, W, mp, ymax)
-                y = torch.empty(imgs, cout, H, mp, dtype=torch.float32, device=dev)
-                _check(L.ace_hpx_conv_packed(planes[0].data_ptr(), planes[1].data_ptr(), cpad, self._weight_packed(cpad),
-                                             _lib.ptr(bias) if bias is not None else None, 0.0, y.data_ptr(), None, None, imgs, cout, H, W, mp,
-                                             self._k, self._dil, act[0], act[1], pmax.data_ptr(), ymax.data_ptr(), st))
-                return Hpx(y, W, ymax)
+                return self.conv_padded(self.pad_planes(x, x2), act=act, out="planes" if planes_out else "fp32")
             flat = torch.empty(imgs * ctot * m * mp + _SLACK, dtype=torch.float32, device=dev)
             xmax = _RT.slot(dev)
             for src, c0 in ((x, 0), (x2, cin)):
@@ -509,35 +589,43 @@ def _act_code(m: Optional[nn.Module]) -> Tuple[int, float]:
     raise NotImplementedError(f"activation {type(m).__name__} is not built")
 
 
-def _run_convblock(convblock: nn.Sequential, x: Hpx, x2: Optional[Hpx] = None, residual: Optional[Hpx] = None) -> Hpx:
+def _run_convblock(convblock: nn.Sequential, x, x2: Optional[Hpx] = None, residual: Optional[Hpx] = None) -> Hpx:
     """A Sequential of HEALPixLayer(conv) [+ activation] pairs: each activation is fused into its convolution; `residual` is
-    added by the last convolution (k = 1)."""
+    added by the last convolution (k = 1).  On the packed engine the activations BETWEEN the convolutions never exist in fp32:
+    a k x k convolution writes the next k x k one's padded planes (interior; the halo is gathered in place) or the planes a 1 x 1
+    one reads.  x: Hpx, or the PaddedPlanes already made for the first convolution (shared with the block's skip convolution)."""
     mods = list(convblock)
-    i = 0
-    while i < len(mods):
-        layer = mods[i]
-        nxt = mods[i + 1] if i + 1 < len(mods) and not isinstance(mods[i + 1], HEALPixLayer) else None
-        step = 2 if nxt is not None else 1
-        last = (i + step) >= len(mods)
-        # k x k convolution followed by a 1 x 1 one (ConvNeXt: 3 x 3 -> GELU -> 1 x 1): the activation between them is handed over
-        # as the packed engine's planes, never written in fp32
-        j = i + step
-        follower = mods[j] if j < len(mods) and isinstance(mods[j], HEALPixLayer) else None
-        if (follower is not None and not last and layer.packs_planes() and isinstance(follower.base, nn.Conv2d) and follower._k == 1
-                and follower._pad == 0):
-            fact = mods[j + 1] if j + 1 < len(mods) and not isinstance(mods[j + 1], HEALPixLayer) else None
-            if _act_code(fact)[1] == _INF:
-                p = layer.conv(x, x2=x2, act=_act_code(nxt), planes_out=True)
-                fstep = 2 if fact is not None else 1
-                flast = (j + fstep) >= len(mods)
-                x = follower.conv_planes(p, residual=residual if flast else None, act=_act_code(fact))
-                x2 = None
-                i = j + fstep
-                continue
-        x = layer.conv(x, x2=x2, residual=residual if last else None, act=_act_code(nxt))
+    convs = [(i, m) for i, m in enumerate(mods) if isinstance(m, HEALPixLayer)]
+    cur = x
+    for n_, (i, layer) in enumerate(convs):
+        nxt_act = mods[i + 1] if i + 1 < len(mods) and not isinstance(mods[i + 1], HEALPixLayer) else None
+        act = _act_code(nxt_act)
+        follower = convs[n_ + 1][1] if n_ + 1 < len(convs) else None
+        last = follower is None
+        if isinstance(cur, HpxPlanes):                         # 1 x 1 convolution on planes
+            cur = layer.conv_planes(cur, residual=residual if last else None, act=act)
+            continue
+        if isinstance(cur, Hpx) and layer._pad > 0 and _PACKED_CONV and (layer._k - 1) * layer._dil <= _SLACK and isinstance(layer.base, nn.Conv2d):
+            cur = layer.pad_planes(cur, x2)
+            x2 = None
+        if isinstance(cur, PaddedPlanes):
+            if not layer.accepts(cur):
+                raise TypeError("padded planes handed to a convolution that cannot read them")
+            out = "fp32"
+            if follower is not None and layer.base.out_channels % 8 == 0 and isinstance(follower.base, nn.Conv2d):
+                fact = mods[convs[n_ + 1][0] + 1] if convs[n_ + 1][0] + 1 < len(mods) and not isinstance(mods[convs[n_ + 1][0] + 1], HEALPixLayer) else None
+                if follower._k == 1 and follower._pad == 0 and _act_code(fact)[1] == _INF and follower.base.in_channels % 8 == 0:
+                    out = "planes"
+                elif (follower._k > 1 and follower._pad > 0 and (follower._k - 1) * follower._dil <= _SLACK
+                      and max(_RT.pitch_for(cur.width), _round4(cur.width + 2 * follower._pad)) == cur.pitch):
+                    out = "padded"
+            if last and residual is not None:
+                raise NotImplementedError("a residual on a k x k convolution")
+            cur = layer.conv_padded(cur, act=act, out=out, pad_for=follower if out == "padded" else None)
+            continue
+        cur = layer.conv(cur, x2=x2, residual=residual if last else None, act=act)
         x2 = None
-        i += step
-    return x
+    return cur
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -663,6 +751,16 @@ class ConvNeXtBlock(nn.Module):
             else:
                 skip = _repitch(x, target)
         else:
+            packed_first = (_PACKED_CONV and first._pad > 0 and isinstance(first.base, nn.Conv2d) and (first._k - 1) * first._dil <= _SLACK)
+            if packed_first:
+                # ONE padded, packed copy of the block input serves both branches: the k x k convolution reads it whole, the 1 x 1
+                # skip convolution its interior (pitch of the padded faces = `target`)
+                pp = first.pad_planes(x, x2)
+                if self.skip_module.accepts(pp):
+                    skip = self.skip_module.conv_padded(pp)
+                    return _run_convblock(self.convblock, pp, residual=skip)
+                skip = self.skip_module.conv(_repitch(x, target), x2=_repitch(x2, target) if x2 is not None else None)
+                return _run_convblock(self.convblock, pp, residual=skip)
             skip = self.skip_module.conv(_repitch(x, target), x2=_repitch(x2, target) if x2 is not None else None)
         return _run_convblock(self.convblock, x, x2=x2, residual=skip)
 

@@ -331,13 +331,19 @@ int ace_hpx_conv(const float* x, const float* x2, int cin, int cin2, const ace_h
 int ace_hpx_pad_planes(const float* x, long x_img_stride, long x_chan_stride, int x_pitch, const float* x2, long x2_img_stride,
                        long x2_chan_stride, int x2_pitch, int cin, int cin2, void* hi, void* lo, const int* idx_a_dev, const int* idx_b_dev,
                        int items, int nside, int p, int y_pitch, const unsigned* xmax, const unsigned* x2max, unsigned* pmax, void* stream);
-int ace_hpx_conv_packed(const void* xhi, const void* xlo, int cpad, const ace_hpx_weight* w, const float* bias, float bias_max, float* y,
-                        void* yhi, void* ylo, int imgs, int cout, int H, int W, int pitch, int k, int dil, int act, float cap,
-                        const unsigned* pmax, unsigned* ymax, void* stream);
+int ace_hpx_conv_packed(const void* xhi, const void* xlo, int cpad, long x_plane_cells, const ace_hpx_weight* w, const float* bias,
+                        float bias_max, float* y, void* yhi, void* ylo, long y_plane_cells, int imgs, int cout, int H, int W, int pitch, int k,
+                        int dil, int act, float cap, const unsigned* pmax, unsigned* ymax, void* stream);
 /* ... whose result may (also / instead: y NULL) be written in the same format - yhi / ylo: [imgs][cout / 8][H pitch][8], cout % 8 == 0,
  * scaled by the bound winf max|x| + bias_max (bias_max = max |bias|; <= cap for a capped activation) published to ymax - for a 1 x 1
  * convolution that follows (ConvNeXt: 3 x 3 -> GELU -> 1 x 1): ace_hpx_conv1_packed reads it (+ bias, + residual R, activation without a
- * cap), so the widest activation of the block never exists in fp32. */
+ * cap), so the widest activation of the block never exists in fp32.
+ * x_plane_cells / y_plane_cells (0: the natural sizes): entries per channel-group plane when xhi / yhi point at a shifted origin inside
+ * the planes of a larger padded tensor: k = 1 reading the interior of planes padded for a k x k convolution (the ConvNeXt skip
+ * convolution shares the block's padded input), or a k x k result written into the interior of the NEXT convolution's padded planes,
+ * whose halo ace_hpx_halo_planes then gathers in place from the neighbouring faces' interiors (no second padding pass). */
+int ace_hpx_halo_planes(void* hi, void* lo, int cpad, const int* idx_a_dev, const int* idx_b_dev, int items, int nside, int p, int y_pitch,
+                        void* stream);
 int ace_hpx_conv1_packed(const void* xhi, const void* xlo, int cin, const ace_hpx_weight* w, const float* bias, const float* R, float* y,
                          int imgs, int cout, int H, int W, int pitch, int act, const unsigned* xslot, unsigned* ymax, void* stream);
 /* nn.AvgPool2d(2) / nn.MaxPool2d(2) on `planes` = imgs * channels planes (the input's bound also bounds the result). */

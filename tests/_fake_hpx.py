@@ -168,15 +168,17 @@ class FakeHpx:
             dst[n:] = 0
         return 0
 
-    def ace_hpx_conv_packed(self, xhi, xlo, cpad, w, bias, bias_max, y, yhi, ylo, imgs, cout, H, W, pitch, k, dil, act, cap, pmax, ymax, stream):
-        self.calls.append(f"conv{k}" + ("->planes" if yhi else ""))
+    def ace_hpx_conv_packed(self, xhi, xlo, cpad, x_plane_cells, w, bias, bias_max, y, yhi, ylo, y_plane_cells, imgs, cout, H, W, pitch, k, dil,
+                            act, cap, pmax, ymax, stream):
+        """xhi / yhi may point at a shifted origin inside larger padded planes (x_plane_cells / y_plane_cells = their entries per plane)"""
+        self.calls.append(f"conv{k}" + ("<-interior" if k == 1 else "") + ("->planes" if yhi and not y_plane_cells else "") + ("->padded" if y_plane_cells else ""))
         Wm = self._w(w)
         K = cpad * k * k
-        if Wm.shape != (cout, K) or pitch % 4 or pitch < W + (k - 1) * dil or cpad % 8 or k < 2:
+        if Wm.shape != (cout, K) or pitch % 4 or pitch < W + (k - 1) * dil or cpad % 8 or k < 1:
             return 1
         rows_in, cg8 = H + (k - 1) * dil, cpad // 8
-        cells, N = rows_in * pitch, H * pitch
-        n = imgs * cg8 * cells * 8 + 16 * 8
+        cells, N = (x_plane_cells or rows_in * pitch), H * pitch
+        n = (imgs * cg8 - 1) * cells * 8 + (((k - 1) * pitch + (k - 1)) * dil + N) * 8
         xs = (_view(xhi, n, ctypes.c_uint16, torch.int16).view(torch.float16).double() + _view(xlo, n, ctypes.c_uint16, torch.int16).view(torch.float16).double())
         ent = xs.view(-1, 8)                                                              # [entry][8 channels]
         col = torch.arange(N)
@@ -193,14 +195,51 @@ class FakeHpx:
         res = _act(out, act, cap).float()
         if y:
             _f32(y, imgs * cout * N).view(imgs, cout, N).copy_(res)
-        if yhi:                                                                           # [img][cout / 8][N][8], emulated scale 2^0
+        if yhi:                                                                           # [img][cout / 8][plane cells][8], emulated scale 2^0
             if cout % 8:
                 return 1
-            ent_o = res.view(imgs, cout // 8, 8, N).permute(0, 1, 3, 2).contiguous()
+            ycells = y_plane_cells or N
+            ent_o = res.view(imgs, cout // 8, 8, N).permute(0, 1, 3, 2).contiguous()      # [img][cg][N][8]
             h16 = ent_o.to(torch.float16)
             l16 = (ent_o - h16.float()).to(torch.float16)
+            span = (imgs * (cout // 8) - 1) * ycells * 8 + N * 8
             for ptr, val in ((yhi, h16), (ylo, l16)):
-                _view(ptr, imgs * cout * N, ctypes.c_uint16, torch.int16).copy_(val.reshape(-1).view(torch.int16))
+                dst = torch.as_strided(_view(ptr, span, ctypes.c_uint16, torch.int16), (imgs, cout // 8, N, 8), ((cout // 8) * ycells * 8, ycells * 8, 8, 1))
+                dst.copy_(val.view(torch.int16))
+        return 0
+
+    def ace_hpx_halo_planes(self, hi, lo, cpad, ia, ib, items, nside, p, y_pitch, stream):
+        """halo cells gathered in place from the interiors of the neighbouring faces' planes; gap columns and slack zeroed"""
+        self.calls.append("halo")
+        m = nside + 2 * p
+        if y_pitch < m or p < 1 or cpad % 8:
+            return 1
+        a = _view(ia, 12 * m * m, ctypes.c_int32, torch.int32).long().reshape(12, m, m)
+        b = _view(ib, 12 * m * m, ctypes.c_int32, torch.int32).long().reshape(12, m, m)
+        imgs, cg8, cells = items * 12, cpad // 8, m * y_pitch
+        n = imgs * cg8 * cells * 8
+        bufs = [_view(ptr, n + 16 * 8, ctypes.c_uint16, torch.int16) for ptr in (hi, lo)]
+        val = sum(buf[:n].view(torch.float16).double() for buf in bufs).view(items, 12, cg8, m, y_pitch, 8)
+        interior = val[:, :, :, p:p + nside, p:p + nside, :]                              # [item][face][cg][y][x][8]
+
+        def gather(s_):                                                                   # -> [item][12][cg][m][m][8]
+            src = interior.permute(1, 3, 4, 0, 2, 5)                                      # [face][y][x][item][cg][8]
+            return src[s_ >> 24, (s_ >> 12) & 4095, s_ & 4095].permute(3, 0, 4, 1, 2, 5)  # [12][m][m][item][cg][8] -> target order
+
+        g = 0.5 * gather(a) + 0.5 * gather(b)
+        out = torch.zeros_like(val)
+        out[:, :, :, :, :m, :] = g
+        out[:, :, :, p:p + nside, p:p + nside, :] = interior
+        flat = out.reshape(-1).float()
+        h16 = flat.to(torch.float16)
+        l16 = (flat - h16.float()).to(torch.float16)
+        keep = torch.zeros(items, 12, cg8, m, y_pitch, 8, dtype=torch.bool)
+        keep[:, :, :, p:p + nside, p:p + nside, :] = True                                 # interiors keep their bits
+        keep = keep.reshape(-1)
+        for buf, v16 in zip(bufs, (h16, l16)):
+            b16 = buf.view(torch.int16)
+            b16[:n] = torch.where(keep, b16[:n], v16.view(torch.int16))
+            b16[n:] = 0
         return 0
 
     def ace_hpx_conv1_packed(self, xhi, xlo, cin, w, bias, R, y, imgs, cout, H, W, pitch, act, xslot, ymax, stream):

@@ -1359,7 +1359,7 @@ def test_healpix_packed_operators_vs_torch(dev, nside, cin, cin2, cout, k, dil, 
     y = torch.empty(imgs, cout, nside, mp, device=dev)
     ymax = torch.zeros(64, dtype=torch.int32, device=dev)
     null = ctypes.c_void_p(0)
-    assert L.ace_hpx_conv_packed(planes[0].data_ptr(), planes[1].data_ptr(), cpad, hw, bd.data_ptr(), 0.0, y.data_ptr(), null, null, imgs, cout,
+    assert L.ace_hpx_conv_packed(planes[0].data_ptr(), planes[1].data_ptr(), cpad, 0, hw, bd.data_ptr(), 0.0, y.data_ptr(), null, null, 0, imgs, cout,
                                  nside, nside, mp, k, dil, act, cap, pmax.data_ptr(), ymax.data_ptr(), st) == 0, L.ace_hpx_last_error()
     torch.cuda.synchronize()
     assert rel_max(y[..., :nside], ref) <= tol, rel_max(y[..., :nside], ref)
@@ -1371,8 +1371,8 @@ def test_healpix_packed_operators_vs_torch(dev, nside, cin, cin2, cout, k, dil, 
         r3 = torch.randn(imgs, c3, nside, mp, generator=g)
         oplanes = torch.empty(2, imgs * cout * nside * mp, dtype=torch.float16, device=dev)
         oslot = torch.zeros(64, dtype=torch.int32, device=dev)
-        assert L.ace_hpx_conv_packed(planes[0].data_ptr(), planes[1].data_ptr(), cpad, hw, bd.data_ptr(), float(b.abs().max()), null,
-                                     oplanes[0].data_ptr(), oplanes[1].data_ptr(), imgs, cout, nside, nside, mp, k, dil, act, cap, pmax.data_ptr(),
+        assert L.ace_hpx_conv_packed(planes[0].data_ptr(), planes[1].data_ptr(), cpad, 0, hw, bd.data_ptr(), float(b.abs().max()), null,
+                                     oplanes[0].data_ptr(), oplanes[1].data_ptr(), 0, imgs, cout, nside, nside, mp, k, dil, act, cap, pmax.data_ptr(),
                                      oslot.data_ptr(), st) == 0, L.ace_hpx_last_error()
         assert float(oslot.view(torch.float32).max()) >= float(ref.abs().max()) * (1.0 - 1e-6)   # a bound (fp32), not the maximum
         h3 = ctypes.c_void_p()
@@ -1387,6 +1387,46 @@ def test_healpix_packed_operators_vs_torch(dev, nside, cin, cin2, cout, k, dil, 
         ref3 = torch.einsum("oc,nchw->nohw", w3.double(), ref) + b3.double().view(1, c3, 1, 1) + r3.double()[..., :nside]
         assert rel_max(y3[..., :nside], ref3) <= tol, rel_max(y3[..., :nside], ref3)
         L.ace_hpx_weight_destroy(h3)
+        # ... and written into the interior of the padded planes of a second (k, dil) convolution, halo gathered in place
+        c2 = 9
+        w2 = torch.randn(c2, cout, k, k, generator=g) / (3.0 * cout) ** 0.5
+        pp2 = torch.full((2, imgs * cout * m * mp + 16 * 8), float("nan"), dtype=torch.float16, device=dev)
+        slot2 = torch.zeros(64, dtype=torch.int32, device=dev)
+        yo = (p * mp + p) * 16
+        assert L.ace_hpx_conv_packed(planes[0].data_ptr(), planes[1].data_ptr(), cpad, 0, hw, bd.data_ptr(), float(b.abs().max()), null,
+                                     pp2[0].data_ptr() + yo, pp2[1].data_ptr() + yo, m * mp, imgs, cout, nside, nside, mp, k, dil, act, cap,
+                                     pmax.data_ptr(), slot2.data_ptr(), st) == 0, L.ace_hpx_last_error()
+        assert L.ace_hpx_halo_planes(pp2[0].data_ptr(), pp2[1].data_ptr(), cout, iad.data_ptr(), ibd.data_ptr(), 1, nside, p, mp, st) == 0, L.ace_hpx_last_error()
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(pp2.float()).all())                  # every cell defined: interior, halo, gap columns, slack
+        w2p = w2.permute(0, 2, 3, 1).reshape(c2, k * k * cout).contiguous().to(dev)
+        h2 = ctypes.c_void_p()
+        assert L.ace_hpx_weight_create(w2p.data_ptr(), c2, k * k * cout, st, ctypes.byref(h2)) == 0
+        y2 = torch.empty(imgs, c2, nside, mp, device=dev)
+        y2max = torch.zeros(64, dtype=torch.int32, device=dev)
+        assert L.ace_hpx_conv_packed(pp2[0].data_ptr(), pp2[1].data_ptr(), cout, 0, h2, null, 0.0, y2.data_ptr(), null, null, 0, imgs, c2, nside, nside,
+                                     mp, k, dil, 0, float("inf"), slot2.data_ptr(), y2max.data_ptr(), st) == 0, L.ace_hpx_last_error()
+        torch.cuda.synchronize()
+        ref2 = torch.nn.functional.conv2d(host_pad(ref), w2.double(), None, dilation=dil)
+        assert rel_max(y2[..., :nside], ref2) <= tol, rel_max(y2[..., :nside], ref2)
+        L.ace_hpx_weight_destroy(h2)
+    # a 1 x 1 convolution (the ConvNeXt skip branch) on the INTERIOR of the same padded planes
+    c1 = 11
+    w1 = torch.randn(c1, ctot, generator=g) / ctot ** 0.5
+    w1p = torch.zeros(c1, cpad)
+    w1p[:, :ctot] = w1
+    w1p = w1p.contiguous().to(dev)
+    h1 = ctypes.c_void_p()
+    assert L.ace_hpx_weight_create(w1p.data_ptr(), c1, cpad, st, ctypes.byref(h1)) == 0
+    y1 = torch.empty(imgs, c1, nside, mp, device=dev)
+    y1max = torch.zeros(64, dtype=torch.int32, device=dev)
+    xo = (p * mp + p) * 16
+    assert L.ace_hpx_conv_packed(planes[0].data_ptr() + xo, planes[1].data_ptr() + xo, cpad, m * mp, h1, null, 0.0, y1.data_ptr(), null, null, 0, imgs,
+                                 c1, nside, nside, mp, 1, 1, 0, float("inf"), pmax.data_ptr(), y1max.data_ptr(), st) == 0, L.ace_hpx_last_error()
+    torch.cuda.synchronize()
+    ref1 = torch.einsum("oc,nchw->nohw", w1.double(), torch.cat([t.double() for t in xs], dim=1))
+    assert rel_max(y1[..., :nside], ref1) <= OP_TOL, rel_max(y1[..., :nside], ref1)
+    L.ace_hpx_weight_destroy(h1)
     L.ace_hpx_weight_destroy(hw)
 
 
