@@ -510,8 +510,6 @@ class HEALPixLayer(nn.Module):
         cin2 = x2.data.shape[1] if x2 is not None else 0
         cout = base.out_channels
         bias = base.bias
-        w = self._weight()
-        ymax = _RT.slot(dev)
         if self._pad > 0:
             p, m = self._pad, W + 2 * self._pad
             mp = max(_RT.pitch_for(W), _round4(m))
@@ -523,6 +521,7 @@ class HEALPixLayer(nn.Module):
             ctot = cin + cin2
             if _PACKED_CONV and (self._k - 1) * self._dil <= _SLACK:
                 return self.conv_padded(self.pad_planes(x, x2), act=act, out="planes" if planes_out else "fp32")
+            ymax = _RT.slot(dev)
             flat = torch.empty(imgs * ctot * m * mp + _SLACK, dtype=torch.float32, device=dev)
             xmax = _RT.slot(dev)
             for src, c0 in ((x, 0), (x2, cin)):
@@ -533,7 +532,7 @@ class HEALPixLayer(nn.Module):
                                      ia.data_ptr(), ib.data_ptr(), imgs // 12, W, p, mp, xmax.data_ptr(), st))
             y = torch.empty(imgs, cout, H, mp, dtype=torch.float32, device=dev)
             rows = self._row_offsets(ctot, m, mp, dev)
-            _check(L.ace_hpx_conv(flat.data_ptr(), None, ctot, 0, w, rows.data_ptr(), _lib.ptr(bias) if bias is not None else None, None,
+            _check(L.ace_hpx_conv(flat.data_ptr(), None, ctot, 0, self._weight(), rows.data_ptr(), _lib.ptr(bias) if bias is not None else None, None,
                                   y.data_ptr(), imgs, cout, H, W, mp, self._k, self._dil, act[0], act[1], xmax.data_ptr(), None,
                                   ymax.data_ptr(), st))
             return Hpx(y, W, ymax)
@@ -543,8 +542,9 @@ class HEALPixLayer(nn.Module):
             x2 = _repitch(x2, pitch)
         if residual is not None:
             residual = _repitch(residual, pitch)
+        ymax = _RT.slot(dev)
         y = torch.empty(imgs, cout, H, pitch, dtype=torch.float32, device=dev)
-        _check(L.ace_hpx_conv(x.data.data_ptr(), x2.data.data_ptr() if x2 is not None else None, cin, cin2, w, None,
+        _check(L.ace_hpx_conv(x.data.data_ptr(), x2.data.data_ptr() if x2 is not None else None, cin, cin2, self._weight(), None,
                               _lib.ptr(bias) if bias is not None else None, residual.data.data_ptr() if residual is not None else None,
                               y.data_ptr(), imgs, cout, H, W, pitch, 1, 1, act[0], act[1], _bound(x).data_ptr(),
                               _bound(x2).data_ptr() if x2 is not None else None, ymax.data_ptr(), st))
