@@ -27,6 +27,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .rand import randn
 from .registry import ModuleConfig, ModuleSelector
 from .sfno import _ACT, _ACT_LAYER, _GRID, _PRECISION, DEFAULT_PRECISION, trunc_normal_
 from .sht import InverseRealSHT
@@ -268,8 +269,8 @@ class NoiseConditionedSFNO(nn.Module):
         J = self.cfg.noise_embed_dim
         if self.cfg.noise_type == "isotropic":
             shape = (batch, J, self._lmax, self._mmax)
-            real = torch.randn(shape, dtype=torch.float32, device=device)
-            imag = torch.randn(shape, dtype=torch.float32, device=device)
+            real = randn(shape, dtype=torch.float32, device=device)      # fme.core.rand: the active CPU generator of a seeded
+            imag = randn(shape, dtype=torch.float32, device=device)      # rollout, else the device's global RNG
             imag[..., :, 0] = 0.0
             real[..., :, 1:] /= math.sqrt(2.0)
             imag[..., :, 1:] /= math.sqrt(2.0)
@@ -277,7 +278,7 @@ class NoiseConditionedSFNO(nn.Module):
             if self._isht is None:
                 self._isht = InverseRealSHT(self.img_shape[0], self.img_shape[1], self._lmax, self._mmax, self.cfg.data_grid)
             return self._isht(alm)
-        return torch.randn(torch.Size([batch, J, *self.img_shape]), device=device, dtype=torch.float32)
+        return randn(torch.Size([batch, J, *self.img_shape]), device=device, dtype=torch.float32)
 
     def conditioning_field(self, batch: int, device: torch.device, labels: Optional[torch.Tensor] = None,
                            noise: Optional[torch.Tensor] = None) -> torch.Tensor:

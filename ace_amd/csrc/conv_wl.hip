@@ -27,7 +27,16 @@
 namespace ace {
 namespace {
 
-constexpr int WL_WAVES = 8;            // two per SIMD, <= 256 registers each
+#ifndef ACE_WL_WAVES
+#define ACE_WL_WAVES 8
+#endif
+#ifndef ACE_WL_D
+#define ACE_WL_D 4
+#endif
+#ifndef ACE_WL_ABL
+#define ACE_WL_ABL 0                   // measurement builds only (wrong results): bit 0 no epilogue chunks, bit 1 no B-fragment loads in the loop
+#endif
+constexpr int WL_WAVES = ACE_WL_WAVES;   // 8: two per SIMD, <= 256 registers each
 #ifdef ACE_X_TRACE   // measurement builds: first / last s_memtime of every workgroup's wave 0, its XCC id
 __device__ unsigned long long wl_wg_span[4096][3];
 #define WG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) wl_wg_span[blockIdx.x][k] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
     auto slot = [&](auto mc) {           // what rides behind MFMA m of the tile
         constexpr int m = decltype(mc)::value;
         constexpr int NMT = MPS * KS;
-        static_for<(m * NCH) / NMT, ((m + 1) * NCH) / NMT>([&](auto kc) { chunk(kc); });
+        if constexpr (!(ACE_WL_ABL & 1)) static_for<(m * NCH) / NMT, ((m + 1) * NCH) / NMT>([&](auto kc) { chunk(kc); });
         __builtin_amdgcn_sched_barrier(0);
     };
     (void)NM;
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
             static_for<0, RT>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][t], ch, acc[t], 0, 0, 0);
-                if constexpr (t == RT - 1 && j + D < KS) {   // this k-step's B registers are free: the fragment of step j + D
+                if constexpr (t == RT - 1 && j + D < KS && !(ACE_WL_ABL & 2)) {   // this k-step's B registers are free: the fragment of step j + D
                     bh[j % D] = *reinterpret_cast<const half8*>(bh0 + (j + D) * kstep);
                     bl[j % D] = *reinterpret_cast<const half8*>(bl0 + (j + D) * kstep);
                 }
@@ -262,7 +271,7 @@ hipError_t launch_conv_wl(const ConvStripArgs& a, hipStream_t s) {
         return hipErrorInvalidValue;
     switch (a.C) {
         case 512: return launch_wl<32, 2, 4>(a, s);
-        case 384: return launch_wl<24, 3, 4>(a, s);
+        case 384: return launch_wl<24, 3, ACE_WL_D>(a, s);
         case 256: return launch_wl<16, 2, 4>(a, s);
         case 128: return launch_wl<8, 2, 4>(a, s);
         default: return hipErrorInvalidValue;

@@ -55,6 +55,10 @@ class RolloutEngine:
         self.net = step.module.torch_module
         self._conditioned = hasattr(self.net, "draw_noise")
         self._labels = None          # (B, n_labels) tensor in the module's label encoding: set_labels()
+        # seedable random source of a stochastic module (fme/core/random_state.py; StepperState.random_state): active around every
+        # network call of a window, as Stepper.step activates it (single_module.py:1063-1068).  The draw happens on the host,
+        # outside any captured region, and reaches the device as a plain copy.
+        self._random_state = None
         if self._conditioned and graph == "window":
             raise NotImplementedError("graph='window' with a noise-conditioned net: the noise draw is not captured")
         self.B, self.T = batch, n_forward_steps
@@ -348,8 +352,17 @@ class RolloutEngine:
         if self._physics is not None and self._physics.tracks_dry_air:
             self._physics.reset(_lib.current_stream())
 
+    def set_random_state(self, random_state) -> None:
+        """``ace_amd.rand.RandomState`` (or None: the global RNG) the conditioning noise of the following windows is drawn from."""
+        self._random_state = random_state
+
     def run_window(self):
         """Enqueue the T steps of the window on the current stream (no host synchronisation)."""
+        from .rand import use_generator
+        with use_generator(None if self._random_state is None else self._random_state.generator):
+            self._run_window()
+
+    def _run_window(self):
         # parameters changed since the last window (load_state_dict / stepper.load_state): upload them; the library drops
         # its captured per-step graphs itself, the window graph captured here is dropped too
         self.net.sync_weights()
@@ -415,6 +428,7 @@ class RolloutEngine:
         with torch.no_grad():
             self.load(initial_condition, forcing)
             carried = getattr(initial_condition, "stepper_state", None)
+            self._random_state = getattr(carried, "random_state", None) if carried is not None else self._random_state
             if carried is not None:
                 self._mc_state = carried.corrector_state
                 self._corrector_state = carried.corrector_state
@@ -431,8 +445,8 @@ class RolloutEngine:
                 mass = self._physics.get_reference(_lib.current_stream())   # (synchronises: once per window, with the result)
                 self._corrector_state = CorrectorState(global_dry_air_mass=mass) if mass is not None else None
         state = PrognosticState({n: self.out[n][:, -1:] for n in self.prognostic})
-        if self._corrector_state is not None:
-            state.stepper_state = StepperState(corrector_state=self._corrector_state)
+        if self._corrector_state is not None or self._random_state is not None:
+            state.stepper_state = StepperState(corrector_state=self._corrector_state, random_state=self._random_state)
         return self.out, state
 
     def continue_from_last(self):

@@ -53,8 +53,37 @@ class StepArgs:
 
 @dataclasses.dataclass
 class StepperState:
-    """The per-sample state threaded from one step to the next (fme/core/step/args.py): here the corrector's."""
+    """fme/core/stepper_state.py:22-127: the state threaded from one step to the next and from one ``predict`` call to the
+    next - the corrector's per-sample state and the seedable random source of stochastic modules (``ace_amd.rand.RandomState``;
+    None: the global torch RNG).  The stepper does not look inside either."""
     corrector_state: Any = None
+    random_state: Any = None
+
+    def to_state_dict(self) -> Dict[str, torch.Tensor]:
+        """stepper_state.py:87-107: present sub-states, keys namespaced, a ``<name>.present`` marker each (restart files)"""
+        out: Dict[str, torch.Tensor] = {}
+        if self.corrector_state is not None:
+            out["corrector_state.present"] = torch.tensor(True)
+            mass = getattr(self.corrector_state, "global_dry_air_mass", None)
+            if mass is not None:
+                out["corrector_state.global_dry_air_mass"] = mass
+        if self.random_state is not None:
+            out["random_state.present"] = torch.tensor(True)
+            for k, v in self.random_state.to_state_dict().items():
+                out[f"random_state.{k}"] = v
+        return out
+
+    @classmethod
+    def from_state_dict(cls, state: Mapping[str, torch.Tensor]) -> "StepperState":
+        """stepper_state.py:109-124: a sub-state without its marker comes back as None"""
+        from .corrector import CorrectorState
+        from .rand import RandomState
+        cs = rs = None
+        if "corrector_state.present" in state:
+            cs = CorrectorState(global_dry_air_mass=state.get("corrector_state.global_dry_air_mass"))
+        if "random_state.present" in state:
+            rs = RandomState.from_state_dict({"generator_state": state["random_state.generator_state"]})
+        return cls(corrector_state=cs, random_state=rs)
 
 
 @dataclasses.dataclass

@@ -173,11 +173,16 @@ class Stepper:
 
     def step(self, args: StepArgs, wrapper: Callable[[nn.Module], nn.Module] = lambda x: x) -> StepOutput:
         """single_module.py:1045-1075."""
+        from .rand import use_generator
         args = args.apply_input_process_func(self._input_process_func)
-        result = self._step_obj.step(args=args, wrapper=wrapper)
-        output = result.output
-        if self._multi_call is not None:     # multi_call.py:296-312: its own state and diagnostics are discarded
-            output = {**self._multi_call.step(args=args, wrapper=wrapper).output, **output}
+        # single_module.py:1063-1068: a seeded rollout's generator is active around every network call of the step (the
+        # multi-call copies run inside the wrapped step there, i.e. under the same generator, in call order)
+        random_state = args.stepper_state.random_state if args.stepper_state is not None else None
+        with use_generator(None if random_state is None else random_state.generator):
+            result = self._step_obj.step(args=args, wrapper=wrapper)
+            output = result.output
+            if self._multi_call is not None:     # multi_call.py:296-312: its own state and diagnostics are discarded
+                output = {**self._multi_call.step(args=args, wrapper=wrapper).output, **output}
         # the wrapped step's corrector diagnostics travel with the output, masked the same way (single_module.py:1063-1075)
         diags = result.corrector_diagnostics
         return StepOutput(output=self._output_masking(output), stepper_state=result.stepper_state,

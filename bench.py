@@ -168,7 +168,7 @@ def cpu_baseline(stepper, x_cpu, budget_s=45.0):
                        f"{best:.2f} s/step on {threads} of {ncpu} host threads"), y
 
 
-def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, world, rank):
+def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, world, rank, zero=False):
     """One precision mode: K timed steps (barrier + sync on both sides, max over ranks) + per-stage HIP-event times."""
     from ace_amd import _lib
     from ace_amd.rollout import RolloutEngine
@@ -180,6 +180,8 @@ def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, 
     g = torch.Generator().manual_seed(1 + rank)                   # member `rank`: its own initial state
     norm = stepper._step_obj.normalizer
     phys = lambda n, t: (t * float(norm.stds[n]) + float(norm.means[n])) if n in norm.means else t   # noqa: E731
+    if zero:   # --zero-data: the normalised state is exactly zero as well
+        phys = lambda n, t: (t * 0.0 + float(norm.means[n])) if n in norm.means else t * 0.0   # noqa: E731
     ic = {n: phys(n, torch.randn(1, 1, *IMG, generator=g)).to(dev) for n in prog}
     fc = {n: phys(n, torch.randn(1, T + 1, *IMG, generator=g)).to(dev) for n in list(forcing_names) + list(eng.target_names)}
     if "ocean_fraction" in fc:
@@ -302,6 +304,9 @@ def main():
     ap.add_argument("--precision", default="both", choices=["both", "f16x3", "fp32"],
                     help="'both': time the default (f16x3) and the exact-fp32 arithmetic in the same run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--zero-data", action="store_true",
+                    help="DIAGNOSTIC (DVFS give-back check, MI355X_MICROARCH.md): all weights and all inputs zero - same kernels, same "
+                         "instruction streams, no operand switching; the line is marked invalid as a result")
     ap.add_argument("--hooks", action="store_true",
                     help="ACE2-style post-step physics (atmosphere corrector + prescribed-SST ocean) inside the timed loop")
     args = ap.parse_args()
@@ -322,10 +327,14 @@ def main():
 
     K, Wm = args.steps, args.warmup
     stepper, forcing, prog, diag = build_stepper(dev, seed=0, hooks=args.hooks)   # same weights on every rank (one model, N members)
+    if args.zero_data:
+        with torch.no_grad():
+            for p_ in stepper.modules[0].parameters():
+                p_.zero_()
     modes = [DEFAULT_PRECISION] + (["fp32" if DEFAULT_PRECISION != "fp32" else "f16x3"] if args.precision == "both" else [])
     if args.precision in ("f16x3", "fp32"):
         modes = [args.precision]
-    runs = {m: time_mode(stepper, m, forcing, prog, dist, dev, K, Wm, args.graph, world, rank) for m in modes}
+    runs = {m: time_mode(stepper, m, forcing, prog, dist, dev, K, Wm, args.graph, world, rank, zero=args.zero_data) for m in modes}
 
     # who ran what: one record per rank (device, its member's wall time and its all-reduce time), gathered on every rank
     ranks_info = [None] * world
@@ -389,7 +398,8 @@ def main():
             "metric": "rollout steps/sec (6-hourly forward steps of the 1-degree SFNO, whole job)",
             "value": round(steps_per_s, 3), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(r["dt"] / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": dtype[main_mode], "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype[main_mode],
+            "data": "synthetic" if not args.zero_data else "ALL-ZERO weights and state (--zero-data diagnostic; not a result)",
             "simulated_years_per_day": round(steps_per_s * 86400 / 1460, 1),
             "config": {"workload": "ACE2-ERA5-shape 1deg SFNO rollout (BASELINE.json configs[1]): embed 384, 8 layers, "
                                    "dhconv, 44 in / 50 out channels, 180x360 legendre-gauss, lmax 180, mmax 181, "

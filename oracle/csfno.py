@@ -52,12 +52,13 @@ class CSFNOConfig:
 _ACT = {"gelu": F.gelu, "relu": F.relu, "silu": F.silu}
 
 
-def isotropic_noise(leading_shape, lmax: int, mmax: int, isht, dtype=torch.float32) -> torch.Tensor:
+def isotropic_noise(leading_shape, lmax: int, mmax: int, isht, dtype=torch.float32, generator=None) -> torch.Tensor:
     """stochastic_sfno.py:21-47: a_lm ~ CN(0, 1) (real for m = 0), scaled so that the field has unit variance; draws
-    from torch's global RNG in the reference's order (real parts, then imaginary parts, both fp32)."""
+    in the reference's order (real parts, then imaginary parts, both fp32) from torch's global RNG or - fme/core/rand.py:55-63
+    under ``use_generator`` - from the given CPU generator."""
     shape = (*leading_shape, lmax, mmax)
-    real = torch.randn(shape, dtype=torch.float32)
-    imag = torch.randn(shape, dtype=torch.float32)
+    real = torch.randn(shape, dtype=torch.float32, generator=generator)
+    imag = torch.randn(shape, dtype=torch.float32, generator=generator)
     imag[..., :, 0] = 0.0
     sqrt2 = math.sqrt(2.0)
     real[..., :, 1:] /= sqrt2
@@ -153,17 +154,20 @@ class CSFNOOracle:
             y = F.conv2d(y, p[pre + "mlp.fwd.2.weight"], p[pre + "mlp.fwd.2.bias"])
         return y + residual                                            # outer skip = identity on the filter's residual
 
-    def forward(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
+                generator: Optional[torch.Generator] = None) -> torch.Tensor:
         """x: (B, in_chans, H, W).  ``noise`` (B, noise_embed_dim, H, W): if None it is drawn from torch's global RNG
-        exactly as the reference does (seed with torch.manual_seed to reproduce).  ``labels`` (B, n_labels): one-hot (or
+        exactly as the reference does (seed with torch.manual_seed to reproduce), or from ``generator`` - the CPU generator a seeded
+        rollout's ``StepperState.random_state`` carries (fme/ace/stepper/single_module.py:1063-1068).  ``labels`` (B, n_labels): one-hot (or
         soft) label encoding, stochastic_sfno.py:128-175."""
         cfg, p = self.cfg, self.p
         x = x.reshape(-1, *x.shape[-3:]).to(self.dtype)
         if noise is None:
             if cfg.noise_type == "isotropic":
-                noise = isotropic_noise((x.shape[0], cfg.noise_embed_dim), self.L, self.M, self.itrans_up, self.dtype)
+                noise = isotropic_noise((x.shape[0], cfg.noise_embed_dim), self.L, self.M, self.itrans_up, self.dtype, generator)
             else:
-                noise = torch.randn(torch.Size([x.shape[0], cfg.noise_embed_dim, *x.shape[-2:]]), dtype=torch.float32)
+                noise = torch.randn(torch.Size([x.shape[0], cfg.noise_embed_dim, *x.shape[-2:]]), dtype=torch.float32,
+                                    generator=generator)
         noise = noise.to(self.dtype)
         w = self.wrap
         if labels is not None:

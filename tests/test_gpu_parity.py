@@ -1034,6 +1034,51 @@ def test_reference_checkpoint_rollout_matches_reference_stepper(dev, precision, 
         assert torch.equal(v[:, 0], out[k][:, -1])
 
 
+@pytest.mark.parametrize("engine", ["stepper", None, "step"])
+@pytest.mark.parametrize("case", ["isotropic", "gaussian_groups2"])
+def test_seeded_stochastic_rollout_matches_reference_stepper(dev, precision, case, engine):
+    """The reference's RNG contract (fme/core/rand.py:39-104, fme/ace/stepper/single_module.py:1063-1068):
+    a NoiseConditionedSFNO stepper rolled 3 steps from ``StepperState(random_state=RandomState.from_seed(seed))`` reproduces the
+    REAL reference stepper's seeded rollout (tests/golden/gen_rng.pt: isotropic noise through the inverse SHT, and gaussian noise
+    with a grouped filter) - the draw comes from the rollout's CPU generator whatever the device's global RNG holds, through
+    Stepper.predict and through the static-buffer RolloutEngine (eager / per-step hipGraph).  Bar: 1e-5 of the field maximum
+    per step (carried through s + 1 networks), per channel."""
+    import ace_amd
+    from ace_amd.rand import RandomState
+    from ace_amd.rollout import RolloutEngine
+    from ace_amd.step import StepperState
+    from ace_amd.stepper import PrognosticState
+    g = load_golden("gen_rng.pt")[case]
+    stepper = ace_amd.load_stepper(g["state"], device=dev).stepper
+    stepper._step_obj.module.torch_module.set_precision(precision)
+    T = len(g["steps"])
+    forcing = {k: v.to(dev) for k, v in g["forcing"].items()}
+
+    def run():
+        ic = PrognosticState({k: v.to(dev) for k, v in g["ic"].items()})
+        ic.stepper_state = StepperState(random_state=RandomState.from_seed(g["seed"]))
+        torch.manual_seed(int(torch.randint(0, 1 << 30, (1,))))          # the global RNGs (host and device) must not matter
+        if engine == "stepper":
+            return stepper.predict(ic, forcing)
+        return RolloutEngine(stepper, batch=2, n_forward_steps=T, graph=engine).predict(ic, forcing)
+
+    out, state = run()
+    out = {k: v.clone() for k, v in out.items()}
+    torch.cuda.synchronize()
+    for s, want_all in enumerate(g["steps"]):
+        for k, want in want_all.items():
+            err = float((out[k][:, s].cpu() - want).abs().max() / want.abs().max())
+            assert err <= NET_TOL * (s + 1), (case, engine, s, k, err)
+    rs = state.stepper_state.random_state
+    assert torch.equal(rs.generator.get_state(), g["generator_state_after"])     # consumed exactly what the reference consumed
+    again, _ = run()
+    for k in out:
+        assert torch.equal(out[k], again[k]), k                                   # a seeded rollout is reproducible to the bit
+    with torch.no_grad():      # without a random state: the device's RNG, a different rollout every time
+        a, _ = stepper.predict({k: v.to(dev) for k, v in g["ic"].items()}, forcing)
+    assert not torch.equal(a["p0"], out["p0"])
+
+
 @pytest.mark.parametrize("how", ["stepper", "engine"])
 def test_windowed_inference_matches_reference_continuous_rollout(dev, how, tmp_path):
     """run_inference over forcing windows of 2 + 1 steps (ace_amd/inference.py: window feeder with the one-ahead upload,
