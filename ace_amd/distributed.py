@@ -142,14 +142,19 @@ class AsyncEnsembleMean:
             self.dist.reduce_mean(self.buf)
             self._pending = True
             return
+        fields = fields if torch.is_tensor(fields) else list(fields)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready)
+            # the inputs are read on the side stream: tell the caching allocator, so that a temporary the caller drops right
+            # after submit() (2.0 * state) is not handed to step-stream kernels before the stack / copy below has run
+            for t in ([fields] if torch.is_tensor(fields) else fields):
+                t.record_stream(self.stream)
             if torch.is_tensor(fields):
                 self.buf.copy_(fields)
             else:
-                torch.stack(list(fields), out=self.buf)
+                torch.stack(fields, out=self.buf)
             self.begin.record(self.stream)
             self.dist.reduce_mean(self.buf)
             self.done.record(self.stream)

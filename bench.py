@@ -38,20 +38,24 @@ def names():
 
 
 def stage_model(C=384, H=180, W=360, L=180, M=181, hid=768, cin=44, cout=50):
-    """Algorithmic flops / bytes per launch of each stage (DESIGN.md section 'Kernels'), B = 1."""
+    """(flops, algorithmic bytes, moved bytes) per launch of each stage (DESIGN.md section 'Kernels'), B = 1."""
     act = C * H * W * 4
     tiles = (H * W + 31) // 32                      # fc2 emits one statistics partial (16 B) per 32-pixel tile and channel
     groups = 8 * (32 // (C // 128) + (32 - (32 // (C // 128)) * (C // 128))) if C % 128 == 0 else tiles   # inner skip: one per pixel group
     coef = C * L * M * 8
     tab = M * L * H * 4
     fft_flops = 2 * 21_000 * C * H      # two-level 20 x 18 FFT on the vector ALUs: ~21 k fp32 FMAs per row (csrc/fft.hip)
-    return {
-        # name: (flops, hbm_bytes)  - dense counts; the triangular (l >= m) work actually done is ~half for legendre
-        "forward_transform.dft": (fft_flops, act + coef),
-        "forward_transform.legendre": (2 * 2 * C * M * L * H, 2 * coef + tab),
-        "dhconv": (8 * C * C * L * M, 2 * coef + 2 * C * C * L * 4),      # SURVEY 8(d): coef_in + Wf (212 MB) + coef_out
-        "inverse_transform.legendre": (2 * 2 * C * M * L * H, 2 * coef + tab),
-        "inverse_transform.dft": (fft_flops, act + coef),
+    tri = C * 8 * sum(min(l + 1, M) for l in range(L))   # coefficients with l >= m only: what D / E hold (csrc/strip_fold.hip)
+    tabf = 8_600_000 if (H, L, M) == (180, 180, 181) else tab // 2 + tab // 8   # packed folded table (strip_pack.h): 8.6 MB at 1 degree
+    wf = 2 * C * C * L * 4
+    f = {
+        # name: (flops, algorithmic HBM bytes = SURVEY 8(d): every operand once, dense, moved bytes = what the layout of this
+        # build transfers: triangular D / E, folded packed table)
+        "forward_transform.dft": (fft_flops, act + coef, act + coef),
+        "forward_transform.legendre": (2 * 2 * C * M * L * H, 2 * coef + tab, coef + tabf + tri),
+        "dhconv": (8 * C * C * L * M, 2 * coef + wf, 2 * tri + wf),      # SURVEY 8(d): coef_in + Wf (212 MB) + coef_out
+        "inverse_transform.legendre": (2 * 2 * C * M * L * H, 2 * coef + tab, coef + tabf + tri),
+        "inverse_transform.dft": (fft_flops, act + coef, act + coef),
         "inner_skip+activation": (2 * C * C * H * W, 3 * act),
         "mlp.fc1": (2 * hid * C * H * W, act + hid * H * W * 4),
         "mlp.fc2+outer_skip": (2 * hid * C * H * W, 2 * act + hid * H * W * 4),
@@ -62,6 +66,7 @@ def stage_model(C=384, H=180, W=360, L=180, M=181, hid=768, cin=44, cout=50):
         "encoder": (2 * (cin * C + C * C) * H * W, cin * H * W * 4 + 4 * act),
         "decoder": (2 * ((C + cin) * C + C * cout) * H * W, 3 * act + (cin + cout) * H * W * 4),
     }
+    return {k: (v if len(v) == 3 else (v[0], v[1], v[1])) for k, v in f.items()}
 
 
 def hook_names():
@@ -168,8 +173,88 @@ def cpu_baseline(stepper, x_cpu, budget_s=45.0):
                        f"{best:.2f} s/step on {threads} of {ncpu} host threads"), y
 
 
-def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, world, rank, zero=False):
-    """One precision mode: K timed steps (barrier + sync on both sides, max over ranks) + per-stage HIP-event times."""
+def _sync(dev):
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize()
+
+
+def timed_window(eng, ens, dist, dev, K, Wm, world):
+    """The rank orchestration of one measurement, identical on every rank: untimed warm-up (graph capture; for N > 1 two
+    all-reduces - RCCL sets its channels / buffers up on the first collective of a size, the second gives its steady-state
+    device time), then [sync; barrier; sync; K steps; for N > 1 ONE ensemble-mean all-reduce of the final state on the side
+    stream (reference cadence: fme/ace/aggregator/one_step/ensemble.py:93-112,299); sync; barrier; sync], then the MAX of the
+    wall time over ranks (fme/core/distributed/torch_distributed.py:130-132 reductions).  `eng` needs: graph_mode,
+    run_window(), _enqueue_step(s, use_library_graph), out (name -> (B, T, H, W)), out_names - ace_amd.rollout.RolloutEngine,
+    or the stub engine of tests/test_bench_ranks_cpu.py that drives this very function under gloo with world_size 2.
+    Returns (seconds, steady-state all-reduce ms or None)."""
+    T = K
+
+    def window(n_steps):
+        for s in range(n_steps):
+            eng._enqueue_step(s % T, eng.graph_mode == "step")
+
+    allreduce_ms = None
+    with torch.no_grad():
+        if eng.graph_mode == "window":
+            eng.run_window()                                      # untimed: captures the K-step window and replays it
+        else:
+            window(max(Wm, 1))                                    # untimed warm-up (graph capture happens here)
+        if world > 1:
+            ens.submit([eng.out[n][0, 0] for n in eng.out_names])
+            ens.result()
+            ens.submit([eng.out[n][0, 0] for n in eng.out_names])
+            allreduce_ms = ens.last_allreduce_ms()
+        _sync(dev)
+        dist.barrier()
+        _sync(dev)
+        t0 = time.perf_counter()
+        if eng.graph_mode == "window":
+            eng.run_window()
+        else:
+            window(K)
+        if world > 1:
+            ens.submit([eng.out[n][0, K - 1] for n in eng.out_names])
+            ens.result()
+        _sync(dev)
+        dist.barrier()
+        _sync(dev)
+        dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.reduce_max(tmax)
+    return float(tmax.item()), allreduce_ms
+
+
+def gather_rank_records(dist, dev, rank, local_rank, world, allreduce_ms):
+    """who ran what: one record per rank (device, backend, its all-reduce time), gathered on every rank"""
+    dev = torch.device(dev)
+    mine = {"rank": rank, "local_rank": local_rank,
+            "device": torch.cuda.get_device_name(dev) if dev.type == "cuda" else "cpu",
+            "backend": (torch.distributed.get_backend() if dist.is_distributed() else "none"),
+            "allreduce_ms": allreduce_ms}
+    if not dist.is_distributed():
+        return [mine]
+    ranks_info = [None] * world
+    torch.distributed.all_gather_object(ranks_info, mine)
+    return ranks_info
+
+
+def multi_gpu_block(world, ranks_info, allreduce_bytes):
+    return {"world_size": world, "ranks": ranks_info, "allreduce_bytes": allreduce_bytes,
+            "allreduce_stream": "side stream, event-ordered after the step stream (ace_amd/distributed.py AsyncEnsembleMean)",
+            "timing": "max over ranks of [barrier; K steps; one ensemble-mean all-reduce; sync; barrier]"}
+
+
+def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, world, rank, zero=False, engine_factory=None):
+    """One precision mode: K timed steps (barrier + sync on both sides, max over ranks) + per-stage HIP-event times.
+    engine_factory(K, rank) -> engine: a stand-in engine (CPU test of the N > 1 orchestration); no stage timing then."""
+    from ace_amd.distributed import AsyncEnsembleMean
+    if engine_factory is not None:
+        eng = engine_factory(K, rank)
+        shape = (len(eng.out_names), *eng.out[eng.out_names[0]].shape[-2:])
+        ens = AsyncEnsembleMean(shape, dev, dist)
+        dt, allreduce_ms = timed_window(eng, ens, dist, dev, K, Wm, world)
+        return dict(dt=dt, stages=None, x_cpu=None, y_gpu=None, allreduce_ms=allreduce_ms, allreduce_bytes=ens.buf.numel() * 4,
+                    ensemble_mean=ens.result().clone())
     from ace_amd import _lib
     from ace_amd.rollout import RolloutEngine
 
@@ -187,42 +272,8 @@ def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, 
     if "ocean_fraction" in fc:
         fc["ocean_fraction"] = torch.rand(1, T + 1, *IMG, generator=g).to(dev)
     eng.load(ic, fc)
-    from ace_amd.distributed import AsyncEnsembleMean
     ens = AsyncEnsembleMean((len(eng.out_names), *IMG), dev, dist)   # side stream + events: the step stream never waits for RCCL
-
-    def window(n_steps):
-        for s in range(n_steps):
-            eng._enqueue_step(s % T, eng.graph_mode == "step")
-
-    allreduce_ms = None
-    with torch.no_grad():
-        if eng.graph_mode == "window":
-            eng.run_window()                                      # untimed: captures the K-step window and replays it
-        else:
-            window(max(Wm, 1))                                    # untimed warm-up (graph capture happens here)
-        if world > 1:                                             # ... and of the one collective: RCCL sets its channels / buffers
-            ens.submit([eng.out[n][0, 0] for n in eng.out_names])  # up on the first all-reduce of a size
-            ens.result()
-            ens.submit([eng.out[n][0, 0] for n in eng.out_names])  # second one: the steady-state time of the collective
-            allreduce_ms = ens.last_allreduce_ms()
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        if eng.graph_mode == "window":
-            eng.run_window()
-        else:
-            window(K)
-        if world > 1:  # ensemble-mean diagnostic of the final state, once per window (reference cadence), on the side stream
-            ens.submit([eng.out[n][0, K - 1] for n in eng.out_names])
-            ens.result()
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    dist.reduce_max(tmax)
-    dt = float(tmax.item())
+    dt, allreduce_ms = timed_window(eng, ens, dist, dev, K, Wm, world)
 
     stages = None
     if rank == 0:  # per-stage HIP-event timing of the forward, on the stream the kernels are launched on
@@ -237,17 +288,20 @@ def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, 
                                                 _lib.current_stream(), ms, calls))
             for i in range(ns):
                 acc[i] += ms[i] / reps
-        model = stage_model()
+        model = stage_model(cin=len(stepper._step_obj.in_packer.names), cout=len(stepper._step_obj.out_packer.names))
         if precision == "fp32":   # exact-fp32 mode: the norm statistics are a stand-alone pass over the activation
             act_b = 384 * IMG[0] * IMG[1] * 4
-            model["norm0_stats"] = model["norm1_stats"] = (3 * 384 * IMG[0] * IMG[1], act_b)
+            model["norm0_stats"] = model["norm1_stats"] = (3 * 384 * IMG[0] * IMG[1], act_b, act_b)
         stages = {}
         for i in range(ns):
             nm = L.ace_sfno_stage_name(i).decode()
             per_launch_ms = acc[i] / max(calls[i], 1)
-            fl, by = model[nm]
+            fl, by, moved = model[nm]
+            # gbps: SURVEY 8(d)'s algorithmic bytes (dense operands) per launch time - the roofline convention; moved_gbps: the
+            # bytes this build's layout actually transfers (triangular coefficients, folded table) - what the memory system sees
             stages[nm] = dict(ms_per_step=round(acc[i], 4), launches=calls[i], us_per_launch=round(per_launch_ms * 1e3, 2),
-                              tflops=round(fl / per_launch_ms / 1e9, 2), gbps=round(by / per_launch_ms / 1e6, 1))
+                              tflops=round(fl / per_launch_ms / 1e9, 2), gbps=round(by / per_launch_ms / 1e6, 1),
+                              moved_bytes=int(moved), moved_gbps=round(moved / per_launch_ms / 1e6, 1))
     x_cpu = eng.x.detach().cpu() if rank == 0 else None
     y_gpu = eng.y.detach().cpu() if rank == 0 else None
     del eng
@@ -295,7 +349,118 @@ KERNEL_OF_STAGE = {
 }
 
 
-def main():
+def rooflines(main_mode, stages):
+    """`roofline` (dominant kernel on its slowest stage) and `roofline_sht` (forward FFT + Legendre) from the per-stage event times"""
+    model = stage_model()
+    # dominant kernel = the kernel with the largest total time per step; it is reported on its slowest stage
+    per_kernel = {}
+    for st, v in stages.items():
+        per_kernel[KERNEL_OF_STAGE.get(st, st)] = per_kernel.get(KERNEL_OF_STAGE.get(st, st), 0.0) + v["ms_per_step"]
+    if main_mode == "fp32":
+        dom = max(stages, key=lambda k: stages[k]["ms_per_step"])
+    else:
+        kdom = max(per_kernel, key=per_kernel.get)
+        dom = max((st for st in stages if KERNEL_OF_STAGE.get(st, st) == kdom), key=lambda k: stages[k]["ms_per_step"])
+    fl, by = model[dom][:2]
+    t_launch = stages[dom]["us_per_launch"] * 1e-6
+    pmc, pmc_note = measured_counters()
+    ent = pmc.get((main_mode, dom), {})
+    if main_mode == "fp32":   # exact-fp32 MFMA: the contraction kernels are bound by the fp32 matrix pipe
+        roofline = dict(kernel=f"gemm_f32 engine ({dom})", bound="mfma", achieved=round(fl / t_launch / 1e12, 2),
+                        peak=PEAK_MFMA_F32, unit="TFLOP/s", frac=round(fl / t_launch / 1e12 / PEAK_MFMA_F32, 4),
+                        traffic=ent.get("bytes"), traffic_note=pmc_note)
+    else:                     # compensated-fp16 MFMA (3 x 1/16 of the fp32 cost): HBM is the bounding roofline
+        roofline = dict(kernel=f"{KERNEL_OF_STAGE.get(dom, dom)} ({dom})", bound="hbm", achieved=round(by / t_launch / 1e9, 1),
+                        peak=PEAK_HBM, unit="GB/s", frac=round(by / t_launch / 1e9 / PEAK_HBM, 4),
+                        traffic=ent.get("bytes"), traffic_note=pmc_note,
+                        # north_star: MFMA-busy against the chip's peak.  Issue rate from the flop count (3 fp16 MFMAs per
+                        # product) and, when the counters are of this build, SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x
+                        # active cycles of one XCD)
+                        mfma_f16_tflops=round(3 * fl / t_launch / 1e12, 1), mfma_f16_peak=2500.0,
+                        mfma_busy_frac=round(3 * fl / t_launch / 1e12 / 2500.0, 4), mfma_busy_pmc=ent.get("mfma_busy"))
+    sht_us = stages["forward_transform.dft"]["us_per_launch"] + stages["forward_transform.legendre"]["us_per_launch"]
+    sht_bytes = 384 * 180 * 360 * 4 + 181 * 180 * 180 * 4 + 384 * 180 * 181 * 8     # SURVEY 8(d): 223.1 MB
+    sht_moved = model["forward_transform.dft"][2] + model["forward_transform.legendre"][2] - 384 * 180 * 181 * 8   # X counted once each way
+    roofline_sht = dict(kernel="forward SHT (dft_forward_fft_kernel + legendre_fold_kernel)", bound="hbm",
+                        achieved=round(sht_bytes / (sht_us * 1e-6) / 1e9, 1), peak=PEAK_HBM, unit="GB/s",
+                        frac=round(sht_bytes / (sht_us * 1e-6) / 1e9 / PEAK_HBM, 4),
+                        moved_bytes_two_kernels=model["forward_transform.dft"][2] + model["forward_transform.legendre"][2],
+                        traffic=(pmc[(main_mode, "forward_transform.dft")]["bytes"] +
+                                 pmc[(main_mode, "forward_transform.legendre")]["bytes"])
+                        if (main_mode, "forward_transform.dft") in pmc and
+                           (main_mode, "forward_transform.legendre") in pmc else None, traffic_note=pmc_note)
+    del sht_moved
+    return roofline, roofline_sht
+
+
+def extra_legs(stepper, forcing, prog, dist, dev, K, rank, hooks):
+    """Two more legs of the same job, reported as extra keys: the one-year rollout BASELINE configs[1] names (1460
+    six-hourly steps as 1460 / K windows chained through the engine's state feedback, per-step hipGraph) and the "S80" state
+    (8 forcing + 36 prognostic in = 44, 36 prognostic + 36 diagnostic out = 72 channels; the headline state is ACE2's 44 / 50)."""
+    from ace_amd.rollout import RolloutEngine
+    out = {}
+    # ---- 1460 steps: windows of K steps, the last state of a window is the next one's initial condition
+    eng = RolloutEngine(stepper, batch=1, n_forward_steps=K, graph="step")
+    g = torch.Generator().manual_seed(1 + rank)
+    norm = stepper._step_obj.normalizer
+    phys = lambda n, t: (t * float(norm.stds[n]) + float(norm.means[n])) if n in norm.means else t   # noqa: E731
+    ic = {n: phys(n, torch.randn(1, 1, *IMG, generator=g)).to(dev) for n in prog}
+    fc = {n: phys(n, torch.randn(1, K + 1, *IMG, generator=g)).to(dev) for n in list(forcing) + list(eng.target_names)}
+    if "ocean_fraction" in fc:
+        fc["ocean_fraction"] = torch.rand(1, K + 1, *IMG, generator=g).to(dev)
+    eng.load(ic, fc)
+    n_year, done = 1460, 0
+    with torch.no_grad():
+        eng.run_window()                                          # untimed: graph capture
+        eng.load(ic, fc)
+        _sync(dev)
+        t0 = time.perf_counter()
+        while done < n_year:
+            n = min(K, n_year - done)
+            for s_ in range(n):
+                eng._enqueue_step(s_, True)
+            done += n
+            if done < n_year:
+                for nme in eng.prognostic:                         # (continue_from_last, for a possibly partial last window)
+                    eng.ic[nme].copy_(eng.out[nme][:, n - 1:n])
+        _sync(dev)
+        dt = time.perf_counter() - t0
+    last = torch.stack([eng.out[nme][0, (n_year - 1) % K] for nme in eng.out_names])
+    out["one_year_rollout"] = {"steps": n_year, "seconds": round(dt, 3), "steps_per_s": round(n_year / dt, 2),
+                               "ms_per_step": round(dt / n_year * 1e3, 4), "graph": "step", "windows_of": K,
+                               "final_state_finite": bool(torch.isfinite(last).all()),
+                               "final_state_absmax": float(last.abs().max()),
+                               "simulated_years_per_day": round(86400.0 / dt, 1)}
+    del eng
+    if hooks:
+        return out
+    # ---- S80: the same network body with 72 output channels
+    import ace_amd
+    from ace_amd.step import NormalizationConfig
+    f80 = [f"forcing_{i}" for i in range(8)]
+    p80 = [f"prog_{i}" for i in range(36)]
+    d80 = [f"diag_{i}" for i in range(36)]
+    cfg = ace_amd.SingleModuleStepConfig(
+        builder=ace_amd.ModuleSelector(type="SphericalFourierNeuralOperatorNet", config=ACE2),
+        in_names=f80 + p80, out_names=p80 + d80,
+        normalization=NormalizationConfig(means={k: 0.1 for k in f80 + p80 + d80}, stds={k: 1.1 for k in f80 + p80 + d80}))
+    torch.manual_seed(0)
+    st80 = ace_amd.Stepper.from_config(cfg, ace_amd.DatasetInfo(IMG), device=dev)
+    st80.set_eval()
+    r80 = time_mode(st80, stepper.modules[0].precision if hasattr(stepper.modules[0], "precision") else "f16x3", f80, p80, dist, dev,
+                    K, 2, "step", 1, rank)
+    out["state_s80"] = {"in_channels": 44, "out_channels": 72, "steps_per_s": round(K / r80["dt"], 3),
+                        "ms_per_step": round(r80["dt"] / K * 1e3, 4),
+                        "decoder_us": r80["stages"]["decoder"]["us_per_launch"] if r80["stages"] else None}
+    del st80
+    torch.cuda.empty_cache()
+    return out
+
+
+def main(argv=None, engine_factory=None, device=None):
+    """engine_factory / device: the CPU test of the rank orchestration (tests/test_bench_ranks_cpu.py) passes a stand-in engine
+    and "cpu"; everything below - argument checks, the distributed facade, warm-up, timed region, max over ranks, the gather of
+    the per-rank records and the JSON line - is then the code `bench.py --gpus N` runs on the devices."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
@@ -304,12 +469,13 @@ def main():
     ap.add_argument("--precision", default="both", choices=["both", "f16x3", "fp32"],
                     help="'both': time the default (f16x3) and the exact-fp32 arithmetic in the same run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the 1460-step and the S80 (44 in / 72 out) legs")
     ap.add_argument("--zero-data", action="store_true",
                     help="DIAGNOSTIC (DVFS give-back check, MI355X_MICROARCH.md): all weights and all inputs zero - same kernels, same "
                          "instruction streams, no operand switching; the line is marked invalid as a result")
     ap.add_argument("--hooks", action="store_true",
                     help="ACE2-style post-step physics (atmosphere corrector + prescribed-SST ocean) inside the timed loop")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     from ace_amd.distributed import Distributed
     from ace_amd.sfno import DEFAULT_PRECISION
@@ -317,78 +483,43 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
     if args.gpus != world:
         assert world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
         assert args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if engine_factory is None:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device(device or "cpu")
     dist = Distributed.get_instance()
 
     K, Wm = args.steps, args.warmup
-    stepper, forcing, prog, diag = build_stepper(dev, seed=0, hooks=args.hooks)   # same weights on every rank (one model, N members)
-    if args.zero_data:
-        with torch.no_grad():
-            for p_ in stepper.modules[0].parameters():
-                p_.zero_()
+    stepper = forcing = prog = None
+    if engine_factory is None:
+        stepper, forcing, prog, _diag = build_stepper(dev, seed=0, hooks=args.hooks)   # same weights on every rank (one model, N members)
+        if args.zero_data:
+            with torch.no_grad():
+                for p_ in stepper.modules[0].parameters():
+                    p_.zero_()
     modes = [DEFAULT_PRECISION] + (["fp32" if DEFAULT_PRECISION != "fp32" else "f16x3"] if args.precision == "both" else [])
     if args.precision in ("f16x3", "fp32"):
         modes = [args.precision]
-    runs = {m: time_mode(stepper, m, forcing, prog, dist, dev, K, Wm, args.graph, world, rank, zero=args.zero_data) for m in modes}
-
-    # who ran what: one record per rank (device, its member's wall time and its all-reduce time), gathered on every rank
-    ranks_info = [None] * world
-    mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(dev),
-            "backend": (torch.distributed.get_backend() if dist.is_distributed() else "none"),
-            "allreduce_ms": runs[modes[0]]["allreduce_ms"]}
-    if dist.is_distributed():
-        torch.distributed.all_gather_object(ranks_info, mine)
-    else:
-        ranks_info = [mine]
+    if engine_factory is not None:
+        modes = modes[:1]
+    runs = {m: time_mode(stepper, m, forcing, prog, dist, dev, K, Wm, args.graph, world, rank, zero=args.zero_data,
+                         engine_factory=engine_factory) for m in modes}
+    ranks_info = gather_rank_records(dist, dev, rank, local_rank, world, runs[modes[0]]["allreduce_ms"])
 
     result = None
     if rank == 0:
         main_mode = modes[0]
         r = runs[main_mode]
         stages = r["stages"]
-        model = stage_model()
-        # dominant kernel = the kernel with the largest total time per step; it is reported on its slowest stage
-        per_kernel = {}
-        for st, v in stages.items():
-            per_kernel[KERNEL_OF_STAGE.get(st, st)] = per_kernel.get(KERNEL_OF_STAGE.get(st, st), 0.0) + v["ms_per_step"]
-        if main_mode == "fp32":
-            dom = max(stages, key=lambda k: stages[k]["ms_per_step"])
-        else:
-            kdom = max(per_kernel, key=per_kernel.get)
-            dom = max((st for st in stages if KERNEL_OF_STAGE.get(st, st) == kdom), key=lambda k: stages[k]["ms_per_step"])
-        fl, by = model[dom]
-        t_launch = stages[dom]["us_per_launch"] * 1e-6
-        pmc, pmc_note = measured_counters()
-        ent = pmc.get((main_mode, dom), {})
-        if main_mode == "fp32":   # exact-fp32 MFMA: the contraction kernels are bound by the fp32 matrix pipe
-            roofline = dict(kernel=f"gemm_f32 engine ({dom})", bound="mfma", achieved=round(fl / t_launch / 1e12, 2),
-                            peak=PEAK_MFMA_F32, unit="TFLOP/s", frac=round(fl / t_launch / 1e12 / PEAK_MFMA_F32, 4),
-                            traffic=ent.get("bytes"), traffic_note=pmc_note)
-        else:                     # compensated-fp16 MFMA (3 x 1/16 of the fp32 cost): HBM is the bounding roofline
-            roofline = dict(kernel=f"{KERNEL_OF_STAGE.get(dom, dom)} ({dom})", bound="hbm", achieved=round(by / t_launch / 1e9, 1),
-                            peak=PEAK_HBM, unit="GB/s", frac=round(by / t_launch / 1e9 / PEAK_HBM, 4),
-                            traffic=ent.get("bytes"), traffic_note=pmc_note,
-                            # north_star: MFMA-busy against the chip's peak.  Issue rate from the flop count (3 fp16 MFMAs per
-                            # product) and, when the counters are of this build, SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x
-                            # active cycles of one XCD)
-                            mfma_f16_tflops=round(3 * fl / t_launch / 1e12, 1), mfma_f16_peak=2500.0,
-                            mfma_busy_frac=round(3 * fl / t_launch / 1e12 / 2500.0, 4), mfma_busy_pmc=ent.get("mfma_busy"))
-        sht_us = stages["forward_transform.dft"]["us_per_launch"] + stages["forward_transform.legendre"]["us_per_launch"]
-        sht_bytes = 384 * 180 * 360 * 4 + 181 * 180 * 180 * 4 + 384 * 180 * 181 * 8     # 223.1 MB
-        roofline_sht = dict(kernel="forward SHT (dft_forward_fft_kernel + legendre_fold_kernel)", bound="hbm",
-                            achieved=round(sht_bytes / (sht_us * 1e-6) / 1e9, 1), peak=PEAK_HBM, unit="GB/s",
-                            frac=round(sht_bytes / (sht_us * 1e-6) / 1e9 / PEAK_HBM, 4),
-                            traffic=(pmc[(main_mode, "forward_transform.dft")]["bytes"] +
-                                     pmc[(main_mode, "forward_transform.legendre")]["bytes"])
-                            if (main_mode, "forward_transform.dft") in pmc and
-                               (main_mode, "forward_transform.legendre") in pmc else None, traffic_note=pmc_note)
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is a single-GPU-run leg (rank 0 at N = 1 only)
+        roofline = roofline_sht = cpu = None
+        if stages is not None:
+            roofline, roofline_sht = rooflines(main_mode, stages)
+        if stages is not None and not args.no_cpu_baseline and world == 1:   # the CPU baseline is a single-GPU-run leg (rank 0 at N = 1 only)
             cpu, y_cpu = cpu_baseline(stepper, r["x_cpu"])
             cpu["parity_rel_err_vs_gpu"] = {m: float((runs[m]["y_gpu"] - y_cpu).abs().max() / y_cpu.abs().max()) for m in modes}
         steps_per_s = world * K / r["dt"]
@@ -407,18 +538,22 @@ def main():
                        "members": world, "members_per_gpu": 1, "graph": args.graph, "precision": main_mode,
                        "collective": "RCCL all-reduce mean of the (50,180,360) output state once per window" if world > 1 else "none"},
             "roofline": roofline, "roofline_sht": roofline_sht, "stages": stages, "cpu_baseline": cpu,
-            "lib_sha256": lib_sha256(),
-            "multi_gpu": {"world_size": world, "ranks": ranks_info, "allreduce_bytes": r["allreduce_bytes"],
-                          "allreduce_stream": "side stream, event-ordered after the step stream (ace_amd/distributed.py AsyncEnsembleMean)",
-                          "timing": "max over ranks of [barrier; K steps; one ensemble-mean all-reduce; sync; barrier]"},
+            "lib_sha256": lib_sha256() if engine_factory is None else None,
+            "multi_gpu": multi_gpu_block(world, ranks_info, r["allreduce_bytes"]),
         }
         for m in modes[1:]:
             result[f"mode_{m}"] = {"value": round(world * K / runs[m]["dt"], 3), "unit": "steps/s",
                                    "ms_per_step": round(runs[m]["dt"] / K * 1e3, 4), "stages": runs[m]["stages"]}
+    if engine_factory is None and world == 1 and not args.no_extra_legs and not args.zero_data:
+        stepper.modules[0].set_precision(modes[0])
+        legs = extra_legs(stepper, forcing, prog, dist, dev, K, rank, args.hooks)
+        if result is not None:
+            result.update(legs)
     dist.barrier()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     dist.shutdown()
+    return result if rank == 0 else runs[modes[0]]
 
 
 if __name__ == "__main__":
