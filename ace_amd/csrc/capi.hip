@@ -613,8 +613,17 @@ extern "C" int ace_conditional_layer_norm_f16x3(const float* x, const float* noi
     ClnMfmaArgs a;
     a.x = x; a.y = y; a.sx = (long)c * hw; a.C = c; a.HW = hw; a.nbatch = n; a.eps = eps; a.gamma = gamma; a.beta = beta;
     DevBuf fs, fb, cslot;
+    {   // the shape requirement, checked BEFORE any weight is copied or packed (same predicate as the launch: the conditioning
+        // operands are stood in for by the input pointer, only their presence matters to it)
+        ClnMfmaArgs probe = a;
+        if (w_scale) {
+            probe.cond = noise; probe.scond = (long)noise_dim * hw; probe.J = noise_dim;
+            probe.As = probe.Ab = reinterpret_cast<const _Float16*>(x); probe.cslot = reinterpret_cast<const unsigned*>(x);
+        }
+        if (!cln_mfma_eligible(probe))
+            return fail(ACE_ERR_INVALID, "ace_conditional_layer_norm_f16x3: needs c % 256 == 0 (c <= 1024), hw % 4 == 0 (c > 512: hw % 32 == 0), noise_dim <= 128");
+    }
     if (w_scale) {   // one-off weight preparation (what ace_sfno_set_weight does once per parameter) + the conditioning field's bound
-        if (c % 32 != 0 || noise_dim > 128) return fail(ACE_ERR_INVALID, "ace_conditional_layer_norm_f16x3: needs c % 256 == 0, noise_dim <= 128");
         const size_t halves = cln_frag_halves(c, noise_dim);
         std::vector<float> host((size_t)c * noise_dim);
         std::vector<uint16_t> frags(halves);

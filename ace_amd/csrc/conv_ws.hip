@@ -43,6 +43,9 @@ constexpr int WS_OOBV = 0x7fffff00;   // buffer offset beyond every resource of 
 #ifndef ACE_WS_FD4
 #define ACE_WS_FD4 1     // fragment read-ahead of mode 4 at K = 768 (mode 2 there has no registers for it) (r03 same-box: mode 4 155.8 -> 149.1 us; holding the store data instead: 153.2)
 #endif
+#ifndef ACE_WS_ABL
+#define ACE_WS_ABL 0     // measurement builds only (WRONG results), fc2 modes (NSTG == 2): bit 0 no epilogue (values, stores, statistics),
+#endif                   // bit 1 no store-retire wait before the next stage's pieces, bit 2 no residual loads, bit 3 no barrier / piece wait
 #ifndef ACE_WS_VSPAN
 #define ACE_WS_VSPAN 8    // interleaved epilogue: its eight values are spread over the first VSPAN twelfths of the stage
 #endif
@@ -420,9 +423,9 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
                 if constexpr (INTER) {
                     ctx = tile_ctx(pt > 0 ? pt - 1 : 0, pt > 0);
                 } else {
-                    epilogue(pt > 0 ? pt - 1 : 0, pt > 0, eo);
+                    if constexpr (!(ACE_WS_ABL & 1)) epilogue(pt > 0 ? pt - 1 : 0, pt > 0, eo);
                     if constexpr (!HOLD) {   // no registers to hold the store data through the stage: retire the stores first
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if constexpr (!(ACE_WS_ABL & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         hold(eo);
 #pragma unroll
                         for (int k = 0; k < PW; ++k) piece(u + 1, k);
@@ -431,7 +434,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { v[r] = 0.f; if (ACC2) v2[r] = 0.f; }
             }
-            if constexpr (RES && q == NSTG - 1) load_residual(pt);
+            if constexpr (RES && q == NSTG - 1 && !(ACE_WS_ABL & 4)) load_residual(pt);
             const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (u & 1) * SLOT) + h * (KSW * 2048) + lane * 16;
             pipelined_steps<KSW, FDEPTH>(sl, [&](auto ss, const Frag& f) {
                 constexpr int st = decltype(ss)::value;
@@ -491,7 +494,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
                 *reinterpret_cast<f32x4*>(xw) = sa;
                 *reinterpret_cast<f32x4*>(xw + 1024) = sb;
             }
-            stage_top();
+            if constexpr (!(ACE_WS_ABL & 8)) stage_top();
             if constexpr (INTER && RES) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) res[e] = resn[e];

@@ -315,6 +315,10 @@ bool legendre_strip_eligible(const LegStripArgs& a) {
     if (a.K < 1 || a.R < 1 || a.N < 1 || a.nbatch < 1) return false;
     if ((a.K + 15) / 16 > KS_MAX) return false;
     if (!a.A || !a.tile_off || !a.B || !a.bmax) return false;
+    // the data operand is addressed with 32-bit byte offsets through a range-checked buffer descriptor (rows up to 15 past the
+    // last k-step, clamped to 4 GiB - 1): a batch whose K rows do not fit wraps the offsets and reads in-range wrong rows
+    // (inverse transform: b_kstride = mmax * 2 * B * C, i.e. B * C >= ~16 k at 1 degree).  Larger operands go to the tile engine.
+    if (((double)a.K + 16.0) * (double)a.b_kstride * 4.0 >= 4.0e9) return false;
     if (a.Chi) return a.N % 4 == 0 && a.c_rstride % 4 == 0 && a.c_moff % 4 == 0 && a.cslot &&
                       (reinterpret_cast<uintptr_t>(a.Chi) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.Clo) & 7) == 0;
     return a.C != nullptr;

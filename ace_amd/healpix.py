@@ -446,6 +446,13 @@ class HEALPixLayer(nn.Module):
                                              _lib.current_stream()))
         return PaddedPlanes(planes, imgs, cin + cin2, cpad, x.rows, W, p, mp, pmax, pad_layer.mode)
 
+    def packable(self) -> bool:
+        """does the packed engine cover this convolution when it pads its own input?  Odd-reach kernels (k = 4 ...) and paddings other
+        than reach / 2 keep the fp32-operand route (gemm3 with a row-offset table), which handles any k / padding."""
+        reach = (self._k - 1) * self._dil
+        return (_PACKED_CONV and isinstance(self.base, nn.Conv2d) and self._pad > 0 and reach % 2 == 0 and reach <= _SLACK
+                and self._pad == reach // 2)
+
     def accepts(self, pp: PaddedPlanes) -> bool:
         """can this convolution read `pp` (padded for a convolution with at least its own reach, in its own padding mode)?"""
         if not (_PACKED_CONV and isinstance(self.base, nn.Conv2d) and self.base.in_channels == pp.channels):
@@ -482,6 +489,9 @@ class HEALPixLayer(nn.Module):
                                          cout, H, W, mp, self._k, self._dil, act[0], act[1], pp.amax.data_ptr(), ymax.data_ptr(), st))
             return HpxPlanes(o, imgs, cout, H, W, mp, ymax)
         # "padded": the next convolution's padded planes - same face size and pitch rule, its own padding width
+        if pad_for.layers[0].mode == "isolatitude" and W != pad_for.layers[0]._nside:       # the check pad_planes() makes
+            raise ValueError(f"HEALPixPaddingIsolatitude expected face size H={pad_for.layers[0]._nside} (from init), but input has H={W}. "
+                             "Make sure that nside was set correctly in the model config.")
         q = pad_for._pad
         m2 = W + 2 * q
         mp2 = max(_RT.pitch_for(W), _round4(m2))
@@ -519,7 +529,7 @@ class HEALPixLayer(nn.Module):
                                  "Make sure that nside was set correctly in the model config.")
             ia, ib = _RT.table(W, p, dev, pad_layer.mode)
             ctot = cin + cin2
-            if _PACKED_CONV and (self._k - 1) * self._dil <= _SLACK:
+            if self.packable():
                 return self.conv_padded(self.pad_planes(x, x2), act=act, out="planes" if planes_out else "fp32")
             ymax = _RT.slot(dev)
             flat = torch.empty(imgs * ctot * m * mp + _SLACK, dtype=torch.float32, device=dev)
@@ -605,7 +615,7 @@ def _run_convblock(convblock: nn.Sequential, x, x2: Optional[Hpx] = None, residu
         if isinstance(cur, HpxPlanes):                         # 1 x 1 convolution on planes
             cur = layer.conv_planes(cur, residual=residual if last else None, act=act)
             continue
-        if isinstance(cur, Hpx) and layer._pad > 0 and _PACKED_CONV and (layer._k - 1) * layer._dil <= _SLACK and isinstance(layer.base, nn.Conv2d):
+        if isinstance(cur, Hpx) and layer.packable():
             cur = layer.pad_planes(cur, x2)
             x2 = None
         if isinstance(cur, PaddedPlanes):
@@ -616,7 +626,7 @@ def _run_convblock(convblock: nn.Sequential, x, x2: Optional[Hpx] = None, residu
                 fact = mods[convs[n_ + 1][0] + 1] if convs[n_ + 1][0] + 1 < len(mods) and not isinstance(mods[convs[n_ + 1][0] + 1], HEALPixLayer) else None
                 if follower._k == 1 and follower._pad == 0 and _act_code(fact)[1] == _INF and follower.base.in_channels % 8 == 0:
                     out = "planes"
-                elif (follower._k > 1 and follower._pad > 0 and (follower._k - 1) * follower._dil <= _SLACK
+                elif (follower._k > 1 and follower.packable()
                       and max(_RT.pitch_for(cur.width), _round4(cur.width + 2 * follower._pad)) == cur.pitch):
                     out = "padded"
             if last and residual is not None:
@@ -751,7 +761,7 @@ class ConvNeXtBlock(nn.Module):
             else:
                 skip = _repitch(x, target)
         else:
-            packed_first = (_PACKED_CONV and first._pad > 0 and isinstance(first.base, nn.Conv2d) and (first._k - 1) * first._dil <= _SLACK)
+            packed_first = first.packable()
             if packed_first:
                 # ONE padded, packed copy of the block input serves both branches: the k x k convolution reads it whole, the 1 x 1
                 # skip convolution its interior (pitch of the padded faces = `target`)

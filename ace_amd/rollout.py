@@ -90,9 +90,9 @@ class RolloutEngine:
         # The secondary decoder's diagnostics are unpacked straight into their output planes: they do not pass through the post-step
         # hooks here (the reference and Stepper.predict put them in the dict the corrector and the ocean see).  Refuse the
         # configurations where that difference would show instead of raising KeyError mid-rollout.
+        # (the ocean's surface temperature cannot clash: OceanConfig.build requires it among the step's in_names AND out_names,
+        # and a secondary diagnostic may be neither - step.py's configuration checks)
         hooked = set(getattr(self._corrector, "force_positive_names", []) or [])
-        if self._ocean is not None:
-            hooked |= {getattr(getattr(self._ocean, "config", None), "surface_temperature_name", None)}
         clash = sorted(hooked.intersection(self.sec_names))
         if clash:
             raise NotImplementedError(f"secondary-decoder diagnostics {clash} are also touched by the post-step hooks (force_positive / "
@@ -379,7 +379,7 @@ class RolloutEngine:
             # prescribe) or that the fused kernels do not know cannot be swapped in - ask for a new engine instead of failing
             # mid-run on a missing buffer.
             new_ocean = step._ocean
-            needed = set(getattr(getattr(new_ocean, "config", None) or getattr(step._config, "ocean", None) or object(), "forcing_names", []) or [])
+            needed = set(getattr(new_ocean, "forcing_names", None) or [])      # ace_amd.ocean.Ocean.forcing_names, however it was swapped in
             missing = sorted(needed - set(self.forcing_names) - set(self.target_names))
             if missing or (self._physics is not None and new_ocean is not None and getattr(new_ocean, "is_slab", False)):
                 raise RuntimeError("the stepper's ocean was replaced after this RolloutEngine was built and the new one needs fields / "

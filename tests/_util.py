@@ -22,6 +22,27 @@ def rel_max(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-300))
 
 
+def rel_max_per_channel(a: torch.Tensor, b: torch.Tensor, channel_dim: int = 1) -> float:
+    """worst channel of max|a - b| over the channel / max|b| over THAT channel: a max norm over the whole tensor does not see
+    an output channel of small magnitude"""
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    dims = [d for d in range(b.dim()) if d != channel_dim % b.dim()]
+    err = (a - b).abs().amax(dim=dims)
+    return float((err / b.abs().amax(dim=dims).clamp_min(1e-300)).max())
+
+
+def assert_net_close(y: torch.Tensor, ref: torch.Tensor, tol: float = 1e-5, channel_factor: float = 3.0, channel_dim: int = 1, what=""):
+    """the network-level bar of the GPU parity tests: max|err| / max|ref| <= tol over the whole output (north_star: 1e-5 per step)
+    AND channel by channel within channel_factor x tol of the channel's own maximum (the first alone lets a
+    small-magnitude channel through)"""
+    whole = rel_max(y, ref)
+    assert whole <= tol, (what, "whole-tensor", whole)
+    if y.dim() > channel_dim:
+        chan = rel_max_per_channel(y, ref, channel_dim)
+        assert chan <= channel_factor * tol, (what, "per-channel", chan)
+
+
 def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
     a = a.detach().cpu()
     b = b.detach().cpu()

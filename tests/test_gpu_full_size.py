@@ -10,7 +10,7 @@ from types import SimpleNamespace
 import pytest
 import torch
 
-from _util import rel_max
+from _util import assert_net_close, rel_max
 
 pytestmark = pytest.mark.gpu
 
@@ -81,4 +81,30 @@ def test_quarter_degree_network_at_its_real_shape():
         assert torch.equal(a, b) and torch.equal(out, a)
         net.set_precision("fp32")
         exact = net(x)
-        assert rel_max(a, exact) <= 1e-5
+        assert_net_close(a, exact, 1e-5)      # whole tensor and channel by channel
+
+
+def test_inverse_sht_whose_operand_passes_the_32_bit_row_offsets():
+    """The register-resident Legendre kernels address their data operand with 32-bit byte offsets through a range-checked buffer
+    descriptor; the inverse transform's row pitch is mmax * 2 * n floats, so from n ~ 16 k fields on the 1-degree grid one
+    batch's rows no longer fit 4 GiB and the launch has to leave those kernels (round-4 ADVICE: the unfolded kernel had no size
+    guard and wrapped - in-range, wrong rows, silently).  One call with n = 16 416 fields against the same fields in two halves
+    that stay inside the kernels' range: the same result within the transform's bound."""
+    import ace_amd
+    dev = torch.device("cuda")
+    H, W = GRIDS["one_degree"]
+    L, M = H, W // 2 + 1
+    n = 16416
+    assert (L + 16) * (M * 2 * n) * 4 >= 4.0e9 > (L + 16) * (M * 2 * (n // 2)) * 4
+    inv = ace_amd.InverseRealSHT(H, W, L, M, "legendre-gauss", precision="f16x3")
+    gen = torch.Generator(device=dev).manual_seed(5)
+    c = torch.complex(torch.randn(n, L, M, generator=gen, device=dev), torch.randn(n, L, M, generator=gen, device=dev))
+    whole = inv(c)
+    assert bool(torch.isfinite(whole).all())
+    worst = 0.0
+    for h in range(2):
+        part = inv(c[h * (n // 2):(h + 1) * (n // 2)])
+        ref = whole[h * (n // 2):(h + 1) * (n // 2)]
+        worst = max(worst, float((part - ref).abs().max() / part.abs().max()))
+        del part
+    assert worst <= 1e-5, worst

@@ -13,8 +13,8 @@ import ctypes
 import pytest
 import torch
 
-from _util import (build_native_net, checkpoint_case, checkpoint_override, conditioning_floor, load_golden, rel_l2,
-                   rel_max)
+from _util import (assert_net_close, build_native_net, checkpoint_case, checkpoint_override, conditioning_floor, load_golden,
+                   rel_l2, rel_max)
 
 pytestmark = pytest.mark.gpu
 
@@ -289,7 +289,7 @@ def test_modulus_sfnonet_golden(dev, precision):
     with torch.no_grad():
         y = net(d["x"].to(dev))
     torch.testing.assert_close(y.cpu(), g)
-    assert rel_max(y, g) <= NET_TOL
+    assert_net_close(y, g, NET_TOL)
 
 
 @pytest.mark.parametrize("name", ["gen_sfno_dhconv_12x24.pt", "gen_sfno_dhconv_equiangular_9x18.pt",
@@ -303,7 +303,7 @@ def test_dhconv_nets_vs_reference(dev, name, precision):
     net = build_native_net(cfg, state, dev, precision)
     with torch.no_grad():
         y = net(x.to(dev))
-    assert rel_max(y, d["y"]) <= NET_TOL
+    assert_net_close(y, d["y"], NET_TOL)
 
 
 @pytest.mark.parametrize("kw", [
@@ -318,7 +318,7 @@ def test_config_variants_vs_oracle(dev, kw, precision):
     state = init_state(cfg, seed=3)
     x = torch.randn(2, 5, 16, 32, generator=torch.Generator().manual_seed(9))
     y, ref32, ref64, _ = _oracle_and_native(cfg, state, x, dev, precision)
-    assert rel_max(y, ref64) <= NET_TOL
+    assert_net_close(y, ref64, NET_TOL)
 
 
 def test_block_taps_vs_oracle(dev, precision):
@@ -333,7 +333,7 @@ def test_block_taps_vs_oracle(dev, precision):
     ref, rtaps = SFNOOracle(cfg, state, dtype=torch.float64).forward(x, return_blocks=True)
     for i, rt in enumerate(rtaps):
         assert rel_max(taps[i + 1], rt) <= NET_TOL, f"block {i}"
-    assert rel_max(y, ref) <= NET_TOL
+    assert_net_close(y, ref, NET_TOL)
 
 
 @pytest.mark.parametrize("offset", [0.0, 4.0])
@@ -360,7 +360,7 @@ def test_packed_fused_path_vs_oracle(dev, precision, offset):
     ref, rtaps = SFNOOracle(cfg, state, dtype=torch.float64).forward(x, return_blocks=True)
     for i, rt in enumerate(rtaps):
         assert rel_max(taps[i + 1], rt) <= NET_TOL, f"block {i}: {rel_max(taps[i + 1], rt)}"
-    assert rel_max(y, ref) <= NET_TOL
+    assert_net_close(y, ref, NET_TOL)
 
 
 @pytest.mark.parametrize("kw", [
@@ -383,7 +383,7 @@ def test_packed_path_config_variants(dev, kw):
     with torch.no_grad():
         y = net(x.to(dev))
     ref = SFNOOracle(cfg, state, dtype=torch.float64).forward(x)
-    assert rel_max(y, ref) <= NET_TOL, rel_max(y, ref)
+    assert_net_close(y, ref, NET_TOL)
 
 
 def test_corrector_and_ocean_on_device(dev):
@@ -461,9 +461,9 @@ def test_noise_conditioned_sfno_vs_reference(dev, name, precision):
         y = net(case["x"].to(dev), noise=noise.to(dev))
         y2 = net(case["x"].to(dev), noise=noise.to(dev))
     assert torch.equal(y, y2)
-    assert rel_max(y, case["y"]) <= NET_TOL
+    assert_net_close(y, case["y"], NET_TOL)
     ref64 = CSFNOOracle(cfg, case["state"], dtype=torch.float64).forward(case["x"], noise=noise)
-    assert rel_max(y, ref64) <= NET_TOL
+    assert_net_close(y, ref64, NET_TOL)
     with torch.no_grad():                                         # own noise draw: runs, finite, differs per call
         a, b = net(case["x"].to(dev)), net(case["x"].to(dev))
     assert torch.isfinite(a).all() and not torch.equal(a, b)
@@ -496,7 +496,7 @@ def test_noise_conditioned_sfno_wide_vs_oracle(dev, embed, noise_dim, groups):
     with torch.no_grad():
         y = net(x.to(dev), noise=noise.to(dev))
     ref64 = CSFNOOracle(cfg, state, dtype=torch.float64).forward(x, noise=noise)
-    assert rel_max(y, ref64) <= NET_TOL, rel_max(y, ref64)
+    assert_net_close(y, ref64, NET_TOL)
 
 
 @pytest.mark.parametrize("name", ["labels3_pos4", "labels3_embed2_pos2_isotropic", "labels2_nopos"])
@@ -523,9 +523,9 @@ def test_noise_conditioned_sfno_with_labels_and_positional_context(dev, name, pr
     labels = case["labels"].to(dev)
     with torch.no_grad():
         y = net(case["x"].to(dev), labels=labels, noise=noise.to(dev))
-    assert rel_max(y, case["y"]) <= NET_TOL, rel_max(y, case["y"])
+    assert_net_close(y, case["y"], NET_TOL)
     ref64 = CSFNOOracle(cfg, case["state"], dtype=torch.float64).forward(case["x"], noise=noise, labels=case["labels"])
-    assert rel_max(y, ref64) <= NET_TOL
+    assert_net_close(y, ref64, NET_TOL)
     with torch.no_grad():                                         # through the registry wrapper, columns in another order
         perm = list(reversed(range(len(case["all_labels"]))))
         bl = BatchLabels(labels[:, perm], [case["all_labels"][i] for i in perm])
@@ -615,7 +615,7 @@ def test_noise_conditioned_sfno_reference_held_checkpoint_golden(dev, precision)
     with torch.no_grad():
         y = net(c["x"].to(dev), labels=c["label_vector"].to(dev), noise=c["noise"].to(dev))
     torch.testing.assert_close(y.cpu(), c["y"])
-    assert rel_max(y, c["y"]) <= NET_TOL
+    assert_net_close(y, c["y"], NET_TOL)
 
 
 @pytest.mark.parametrize("name", ["csfno_block", "csfno_block_8_groups"])
@@ -639,7 +639,7 @@ def test_noise_conditioned_sfno_reference_held_block_goldens(dev, name, precisio
         y = net(c["x"].to(dev), labels=c["label_vector"].to(dev), noise=c["noise"].to(dev))
     block = (y.cpu().double() - csfno_block_norm0(c)).float()
     torch.testing.assert_close(block, c["y"])
-    assert rel_max(block, c["y"]) <= NET_TOL
+    assert_net_close(block, c["y"], NET_TOL)
 
 
 def test_noise_conditioned_sfno_errors(dev):
@@ -679,7 +679,7 @@ def test_quarter_degree_grid(dev):
         net = build_native_net(cfg, st, dev, prec)
         with torch.no_grad():
             out = net(xin.to(dev))
-        assert rel_max(out, ref) <= NET_TOL, prec
+        assert_net_close(out, ref, NET_TOL)
 
 
 def test_graph_replay_matches_eager(dev, precision):
@@ -718,7 +718,7 @@ def test_f16x3_dynamic_range(dev, scale):
         y = net(x.to(dev))
     ref = SFNOOracle(cfg, state, dtype=torch.float64)(x)
     assert torch.isfinite(y).all()
-    assert rel_max(y, ref) <= NET_TOL
+    assert_net_close(y, ref, NET_TOL)
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "fp32"])
@@ -738,7 +738,7 @@ def test_shrinking_batch_after_large_magnitudes(dev, prec):
         yb = net(big.to(dev))
         ys = net(small.to(dev))
     assert torch.isfinite(yb).all() and torch.isfinite(ys).all()
-    assert rel_max(ys, SFNOOracle(cfg, state, dtype=torch.float64)(small)) <= NET_TOL
+    assert_net_close(ys, SFNOOracle(cfg, state, dtype=torch.float64)(small), NET_TOL)
     if prec == "f16x3":
         import ace_amd
         f = ace_amd.RealSHT(24, 48, 24, 25, "legendre-gauss", precision="f16x3").to(dev)
@@ -1268,7 +1268,7 @@ def test_healpix_unet_vs_reference(dev, name):
         y2 = net(g["x"].to(dev))
     assert y.shape == g["y"].shape
     assert torch.equal(y, y2)
-    assert rel_max(y, g["y"]) <= NET_TOL, rel_max(y, g["y"])
+    assert_net_close(y, g["y"], NET_TOL)
 
 
 def test_healpix_isolatitude_padding_and_unet_vs_reference(dev):
@@ -1299,7 +1299,7 @@ def test_healpix_isolatitude_padding_and_unet_vs_reference(dev):
     net.load_state_dict(g["state_dict"], strict=True)
     with torch.no_grad():
         out = net(g["x"].to(dev))
-    assert rel_max(out, g["y"]) <= NET_TOL, rel_max(out, g["y"])
+    assert_net_close(out, g["y"], NET_TOL)
 
 
 def test_healpix_interpolate_upsample_unet_vs_reference(dev):
@@ -1314,7 +1314,7 @@ def test_healpix_interpolate_upsample_unet_vs_reference(dev):
     net.load_state_dict(g["state_dict"], strict=True)
     with torch.no_grad():
         y = net(g["x"].to(dev))
-    assert rel_max(y, g["y"]) <= NET_TOL, rel_max(y, g["y"])
+    assert_net_close(y, g["y"], NET_TOL)
     with pytest.raises(NotImplementedError):
         dec = dict(case["config"]["decoder"])
         dec["up_sampling_block"] = {"block_type": "Interpolate", "upsample_mode": "bilinear"}
@@ -1334,7 +1334,7 @@ def test_healpix_symmetric_convnext_unet_vs_reference(dev):
     with torch.no_grad():
         y = net(g["x"].to(dev))
         assert torch.equal(y, net(g["x"].to(dev)))
-    assert rel_max(y, g["y"]) <= NET_TOL, rel_max(y, g["y"])
+    assert_net_close(y, g["y"], NET_TOL)
 
 
 @pytest.mark.parametrize("nside,cin,cin2,cout,k,dil,act,cap", [(8, 12, 0, 24, 3, 1, 1, 10.0), (8, 5, 6, 136, 3, 2, 1, 0.7), (16, 16, 0, 20, 3, 4, 0, float("inf")),
@@ -1489,7 +1489,7 @@ def test_healpix_forward_captured_in_a_graph(dev):
     with torch.no_grad():
         y = cap(x).clone()
         assert torch.equal(y, net(x))
-        assert rel_max(y, g["y"]) <= NET_TOL
+        assert_net_close(y, g["y"], NET_TOL)
         x2 = torch.randn_like(x) * 2.0 + 0.5                  # another range: the bound slots are recomputed inside the graph
         assert torch.equal(cap(x2), net(x2))
         assert torch.equal(cap(x), y)
@@ -1516,7 +1516,7 @@ def test_healpix_weight_update_is_seen(dev):
             out_conv[0].bias.mul_(2.0)
         y1 = net(x)
     assert rel_max(y1, 2.0 * y0) <= 1e-6
-    assert rel_max(y0, g["y"]) <= NET_TOL
+    assert_net_close(y0, g["y"], NET_TOL)
 
 
 def test_healpix_stepper_rollout(dev):

@@ -16,7 +16,7 @@ import torch
 import ace_amd
 from ace_amd.healpix import DealiasedDownsample, Hpx, SmoothedInterpolateConv, _RT
 from _fake_hpx import fake_hpx
-from _util import load_golden, rel_max
+from _util import assert_net_close, load_golden, rel_max
 
 NET_TOL = 1e-5
 UNETS = [("gen_healpix.pt", "convnext_avgpool_tconv"), ("gen_healpix.pt", "basic_maxpool"),
@@ -56,7 +56,7 @@ def test_unet_host_logic_on_the_emulated_operators(file, name, packed, monkeypat
     with fake_hpx() as fake, torch.no_grad():
         y = net._run(g["x"])
     assert y.shape == g["y"].shape
-    assert rel_max(y, g["y"]) <= NET_TOL, rel_max(y, g["y"])
+    assert_net_close(y, g["y"], NET_TOL)
     assert ("pad_planes" in fake.calls) == packed and (packed or "pad" in fake.calls)     # (the resampler blocks keep their own ace_hpx_pad)
     assert any(c.startswith("conv") for c in fake.calls)
     if packed and "convnext" in name:       # 3 x 3 -> GELU -> 3 x 3 -> GELU -> 1 x 1: no activation between them exists in fp32, the skip
@@ -113,7 +113,7 @@ def test_resampler_unets_vs_reference(name):
     with torch.no_grad():
         y = net(g["x"].to("cuda"))
         assert torch.equal(y, net(g["x"].to("cuda")))
-    assert rel_max(y, g["y"]) <= NET_TOL, rel_max(y, g["y"])
+    assert_net_close(y, g["y"], NET_TOL)
 
 
 @pytest.mark.gpu

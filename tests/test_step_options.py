@@ -205,3 +205,23 @@ def test_stepper_with_multi_call_and_secondary_decoder_on_the_device():
     assert set(eng_out) == set(out)
     for k in eng_out:
         assert rel_max(eng_out[k], out[k]) <= 5e-6, k
+
+
+def test_rollout_engine_refuses_secondary_diagnostics_the_hooks_touch():
+    """a secondary-decoder diagnostic that the corrector clamps (force_positive_names) would skip that hook in the engine's
+    unpack-in-place layout: refused at construction with a pointer to Stepper.predict.  (The ocean's surface temperature cannot
+    clash: it has to be an input and an output of the step, which a secondary diagnostic may not be.)"""
+    from ace_amd.rollout import RolloutEngine
+    from ace_amd.step import NormalizationConfig
+    from _fake_sfno import fake_sfno
+    names = ["f", "p", "q"]
+    norm = NormalizationConfig(means={k: 0.0 for k in names}, stds={k: 1.0 for k in names})
+    cfg = ace_amd.SingleModuleStepConfig(
+        builder=ace_amd.ModuleSelector(type="SphericalFourierNeuralOperatorNet", config={"embed_dim": 4, "num_layers": 1}),
+        in_names=["f", "p"], out_names=["p"], normalization=norm,
+        secondary_decoder={"secondary_diagnostic_names": ["q"], "network": {"type": "MLP", "config": {"hidden_dim": 4, "depth": 2}}},
+        corrector={"force_positive_names": ["q"]})
+    with fake_sfno():
+        stepper = ace_amd.Stepper.from_config(cfg, ace_amd.DatasetInfo((4, 8)), device="cpu")
+        with pytest.raises(NotImplementedError, match="q"):
+            RolloutEngine(stepper, batch=1, n_forward_steps=2, graph=None)
