@@ -59,6 +59,7 @@ Switches read_switches() {
     sw.no_enc_pk = on("ACE_NO_ENC_PK");
     sw.no_cln_mfma = on("ACE_NO_CLN_MFMA");
     sw.no_cln_planes = on("ACE_NO_CLN_PLANES");
+    sw.dense_grouped_filter = on("ACE_DENSE_GROUPED_FILTER");
     if (const char* e = std::getenv("ACE_CONV_WL")) sw.conv_wl = !(e[0] == '0' && !e[1]);
     if (const char* e = std::getenv("ACE_PLANES_STREAM")) sw.planes_stream = !(e[0] == '0' && !e[1]);
     if (const char* e = std::getenv("ACE_CONV_WS")) {
@@ -704,6 +705,7 @@ struct ace_sfno {
     std::vector<DevBuf> wx_hi, wx_lo;  // per block: the same operand k-packed as fp16 hi/lo planes (f16x3 engine)
     std::vector<float> wx_scale;
     std::vector<char> wx_compact;   // per block: wx_hi/lo hold the compact (Wr | Wi) form of Gemm4Args::cplx
+    std::vector<char> wx_native;    // per block: ... of a grouped filter with its diagonal blocks only (1 / G of the dense form)
     // workspace
     DevBuf h0, h1, Y, T, R, U, X, D, E, stats;
     DevBuf P;  // f16x3: a C-channel activation as P-format fp16 hi/lo planes (input of the packed-operand GEMM)
@@ -853,12 +855,16 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     n->wx_lo.resize(c.num_layers);
     n->wx_scale.assign(c.num_layers, 1.f);
     n->wx_compact.assign(c.num_layers, 0);
+    n->wx_native.assign(c.num_layers, 0);
     for (int i = 0; i < c.num_layers; ++i) {
         // blocks whose input/output grid differs from the internal one keep D in fp32 (residual round trip) and use
         // the expanded operand
         const bool mixed = (n->plan_data != n->plan_lg.get()) && (i == 0 || i == c.num_layers - 1);
         n->wx_compact[i] = (!n->sw.no_pk_sht && c.precision == 1 && c.operator_type == 1 && n->C % 128 == 0 && !mixed &&
                             ((long)n->Bmax * 2 * n->C) % 4 == 0) ? 1 : 0;
+        // grouped filter of the NoiseConditionedSFNO kept as the reference keeps it: the strip kernel is then the ONLY reader
+        n->wx_native[i] = (n->wx_compact[i] && cln && c.filter_num_groups > 1 && !n->sw.dense_grouped_filter && !n->sw.no_dhconv_strip &&
+                           dhconv_native_groups_ok(n->C, c.filter_num_groups)) ? 1 : 0;
     }
     const size_t act = (size_t)n->Bmax * C * HW;
     // + slack rows read (never used) by the strip Legendre kernels past the last contraction row
@@ -968,7 +974,13 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
         return fail(ACE_ERR_INVALID, std::string("size mismatch for ") + name + ": expected " +
                                          std::to_string(expect) + " elements, got " + std::to_string(numel));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (w.ext_numel) {   // grouped csfno filter: (G, L, C/G, C/G, 2) -> dense (Cin, Cout, L, 2), then as any dhconv weight
+    const bool native_groups = w.ext_numel && w.is_filter && w.block >= 0 && n->wx_native[w.block];
+    if (native_groups) {   // grouped csfno filter kept AS IT IS, (G, L, C/G, C/G, 2): fp32 copy and packed planes hold the diagonal blocks only
+        if (!w.buf.p) HIP_TRY(w.buf.alloc((size_t)w.ext_numel, false));
+        HIP_TRY(hipMemcpyAsync(w.buf.p, src, sizeof(float) * w.ext_numel, hipMemcpyDeviceToDevice, s));
+        src = nullptr;
+        numel = w.ext_numel;
+    } else if (w.ext_numel) {   // ... or (shapes the strip kernel does not read that way) -> dense (Cin, Cout, L, 2), then as any dhconv weight
         if (!w.buf.p) HIP_TRY(w.buf.alloc((size_t)w.numel, false));
         HIP_TRY(launch_csfno_weight_to_dense(src, w.buf.p, n->C, n->cfg.filter_num_groups, n->L, s));
         src = nullptr;
@@ -998,10 +1010,13 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
             if (mx > 0.f && std::isfinite(mx)) { (void)std::frexp(mx, &e); e = 10 - e; }
             n->wx_scale[w.block] = std::ldexp(1.0f, e);
             const bool compact = n->wx_compact[w.block] != 0;
-            const size_t halves = compact ? cnt / 2 : cnt;
+            const size_t halves = native_groups ? cnt / 2 / n->cfg.filter_num_groups : (compact ? cnt / 2 : cnt);
             if (!n->wx_hi[w.block].p) HIP_TRY(n->wx_hi[w.block].alloc((halves + 1) / 2, false));
             if (!n->wx_lo[w.block].p) HIP_TRY(n->wx_lo[w.block].alloc((halves + 1) / 2, false));
-            if (compact)
+            if (native_groups)
+                HIP_TRY(launch_pack_dhconv_f16g(w.buf.p, n->wx_hi[w.block].p, n->wx_lo[w.block].p, n->C, n->cfg.filter_num_groups, n->L,
+                                                n->wx_scale[w.block], s));
+            else if (compact)
                 HIP_TRY(launch_pack_dhconv_f16c(w.buf.p, n->wx_hi[w.block].p, n->wx_lo[w.block].p, n->C, n->C, n->L,
                                                 n->wx_scale[w.block], s));
             else
@@ -1499,7 +1514,10 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 ds.E = n->E.p; ds.sE = (long)n->Mm * N2; ds.omax = emax;
                 ds.C = C; ds.L = n->L; ds.Mrows = n->Mm * B; ds.trimul = B;
                 ds.groups = cln ? c.filter_num_groups : 1;
+                if (n->wx_native[i]) { ds.kstore = C / ds.groups; ds.sW = (long)2 * ds.kstore * C; }
             }
+            if (n->wx_native[i] && !(dplanes && dhconv_strip_eligible(ds)))
+                return fail(ACE_ERR_STATE, "grouped filter stored as diagonal blocks, but the strip kernel cannot run this launch");
             if (dplanes && n->wx_compact[i] && !n->sw.no_dhconv_strip && dhconv_strip_eligible(ds)) {
                 HIP_TRY(launch_dhconv_strip(ds, s));
             } else if (dplanes) {

@@ -61,6 +61,13 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
     const int tb = skip ? ((128 * j) / kspan) * (kspan / 32) : 0;   // first stage
     const int nstages = kspan / 32;               // stage t = k in [32 (tb + t), + 32) of BOTH halves of the row (D_re | D_im)
     const int oc = 128 * j + 32 * wave;           // this wave's 32 output channels (real and imaginary part)
+    // Diagonal blocks only (kstore = C / G rows per column, the reference's grouped parameter as it is): row kk of column o is
+    // input channel (o / cg) cg + kk.  The stages outside this WAVE's group (cg < 128: the workgroup's 128 columns span 128 / cg
+    // groups) multiply exact zeros in the dense form: their fragments are fetched from a clamped address (uniform operation
+    // counts for the counted waits) and their MFMAs skipped (wave-uniform) - no bit changes, half / a quarter of the matrix work.
+    const int kstore = p.kstore > 0 ? p.kstore : C;
+    const bool native = kstore != C;
+    const int kbase = native ? (oc / cg) * cg : 0;
 
     const unsigned raw_a = slot_load(p.amax + lane);
 
@@ -96,7 +103,9 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
-                const long off = (long)blk * C * C + ((long)(4 * tt + 2 * c + g) * C + oc + i) * 8;
+                int kg = 4 * tt + 2 * c + g - kbase / 8;          // k-group relative to this wave's first stored row
+                if (native) kg = kg < 0 ? 0 : (kg >= kstore / 8 ? kstore / 8 - 1 : kg);
+                const long off = (long)blk * kstore * C + ((long)kg * C + oc + i) * 8;
                 gload16(b.h[c][blk], Wh + off);
                 gload16(b.l[c][blk], Wl + off);
             }
@@ -136,6 +145,8 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
         wait_b(b, std::integral_constant<int, 2 * (NA + 8)>{});
         __builtin_amdgcn_s_barrier();             // every wave's pieces of stage t landed
         const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (t % NSTG) * STAGE);
+        const int k0 = 32 * (tb + t);
+        const bool live = !native || (k0 >= kbase && k0 < kbase + cg);   // wave-uniform: this stage's k range lies in this wave's group
         // A fragment of (strip s, slice sl), k16 step c: rows 32 s + i (row piece i >> 4), logical slot 2 c + g, physical ^ key
         const unsigned la = sl + ((i >> 4) * 2) * 1024 + (i & 15) * 64;
         // four phases (c, slice) = (0, re) (0, im) (1, re) (1, im); the fragments of phase ph + 1 are requested strip by strip
@@ -156,7 +167,8 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
                 Frag& f = (ph & 1) ? fb[s] : fa[s];
                 constexpr int newer = ph < 3 ? 2 * (NS - 1) : 2 * (NS - 1 - s);
                 asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.h), "+v"(f.l) : "n"(newer));
-                if constexpr (!im) {   // D_re: real += D_re Wr, imaginary += D_re Wi
+                if (!live) {
+                } else if constexpr (!im) {   // D_re: real += D_re Wr, imaginary += D_re Wi
                     acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l, b.h[c][0], acc[s][0], 0, 0, 0);
                     acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l, b.h[c][1], acc[s][1], 0, 0, 0);
                     acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h, b.l[c][0], acc[s][0], 0, 0, 0);
@@ -266,7 +278,14 @@ __global__ __launch_bounds__(256, 1) void dhconv_strip_kernel(DhconvStripArgs p)
 
 }  // namespace
 
+bool dhconv_native_groups_ok(int C, int groups) {
+    if (groups <= 1 || C % groups != 0 || C % 128 != 0) return false;
+    const int cg = C / groups;
+    return cg % 32 == 0 && (cg % 128 == 0 || 128 % cg == 0);
+}
+
 bool dhconv_strip_eligible(const DhconvStripArgs& a) {
+    if (a.kstore > 0 && a.kstore != a.C && !(a.groups > 1 && a.kstore == a.C / a.groups && dhconv_native_groups_ok(a.C, a.groups))) return false;
     return a.C % 128 == 0 && a.C >= 128 && a.groups >= 1 && a.C % a.groups == 0 && a.Mrows >= 1 && (a.Mrows + 191) / 192 <= 65535 && a.L >= 1 && a.Dhi && a.Dlo && a.Whi && a.Wlo && a.E && a.amax;
 }
 

@@ -21,6 +21,8 @@ struct Switches {
     int conv_ws_roles = 7;         // ACE_CONV_WS=skip,fc1,fc2|all|none: roles on conv_ws.hip (bit 0 inner skip, 1 fc1, 2 fc2)
     bool conv_wl = true;           // ACE_CONV_WL=0: fc1 on conv_ws.hip instead of conv_wl.hip (weights in LDS, unsynchronised waves)
     bool planes_stream = true;     // ACE_PLANES_STREAM=0: fc2 also writes the block output as fp32 (the residual stream round-trips twice)
+    bool dense_grouped_filter = false;   // ACE_DENSE_GROUPED_FILTER: a grouped (block-diagonal) csfno filter expanded to the dense (C x C) form (r04)
+                                         // instead of stored as the reference stores it, (G, L, C/G, C/G, 2) blocks only
 };
 Switches read_switches();
 
@@ -224,7 +226,12 @@ struct DhconvStripArgs {
     unsigned* omax = nullptr;
     int C = 0, L = 0, Mrows = 0, trimul = 1;                                      // rows of degree l: min((l + 1) * trimul, Mrows)
     int groups = 1;                                                               // block-diagonal filter (grouped csfno filter, s2convolutions.py:119-135): zero blocks are skipped
+    int kstore = 0;                                                               // rows (input channels) each Wr / Wi block holds per output column: 0 / C = dense form;
+                                                                                  // C / groups = ONLY the diagonal blocks (the reference's (G, L, C/G, C/G, 2) parameter):
+                                                                                  // [l][Wr|Wi][(C/G)/8][C][8], row index relative to the column's own group
 };
+bool dhconv_native_groups_ok(int C, int groups);   // can the strip kernel read the diagonal-blocks-only form?
+hipError_t launch_pack_dhconv_f16g(const float* w_grouped, void* hi, void* lo, int C, int G, int L, float scale, hipStream_t s);
 bool dhconv_strip_eligible(const DhconvStripArgs& a);
 hipError_t launch_dhconv_strip(const DhconvStripArgs& a, hipStream_t s);
 

@@ -1514,6 +1514,40 @@ hipError_t launch_pack_dhconv_f16c(const float* w, void* hi, void* lo, int Cin, 
     return hipGetLastError();
 }
 
+// the grouped csfno filter AS THE REFERENCE STORES IT, (G, L, C/G [out], C/G [in], 2) (conditional_sfno/s2convolutions.py:119-135, 229-240),
+// compact per l like the kernel above but with the diagonal blocks only: [l][Wr | Wi][kg < (C/G)/8][o < C][8], row kg * 8 + e = input
+// channel RELATIVE to the group of output column o.  1 / G of the dense form's memory and upload; csrc/dhconv_strip.hip reads it.
+__global__ void pack_dhconv_f16g_kernel(const float* __restrict__ w, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                        int C, int G, int L, float scale) {
+    const int cg = C / G;
+    const long total = (long)L * 2 * cg * C;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int e = t % 8;
+        long q = t / 8;
+        const int o = q % C;
+        q /= C;
+        const int kg = q % (cg / 8);
+        q /= (cg / 8);
+        const int blk = q % 2;
+        const int l = q / 2;
+        const int grp = o / cg, orel = o % cg, irel = kg * 8 + e;
+        const float2 wv = *reinterpret_cast<const float2*>(w + ((((long)grp * L + l) * cg + orel) * cg + irel) * 2);
+        const float v = __builtin_amdgcn_fmed3f((blk == 0 ? wv.x : wv.y) * scale, -65504.f, 65504.f);
+        const _Float16 h = (_Float16)v;
+        hi[t] = h;
+        lo[t] = (_Float16)(v - (float)h);
+    }
+}
+hipError_t launch_pack_dhconv_f16g(const float* w, void* hi, void* lo, int C, int G, int L, float scale, hipStream_t s) {
+    if (G < 1 || C % G != 0 || (C / G) % 8 != 0) return hipErrorInvalidValue;
+    const long total = (long)L * 2 * (C / G) * C;
+    long gsz = (total + 255) / 256;
+    if (gsz > 32768) gsz = 32768;
+    hipLaunchKernelGGL(pack_dhconv_f16g_kernel, dim3((unsigned)gsz), dim3(256), 0, s, w, static_cast<_Float16*>(hi),
+                       static_cast<_Float16*>(lo), C, G, L, scale);
+    return hipGetLastError();
+}
+
 // f16x3 with the roles mirrored: A = fp32 activations (split on the fly, dynamic scale from amax), B = packed static
 // operand (planes Bhi/Blo, [K/8][ldn][8] per batch with batch stride sB_halves).  Requirements: K % 32 == 0, lda % 4 == 0,
 // A 16B aligned.  g.B / g.ldb are ignored (ldn and the plane pointers describe B).

@@ -469,7 +469,8 @@ def test_noise_conditioned_sfno_vs_reference(dev, name, precision):
     assert torch.isfinite(a).all() and not torch.equal(a, b)
 
 
-@pytest.mark.parametrize("embed,noise_dim,groups", [(128, 8, 1), (256, 8, 1), (512, 33, 1), (256, 8, 4), (256, 8, 2), (512, 8, 2), (384, 8, 2)])
+@pytest.mark.parametrize("embed,noise_dim,groups", [(128, 8, 1), (256, 8, 1), (512, 33, 1), (256, 8, 4), (256, 8, 2), (512, 8, 2), (384, 8, 2),
+                                                    (512, 8, 8), (256, 8, 8)])
 def test_noise_conditioned_sfno_wide_vs_oracle(dev, embed, noise_dim, groups):
     """Channel widths at which the noise-conditioned net's fc1 runs on csrc/conv_wl.hip (weights in LDS; K = 128 / 256 here,
     512 at the ERA5 configuration), the other convolutions on the packed-operand engine and - C % 256 == 0 - the conditional
@@ -497,6 +498,31 @@ def test_noise_conditioned_sfno_wide_vs_oracle(dev, embed, noise_dim, groups):
         y = net(x.to(dev), noise=noise.to(dev))
     ref64 = CSFNOOracle(cfg, state, dtype=torch.float64).forward(x, noise=noise)
     assert_net_close(y, ref64, NET_TOL)
+    if groups > 1:
+        # The grouped filter is stored as the reference stores it - (G, L, C/G, C/G, 2), diagonal blocks only - wherever the strip
+        # kernel reads that form (C / G a multiple of 32 that divides or is a multiple of 128); ACE_DENSE_GROUPED_FILTER=1 expands
+        # it to the dense (C x C) form of round 4.  Skipping exact zeros changes no bit; the memory is 1 / G.
+        import os
+        from ace_amd import _lib
+        native_bytes = _lib.lib().ace_sfno_workspace_size(net._native, 2)
+        os.environ["ACE_DENSE_GROUPED_FILTER"] = "1"
+        try:
+            dense = ace_amd.ModuleSelector(type="NoiseConditionedSFNO", config=dict(kwargs)).build(5, 4, ace_amd.DatasetInfo((16, 32))).torch_module
+            dense.load_state_dict(state, strict=True)
+            dense.to(dev).set_precision("f16x3")
+            with torch.no_grad():
+                yd = dense(x.to(dev), noise=noise.to(dev))
+            dense_bytes = _lib.lib().ace_sfno_workspace_size(dense._native, 2)
+        finally:
+            del os.environ["ACE_DENSE_GROUPED_FILTER"]
+        assert torch.equal(y, yd)
+        cg = embed // groups
+        if cg % 32 == 0 and (cg % 128 == 0 or 128 % cg == 0):
+            L = 16
+            saved = 2 * (embed * embed * L * 2 * 4) * (1 - 1 / groups) * 2          # 2 layers x (fp32 copy + hi / lo planes) x the off-diagonal share
+            assert dense_bytes - native_bytes >= 0.95 * saved, (dense_bytes, native_bytes, saved)
+        else:
+            assert dense_bytes == native_bytes
 
 
 @pytest.mark.parametrize("name", ["labels3_pos4", "labels3_embed2_pos2_isotropic", "labels2_nopos"])

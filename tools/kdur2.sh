@@ -5,7 +5,7 @@ tag=$1; lib=$2
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/kdur_$tag; rm -rf /tmp/p_$tag; mkdir -p gpurun_out
 [ -n "$lib" ] && export ACE_SFNO_LIB=$lib ACE_LIB=$lib
-timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/p_$tag -o o -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --precision f16x3 $BENCH_EXTRA > /tmp/p_$tag.json 2>/tmp/p_$tag.err
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/p_$tag -o o -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-legs --precision f16x3 $BENCH_EXTRA > /tmp/p_$tag.json 2>/tmp/p_$tag.err
 python - "$tag" > $out.txt 2>&1 <<PY
 import csv, collections, json, sys, glob
 tag = sys.argv[1]
