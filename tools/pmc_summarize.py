@@ -17,13 +17,18 @@ def short(name):
 
 def one(path):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(dict)
     for r in csv.DictReader(open(path)):
         k = short(r["Kernel_Name"]) + " g" + r.get("Grid_Size", r.get("Grid_Size_X", "?"))
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if r.get("Start_Timestamp") and r.get("End_Timestamp"):   # the launch's own duration IN THIS PASS (one row per counter: dedupe)
+            dur[k][r.get("Dispatch_Id", len(dur[k]))] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     out = {}
     for k, d in acc.items():
         out[k] = {c: sum(v) / len(v) for c, v in d.items()}
         out[k]["_dispatches"] = max(len(v) for v in d.values())
+        if dur[k]:
+            out[k]["_us"] = sum(dur[k].values()) / len(dur[k])
     return out
 
 
@@ -33,6 +38,8 @@ def merge(d):
         if f.endswith(".json"):
             try:
                 for k, v in json.load(open(os.path.join(d, f))).items():
+                    if "_us" in v:   # mean launch duration in that pass: effective clock = that pass's GRBM_GUI_ACTIVE / 8 / this
+                        v["_us_" + f[:-5]] = v.pop("_us")
                     tot[k].update(v)
             except ValueError:
                 pass
