@@ -13,7 +13,8 @@ from .sht import InverseRealSHT, RealSHT  # noqa: F401
 from .sfno import SphericalFourierNeuralOperatorBuilder, SphericalFourierNeuralOperatorNet  # noqa: F401
 from .packer import Packer  # noqa: F401
 from .normalizer import StandardNormalizer  # noqa: F401
-from .step import SecondaryDecoderConfig, SingleModuleStep, SingleModuleStepConfig, StepArgs, StepOutput  # noqa: F401
+from .step import SecondaryDecoderConfig, SingleModuleStep, SingleModuleStepConfig, StepArgs, StepOutput, StepperState  # noqa: F401
+from .rand import RandomState, randn, randn_like, use_cpu_randn, use_generator  # noqa: F401
 from .mlp import ColumnMLP, MLPConfig  # noqa: F401
 from .checkpoint import LoadedStepper, StepperOverrideConfig, apply_stepper_override, load_stepper  # noqa: F401
 from .csfno import NoiseConditionedSFNO, NoiseConditionedSFNOBuilder  # noqa: F401
