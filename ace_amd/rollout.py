@@ -59,8 +59,9 @@ class RolloutEngine:
         # network call of a window, as Stepper.step activates it (single_module.py:1063-1068).  The draw happens on the host,
         # outside any captured region, and reaches the device as a plain copy.
         self._random_state = None
-        if self._conditioned and graph == "window":
-            raise NotImplementedError("graph='window' with a noise-conditioned net: the noise draw is not captured")
+        # graph="window" with a noise-conditioned net: the draws of the whole window are made on the host BEFORE the replay, in step
+        # order (the same generator consumption as the eager loop), into a static (T, B, cond, H, W) buffer the captured steps read
+        self._cond_window = None
         self.B, self.T = batch, n_forward_steps
         self.H, self.W = step._img_shape
         self.HW = self.H * self.W
@@ -215,7 +216,10 @@ class RolloutEngine:
         if self._fill_in:
             torch.nan_to_num_(self.x, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
         if self._conditioned:   # NoiseConditionedSFNO: fresh conditioning noise every step (stochastic_sfno.py:128-146), merged
-            noise = self.net.conditioning_field(self.B, self.device, labels=self._labels)   # with the label / positional context
+            if self.graph_mode == "window":      # drawn for the whole window by _draw_window_conditioning(), static address per step
+                noise = self._cond_window[s]
+            else:
+                noise = self.net.conditioning_field(self.B, self.device, labels=self._labels)   # with the label / positional context
             _lib.check(L.ace_sfno_forward_conditioned(self.net._native, self.x.data_ptr(), noise.data_ptr(), self.y.data_ptr(),
                                                       self.B, stream))
         else:
@@ -356,10 +360,21 @@ class RolloutEngine:
         """``ace_amd.rand.RandomState`` (or None: the global RNG) the conditioning noise of the following windows is drawn from."""
         self._random_state = random_state
 
+    def _draw_window_conditioning(self):
+        """graph="window": the conditioning fields of the T steps, drawn now (through fme.core.rand's contract: the active CPU
+        generator of a seeded rollout, else the device RNG) in step order and copied into the static buffer the captured steps read"""
+        for s in range(self.T):
+            field = self.net.conditioning_field(self.B, self.device, labels=self._labels)
+            if self._cond_window is None:
+                self._cond_window = torch.empty(self.T, *field.shape, dtype=torch.float32, device=self.device)
+            self._cond_window[s].copy_(field)
+
     def run_window(self):
         """Enqueue the T steps of the window on the current stream (no host synchronisation)."""
         from .rand import use_generator
         with use_generator(None if self._random_state is None else self._random_state.generator):
+            if self._conditioned and self.graph_mode == "window":
+                self._draw_window_conditioning()
             self._run_window()
 
     def _run_window(self):

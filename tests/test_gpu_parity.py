@@ -1107,14 +1107,15 @@ def test_reference_checkpoint_rollout_matches_reference_stepper(dev, precision, 
         assert torch.equal(v[:, 0], out[k][:, -1])
 
 
-@pytest.mark.parametrize("engine", ["stepper", None, "step"])
+@pytest.mark.parametrize("engine", ["stepper", None, "step", "window"])
 @pytest.mark.parametrize("case", ["isotropic", "gaussian_groups2"])
 def test_seeded_stochastic_rollout_matches_reference_stepper(dev, precision, case, engine):
     """The reference's RNG contract (fme/core/rand.py:39-104, fme/ace/stepper/single_module.py:1063-1068):
     a NoiseConditionedSFNO stepper rolled 3 steps from ``StepperState(random_state=RandomState.from_seed(seed))`` reproduces the
     REAL reference stepper's seeded rollout (tests/golden/gen_rng.pt: isotropic noise through the inverse SHT, and gaussian noise
     with a grouped filter) - the draw comes from the rollout's CPU generator whatever the device's global RNG holds, through
-    Stepper.predict and through the static-buffer RolloutEngine (eager / per-step hipGraph).  Bar: 1e-5 of the field maximum
+    Stepper.predict and through the static-buffer RolloutEngine (eager / per-step hipGraph / the whole window captured, its
+    conditioning fields drawn in front of the replay into a static buffer).  Bar: 1e-5 of the field maximum
     per step (carried through s + 1 networks), per channel."""
     import ace_amd
     from ace_amd.rand import RandomState
