@@ -546,7 +546,10 @@ def main(argv=None, engine_factory=None, device=None):
                                    "ms_per_step": round(runs[m]["dt"] / K * 1e3, 4), "stages": runs[m]["stages"]}
     if engine_factory is None and world == 1 and not args.no_extra_legs and not args.zero_data:
         stepper.modules[0].set_precision(modes[0])
-        legs = extra_legs(stepper, forcing, prog, dist, dev, K, rank, args.hooks)
+        try:
+            legs = extra_legs(stepper, forcing, prog, dist, dev, K, rank, args.hooks)
+        except Exception as e:   # the headline line must not depend on an extra leg
+            legs = {"extra_legs_error": f"{type(e).__name__}: {e}"}
         if result is not None:
             result.update(legs)
     dist.barrier()
