@@ -37,13 +37,15 @@ class Distributed:
         self._owns_group = False
         if self.world_size > 1 and not dist.is_initialized():
             use_gpu = torch.cuda.is_available() and os.environ.get("FME_FORCE_CPU", "0") != "1"
-            backend = backend or ("nccl" if use_gpu else "gloo")
+            # ACE_DIST_BACKEND=gloo: the N > 1 path on device tensors without RCCL - a pre-flight of bench.py --gpus N on a box with
+            # fewer devices than ranks (ranks then share devices: local rank modulo the device count; RCCL refuses that)
+            backend = backend or os.environ.get("ACE_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
             if use_gpu:
-                torch.cuda.set_device(self.local_rank)
+                torch.cuda.set_device(self.local_rank % torch.cuda.device_count())
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             kw = {}
-            if use_gpu:
+            if use_gpu and backend == "nccl":
                 kw["device_id"] = torch.device("cuda", self.local_rank)
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size, **kw)
             self._owns_group = True

@@ -488,8 +488,12 @@ def main(argv=None, engine_factory=None, device=None):
         assert args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
     if engine_factory is None:
         assert torch.cuda.is_available(), "bench.py needs an MI355X"
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
+        ndev = torch.cuda.device_count()
+        if local_rank >= ndev and os.environ.get("ACE_DIST_BACKEND") != "gloo":
+            raise SystemExit(f"LOCAL_RANK {local_rank} but {ndev} device(s): one rank per GPU (ACE_DIST_BACKEND=gloo lets ranks share "
+                             "devices for a pre-flight of the N > 1 path without RCCL)")
+        torch.cuda.set_device(local_rank % ndev)
+        dev = torch.device("cuda", local_rank % ndev)
     else:
         dev = torch.device(device or "cpu")
     dist = Distributed.get_instance()
