@@ -10,6 +10,9 @@ import json
 import sys
 
 pmc = json.load(open(sys.argv[1]))
+print("# GRBM_GUI_ACTIVE covers the whole dispatch - a few microseconds of launch and drain outside the kernel's own start / end timestamps -")
+print("# so `clock` is an UPPER bound (the part's maximum is 2.4 GHz: values above it show the size of that margin, ~15 % at 40 us, ~3 % at 140 us)")
+print("# and `MFMA busy` (busy cycles / those cycles) a LOWER bound by the same margin.  tools/clock_probe.hip has the three clocks side by side.")
 print("%-52s %8s %9s %9s | %8s %9s %8s | %9s" % ("kernel (grid threads)", "us (pass)", "clock GHz", "MFMA busy", "issuing", "iss-stall", "parked", "wave life"))
 for k, v in pmc.items():
     if not isinstance(v, dict) or "GRBM_GUI_ACTIVE" not in v or "SQ_WAVE_CYCLES" not in v or "_us_sq1" not in v:
