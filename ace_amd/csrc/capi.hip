@@ -1064,7 +1064,9 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
             HIP_TRY(launch_pack_conv_frag(w.buf.p, w.pitch, w.rows, w.cols, 0, nullptr, 0.f, w.ascale, nullptr, w.frag0.p,
                                           0, 1, s));
         }
-        if ((is_skip || is_fc2 || is_enc2) && conv_ws_eligible(w.cols, w.rows, n->HW, is_skip ? 0 : 2, n->sw.conv_ws_roles)) {
+        // (the inner skip of a noise-conditioned net has no per-step weight fold and any K of conv_ws.hip: its mode 6)
+        const bool cln_skip = is_skip && n->cfg.normalization_layer == 2;
+        if ((is_skip || is_fc2 || is_enc2) && conv_ws_eligible(w.cols, w.rows, n->HW, (is_skip && !cln_skip) ? 0 : 2, n->sw.conv_ws_roles)) {
             if (!w.frag0.p) HIP_TRY(w.frag0.alloc((size_t)w.rows * w.cols, false));
             HIP_TRY(launch_pack_conv_frag(w.buf.p, w.pitch, w.rows, w.cols, 0, nullptr, 0.f, w.ascale, nullptr, w.frag0.p,
                                           0, 1, s));
@@ -1707,8 +1709,21 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             have_ph = have_hstats = false;
             const Weight& ws = *n->weights[n->index.at(p + "inner_skip.weight")];
             if (!n0_planes) ACE_TRY(pack_act(n, res, actB, C, ra, rb, skip_max, Ph, Pl, B, s));
-            ACE_TRY(conv_pk(n, ws, W(p + "inner_skip.bias"), Ph, Pl, C, skip_max, n->T.p, C, n->Y.p, actB, nullptr, nullptr,
-                            act, B, s, slot(sb + 4)));
+            const bool gelu0 = act == ACT_GELU || act == ACT_GELU_FAST;
+            if (cln && gelu0 && ws.frag0.p && (n->sw.conv_ws_roles & 1) && conv_ws_eligible(C, C, HW, 2, n->sw.conv_ws_roles | 4)) {
+                // weight-stationary kernel, mode 6: GELU(W . planes + bias + Y) -> fp32 T (the conditional norm that follows reads fp32)
+                ConvStripArgs k;
+                k.Xhi = Ph; k.Xlo = Pl; k.ldn = HW; k.sX = (long)C * HW; k.xslot = skip_max;
+                k.A = reinterpret_cast<const _Float16*>(ws.frag0.p); k.sA = 0; k.ascale = ws.ascale;
+                k.bias = W(p + "inner_skip.bias"); k.sbias = 0;
+                k.R = n->Y.p; k.sR = actB;
+                k.Cf = n->T.p; k.sCf = actB; k.omax = slot(sb + 4);
+                k.C = C; k.M = C; k.HW = (int)HW; k.nbatch = B; k.act = ACT_GELU;
+                HIP_TRY(launch_conv_ws(k, s));
+            } else {
+                ACE_TRY(conv_pk(n, ws, W(p + "inner_skip.bias"), Ph, Pl, C, skip_max, n->T.p, C, n->Y.p, actB, nullptr, nullptr,
+                                act, B, s, slot(sb + 4)));
+            }
         } else {
             if (ra && !skip_f16) ACE_TRY(fold(n, wskip, C, C, ra, rb, n->Wf0.p, n->bf0.p, B, s, &wskip));
             ACE_TRY(conv(n, wskip, res, actB, C, nullptr, 0, -1, n->T.p, C, n->Y.p, actB, nullptr, nullptr, act, B, s,
