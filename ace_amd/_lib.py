@@ -64,6 +64,7 @@ SIGNATURES = {
     "ace_sht_plan_create_ex": (c_int, [c_int, c_int, c_int, c_int, c_char_p, c_int, POINTER(c_void_p)]),
     "ace_sht_plan_destroy": (None, [c_void_p]),
     "ace_sht_plan_dims": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "ace_sht_plan_route": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "ace_sht_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ace_sht_inverse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ace_sht_tables_host": (c_int, [c_int, c_int, c_int, c_int, c_char_p, c_int, c_void_p]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "ace_sfno_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ace_sfno_forward_conditioned": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ace_sfno_forward_conditioned_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "ace_sfno_sht_route": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "ace_sfno_num_stages": (c_int, []),
     "ace_sfno_stage_name": (c_char_p, [c_int]),
     "ace_sfno_forward_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, POINTER(c_float), POINTER(c_int)]),

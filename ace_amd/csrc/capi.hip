@@ -128,7 +128,11 @@ struct ace_sht_plan {
     bool fold = false;
     DevBuf slots;   // standalone transforms in f16x3 mode: dynamic-range slots (max|X|, max|coefficients|)
     Switches sw;    // measurement switches, read when the plan was built
+    // which kernel family the last Legendre launch of each direction took (ace_sht_plan_route): 0 tile engine, 1 strip.hip,
+    // 2 strip_fold.hip, 3 strip_fold.hip big form (more than 96 folded latitudes); -1 = no launch yet
+    mutable int route[2] = {-1, -1};
 };
+static int fold_route(const LegStripArgs& f) { return legendre_fold_is_big(f) ? 3 : 2; }
 
 static float pow2_scale_for(const std::vector<float>& v) {  // puts max|v| in [2^9, 2^10)
     float mx = 0.f;
@@ -253,14 +257,17 @@ static int run_legendre_forward(const ace_sht_plan& pl, const float* X, float* D
             f.A = reinterpret_cast<const _Float16*>(pl.wt_ffrag.p); f.tile_off = reinterpret_cast<const int*>(pl.wt_foff.p);
             if (legendre_fold_eligible(f)) {
                 HIP_TRY(launch_legendre_fold(f, s));
+                pl.route[0] = fold_route(f);
                 return ACE_OK;
             }
         }
         if (pl.strip && legendre_strip_eligible(a)) {
             HIP_TRY(launch_legendre_strip(a, s));
+            pl.route[0] = 1;
             return ACE_OK;
         }
     }
+    pl.route[0] = 0;
     if (planes) {
         // D as fp16 hi/lo planes in D's own layout [l][m][n2] (the buffer holds two planes instead of one fp32 tensor):
         // the dhconv contracts over n2's channel index, so this IS the v4 engine's A operand.  dmax receives the bound.
@@ -298,14 +305,17 @@ static int run_legendre_inverse(const ace_sht_plan& pl, const float* E, float* X
             f.A = reinterpret_cast<const _Float16*>(pl.pt_ffrag.p); f.tile_off = reinterpret_cast<const int*>(pl.pt_foff.p);
             if (legendre_fold_eligible(f)) {
                 HIP_TRY(launch_legendre_fold(f, s));
+                pl.route[1] = fold_route(f);
                 return ACE_OK;
             }
         }
         if (pl.strip && legendre_strip_eligible(a)) {
             HIP_TRY(launch_legendre_strip(a, s));
+            pl.route[1] = 1;
             return ACE_OK;
         }
     }
+    pl.route[1] = 0;
     if (pl.f16 && emax && gemm_f16x3_eligible(g)) {
         HIP_TRY(launch_gemm_f16x3(g, pl.pt_hi.p, pl.pt_lo.p, pl.pt_scale, 1.f, s, emax, nullptr));
         return ACE_OK;
@@ -337,6 +347,13 @@ extern "C" int ace_sht_plan_dims(const ace_sht_plan* p, int* nlat, int* nlon, in
     if (nlon) *nlon = p->nlon;
     if (lmax) *lmax = p->lmax;
     if (mmax) *mmax = p->mmax;
+    return ACE_OK;
+}
+
+extern "C" int ace_sht_plan_route(const ace_sht_plan* p, int* forward, int* inverse) {
+    if (!p) return fail(ACE_ERR_INVALID, "null plan");
+    if (forward) *forward = p->route[0];
+    if (inverse) *inverse = p->route[1];
     return ACE_OK;
 }
 
@@ -863,8 +880,12 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
         n->wx_compact[i] = (!n->sw.no_pk_sht && c.precision == 1 && c.operator_type == 1 && n->C % 128 == 0 && !mixed &&
                             ((long)n->Bmax * 2 * n->C) % 4 == 0) ? 1 : 0;
         // grouped filter of the NoiseConditionedSFNO kept as the reference keeps it: the strip kernel is then the ONLY reader
+        // (every runtime precondition of that kernel is decided HERE, from the shape and max_batch: plan arithmetic = c.precision,
+        // column alignment = wx_compact, and its row-chunk grid limit for the largest batch - a handle that stores the native form
+        // can always run it)
+        const bool strip_rows_ok = ((long)n->Mm * n->Bmax + 191) / 192 <= 65535;
         n->wx_native[i] = (n->wx_compact[i] && cln && c.filter_num_groups > 1 && !n->sw.dense_grouped_filter && !n->sw.no_dhconv_strip &&
-                           dhconv_native_groups_ok(n->C, c.filter_num_groups)) ? 1 : 0;
+                           strip_rows_ok && dhconv_native_groups_ok(n->C, c.filter_num_groups)) ? 1 : 0;
     }
     const size_t act = (size_t)n->Bmax * C * HW;
     // + slack rows read (never used) by the strip Legendre kernels past the last contraction row
@@ -962,6 +983,12 @@ extern "C" const char* ace_sfno_weight_name(const ace_sfno* n, int i) {
 extern "C" long ace_sfno_weight_numel(const ace_sfno* n, int i) {
     if (!n || i < 0 || i >= (int)n->weights.size()) return -1;
     return n->weights[i]->ext_numel ? n->weights[i]->ext_numel : n->weights[i]->numel;
+}
+
+// The inner skip of a noise-conditioned net on conv_ws.hip (mode 6: no per-step weight fold, any K of that file).  ONE predicate for
+// the upload (which packs the static fragments) and the forward (which reads them): the "skip" bit of ACE_CONV_WS switches it.
+static bool cln_skip_on_conv_ws(const ace_sfno* n, int K, int M) {
+    return (n->sw.conv_ws_roles & 1) && conv_ws_eligible(K, M, n->HW, -1, n->sw.conv_ws_roles);
 }
 
 extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* src, long numel, void* stream) {
@@ -1066,7 +1093,9 @@ extern "C" int ace_sfno_set_weight(ace_sfno* n, const char* name, const float* s
         }
         // (the inner skip of a noise-conditioned net has no per-step weight fold and any K of conv_ws.hip: its mode 6)
         const bool cln_skip = is_skip && n->cfg.normalization_layer == 2;
-        if ((is_skip || is_fc2 || is_enc2) && conv_ws_eligible(w.cols, w.rows, n->HW, (is_skip && !cln_skip) ? 0 : 2, n->sw.conv_ws_roles)) {
+        const bool ws_ok = cln_skip ? cln_skip_on_conv_ws(n, w.cols, w.rows)
+                                    : conv_ws_eligible(w.cols, w.rows, n->HW, is_skip ? 0 : 2, n->sw.conv_ws_roles);
+        if ((is_skip || is_fc2 || is_enc2) && ws_ok) {
             if (!w.frag0.p) HIP_TRY(w.frag0.alloc((size_t)w.rows * w.cols, false));
             HIP_TRY(launch_pack_conv_frag(w.buf.p, w.pitch, w.rows, w.cols, 0, nullptr, 0.f, w.ascale, nullptr, w.frag0.p,
                                           0, 1, s));
@@ -1710,7 +1739,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             const Weight& ws = *n->weights[n->index.at(p + "inner_skip.weight")];
             if (!n0_planes) ACE_TRY(pack_act(n, res, actB, C, ra, rb, skip_max, Ph, Pl, B, s));
             const bool gelu0 = act == ACT_GELU || act == ACT_GELU_FAST;
-            if (cln && gelu0 && ws.frag0.p && (n->sw.conv_ws_roles & 1) && conv_ws_eligible(C, C, HW, 2, n->sw.conv_ws_roles | 4)) {
+            if (cln && gelu0 && ws.frag0.p && cln_skip_on_conv_ws(n, C, C)) {
                 // weight-stationary kernel, mode 6: GELU(W . planes + bias + Y) -> fp32 T (the conditional norm that follows reads fp32)
                 ConvStripArgs k;
                 k.Xhi = Ph; k.Xlo = Pl; k.ldn = HW; k.sX = (long)C * HW; k.xslot = skip_max;
@@ -1718,7 +1747,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 k.bias = W(p + "inner_skip.bias"); k.sbias = 0;
                 k.R = n->Y.p; k.sR = actB;
                 k.Cf = n->T.p; k.sCf = actB; k.omax = slot(sb + 4);
-                k.C = C; k.M = C; k.HW = (int)HW; k.nbatch = B; k.act = ACT_GELU;
+                k.C = C; k.M = C; k.HW = (int)HW; k.nbatch = B; k.act = act;
                 HIP_TRY(launch_conv_ws(k, s));
             } else {
                 ACE_TRY(conv_pk(n, ws, W(p + "inner_skip.bias"), Ph, Pl, C, skip_max, n->T.p, C, n->Y.p, actB, nullptr, nullptr,
@@ -1852,6 +1881,10 @@ extern "C" long ace_debug_read_workspace(ace_sfno* n, const char* which, void* d
 }
 #endif
 
+extern "C" int ace_sfno_sht_route(const ace_sfno* n, int* forward, int* inverse) {
+    if (!n || !n->plan_lg) return fail(ACE_ERR_INVALID, "null argument");
+    return ace_sht_plan_route(n->plan_lg.get(), forward, inverse);
+}
 extern "C" int ace_sfno_num_stages(void) { return ST_COUNT; }
 extern "C" const char* ace_sfno_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : nullptr; }
 extern "C" int ace_sfno_forward_timed(ace_sfno* n, const float* in, float* out, int batch, void* stream, float* ms_host,

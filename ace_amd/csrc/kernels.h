@@ -175,6 +175,7 @@ bool legendre_strip_eligible(const LegStripArgs& a);
 hipError_t launch_legendre_strip(const LegStripArgs& a, hipStream_t s);
 // the equatorially folded form (strip_fold.hip): same arguments, A / tile_off from pack_legendre_fold (strip_pack.h); K, R <= 192
 bool legendre_fold_eligible(const LegStripArgs& a);
+bool legendre_fold_is_big(const LegStripArgs& a);   // an eligible launch takes legendre_fold_big_kernel (more than 96 folded rows)
 hipError_t launch_legendre_fold(const LegStripArgs& a, hipStream_t s);
 
 // conv weight (O x I) -> packed MFMA A fragments (fp16 hi/lo), optionally W diag(a) per sample with the scale derived from

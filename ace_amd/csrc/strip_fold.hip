@@ -472,6 +472,8 @@ bool legendre_fold_eligible(const LegStripArgs& a) {
     return a.C != nullptr;
 }
 
+bool legendre_fold_is_big(const LegStripArgs& a) { return fold_geom(a.mode, 0, a.R, a.K).nkp2 > 2 * NH_MAX; }
+
 template <int MODE>
 static hipError_t launch_fold_mode(const LegStripArgs& a, hipStream_t s) {
     const int G = (a.N + 127) / 128;
@@ -508,7 +510,7 @@ static hipError_t launch_fold_big(const LegStripArgs& a, int nh, hipStream_t s) 
 
 hipError_t launch_legendre_fold(const LegStripArgs& a, hipStream_t s) {
     const FoldGeom g0 = fold_geom(a.mode, 0, a.R, a.K);
-    if (g0.nkp2 > 2 * NH_MAX) {
+    if (legendre_fold_is_big(a)) {
         const int nh = g0.nkp2 / 2;
         if (a.mode == 0) return a.Chi ? launch_fold_big<1, 0>(a, nh, s) : launch_fold_big<0, 0>(a, nh, s);
         return launch_fold_big<0, 1>(a, nh, s);

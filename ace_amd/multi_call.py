@@ -133,7 +133,11 @@ class MultiCall:
     def step(self, args: StepArgs, wrapper: Callable = lambda x: x) -> StepOutput:
         if self.forcing_name not in args.input and self.forcing_name not in args.next_step_input_data:
             raise ValueError(f"forcing name {self.forcing_name} not in input or next_step_input_data")
-        if self.batched and len(self.forcing_multipliers) > 1:
+        # A seeded rollout (StepperState.random_state) draws one (real, imaginary) noise pair per CALL, in call order
+        # (_multi_call.py:170-188 calls the module once per multiplier): the batched form would draw one k B-sized batch instead -
+        # other numbers from the same generator - so it is only taken when no generator is carried.
+        seeded = getattr(args.stepper_state, "random_state", None) is not None
+        if self.batched and len(self.forcing_multipliers) > 1 and not seeded:
             return self._step_batched(args, wrapper)
         predictions: Dict[str, torch.Tensor] = {}
         state = args.stepper_state

@@ -1,131 +1,145 @@
-"""The reference's random-number contract for stochastic modules (third item).
+"""Where the random numbers of a stochastic module come from (third item).
 
-fme/core/rand.py:39-104: every draw of a stochastic module goes through ``randn`` / ``randn_like``.  While a CPU
-``torch.Generator`` is active (``use_generator``) the numbers are drawn from it ON THE CPU and moved to the requested device,
-so a seeded rollout is reproducible across devices and independent of what else consumes the global RNG; with
-``use_cpu_randn`` the global CPU RNG is used the same way; otherwise the draw happens directly on the device.
-fme/core/random_state.py:23-92: ``RandomState`` wraps that one generator; it rides on ``StepperState.random_state``
-(fme/core/stepper_state.py:22-34) and ``Stepper.step`` activates it around every network call
-(fme/ace/stepper/single_module.py:1063-1068).  The generator advances in place, so the noise sequence does not depend on how
-a rollout is cut into windows.
+The contract this restates (fme/core/rand.py:39-131, fme/core/random_state.py:23-92, fme/core/stepper_state.py:22-34,
+fme/ace/stepper/single_module.py:1063-1068), in this module's own words:
+
+* a draw has a SOURCE and a DESTINATION.  The destination is the ``device=`` the caller names (or the template tensor's); the
+  source is decided by what is active: a CPU ``torch.Generator`` installed by ``use_generator`` (numbers come from it on the host
+  and are then copied to the destination - a seeded rollout gives the same numbers on any device and is blind to other
+  consumers of the global RNG), else the global CPU RNG under ``use_cpu_randn``, else the destination device's own RNG;
+* ``RandomState`` carries that one generator through a rollout (on ``StepperState.random_state``); it advances in place, so the
+  sequence does not depend on how the rollout is cut into windows, and its state dict is the ADVANCED generator state.
 
 On this path the consumer is ``ace_amd.csfno.NoiseConditionedSFNO.draw_noise``; the draw stays OUTSIDE any captured hipGraph
 (``ace_amd.rollout.RolloutEngine`` copies it into a static device buffer before each replay).
 """
 import contextlib
-import dataclasses
 from typing import Dict, Optional, Set
 
 import torch
 
-USE_CPU_RANDN = False
-_ACTIVE_GENERATOR: Optional[torch.Generator] = None
+
+class _Source:
+    """What is active right now.  One instance (`_src`); the context managers below swap single fields and put them back."""
+
+    __slots__ = ("generator", "host_global")
+
+    def __init__(self):
+        self.generator: Optional[torch.Generator] = None   # set: draw from it, on the host
+        self.host_global = False                           # set (and no generator): draw from the global CPU RNG
+
+
+_src = _Source()
+
+
+def __getattr__(name):   # `rand.USE_CPU_RANDN`: the reference exposes the flag as a module attribute; here it is a view of _src
+    if name == "USE_CPU_RANDN":
+        return _src.host_global
+    raise AttributeError(name)
 
 
 def active_generator() -> Optional[torch.Generator]:
-    return _ACTIVE_GENERATOR
+    return _src.generator
+
+
+def _draw(shape, dtype, destination, options, like: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The one place a normal deviate is made: host generator > global host RNG > the destination's RNG."""
+    on_host = _src.generator is not None or _src.host_global
+    if not on_host and like is not None:
+        return torch.randn_like(like, dtype=dtype, device=destination, **options)   # keeps the template's memory format
+    if not on_host:
+        return torch.randn(shape, dtype=dtype, device=destination, **options)
+    sample = torch.randn(shape, dtype=dtype, generator=_src.generator, device="cpu", **options)
+    return sample if destination is None else sample.to(destination)
 
 
 def randn(shape, **kwargs) -> torch.Tensor:
-    """rand.py:55-63: same keyword handling - `device` is where the result ends up, not where it is drawn."""
-    if _ACTIVE_GENERATOR is not None:
-        device = kwargs.pop("device", None)
-        result = torch.randn(shape, generator=_ACTIVE_GENERATOR, **kwargs)
-        return result if device is None else result.to(device)
-    if USE_CPU_RANDN:
-        device = kwargs.pop("device", None)
-        return torch.randn(shape, device="cpu", **kwargs).to(device)
-    return torch.randn(shape, **kwargs)
+    """``torch.randn(shape, **kwargs)`` under the contract above (rand.py:55-63): `device` names where the result lives."""
+    destination = kwargs.pop("device", None)
+    return _draw(shape, kwargs.pop("dtype", None), destination, kwargs)
 
 
 def randn_like(x: torch.Tensor, **kwargs) -> torch.Tensor:
-    """rand.py:39-52."""
-    if _ACTIVE_GENERATOR is not None:
-        device = kwargs.pop("device", x.device)
-        dtype = kwargs.pop("dtype", x.dtype)
-        return torch.randn(x.shape, generator=_ACTIVE_GENERATOR, dtype=dtype, **kwargs).to(device)
-    if USE_CPU_RANDN:
-        device = kwargs.pop("device", x.device)
-        return torch.randn_like(x, device="cpu", **kwargs).to(device)
-    return torch.randn_like(x, **kwargs)
+    """``torch.randn_like(x, **kwargs)`` under the contract above (rand.py:39-52): shape, dtype and device default to x's."""
+    destination = kwargs.pop("device", x.device)
+    return _draw(x.shape, kwargs.pop("dtype", x.dtype), destination, kwargs, like=x)
 
 
 @contextlib.contextmanager
+def _swapped(field: str, value):
+    previous = getattr(_src, field)
+    setattr(_src, field, value)
+    try:
+        yield
+    finally:
+        setattr(_src, field, previous)
+
+
 def use_generator(generator: Optional[torch.Generator]):
-    """rand.py:82-104: route randn / randn_like through `generator` (None: no-op); nested use restores the previous one."""
-    global _ACTIVE_GENERATOR
-    if generator is None:
-        yield
-        return
-    old = _ACTIVE_GENERATOR
-    _ACTIVE_GENERATOR = generator
-    try:
-        yield
-    finally:
-        _ACTIVE_GENERATOR = old
+    """Context: draws come from `generator` (rand.py:82-104).  ``None`` leaves whatever is active in place; nesting restores."""
+    return contextlib.nullcontext() if generator is None else _swapped("generator", generator)
 
 
-@contextlib.contextmanager
 def use_cpu_randn():
-    """rand.py:107-120 (restored on exceptions too)."""
-    global USE_CPU_RANDN
-    old = USE_CPU_RANDN
-    USE_CPU_RANDN = True
-    try:
-        yield
-    finally:
-        USE_CPU_RANDN = old
+    """Context: draws without a generator come from the global CPU RNG (rand.py:107-120); restored on exceptions as well."""
+    return _swapped("host_global", True)
 
 
 def alternate_seed(seed: int) -> int:
-    """rand.py:123-131."""
+    """A second seed derived from `seed`: the first 31-bit integer of a generator seeded with it (rand.py:123-131)."""
+    return int(torch.randint(0, 2**31, (1,), generator=torch.Generator().manual_seed(seed)).item())
+
+
+def _host_generator(seed: Optional[int] = None, state: Optional[torch.Tensor] = None) -> torch.Generator:
     g = torch.Generator()
-    g.manual_seed(seed)
-    return int(torch.randint(0, 2**31, (1,), generator=g).item())
+    if seed is not None:
+        g.manual_seed(seed)
+    if state is not None:
+        g.set_state(state)
+    return g
 
 
-@dataclasses.dataclass
 class RandomState:
-    """fme/core/random_state.py:23-92: one CPU generator for the whole batch, consumed in place; the device / ensemble
-    transforms return the same advancing object."""
+    """The rollout's one host generator (random_state.py:23-92).  A stepper-state component like the corrector's, but with no
+    per-sample part: every placement / broadcast hook hands back the same, still advancing, object."""
 
-    generator: torch.Generator
+    __slots__ = ("generator",)
+    _STATE_KEY = "generator_state"
 
-    def __post_init__(self):
-        if self.generator.device.type != "cpu":
-            raise ValueError(f"RandomState requires a CPU torch.Generator, got device {self.generator.device}.")
+    def __init__(self, generator: torch.Generator):
+        where = generator.device.type
+        if where != "cpu":
+            raise ValueError(f"RandomState requires a CPU torch.Generator, got device {generator.device}.")
+        self.generator = generator
+
+    def __repr__(self):
+        return f"RandomState(generator=<{self.generator.device} generator, seed {self.generator.initial_seed()}>)"
+
+    def __eq__(self, other):
+        return isinstance(other, RandomState) and other.generator is self.generator
+
+    __hash__ = None
 
     @classmethod
     def from_seed(cls, seed: int) -> "RandomState":
-        generator = torch.Generator()
-        generator.manual_seed(seed)
-        return cls(generator=generator)
-
-    def to_state_dict(self) -> Dict[str, torch.Tensor]:
-        """the ADVANCED Mersenne-Twister state (a CPU uint8 tensor), not the seed: a restart continues the sequence"""
-        return {"generator_state": self.generator.get_state()}
+        return cls(_host_generator(seed=seed))
 
     @classmethod
     def from_state_dict(cls, state: Dict[str, torch.Tensor]) -> "RandomState":
-        generator = torch.Generator()
-        generator.set_state(state["generator_state"])
-        return cls(generator=generator)
+        return cls(_host_generator(state=state[cls._STATE_KEY]))
+
+    def to_state_dict(self) -> Dict[str, torch.Tensor]:
+        # the Mersenne-Twister state as it is NOW (a CPU uint8 tensor), not the seed: a restart continues the sequence
+        return {self._STATE_KEY: self.generator.get_state()}
 
     @staticmethod
     def per_sample_state_keys() -> Set[str]:
         return set()
 
-    def to_device(self) -> "RandomState":
-        return self
-
-    def to_cpu(self) -> "RandomState":
-        return self
-
-    def pin_memory(self) -> "RandomState":
-        return self
-
-    def broadcast_ensemble(self, n_ensemble: int) -> "RandomState":
-        return self
-
     def sample_dim_size(self) -> Optional[int]:
         return None
+
+    def _same(self, *_args, **_kwargs) -> "RandomState":
+        return self
+
+    to_device = to_cpu = pin_memory = broadcast_ensemble = _same

@@ -22,6 +22,11 @@ from .stepper import Stepper
 
 
 class RolloutEngine:
+    # graph="window" with a noise-conditioned net keeps the conditioning fields of all T steps of a window in one static device
+    # buffer (T x B x cond_channels x H x W fp32) that the captured steps read; beyond this size the engine refuses and names
+    # graph="step" (ADVICE r05).  8 GiB = a 40-step window of ~290 conditioning channels at 1 degree.
+    max_window_conditioning_bytes = 8 << 30
+
     def __init__(self, stepper: Stepper, batch: int, n_forward_steps: int, graph: Optional[str] = "step"):
         if graph not in (None, "step", "window"):
             raise ValueError("graph must be None, 'step' or 'window'")
@@ -366,6 +371,11 @@ class RolloutEngine:
         for s in range(self.T):
             field = self.net.conditioning_field(self.B, self.device, labels=self._labels)
             if self._cond_window is None:
+                nbytes = 4 * self.T * field.numel()
+                if nbytes > self.max_window_conditioning_bytes:
+                    raise RuntimeError(f"graph='window' would hold {nbytes / 2**30:.1f} GiB of conditioning fields ({self.T} steps x "
+                                       f"{tuple(field.shape)} fp32) in device memory; use graph='step' (the same captured step, one "
+                                       f"draw per replay) or raise RolloutEngine.max_window_conditioning_bytes")
                 self._cond_window = torch.empty(self.T, *field.shape, dtype=torch.float32, device=self.device)
             self._cond_window[s].copy_(field)
 
@@ -443,7 +453,9 @@ class RolloutEngine:
         with torch.no_grad():
             self.load(initial_condition, forcing)
             carried = getattr(initial_condition, "stepper_state", None)
-            self._random_state = getattr(carried, "random_state", None) if carried is not None else self._random_state
+            carried_random = getattr(carried, "random_state", None)
+            if carried_random is not None:      # a state that carries only the corrector's part keeps set_random_state()'s generator
+                self._random_state = carried_random
             if carried is not None:
                 self._mc_state = carried.corrector_state
                 self._corrector_state = carried.corrector_state

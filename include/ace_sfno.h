@@ -49,6 +49,10 @@ int ace_sht_plan_create(int nlat, int nlon, int lmax, int mmax, const char* grid
 int ace_sht_plan_create_ex(int nlat, int nlon, int lmax, int mmax, const char* grid, int precision, ace_sht_plan** plan);
 void ace_sht_plan_destroy(ace_sht_plan* plan);
 int ace_sht_plan_dims(const ace_sht_plan* plan, int* nlat, int* nlon, int* lmax, int* mmax);
+/* Which kernel family the plan's LAST Legendre launch of each direction took (test instrumentation: parity tests assert that the
+ * launch they check really ran the kernel they mean to check): 0 tile engine, 1 register-resident strip kernel, 2 equatorially
+ * folded strip kernel, 3 its big form (more than 96 folded latitudes: the 0.25-degree grid); -1 = no launch yet. */
+int ace_sht_plan_route(const ace_sht_plan* plan, int* forward, int* inverse);
 
 /* RealSHT.forward (fme/sht_fix.py:119-139): x (n, nlat, nlon) f32 -> coeffs (n, lmax, mmax) complex64
  * stored interleaved (re, im) as 2*n*lmax*mmax floats.  May grow plan-owned scratch (hipMalloc) on
@@ -189,6 +193,8 @@ int ace_sfno_forward_conditioned_timed(ace_sfno* net, const float* in, const flo
  * filter children s2convolutions.py:372-431).  Synchronises `stream`.  ms_host[ace_sfno_num_stages()] receives the
  * milliseconds per stage summed over blocks, calls_host (optional) the number of launch groups per stage. */
 int ace_sfno_num_stages(void);
+/* ace_sht_plan_route of the network's internal (legendre-gauss) plan after a forward. */
+int ace_sfno_sht_route(const ace_sfno* net, int* forward, int* inverse);
 const char* ace_sfno_stage_name(int i);
 int ace_sfno_forward_timed(ace_sfno* net, const float* in, float* out, int batch, void* stream, float* ms_host,
                            int* calls_host);

@@ -52,6 +52,17 @@ def legpoly(mmax, lmax, x, norm="ortho", inverse=False, csphase=True):
     return vdm
 
 
+_LAST = {}   # the most recent table (the 721-latitude one takes most of a minute and several tests build it twice: analysis + synthesis)
+
+
 def precompute_legpoly(mmax, lmax, t, norm="ortho", inverse=False, csphase=True):
-    """cuhpx/tools.py:374-375: table on colatitudes t."""
-    return legpoly(mmax, lmax, np.cos(np.asarray(t, dtype=np.float64)), norm=norm, inverse=inverse, csphase=csphase)
+    """cuhpx/tools.py:374-375: table on colatitudes t.  The returned array is read-only (one shared copy per geometry)."""
+    t = np.asarray(t, dtype=np.float64)
+    # with norm="ortho" the `inverse` flag changes nothing (norm_factor = 1 both ways)
+    key = (mmax, lmax, t.tobytes(), norm, bool(inverse) and norm != "ortho", csphase)
+    if _LAST.get("key") != key:
+        _LAST.clear()
+        table = legpoly(mmax, lmax, np.cos(t), norm=norm, inverse=inverse, csphase=csphase)
+        table.setflags(write=False)
+        _LAST.update(key=key, table=table)
+    return _LAST["table"]

@@ -86,7 +86,7 @@ class InverseRealSHT:
         t = np.flip(np.arccos(cost))
         self.mmax = mmax or nlon // 2 + 1
         pct = precompute_legpoly(self.mmax, self.lmax, t, norm=norm, inverse=True, csphase=csphase)
-        self.pct64 = torch.from_numpy(np.ascontiguousarray(pct))
+        self.pct64 = torch.from_numpy(np.array(pct, order="C"))   # own copy: the table is shared and read-only
         self.dtype = dtype
         self.pct = self.pct64.to(dtype)
 

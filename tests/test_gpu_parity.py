@@ -708,6 +708,69 @@ def test_quarter_degree_grid(dev):
         assert_net_close(out, ref, NET_TOL)
 
 
+def _sht_route(plan_handle):
+    import ctypes
+    from ace_amd import _lib
+    f, i = ctypes.c_int(-9), ctypes.c_int(-9)
+    _lib.check(_lib.lib().ace_sht_plan_route(plan_handle, ctypes.byref(f), ctypes.byref(i)))
+    return f.value, i.value
+
+
+def test_quarter_degree_big_fold_kernel_vs_oracle(dev):
+    """The kernel that carries BASELINE configs[3]: `legendre_fold_big_kernel` (strip_fold.hip; more than 96 folded latitudes, whole
+    128-column groups) against the fp64 oracle - fme/sht_fix.py:119-139 (analysis) and :202-226 (synthesis) at 721 x 1440,
+    lmax = mmax = 721, 64 fields = 128 columns of (re | im, field).  The synthesis operand is NOT band-limited data from the analysis
+    but independent random coefficients, so an error common to both directions cannot cancel.  The route query asserts that both
+    launches really took the big form (route 3), and that the exact-fp32 plan (which has no strip kernels) did not."""
+    import ace_amd
+    from oracle.sht import RealSHT as ORealSHT, InverseRealSHT as OInverseRealSHT
+    H, W, n = 721, 1440, 64
+    L, M = H, W // 2 + 1
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, H, W, generator=g)
+    coef = torch.complex(torch.randn(n, L, M, generator=g), torch.randn(n, L, M, generator=g))
+    coef = coef * (torch.arange(L)[:, None] >= torch.arange(M)[None, :])      # l >= m, as every SHT output has it
+    coef = coef / (1.0 + torch.arange(L, dtype=torch.float32)[:, None]) ** 0.5   # a decaying spectrum, large-scale dominated
+    oc = ORealSHT(H, W, L, M, "legendre-gauss", dtype=torch.float64)(x.double())
+    oy = OInverseRealSHT(H, W, L, M, "legendre-gauss", dtype=torch.float64)(coef.to(torch.complex128))
+    for prec, want_route in (("f16x3", 3), ("fp32", 0)):
+        f = ace_amd.RealSHT(H, W, L, M, "legendre-gauss", precision=prec)
+        i = ace_amd.InverseRealSHT(H, W, L, M, "legendre-gauss", precision=prec)
+        c = f(x.to(dev))
+        y = i(coef.to(dev))
+        torch.cuda.synchronize()
+        assert _sht_route(f._get_plan().handle)[0] == want_route, (prec, _sht_route(f._get_plan().handle))
+        assert _sht_route(i._get_plan().handle)[1] == want_route, (prec, _sht_route(i._get_plan().handle))
+        ec, ey = rel_max(c, oc), rel_max(y, oy)
+        print(f"0.25 degree SHT pair, 64 fields, {prec}: analysis {ec:.3e}, synthesis {ey:.3e} vs fp64")
+        assert ec <= SHT_TOL and ey <= SHT_TOL, (prec, ec, ey)
+        # per field as well: no single column group may hide behind the tensor's maximum
+        for k in (0, 31, 32, 63):
+            assert rel_max(c[k], oc[k]) <= 2 * SHT_TOL and rel_max(y[k], oy[k]) <= 2 * SHT_TOL, (prec, k)
+
+
+def test_quarter_degree_net_on_the_big_fold_kernel_vs_oracle(dev):
+    """The in-network instantiations of the big folded Legendre kernel at 0.25 degree - the forward one writes the coefficients as
+    fp16 hi / lo planes for the filter (`legendre_fold_big_kernel<1, 0>`), which the stand-alone transform never does: a C = 64
+    (128 columns), one-block dhconv net against the fp64 oracle (sfnonet.py:217-252), with the route asserted."""
+    import ctypes
+    from ace_amd import _lib
+    from oracle.sfno import SFNOConfig, SFNOOracle, init_state
+    H, W = 721, 1440
+    cfg = SFNOConfig(in_chans=3, out_chans=2, img_shape=(H, W), embed_dim=64, num_layers=1, operator_type="dhconv")
+    st = init_state(cfg, seed=5)
+    xin = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(6))
+    ref = SFNOOracle(cfg, st, dtype=torch.float64).forward(xin)
+    net = build_native_net(cfg, st, dev, "f16x3")
+    with torch.no_grad():
+        out = net(xin.to(dev))
+    torch.cuda.synchronize()
+    f, i = ctypes.c_int(-9), ctypes.c_int(-9)
+    _lib.check(_lib.lib().ace_sfno_sht_route(net._native, ctypes.byref(f), ctypes.byref(i)))
+    assert (f.value, i.value) == (3, 3), (f.value, i.value)
+    assert_net_close(out, ref, NET_TOL)
+
+
 def test_graph_replay_matches_eager(dev, precision):
     from oracle.sfno import SFNOConfig, init_state
     cfg = SFNOConfig(in_chans=4, out_chans=4, img_shape=(24, 48), embed_dim=16, num_layers=2, operator_type="dhconv")
