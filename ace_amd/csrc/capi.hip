@@ -62,6 +62,7 @@ Switches read_switches() {
     sw.dense_grouped_filter = on("ACE_DENSE_GROUPED_FILTER");
     if (const char* e = std::getenv("ACE_CONV_WL")) sw.conv_wl = !(e[0] == '0' && !e[1]);
     if (const char* e = std::getenv("ACE_PLANES_STREAM")) sw.planes_stream = !(e[0] == '0' && !e[1]);
+    if (const char* e = std::getenv("ACE_FUSED_PACK")) sw.fused_pack = !(e[0] == '0' && !e[1]);
     if (const char* e = std::getenv("ACE_CONV_WS")) {
         const std::string v(e);
         if (v == "all" || v == "1") sw.conv_ws_roles = 7;
@@ -210,8 +211,11 @@ static int plan_build(int nlat, int nlon, int lmax, int mmax, Grid g, std::uniqu
 // X[m][k][b][ri][c] <- longitude DFT of x (Bt, C, H, W), optional per-(b,c) affine on load
 static int run_dft_forward(const ace_sht_plan& pl, const float* x, const float* sc, const float* sh, float* X, int Bt,
                            int C, hipStream_t s, unsigned* xmax = nullptr, const _Float16* xhi = nullptr,
-                           const _Float16* xlo = nullptr, long sxp = 0, const unsigned* xslot = nullptr) {
+                           const _Float16* xlo = nullptr, long sxp = 0, const unsigned* xslot = nullptr,
+                           const PackFragArgs* ride = nullptr, bool* rode = nullptr) {
     DftArgs a;
+    if (rode) *rode = false;
+    if (ride && rode) { a.ride = *ride; a.nride = pack_frag_blocks(*ride); a.rode = rode; }   // a weight-packing job riding in the launch (pack_frag.h)
     a.omax = xmax;
     a.xhi = xhi; a.xlo = xlo; a.sxp = sxp; a.xslot = xslot;   // the field as P-format planes instead of fp32 (FFT form only)
     a.x = xhi ? nullptr : x; a.spec_out = X; a.tc = pl.fc.p; a.ts = pl.fs.p; a.ldt = pl.Kfp; a.sc = sc; a.sh = sh;
@@ -1507,10 +1511,28 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         // kernel they hide.  profiles/r04_s3_kdur_side_pack_*.txt)
         // spectral filter (s2convolutions.py:162-197): SHT -> contraction -> inverse SHT + bias
         unsigned *xmax = slot(sb + 0), *dmax = slot(sb + 1), *emax = slot(sb + 2);
+        // The folded weights of this block's inner skip (W diag(a0), bs + W b0: conv_ws.hip reads them as packed fragments) depend on
+        // norm0's affine only: where that convolution will run on the weight-stationary kernel (the conditions of `ws_skip` below),
+        // the ~300 workgroups that pack them ride in the forward FFT launch instead of a dependent 7 us launch of their own.
+        PackFragArgs skip_pack;
+        bool skip_pack_rode = false, skip_pack_wanted = false;
+        if (n->sw.fused_pack && f16 && norm && !scale_residual && have_ph && c.use_mlp && n->P2.p && packed_ok(n, C) && n->hid % 8 == 0 &&
+            c.activation_function == ACT_GELU && n->Wq0.p) {
+            const Weight& wsk = *n->weights[n->index.at(p + "inner_skip.weight")];
+            const Weight& bsk = *n->weights[n->index.at(p + "inner_skip.bias")];
+            if (wsk.frag0.p && conv_ws_eligible(C, C, HW, 0, n->sw.conv_ws_roles)) {
+                skip_pack.W = wsk.buf.p; skip_pack.ldw = wsk.pitch; skip_pack.O = C; skip_pack.I = C; skip_pack.order = 0;
+                skip_pack.a = a0; skip_pack.wmax = wsk.wabs; skip_pack.scale_static = 1.f; skip_pack.wslot = slot(sb + 8);
+                skip_pack.dst = reinterpret_cast<_Float16*>(n->Wq0.p); skip_pack.sDst = (long)C * C * 2;
+                skip_pack.b = b0; skip_pack.bias = bsk.buf.p; skip_pack.bf = n->bf0.p; skip_pack.nsamples = B;
+                skip_pack_wanted = true;
+            }
+        }
+        const PackFragArgs* ride = skip_pack_wanted ? &skip_pack : nullptr;
         if (h_planes_only)   // the block input exists as planes only (written by the previous block's fc2, mode 4)
-            ACE_TRY(run_dft_forward(fwd, nullptr, a0, b0, n->X.p, B, C, s, xmax, PBh, PBl, (long)C * HW, hslot(i)));
+            ACE_TRY(run_dft_forward(fwd, nullptr, a0, b0, n->X.p, B, C, s, xmax, PBh, PBl, (long)C * HW, hslot(i), ride, &skip_pack_rode));
         else
-            ACE_TRY(run_dft_forward(fwd, h, a0, b0, n->X.p, B, C, s, xmax));
+            ACE_TRY(run_dft_forward(fwd, h, a0, b0, n->X.p, B, C, s, xmax, nullptr, nullptr, 0, nullptr, ride, &skip_pack_rode));
         MARK(ST_DFT_FWD);
         // packed dhconv: D goes from the Legendre epilogue to the filter GEMM as fp16 planes (never fp32)
         const bool dplanes = f16 && !n->sw.no_pk_sht && c.operator_type == 1 && n->wx_hi[i].p && !scale_residual && fwd.f16 &&
@@ -1643,8 +1665,9 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 k.Xhi = PBh; k.Xlo = PBl; k.ldn = HW; k.sX = (long)C * HW; k.xslot = o.in_slot;
                 if (have_ph) {
                     _Float16* Q0 = reinterpret_cast<_Float16*>(n->Wq0.p);
-                    HIP_TRY(launch_pack_conv_frag(ws.buf.p, ws.pitch, C, C, 0, ra, ws.wabs, 1.f, slot(sb + 8), Q0, (long)C * C * 2, B, s,
-                                                  rb, bsw.buf.p, n->bf0.p));
+                    if (!skip_pack_rode)   // (packed by rider workgroups of this block's forward FFT otherwise)
+                        HIP_TRY(launch_pack_conv_frag(ws.buf.p, ws.pitch, C, C, 0, ra, ws.wabs, 1.f, slot(sb + 8), Q0, (long)C * C * 2, B, s,
+                                                      rb, bsw.buf.p, n->bf0.p));
                     k.A = Q0; k.sA = (long)C * C * 2; k.aslot = slot(sb + 8);
                 } else {
                     k.A = reinterpret_cast<const _Float16*>(ws.frag0.p); k.sA = 0; k.ascale = ws.ascale;
@@ -1668,13 +1691,21 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             if (ws_fc1) {
                 _Float16* Q1 = reinterpret_cast<_Float16*>(n->Wq1.p);
                 const long q1s = (long)n->hid * C * 2;
-                HIP_TRY(launch_pack_conv_frag(w1.buf.p, w1.pitch, n->hid, C, 0, sc1, w1.wabs, 1.f, slot(sb + 9), Q1, q1s, B, s,
-                                              sh1, b1w.buf.p, n->bf1.p));
+                // W1 diag(a1), b1 + W1 b1' folded in the convolution's own prologue (conv_wl.hip at the ACE2 width: +1.4 us against a 6.7 us launch)
+                const bool pfold = n->sw.fused_pack && wl_fc1 && C == 384 && w1.pitch % 4 == 0;
+                if (!pfold)
+                    HIP_TRY(launch_pack_conv_frag(w1.buf.p, w1.pitch, n->hid, C, 0, sc1, w1.wabs, 1.f, slot(sb + 9), Q1, q1s, B, s,
+                                                  sh1, b1w.buf.p, n->bf1.p));
                 MARK(ST_NORM1);
                 ConvStripArgs k;
                 k.Xhi = PAh; k.Xlo = PAl; k.ldn = HW; k.sX = (long)C * HW; k.xslot = slot(sb + 4);
-                k.A = Q1; k.sA = q1s; k.aslot = slot(sb + 9);
-                k.bias = n->bf1.p; k.sbias = n->hid;
+                if (pfold) {
+                    k.Wraw = w1.buf.p; k.ldw = w1.pitch; k.wabs = w1.wabs; k.fa = sc1; k.fb = sh1; k.sfa = C;
+                    k.bias = b1w.buf.p; k.sbias = 0;
+                } else {
+                    k.A = Q1; k.sA = q1s; k.aslot = slot(sb + 9);
+                    k.bias = n->bf1.p; k.sbias = n->hid;
+                }
                 k.cw = w1.winf; k.cb = b1w.absmax; k.cinb = slot(sb + 5);
                 k.Chi = Uh; k.Clo = Ul; k.sCp = (long)n->hid * HW; k.cslot = slot(sb + 6);
                 k.C = C; k.M = n->hid; k.HW = (int)HW; k.nbatch = B; k.act = ACT_GELU;

@@ -46,9 +46,14 @@ __device__ unsigned long long wl_wg_span[4096][3];
 constexpr int WL_OOBV = 0x7fffff00;
 
 // KS: k16-steps (K / 16), RT: 32-row tiles per workgroup, D: k-steps of B-fragment read-ahead
-template <int KS, int RT, int D>
+// FOLD: the instance norm in front of this convolution (norm1 of the block) is folded into the weights while the workgroup copies
+// its slice to LDS - W diag(a) scaled by 2^(12 - exponent(max|W| max|a|)) and split into hi / lo fragments, bias + W b - from the
+// fp32 weight and the norm's affine: element for element the arithmetic of pack_conv_frag_kernel, whose launch (7 us behind
+// every norm1) it replaces.
+template <int KS, int RT, int D, bool FOLD = false>
 __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p, int nslice, int groups_per_xcd, int tpx) {
-    __shared__ __attribute__((aligned(16))) char smem[RT * KS * 2048 + 32 * RT * 4];   // the slice's fragments, then its bias
+    constexpr int FTB = FOLD ? (2 * 16 * KS + WL_WAVES * 32 * RT + 16) * 4 : 0;   // a | b | per-wave partial bias dots | max|a| per wave
+    __shared__ __attribute__((aligned(16))) char smem[RT * KS * 2048 + 32 * RT * 4 + FTB];   // the slice's fragments, then its bias
     float* Pb = reinterpret_cast<float*>(smem + RT * KS * 2048);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -69,11 +74,71 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
     MT(0);
     WG_STAMP(0);
     const unsigned raw_x = slot_load(p.xslot + lane);
-    const unsigned raw_a = p.aslot ? slot_load(p.aslot + lane) : 0u;
+    const unsigned raw_a = (!FOLD && p.aslot) ? slot_load(p.aslot + lane) : 0u;
     const unsigned raw_c = p.cinb ? slot_load(p.cinb + lane) : 0u;
 
     // ---- weights of this slice -> LDS (the slice's fragments are one contiguous chunk of the packed operand)
-    {
+    float fscale = 1.f;
+    if constexpr (FOLD) {
+        static_assert(WL_WAVES == 8 && KS % 8 == 0, "fold: wave w takes the k-steps w, w + 8, ... of every row tile");
+        float* Ta = Pb + 32 * RT;                 // a[0 .. K), b[0 .. K)
+        float* Tb = Ta + 16 * KS;
+        float* Pd = Tb + 16 * KS;                 // [wave][32 RT] partial dots of W b
+        float* red = Pd + WL_WAVES * 32 * RT;
+        const float* fa = p.fa + (long)smp * p.sfa;
+        const float* fb = p.fb + (long)smp * p.sfa;
+        float am = 0.f;
+        for (int r = tid; r < 16 * KS; r += 64 * WL_WAVES) {
+            const float av = fa[r];
+            Ta[r] = av; Tb[r] = fb[r];
+            am = fmaxf(am, fabsf(av));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+        if (lane == 0) red[wave] = am;
+        __syncthreads();
+        am = red[0];
+#pragma unroll
+        for (int k = 1; k < WL_WAVES; ++k) am = fmaxf(am, red[k]);
+        fscale = ldexpf(1.0f, pow2_exponent_for(p.wabs * am));   // this sample's own scale (pack_conv_frag_kernel: one over the batch)
+        // block (t, J): lane (i, g) owns row 32 (slice RT + t) + i, columns 16 J + 8 g + e
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const float* Wr = p.Wraw + (long)(32 * (slice * RT + t) + i) * p.ldw + 8 * g;
+            float dot = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < KS / 8; ++jj) {
+                const int J = wave + 8 * jj;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wr + 16 * J), w1 = *reinterpret_cast<const f32x4*>(Wr + 16 * J + 4);
+                const int col = 16 * J + 8 * g;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ta + col), a1 = *reinterpret_cast<const f32x4*>(Ta + col + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(Tb + col), b1 = *reinterpret_cast<const f32x4*>(Tb + col + 4);
+                half8 fh, fl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float wv = e < 4 ? w0[e & 3] : w1[e & 3];
+                    dot = fmaf(wv, e < 4 ? b0[e & 3] : b1[e & 3], dot);
+                    float x = wv * fscale;
+                    x *= e < 4 ? a0[e & 3] : a1[e & 3];
+                    x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+                    const _Float16 hv = (_Float16)x;
+                    fh[e] = hv;
+                    fl[e] = (_Float16)(x - (float)hv);
+                }
+                *reinterpret_cast<half8*>(smem + (t * KS + J) * 2048 + lane * 16) = fh;
+                *reinterpret_cast<half8*>(smem + (t * KS + J) * 2048 + 1024 + lane * 16) = fl;
+            }
+            dot += __shfl_xor(dot, 32, 64);
+            if (g == 0) Pd[wave * (32 * RT) + 32 * t + i] = dot;
+        }
+        __syncthreads();
+        if (tid < 32 * RT) {   // folded bias: bias + W b, the eight waves' partial sums in a fixed order
+            float acc = Pd[tid];
+#pragma unroll
+            for (int k = 1; k < WL_WAVES; ++k) acc += Pd[k * (32 * RT) + tid];
+            Pb[tid] = p.bias[slice * 32 * RT + tid] + acc;
+        }
+    } else {
         const char* A = reinterpret_cast<const char*>(p.A + (long)smp * p.sA) + (long)slice * RT * KS * 2048;
         for (int o = tid * 16; o < RT * KS * 2048; o += 64 * WL_WAVES * 16)
             *reinterpret_cast<u32x4*>(smem + o) = *reinterpret_cast<const u32x4*>(A + o);
@@ -82,7 +147,7 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
     }
     const float xbound = wave_max_bits(raw_x);
     const float inv_x = ldexpf(1.0f, -pow2_exponent_for(xbound));
-    const float inv_a = p.aslot ? ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_a))) : 1.0f / p.ascale;
+    const float inv_a = FOLD ? 1.0f / fscale : (p.aslot ? ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_a))) : 1.0f / p.ascale);
     const float s_acc = inv_x * inv_a;
     // bound of this launch's output, identical in every workgroup; the consumer reads it from cslot
     const float inb = p.cinb ? wave_max_bits(raw_c) : xbound;
@@ -238,7 +303,7 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
 #endif
 }
 
-template <int KS, int RT, int D>
+template <int KS, int RT, int D, bool FOLD = false>
 hipError_t launch_wl(const ConvStripArgs& a, hipStream_t s) {
     const int nslice = a.M / (32 * RT);
     int gpx = 32 / nslice;                      // pixel groups per XCD (32 CUs each)
@@ -247,7 +312,7 @@ hipError_t launch_wl(const ConvStripArgs& a, hipStream_t s) {
     const int tpx = (tiles_px + 7) / 8;
     if (gpx * WL_WAVES > tpx) gpx = (tpx + WL_WAVES - 1) / WL_WAVES;   // small fields: no idle workgroups
     dim3 grid((unsigned)(8 * nslice * gpx * a.nbatch)), block(64 * WL_WAVES);
-    hipLaunchKernelGGL((conv_wl_kernel<KS, RT, D>), grid, block, 0, s, a, nslice, gpx, tpx);
+    hipLaunchKernelGGL((conv_wl_kernel<KS, RT, D, FOLD>), grid, block, 0, s, a, nslice, gpx, tpx);
     return hipGetLastError();
 }
 
@@ -266,9 +331,13 @@ bool conv_wl_eligible(int K, int M, long HW) {
 }
 
 hipError_t launch_conv_wl(const ConvStripArgs& a, hipStream_t s) {
-    if (!conv_wl_eligible(a.C, a.M, a.HW) || !a.bias || !a.xslot || !a.A || !a.Chi || !a.Clo || !a.cslot || a.R || a.part || a.Cf ||
+    if (!conv_wl_eligible(a.C, a.M, a.HW) || !a.bias || !a.xslot || !(a.A || a.Wraw) || !a.Chi || !a.Clo || !a.cslot || a.R || a.part || a.Cf ||
         !(a.act == ACT_GELU || a.act == ACT_GELU_FAST))
         return hipErrorInvalidValue;
+    if (a.Wraw) {   // weight fold in the prologue (the ACE2 width): fp32 weight with 16-byte rows, the norm's affine, the raw bias
+        if (!a.fa || !a.fb || (a.ldw & 3) != 0 || (reinterpret_cast<uintptr_t>(a.Wraw) & 15) != 0 || a.sbias != 0 || a.C != 384) return hipErrorInvalidValue;
+        return launch_wl<24, 3, ACE_WL_D, true>(a, s);
+    }
     switch (a.C) {
         case 512: return launch_wl<32, 2, 4>(a, s);
         case 384: return launch_wl<24, 3, ACE_WL_D>(a, s);

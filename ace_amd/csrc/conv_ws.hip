@@ -23,6 +23,8 @@
 #include <string>
 #include <type_traits>
 
+#include "kernels.h"
+#include "pack_frag.h"
 #include "strip_common.h"
 #include "ws_plan.h"
 
@@ -593,76 +595,26 @@ hipError_t launch_ws_k(const ConvStripArgs& a, int mode, hipStream_t s) {
 
 }  // namespace
 
-// A-fragment packing of a conv weight W (O x I, row pitch ldw), optionally with a per-input-channel scale folded in
-// (instance-norm affine: W diag(a)), as fp16 hi/lo blocks of 64 lanes x 8 halves (strip_pack.h layout: lane = i + 32 g holds
-// row 32 T + i, columns 16 J + 8 g .. + 7):
-//   order 0 (streamed by output-row chunk, fc1): block (T, J) at T * (I / 16) + J
-//   order 1 (streamed by 16-column step, fc2):   block (T, J) at J * (O / 32) + T
-// O % 32 == 0, I % 16 == 0.  scale: a power of two, or derived from `bound` = wmax * max|a| (published to wslot).
-__global__ __launch_bounds__(256) void pack_conv_frag_kernel(const float* __restrict__ W, long ldw, int O, int I, int order,
-                                                             const float* __restrict__ a, float wmax, float scale_static,
-                                                             unsigned* wslot, _Float16* __restrict__ dst, long sDst,
-                                                             const float* __restrict__ b, const float* __restrict__ bias,
-                                                             float* __restrict__ bf) {
-    const int smp = blockIdx.y;
-    if ((int)blockIdx.x >= (O / 32) * (I / 16)) {   // extra workgroups: folded bias of one 32-row tile, bias + W b (8 threads per row,
-        const int T = (int)blockIdx.x - (O / 32) * (I / 16);   // 16 bytes per load) - beside the packing, not after it
-        const int r = threadIdx.x >> 3, l8 = threadIdx.x & 7;
-        const long row = 32L * T + r;
-        const float4* w4 = reinterpret_cast<const float4*>(W + row * ldw);
-        const float4* b4 = reinterpret_cast<const float4*>(b + (long)smp * I);
-        float acc = 0.f;
-        for (int q = l8; q < I / 4; q += 8) {
-            const float4 w = w4[q], v = b4[q];
-            acc = fmaf(w.x, v.x, acc); acc = fmaf(w.y, v.y, acc); acc = fmaf(w.z, v.z, acc); acc = fmaf(w.w, v.w, acc);
-        }
-#pragma unroll
-        for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (l8 == 0) bf[(long)smp * O + row] = (bias ? bias[row] : 0.f) + acc;
-        return;
-    }
-    float scale = scale_static;
-    if (a) {   // one scale for all samples (as fold_affine_f16_kernel)
-        __shared__ float red[4];
-        float am = 0.f;
-        for (int q = threadIdx.x; q < I * (int)gridDim.y; q += 256) am = fmaxf(am, fabsf(a[q]));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
-        __syncthreads();
-        am = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        const float bound = wmax * am;
-        scale = ldexpf(1.0f, pow2_exponent_for(bound));
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(wslot + (smp & 63), __float_as_uint(bound));
-    }
-    const int nJ = I / 16, nT = O / 32;
-    const int blk = blockIdx.x;                 // one workgroup = one (T, J) block: 512 elements, two per thread
-    const int T = blk / nJ, J = blk % nJ;
-    const long bidx = order == 0 ? (long)T * nJ + J : (long)J * nT + T;
-    _Float16* out = dst + (long)smp * sDst + bidx * 1024;
-    const float* as = a ? a + (long)smp * I : nullptr;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int t = threadIdx.x + 256 * u;    // = lane * 8 + e
-        const int e = t & 7, lane = t >> 3, i = lane & 31, g = lane >> 5;
-        const int row = 32 * T + i, col = 16 * J + 8 * g + e;
-        float x = W[(long)row * ldw + col] * scale;
-        if (as) x *= as[col];
-        x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
-        const _Float16 h = (_Float16)x;
-        out[t] = h;
-        out[512 + t] = (_Float16)(x - (float)h);
-    }
+// A-fragment packing of a conv weight (pack_frag.h), one (T, J) block or one folded-bias tile per workgroup
+__global__ __launch_bounds__(256) void pack_conv_frag_kernel(PackFragArgs q) {
+    __shared__ float red[4];
+    pack_frag_block(q, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, red);
+}
+
+bool pack_frag_args_ok(const PackFragArgs& q) {
+    if (q.O % 32 != 0 || q.I % 16 != 0 || (q.order == 1 && q.I % 32 != 0) || (q.a && !q.wslot) || (q.bf && !q.b)) return false;
+    if (q.bf && ((q.ldw & 3) != 0 || (reinterpret_cast<uintptr_t>(q.W) & 15) != 0 || (reinterpret_cast<uintptr_t>(q.b) & 15) != 0)) return false;
+    return q.W && q.dst && q.nsamples >= 1;
 }
 
 hipError_t launch_pack_conv_frag(const float* W, long ldw, int O, int I, int order, const float* a, float wmax,
                                  float scale_static, unsigned* wslot, void* dst, long sDst, int nsamples, hipStream_t s,
                                  const float* b, const float* bias, float* bf) {
-    if (O % 32 != 0 || I % 16 != 0 || (order == 1 && I % 32 != 0) || (a && !wslot) || (bf && !b)) return hipErrorInvalidValue;
-    if (bf && ((ldw & 3) != 0 || (reinterpret_cast<uintptr_t>(W) & 15) != 0 || (reinterpret_cast<uintptr_t>(b) & 15) != 0)) return hipErrorInvalidValue;
-    dim3 grid((unsigned)((O / 32) * (I / 16) + (bf ? O / 32 : 0)), (unsigned)nsamples);
-    hipLaunchKernelGGL(pack_conv_frag_kernel, grid, dim3(256), 0, s, W, ldw, O, I, order, a, wmax, scale_static, wslot,
-                       static_cast<_Float16*>(dst), sDst, b, bias, bf);
+    PackFragArgs q;
+    q.W = W; q.ldw = ldw; q.O = O; q.I = I; q.order = order; q.a = a; q.wmax = wmax; q.scale_static = scale_static; q.wslot = wslot;
+    q.dst = static_cast<_Float16*>(dst); q.sDst = sDst; q.b = b; q.bias = bias; q.bf = bf; q.nsamples = nsamples;
+    if (!pack_frag_args_ok(q)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_conv_frag_kernel, dim3((unsigned)pack_frag_blocks(q), (unsigned)nsamples), dim3(256), 0, s, q);
     return hipGetLastError();
 }
 

@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "pack_frag.h"
 #include "small_fft.h"
 #include "strip_common.h"
 
@@ -109,6 +110,27 @@ FDEV void fft_unit(int& cblk, int& lat) {
     cblk = u % gx;
     lat = u / gx;
 }
+// The forward kernel's form with RIDER workgroups (DftArgs::nride, pack_frag.h): the grid's y extent carries ceil(nride / gx) extra
+// rows; the riders are the FIRST units of every XCD's range - dispatched first, their slots go back to the transform's own
+// workgroups (at the end they would sit in the launch's tail; all on one XCD they cost its range 2 us).  Returns true for a rider
+// (index rid, idle when rid >= nride).
+template <bool XCD>
+FDEV bool fft_unit_ride(int nride, int& cblk, int& lat, int& rid) {
+    const int gx = (int)gridDim.x, id = (int)blockIdx.x + gx * (int)blockIdx.y, total = gx * (int)gridDim.y;
+    const int nextra = nride > 0 ? (nride + gx - 1) / gx * gx : 0;
+    int u;
+    if (XCD && (total & 7) == 0 && (nextra & 7) == 0) {
+        const int xcd = id & 7, pos = id >> 3, nr8 = nextra >> 3;
+        if (pos < nr8) { rid = pos * 8 + xcd; return true; }
+        u = xcd * ((total >> 3) - nr8) + (pos - nr8);
+    } else {
+        if (id < nextra) { rid = id; return true; }
+        u = id - nextra;
+    }
+    cblk = u % gx;
+    lat = u / gx;
+    return false;
+}
 
 // ---- forward ----------------------------------------------------------------------------------------------------------
 // grid = (ceil(C / R), H, Bt); block = R * N2.  LDS: the rows, then - aliased - Z.
@@ -148,8 +170,17 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? 7 : ACE_FFT_FWD_WAV
     v2f* Zs = reinterpret_cast<v2f*>(smem);
 
     const int tid = threadIdx.x;
-    int cblk, k;
-    fft_unit<ACE_FFT_XCD != 0>(cblk, k);
+    int cblk = 0, k = 0, rid = 0;
+    if (fft_unit_ride<ACE_FFT_XCD != 0>(p.nride, cblk, k, rid)) {
+        // rider workgroup: one block of a weight-packing job (pack_frag.h), for every sample, from plane z = 0
+        if (rid >= p.nride || blockIdx.z != 0) return;
+        float* red = smem;
+        for (int smp = 0; smp < p.ride.nsamples; ++smp) {
+            if (smp) __syncthreads();
+            pack_frag_block(p.ride, rid, smp, tid, red);
+        }
+        return;
+    }
     const int c0 = cblk * R, b = blockIdx.z;
     const long HW = (long)p.H * W;
     constexpr int NPF = (R * (W / 4) + NT - 1) / NT;   // 16-byte row pieces per thread
@@ -293,8 +324,13 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? 7 : ACE_FFT_FWD_WAV
 }
 
 template <int N1, int N2, int R = FFT_ROWS>
-hipError_t launch_fwd(const DftArgs& a, hipStream_t s) {
-    dim3 grid((unsigned)((a.C + R - 1) / R), (unsigned)a.H, (unsigned)a.Bt), block(R * N2);
+hipError_t launch_fwd(const DftArgs& a0, hipStream_t s) {
+    DftArgs a = a0;
+    const int gx = (a.C + R - 1) / R;
+    // riders need a workgroup of at least four waves and a y extent that stays in range; otherwise the caller launches the job itself
+    if (a.nride > 0 && (R * N2 < 256 || !pack_frag_args_ok(a.ride) || a.nride != pack_frag_blocks(a.ride) || a.H + (a.nride + gx - 1) / gx > 65535)) a.nride = 0;
+    if (a.rode) *a.rode = a.nride > 0;
+    dim3 grid((unsigned)gx, (unsigned)(a.H + (a.nride > 0 ? (a.nride + gx - 1) / gx : 0)), (unsigned)a.Bt), block(R * N2);
     const bool full = a.Mm == a.W / 2 + 1;
     if (a.xhi) {
         if (!a.xlo || !a.xslot || a.C % 8 != 0) return hipErrorInvalidValue;

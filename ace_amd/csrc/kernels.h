@@ -20,6 +20,8 @@ struct Switches {
     bool no_cln_planes = false;    // ACE_NO_CLN_PLANES: ... which write fp32 only, followed by a pack pass (instead of P-format planes from the norm kernel)
     int conv_ws_roles = 7;         // ACE_CONV_WS=skip,fc1,fc2|all|none: roles on conv_ws.hip (bit 0 inner skip, 1 fc1, 2 fc2)
     bool conv_wl = true;           // ACE_CONV_WL=0: fc1 on conv_ws.hip instead of conv_wl.hip (weights in LDS, unsynchronised waves)
+    bool fused_pack = true;        // ACE_FUSED_PACK=0: the norm-folded weights of inner skip / fc1 from a pack_conv_frag launch behind every norm (r05) instead of
+                                   // rider workgroups of the forward FFT (inner skip) / the convolution's own prologue (fc1 on conv_wl.hip)
     bool planes_stream = true;     // ACE_PLANES_STREAM=0: fc2 also writes the block output as fp32 (the residual stream round-trips twice)
     bool dense_grouped_filter = false;   // ACE_DENSE_GROUPED_FILTER: a grouped (block-diagonal) csfno filter expanded to the dense (C x C) form (r04)
                                          // instead of stored as the reference stores it, (G, L, C/G, C/G, 2) blocks only
@@ -193,6 +195,11 @@ struct ConvStripArgs {
     const unsigned* xslot = nullptr;                  // bound the producer scaled the input planes with
     const _Float16* A = nullptr; long sA = 0;         // packed A fragments (launch_pack_conv_frag order 0), per-sample stride
     const unsigned* aslot = nullptr; float ascale = 1.f;   // dynamic (folded) or static weight scale
+    // ... or (GELU modes of conv_ws.hip, conv_wl.hip) the instance norm in front folded into the weights in the kernel's own prologue:
+    // fp32 weight (M x C, row pitch ldw floats, 16-byte aligned rows), max|W|, the norm's per-(sample, input channel) affine
+    // a (fa) / b (fb); `bias` is then the raw bias (sbias = 0) and A / aslot / ascale are not read
+    const float* Wraw = nullptr; long ldw = 0; float wabs = 0.f;
+    const float* fa = nullptr; const float* fb = nullptr; long sfa = 0;
     const float* bias = nullptr; long sbias = 0;
     const float* R = nullptr; long sR = 0;            // optional fp32 residual (M x HW per sample), added before the activation
     // ... or the residual as P-format planes [M/8][HW][8] (hi | lo) scaled from the bound in rslot: the fc2 modes of a block whose
@@ -236,6 +243,24 @@ hipError_t launch_pack_dhconv_f16g(const float* w_grouped, void* hi, void* lo, i
 bool dhconv_strip_eligible(const DhconvStripArgs& a);
 hipError_t launch_dhconv_strip(const DhconvStripArgs& a, hipStream_t s);
 
+// A-fragment packing of a conv weight W (O x I, row pitch ldw), optionally with a per-input-channel scale folded in
+// (instance-norm affine: W diag(a)), as fp16 hi/lo blocks of 64 lanes x 8 halves (strip_pack.h layout: lane = i + 32 g holds
+// row 32 T + i, columns 16 J + 8 g .. + 7):
+//   order 0 (streamed by output-row chunk, fc1): block (T, J) at T * (I / 16) + J
+//   order 1 (streamed by 16-column step, fc2):   block (T, J) at J * (O / 32) + T
+// O % 32 == 0, I % 16 == 0.  scale: a power of two, or derived from `bound` = wmax * max|a| (published to wslot).
+// Workgroups [0, (O/32)(I/16)) pack one block each; with `bf`, O / 32 more compute the folded bias bias + W b of a 32-row tile.
+struct PackFragArgs {
+    const float* W = nullptr; long ldw = 0; int O = 0, I = 0, order = 0;
+    const float* a = nullptr; float wmax = 0.f, scale_static = 1.f; unsigned* wslot = nullptr;
+    _Float16* dst = nullptr; long sDst = 0;
+    const float* b = nullptr; const float* bias = nullptr; float* bf = nullptr;
+    int nsamples = 1;
+};
+inline int pack_frag_blocks(const PackFragArgs& q) { return (q.O / 32) * (q.I / 16) + (q.bf ? q.O / 32 : 0); }
+
+bool pack_frag_args_ok(const PackFragArgs& q);
+
 // Spectral-space layout used between the kernels ("channel-fastest planar"):
 //   X[m][k][b][ri][c]  (after the longitude DFT)     index ((m*H + k)*Bt + b)*2C + ri*C + c
 //   D[l][m][b][ri][c]  (after the Legendre stage)    index ((l*Mm + m)*Bt + b)*2C + ri*C + c
@@ -253,6 +278,9 @@ struct DftArgs {
     int Bt = 1, C = 0, H = 0, W = 0, Mm = 0;
     unsigned* omax = nullptr;  // atomicMax of bits(max|output|)
     bool no_fft = false;       // Switches::no_fft of the owning plan
+    // forward, FFT form only: a weight-packing job whose workgroups ride in this launch (pack_frag.h); nride = pack_frag_blocks()
+    // per sample, 0 = none.  launch_dft_forward reports through `rode` whether the launch took them along.
+    PackFragArgs ride; int nride = 0; bool* rode = nullptr;
 };
 hipError_t launch_dft_forward(const DftArgs& a, hipStream_t s);
 hipError_t launch_dft_inverse(const DftArgs& a, hipStream_t s);
