@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libace_sfno.so")
 SOURCES = ["kernels.hip", "fft.hip", "strip.hip", "strip_fold.hip", "conv_ws.hip", "conv_wl.hip", "dhconv_strip.hip", "cln_mfma.hip", "physics.hip", "healpix.hip", "capi.hip", "tables.cpp"]
-HEADERS = ["kernels.h", "strip_common.h", "strip_pack.h", "ws_plan.h", "small_fft.h", "tables.h", os.path.join("..", "..", "include", "ace_sfno.h")]
+HEADERS = ["kernels.h", "strip_common.h", "strip_pack.h", "ws_plan.h", "pack_frag.h", "dhconv_units.h", "small_fft.h", "tables.h", os.path.join("..", "..", "include", "ace_sfno.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 

@@ -551,6 +551,15 @@ extern "C" int ace_mlp_f16x3(const float* x, const float* w1, const float* b1, c
     return ACE_OK;
 }
 
+// the work list of a dhconv_strip launch (dhconv_build_units) on the device
+static hipError_t upload_dhconv_units(int L, int Mrows, int trimul, int C, DevBuf& buf, int* per_xcd) {
+    std::vector<int> u;
+    *per_xcd = dhconv_build_units(L, Mrows, trimul, C, u);
+    hipError_t e = buf.alloc(u.size(), false);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(buf.p, u.data(), u.size() * sizeof(int), hipMemcpyHostToDevice);
+}
+
 // _contract_dhconv (fme/ace/models/modulus/contractions.py:183-195): einsum("bixy,iox->boxy") on complex coefficients, on the
 // kernel the network uses (dhconv_strip.hip: compensated fp16, filter streamed once).  Operator-level entry for tests and
 // micro-benchmarks: converts to the internal layouts, prepares the filter planes on every call and synchronises.
@@ -592,6 +601,9 @@ extern "C" int ace_dhconv_f16x3(const float* coeffs, const float* weight, float*
     ds.sW = (long)2 * c * c; ds.bscale = wscale;
     ds.E = E.p; ds.sE = (long)Mm * N2;
     ds.C = c; ds.L = L; ds.Mrows = Mm * n; ds.trimul = n;
+    DevBuf units;
+    HIP_TRY(upload_dhconv_units(L, Mm * n, n, c, units, &ds.units_per_xcd));
+    ds.units = reinterpret_cast<const int*>(units.p);
     if (!dhconv_strip_eligible(ds)) return fail(ACE_ERR_INVALID, "ace_dhconv_f16x3: shape not covered by dhconv_strip.hip");
     HIP_TRY(launch_dhconv_strip(ds, s));
     HIP_TRY(launch_spec_to_ref(E.p, out, n, c, L, Mm, s));
@@ -726,6 +738,7 @@ struct ace_sfno {
     std::vector<DevBuf> wx_hi, wx_lo;  // per block: the same operand k-packed as fp16 hi/lo planes (f16x3 engine)
     std::vector<float> wx_scale;
     std::vector<char> wx_compact;   // per block: wx_hi/lo hold the compact (Wr | Wi) form of Gemm4Args::cplx
+    std::vector<DevBuf> dh_units; std::vector<int> dh_units_per_xcd;   // work lists of the filter contraction, one per batch size 1 .. max_batch
     std::vector<char> wx_native;    // per block: ... of a grouped filter with its diagonal blocks only (1 / G of the dense form)
     // workspace
     DevBuf h0, h1, Y, T, R, U, X, D, E, stats;
@@ -890,6 +903,12 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
         const bool strip_rows_ok = ((long)n->Mm * n->Bmax + 191) / 192 <= 65535;
         n->wx_native[i] = (n->wx_compact[i] && cln && c.filter_num_groups > 1 && !n->sw.dense_grouped_filter && !n->sw.no_dhconv_strip &&
                            strip_rows_ok && dhconv_native_groups_ok(n->C, c.filter_num_groups)) ? 1 : 0;
+    }
+    if (c.operator_type == 1 && c.precision == 1 && n->C % 128 == 0) {   // dhconv_strip.hip's work lists (depend on the batch size)
+        n->dh_units.resize(n->Bmax);
+        n->dh_units_per_xcd.assign(n->Bmax, 0);
+        for (int b = 1; b <= n->Bmax; ++b)
+            HIP_TRY(upload_dhconv_units(n->L, n->Mm * b, b, n->C, n->dh_units[b - 1], &n->dh_units_per_xcd[b - 1]));
     }
     const size_t act = (size_t)n->Bmax * C * HW;
     // + slack rows read (never used) by the strip Legendre kernels past the last contraction row
@@ -1568,10 +1587,11 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                 ds.C = C; ds.L = n->L; ds.Mrows = n->Mm * B; ds.trimul = B;
                 ds.groups = cln ? c.filter_num_groups : 1;
                 if (n->wx_native[i]) { ds.kstore = C / ds.groups; ds.sW = (long)2 * ds.kstore * C; }
+                if ((int)n->dh_units.size() >= B) { ds.units = reinterpret_cast<const int*>(n->dh_units[B - 1].p); ds.units_per_xcd = n->dh_units_per_xcd[B - 1]; }
             }
-            if (n->wx_native[i] && !(dplanes && dhconv_strip_eligible(ds)))
+            if (n->wx_native[i] && !(dplanes && ds.units && dhconv_strip_eligible(ds)))
                 return fail(ACE_ERR_STATE, "grouped filter stored as diagonal blocks, but the strip kernel cannot run this launch");
-            if (dplanes && n->wx_compact[i] && !n->sw.no_dhconv_strip && dhconv_strip_eligible(ds)) {
+            if (dplanes && n->wx_compact[i] && !n->sw.no_dhconv_strip && ds.units && dhconv_strip_eligible(ds)) {
                 HIP_TRY(launch_dhconv_strip(ds, s));
             } else if (dplanes) {
                 Gemm4Args a;

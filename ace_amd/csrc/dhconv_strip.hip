@@ -4,32 +4,52 @@
 // The filter is 212 MB at the ACE2 shape and every element is used by at most 181 rows: the stage is bound by streaming
 // the weights.  The 128 x 128 tile engine moves each weight through L2 -> LDS once per 128-row tile and each coefficient
 // once per 128-column tile (1.1 GB of LDS-DMA traffic per launch, 465 MB of HBM reads for 262 MB of operands: r02 PMC).
-// Here a workgroup owns (degree l, 128 output channels): each of its four waves holds 32 output channels, real AND imaginary
-// part, for ALL rows of the degree (up to 192 = 6 strips of 32, 12 accumulator tiles per wave; degrees with more rows - batch
-// > 1, the 0.25-degree grid - are cut into 192-row chunks, one workgroup each):
+// Here a workgroup owns (degree l, 128 output channels, a chunk of up to 96 rows): each of its four waves holds 32 output channels,
+// real AND imaginary part, for the chunk's rows (1 .. 3 strips of 32, 6 accumulator tiles per wave).  Round 5 gave a workgroup up
+// to 192 rows: 552 workgroups of very unequal size on 256 CUs, the heavy ones matrix-bound at ~40 us, the light ones latency-bound,
+// 98 us per launch against a 50 us stream of the operands.  The chunks of one (degree, column group) are NEIGHBOURS in launch order
+// on one XCD: the second reads the filter slice the first is streaming from that XCD's L2.
 //   * the weights are the MFMA B operand: their stored form (k-packed "P format", compact complex: Wr | Wi per l) IS the
 //     fragment of a lane, so they go global -> registers with coalesced 16-byte loads, two stages ahead, and never touch LDS;
 //     a stage is 32 rows of Wr and the same 32 rows of Wi, each used for two products (with D_re and with D_im), so every
 //     filter element is fetched exactly once per launch;
 //   * the coefficients D_l (fp16 hi/lo planes written by the Legendre stage, row-major (D_re | D_im)) are the A operand
 //     shared by the four waves: a stage holds the 32-wide k slice of BOTH halves of the row, as 1-KiB LDS-DMA pieces of
-//     16 rows x 32 k with a source-side XOR swizzle, three-stage ring, counted waits (all vector-memory operations of the
-//     loop are inline asm, no stores: the count is exact);
+//     16 rows x 32 k with a source-side XOR swizzle, four-stage ring, the pieces of stage t + 3 requested while stage t computes (as
+//     the filter fragments; one or two requests behind every six MFMAs), ONE barrier per stage, counted waits (all vector-memory
+//     operations of the loop are inline asm, no stores: the count is exact);
 //   * complex structure: real += D_re Wr - D_im Wi, imaginary += D_re Wi + D_im Wr; the minus sign is put on the D_im
 //     fragment (8 v_xor per strip and k16 step);
-//   * row strips beyond l are skipped (1 .. 6 active strips of 32 rows).
+//   * row strips beyond l are skipped (1 .. 3 active strips of 32 rows per chunk).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
+#include "dhconv_units.h"
 #include "strip_common.h"
 
 namespace ace {
 namespace {
 
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+#ifdef ACE_DH_TRACE   // measurement builds (tools/trace_dh.py): per workgroup, wave 0: start, after the main loop, end (s_memtime), degree, XCC
+__device__ unsigned long long dh_wg_span[8192][6];
+#define DH_STAMP(k, v) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) dh_wg_span[blockIdx.x][k] = (v); } while (0)
+__device__ unsigned long long dh_stage_trace[4][64];   // per traced workgroup (ACE_DH_TRACE_WG + 8 k, k < 4): stamps of wave 0
+#ifndef ACE_DH_TRACE_WG
+#define ACE_DH_TRACE_WG 0
+#endif
+#define DH_MT(ev) do { const int tw_ = ((int)blockIdx.x - ACE_DH_TRACE_WG) / 264; if (threadIdx.x == 0 && ((int)blockIdx.x - ACE_DH_TRACE_WG) % 264 == 0 && tw_ >= 0 && tw_ < 4 && (ev) < 64) dh_stage_trace[tw_][ev] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DH_STAMP(k, v) do { } while (0)
+#define DH_MT(ev) do { } while (0)
+#endif
+
 
 MDEV void gload16(half8& dst, const _Float16* p) {   // un-waited 16-byte global load (retired by wait_b below)
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
@@ -40,13 +60,15 @@ MDEV half8 neg8(half8 v) {
     return __builtin_bit_cast(half8, u);
 }
 
-// NS: active 32-row strips (1 .. 6) of this workgroup's row chunk [row0, row0 + rows) of degree l
+
+// NS: active 32-row strips (1 .. 3) of this workgroup's row chunk [row0, row0 + rows) of degree l
 template <int NS>
 MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const int j, const int row0, const int rows) {
-    constexpr int NSTG = 3;                       // ring depth (stages)
+    constexpr int PB = 3;                         // A pieces and B fragments of stage t + PB are issued while stage t computes
+    constexpr int NSTG = PB + 1;                  // ring depth (stages): the slot refilled during stage t held stage t - 1, which every
+                                                  // wave had finished before any wave passed the barrier of stage t
     constexpr int STAGE = NS * 8192;              // bytes: NS strips x 2 slices (re, im) x (2 row pieces x 2 planes) x 1 KiB
     constexpr int NA = 2 * NS;                    // A pieces per wave per stage
-    constexpr int PB = 2;                         // B fragments run PB stages ahead (as the A pieces)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,11 +106,13 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
         row = row < rows ? row : rows - 1;
         asrc[k] = (pl ? Dl : Dh) + (long)row * K2 + sl * C + 8 * ls;
     }
-    auto issue_a = [&](int t) {   // stage t -> ring slot t % NSTG; stages past the end re-fetch the last (uniform count)
+    auto issue_a1 = [&](int t, int k) {   // piece k of stage t -> ring slot t % NSTG; stages past the end re-fetch the last (uniform count)
         const int tt = tb + (t < nstages ? t : nstages - 1);
-        char* dst = smem + (t % NSTG) * STAGE;
+        glds16(asrc[k] + 32 * tt, smem + (t % NSTG) * STAGE + (wave + 4 * k) * 1024);
+    };
+    auto issue_a = [&](int t) {
 #pragma unroll
-        for (int k = 0; k < NA; ++k) glds16(asrc[k] + 32 * tt, dst + (wave + 4 * k) * 1024);
+        for (int k = 0; k < NA; ++k) issue_a1(t, k);
     };
     // ---- B fragments of stage t: rows [32 t, 32 t + 32) of Wr and of Wi, this wave's 32 columns.  Each filter element is
     //      loaded by exactly one wave of one workgroup, once (the first version walked k over (D_re | D_im) with the real
@@ -97,18 +121,17 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
     const _Float16* Wh = p.Whi + (long)l * p.sW;
     const _Float16* Wl = p.Wlo + (long)l * p.sW;
     struct BSet { half8 h[2][2], l[2][2]; };      // [k16 step][Wr | Wi]
-    auto issue_b = [&](BSet& b, int t) {
+    auto issue_b1 = [&](BSet& b, int t, auto qc) {   // load q of the eight of a set: (k16 step c, Wr | Wi, hi | lo)
+        constexpr int q = decltype(qc)::value, c = q >> 2, blk = (q >> 1) & 1, lo = q & 1;
         const int tt = tb + (t < nstages ? t : nstages - 1);
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                int kg = 4 * tt + 2 * c + g - kbase / 8;          // k-group relative to this wave's first stored row
-                if (native) kg = kg < 0 ? 0 : (kg >= kstore / 8 ? kstore / 8 - 1 : kg);
-                const long off = (long)blk * kstore * C + ((long)kg * C + oc + i) * 8;
-                gload16(b.h[c][blk], Wh + off);
-                gload16(b.l[c][blk], Wl + off);
-            }
+        int kg = 4 * tt + 2 * c + g - kbase / 8;          // k-group relative to this wave's first stored row
+        if (native) kg = kg < 0 ? 0 : (kg >= kstore / 8 ? kstore / 8 - 1 : kg);
+        const long off = (long)blk * kstore * C + ((long)kg * C + oc + i) * 8;
+        if constexpr (lo) gload16(b.l[c][blk], Wl + off);
+        else gload16(b.h[c][blk], Wh + off);
+    };
+    auto issue_b = [&](BSet& b, int t) {
+        static_for<0, 8>([&](auto qc) { issue_b1(b, t, qc); });
     };
     auto wait_b = [&](BSet& b, auto nn) {         // retire this set: at most nn newer operations stay in flight
         constexpr int N = decltype(nn)::value;
@@ -127,23 +150,38 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[s][tl][r] = 0.f;
 
-    // prologue in the steady-state issue order (stage t issues A(t + 2) then B(t + 2)): A0 B0 | A1 B1
+    // prologue in the steady-state issue order: A0 B0 | A1 B1 | A2 B2
     BSet bs[4];                                   // ring of fragment sets, indexed with compile-time constants only
+    static_assert(PB == 3, "ring of four fragment sets: the one of stage t is refilled for stage t + 4 a stage later");
     issue_a(0); issue_b(bs[0], 0);
     issue_a(1); issue_b(bs[1], 1);
+    issue_a(2); issue_b(bs[2], 2);
 
     const float inv_a = ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_a)));
     const float oscale = inv_a / p.bscale;
     const int key = (i >> 2) & 3;                 // swizzle key of this lane's fragment rows (rows i and i + 16 ... share it mod 4)
 
-    // Stage t issues A(t + 2) and B(t + 2).  Issue order: ... A(t) B(t) | A(t+1) B(t+1) | A(t+2) B(t+2): after this stage's
-    // issue exactly 2 (NA + 8) operations are newer than B(t).  All of them are loads (in-order retirement), the loop has
-    // no stores: vmcnt(2 (NA + 8)) is exact.
+    // The operands of stage t + PB are requested WHILE stage t computes, one or two operations behind each group of six MFMAs
+    // (in front of the stage they cost a wave 800 - 1800 cycles of issue with the matrix pipe idle: tools/trace_dh.py).  Issue
+    // order: ... A(t+1) B(t+1) | A(t+2) B(t+2) | A(t+3) B(t+3): at the top of stage t exactly 2 (NA + 8) operations are newer
+    // than B(t).  All of them are loads (in-order retirement), the loop has no stores: vmcnt(2 (NA + 8)) is exact.  B(t + 3)
+    // goes into the set of stage t - 1, A(t + 3) into its ring slot.
+    constexpr int NOPS = NA + 8, NSLOT = 4 * NS;
     auto stage = [&](const int t, BSet& b, BSet& bnew) {
-        issue_a(t + 2);
-        issue_b(bnew, t + PB);
+        DH_MT(4 * t);
+        DH_MT(4 * t + 1);
         wait_b(b, std::integral_constant<int, 2 * (NA + 8)>{});
-        __builtin_amdgcn_s_barrier();             // every wave's pieces of stage t landed
+        DH_MT(4 * t + 2);
+        __builtin_amdgcn_s_barrier();             // every wave's pieces of stage t landed; every wave is done with stage t - 1
+        DH_MT(4 * t + 3);
+        auto issue_slot = [&](auto sc) {          // the operations of slot sc of the NSLOT MFMA groups of this stage
+            constexpr int sl_ = decltype(sc)::value;
+            static_for<(sl_ * NOPS) / NSLOT, ((sl_ + 1) * NOPS) / NSLOT>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k < NA) issue_a1(t + PB, k);
+                else issue_b1(bnew, t + PB, std::integral_constant<int, k - NA>{});
+            });
+        };
         const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (t % NSTG) * STAGE);
         const int k0 = 32 * (tb + t);
         const bool live = !native || (k0 >= kbase && k0 < kbase + cg);   // wave-uniform: this stage's k range lies in this wave's group
@@ -185,9 +223,11 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
                     acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(nh, b.h[c][1], acc[s][0], 0, 0, 0);
                 }
                 if constexpr (ph < 3) issue_f((ph & 1) ? fa[s] : fb[s], frag_addr(ph + 1, s));
+                __builtin_amdgcn_sched_barrier(0);
+                issue_slot(std::integral_constant<int, ph * NS + s>{});
+                __builtin_amdgcn_sched_barrier(0);
             });
         });
-        __builtin_amdgcn_s_barrier();             // every wave is done reading the slot of stage t (refilled by A(t + 3))
     };
     for (int t0 = 0; t0 < nstages; t0 += 4)       // nstages (C / 32, or the group span / 32) is a multiple of 4
         static_for<0, 4>([&](auto u) { stage(t0 + u, bs[u], bs[(u + PB) % 4]); });
@@ -195,6 +235,8 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
     // them NAMES their registers, or the allocator may hand those registers to the epilogue's values above the wait and the
     // returning loads would land on them (tools/store_hazard.hip, variant 3: the mechanism behind round 2's "store data"
     // corruption).  Two statements: an asm takes at most 30 operands.
+    DH_STAMP(1, __builtin_amdgcn_s_memtime());
+    DH_MT(48);
     auto name_set = [](BSet& b) {
         asm volatile("" : "+v"(b.h[0][0]), "+v"(b.h[0][1]), "+v"(b.h[1][0]), "+v"(b.h[1][1]), "+v"(b.l[0][0]), "+v"(b.l[0][1]),
                           "+v"(b.l[1][0]), "+v"(b.l[1][1]));
@@ -248,35 +290,39 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
 }
 
 __global__ __launch_bounds__(256, 1) void dhconv_strip_kernel(DhconvStripArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[3 * 6 * 8192];
-    // Workgroup b runs on XCD b % 8 (each XCD has its own L2).  The C / 128 column groups of one degree all read the degree's
-    // coefficient rows D[l] (the A operand: up to 181 rows x 768 values as hi / lo planes): deal whole DEGREES to XCDs so that the
-    // groups of a degree follow each other on ONE XCD and the later ones find D[l] in its L2 (round 3 dealt consecutive blocks -
-    // the groups of a degree - to three different XCDs: 176 MB of D traffic for 100 MB of D, profiles/r04_pmc_table.txt).
-    // Heavy degrees first within every XCD: XCD x takes l = L - 1 - x, L - 9 - x, ...
-    const int ncg = p.C / 128;
+    __shared__ __attribute__((aligned(16))) char smem[4 * DH_CHUNK_STRIPS * 8192];
+    // Workgroup b runs on XCD b % 8 (each XCD has its own L2) and, measured (tools/trace_dh.py, profiles/r06_dhconv_dispatch.txt), on
+    // shader engine (b / 8) % 4 of that XCD: the dispatcher deals a launch's workgroups to the four engines in turn WHATEVER their
+    // load, only the 8 CUs of an engine share work dynamically.  With one workgroup per CU and units of unequal size the ORDER of
+    // the units therefore decides the balance: dhconv_build_units (host) lists, per XCD, the units (degree, column group, row
+    // chunk) largest first, the chunks of one (degree, column group) next to each other (they stream the same 393 KB filter slice:
+    // once from HBM, then from this XCD's L2) and in alternating order so that every engine gets the same mix.
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int l = p.L - 1 - ((idx / ncg) * 8 + xcd);
-    const int j = idx % ncg;
-    if (l < 0) return;
-    const int rows_l = (l + 1) * p.trimul < p.Mrows ? (l + 1) * p.trimul : p.Mrows;
-    // degrees with more than 192 rows (a batch of 2 at the 1-degree grid: 362; the 0.25-degree grid: 721) are cut into chunks
-    // of 192 rows, one workgroup each (blockIdx.y); the filter slice of a (degree, column group) is then streamed once per
-    // chunk - the later ones from L2 / MALL (393 KB per slice)
-    const int row0 = (int)blockIdx.y * 192;
-    if (row0 >= rows_l) return;
-    const int rows = rows_l - row0 < 192 ? rows_l - row0 : 192;
-    // active 32-row strips: 1 .. 6 (row granularity 32: 14 % fewer MFMAs than strip pairs at the 1-degree shape, and the
-    // workgroups' sizes - there are only 2.1 per CU - balance better)
+    const int4 u = reinterpret_cast<const int4*>(p.units)[xcd * p.units_per_xcd + idx];   // (l, j, row0, rows); rows = 0: padding
+    const int l = u.x, j = u.y, row0 = u.z, rows = u.w;
+    if (rows <= 0) return;
+#ifdef ACE_DH_TRACE
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
+    // active 32-row strips: 1 .. 3
     if (rows <= 32) dhconv_body<1>(p, smem, l, j, row0, rows);
     else if (rows <= 64) dhconv_body<2>(p, smem, l, j, row0, rows);
-    else if (rows <= 96) dhconv_body<3>(p, smem, l, j, row0, rows);
-    else if (rows <= 128) dhconv_body<4>(p, smem, l, j, row0, rows);
-    else if (rows <= 160) dhconv_body<5>(p, smem, l, j, row0, rows);
-    else dhconv_body<6>(p, smem, l, j, row0, rows);
+    else dhconv_body<3>(p, smem, l, j, row0, rows);
+#ifdef ACE_DH_TRACE
+    DH_MT(49);
+    DH_STAMP(0, t_start);
+    DH_STAMP(2, __builtin_amdgcn_s_memtime());
+    DH_STAMP(3, (unsigned long long)rows);
+    { unsigned xcc, hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); DH_STAMP(4, xcc & 0xf); DH_STAMP(5, hwid); }
+#endif
 }
 
 }  // namespace
+
+#ifdef ACE_DH_TRACE
+extern "C" int ace_debug_dh_stages(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dh_stage_trace), sizeof(dh_stage_trace)); }
+extern "C" int ace_debug_dh_spans(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dh_wg_span), sizeof(dh_wg_span)); }
+#endif
 
 bool dhconv_native_groups_ok(int C, int groups) {
     if (groups <= 1 || C % groups != 0 || C % 128 != 0) return false;
@@ -284,14 +330,16 @@ bool dhconv_native_groups_ok(int C, int groups) {
     return cg % 32 == 0 && (cg % 128 == 0 || 128 % cg == 0);
 }
 
+int dhconv_build_units(int L, int Mrows, int trimul, int C, std::vector<int>& out) { return dhconv_units(L, Mrows, trimul, C, out); }
+
 bool dhconv_strip_eligible(const DhconvStripArgs& a) {
     if (a.kstore > 0 && a.kstore != a.C && !(a.groups > 1 && a.kstore == a.C / a.groups && dhconv_native_groups_ok(a.C, a.groups))) return false;
     return a.C % 128 == 0 && a.C >= 128 && a.groups >= 1 && a.C % a.groups == 0 && a.Mrows >= 1 && (a.Mrows + 191) / 192 <= 65535 && a.L >= 1 && a.Dhi && a.Dlo && a.Whi && a.Wlo && a.E && a.amax;
 }
 
 hipError_t launch_dhconv_strip(const DhconvStripArgs& a, hipStream_t s) {
-    if (!dhconv_strip_eligible(a)) return hipErrorInvalidValue;
-    dim3 grid((unsigned)(((a.L + 7) / 8) * 8 * (a.C / 128)), (unsigned)((a.Mrows + 191) / 192)), block(256);   // whole degrees per XCD (see the kernel)
+    if (!dhconv_strip_eligible(a) || !a.units || a.units_per_xcd < 1 || (long)a.units_per_xcd * 8 > 0x7fffffffL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)(8 * a.units_per_xcd)), block(256);
     hipLaunchKernelGGL(dhconv_strip_kernel, grid, block, 0, s, a);
     return hipGetLastError();
 }

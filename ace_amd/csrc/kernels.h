@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 namespace ace {
 
 // Measurement switches (environment variables, A/B timing only - every path is a gfx950 HIP kernel).  Read ONCE per handle, at
@@ -234,6 +236,7 @@ struct DhconvStripArgs {
     unsigned* omax = nullptr;
     int C = 0, L = 0, Mrows = 0, trimul = 1;                                      // rows of degree l: min((l + 1) * trimul, Mrows)
     int groups = 1;                                                               // block-diagonal filter (grouped csfno filter, s2convolutions.py:119-135): zero blocks are skipped
+    const int* units = nullptr; int units_per_xcd = 0;                            // work list of the launch: dhconv_build_units(L, Mrows, trimul, C), on the device
     int kstore = 0;                                                               // rows (input channels) each Wr / Wi block holds per output column: 0 / C = dense form;
                                                                                   // C / groups = ONLY the diagonal blocks (the reference's (G, L, C/G, C/G, 2) parameter):
                                                                                   // [l][Wr|Wi][(C/G)/8][C][8], row index relative to the column's own group
@@ -241,6 +244,8 @@ struct DhconvStripArgs {
 bool dhconv_native_groups_ok(int C, int groups);   // can the strip kernel read the diagonal-blocks-only form?
 hipError_t launch_pack_dhconv_f16g(const float* w_grouped, void* hi, void* lo, int C, int G, int L, float scale, hipStream_t s);
 bool dhconv_strip_eligible(const DhconvStripArgs& a);
+// host: the launch's work list, 8 x (returned count) entries of 4 ints (l, j, row0, rows), see dhconv_strip.hip
+int dhconv_build_units(int L, int Mrows, int trimul, int C, std::vector<int>& out);
 hipError_t launch_dhconv_strip(const DhconvStripArgs& a, hipStream_t s);
 
 // A-fragment packing of a conv weight W (O x I, row pitch ldw), optionally with a per-input-channel scale folded in

@@ -63,3 +63,14 @@ def test_conditional_layer_norm_mfma_decomposition(tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "worst" in res.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_dhconv_work_list(tmp_path):
+    """ace_amd/csrc/dhconv_units.h (the launch order of dhconv_strip.hip's workgroups): every row of every (degree, column group)
+    in exactly one unit on the owning XCD, chunks of a group neighbours, the four shader engines of an XCD evenly loaded."""
+    exe = str(tmp_path / "dhconv_units_emul")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "emul", "dhconv_units_emul.cpp")], check=True)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "worst" in res.stdout
