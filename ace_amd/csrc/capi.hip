@@ -761,6 +761,11 @@ struct ace_sfno {
     std::vector<DevBuf> taps;
     std::map<GraphKey, hipGraphExec_t> graphs;
     hipStream_t capture_stream = nullptr;
+#ifdef ACE_MEASUREMENT_SWITCHES   // fork experiment (profiles/r06_skip_fork.txt): ACE_SKIP_FORK=1 the inner skip's bias-only GEMM on a side
+    int skip_fork = 0;            // stream beside the spectral chain (an EXTRA kernel: results unchanged), 2 the same kernel in line
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+#endif
     long weights_generation = 0; // bumped by every ace_sfno_set_weight (ace_sfno_weights_generation)
     bool graphs_stale = false;   // a parameter was uploaded since the graphs were captured: re-capture lazily
     Switches sw;                 // measurement switches, read once at ace_sfno_create
@@ -904,6 +909,16 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
         n->wx_native[i] = (n->wx_compact[i] && cln && c.filter_num_groups > 1 && !n->sw.dense_grouped_filter && !n->sw.no_dhconv_strip &&
                            strip_rows_ok && dhconv_native_groups_ok(n->C, c.filter_num_groups)) ? 1 : 0;
     }
+#ifdef ACE_MEASUREMENT_SWITCHES
+    if (const char* e = std::getenv("ACE_SKIP_FORK")) {
+        n->skip_fork = std::atoi(e);
+        if (n->skip_fork) {
+            HIP_TRY(hipStreamCreateWithFlags(&n->side_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
+        }
+    }
+#endif
     if (c.operator_type == 1 && c.precision == 1 && n->C % 128 == 0) {   // dhconv_strip.hip's work lists (depend on the batch size)
         n->dh_units.resize(n->Bmax);
         n->dh_units_per_xcd.assign(n->Bmax, 0);
@@ -963,6 +978,11 @@ extern "C" void ace_sfno_destroy(ace_sfno* n) {
     if (!n) return;
     for (auto& kv : n->graphs) (void)hipGraphExecDestroy(kv.second);
     if (n->capture_stream) (void)hipStreamDestroy(n->capture_stream);
+#ifdef ACE_MEASUREMENT_SWITCHES
+    if (n->side_stream) (void)hipStreamDestroy(n->side_stream);
+    if (n->ev_fork) (void)hipEventDestroy(n->ev_fork);
+    if (n->ev_join) (void)hipEventDestroy(n->ev_join);
+#endif
     delete n;
 }
 
@@ -1548,10 +1568,34 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             }
         }
         const PackFragArgs* ride = skip_pack_wanted ? &skip_pack : nullptr;
+#ifdef ACE_MEASUREMENT_SWITCHES
+        bool forked = false, packed_early = false;
+        if (n->skip_fork && skip_pack_wanted && !tm) {
+            // the skip GEMM without its epilogue (mode 7: S = W diag(a0) h + bias, fp32 into the unused T buffer) beside the chain
+            const Weight& wsk = *n->weights[n->index.at(p + "inner_skip.weight")];
+            hipStream_t q = n->skip_fork == 1 ? n->side_stream : s;
+            if (n->skip_fork == 1) { HIP_TRY(hipEventRecord(n->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(q, n->ev_fork, 0)); }
+            HIP_TRY(launch_pack_conv_frag(wsk.buf.p, wsk.pitch, C, C, 0, a0, wsk.wabs, 1.f, slot(sb + 8), n->Wq0.p, (long)C * C * 2, B, q,
+                                          b0, skip_pack.bias, n->bf0.p));
+            ConvStripArgs k;
+            k.Xhi = PBh; k.Xlo = PBl; k.ldn = HW; k.sX = (long)C * HW; k.xslot = hslot(i);
+            k.A = reinterpret_cast<const _Float16*>(n->Wq0.p); k.sA = (long)C * C * 2; k.aslot = slot(sb + 8);
+            k.bias = n->bf0.p; k.sbias = C;
+            k.Cf = n->T.p; k.sCf = actB;
+            k.C = C; k.M = C; k.HW = (int)HW; k.nbatch = B; k.act = ACT_NONE;
+            HIP_TRY(launch_conv_ws(k, q));
+            forked = n->skip_fork == 1;
+            ride = nullptr;   // (packed above)
+            packed_early = true;
+        }
+#endif
         if (h_planes_only)   // the block input exists as planes only (written by the previous block's fc2, mode 4)
             ACE_TRY(run_dft_forward(fwd, nullptr, a0, b0, n->X.p, B, C, s, xmax, PBh, PBl, (long)C * HW, hslot(i), ride, &skip_pack_rode));
         else
             ACE_TRY(run_dft_forward(fwd, h, a0, b0, n->X.p, B, C, s, xmax, nullptr, nullptr, 0, nullptr, ride, &skip_pack_rode));
+#ifdef ACE_MEASUREMENT_SWITCHES
+        if (packed_early) skip_pack_rode = true;
+#endif
         MARK(ST_DFT_FWD);
         // packed dhconv: D goes from the Legendre epilogue to the filter GEMM as fp16 planes (never fp32)
         const bool dplanes = f16 && !n->sw.no_pk_sht && c.operator_type == 1 && n->wx_hi[i].p && !scale_residual && fwd.f16 &&
@@ -1622,6 +1666,9 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         MARK(ST_LEGENDRE_INV);
         ACE_TRY(run_dft_inverse(inv, n->X.p, W(p + "filter.filter.bias"), n->Y.p, B, C, s, slot(sb + 7)));
         MARK(ST_DFT_INV);
+#ifdef ACE_MEASUREMENT_SWITCHES
+        if (forked) { HIP_TRY(hipEventRecord(n->ev_join, n->side_stream)); HIP_TRY(hipStreamWaitEvent(s, n->ev_join, 0)); }
+#endif
 
         // x = act(filter + inner_skip(residual))   (sfnonet.py:229-232)
         ConvW wskip = conv_weight(n, p + "inner_skip.weight", p + "inner_skip.bias");

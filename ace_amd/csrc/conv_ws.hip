@@ -61,7 +61,7 @@ template <int KSW, int NSTG, int MODE>
 struct WsGeom {
     static constexpr int KH = KSW * NSTG;          // k16-steps per wave: its half of the contraction
     static constexpr int SLOT = 2 * KSW * 2048;    // one stage of activation fragments, both halves
-    static constexpr bool F32 = MODE == 2 || MODE == 3 || MODE == 5 || MODE == 6, STATS = MODE == 0 || MODE == 2 || MODE == 4;
+    static constexpr bool F32 = MODE == 2 || MODE == 3 || MODE == 5 || MODE == 6 || MODE == 7, STATS = MODE == 0 || MODE == 2 || MODE == 4;
     static constexpr bool AFFRES = MODE >= 2;      // fc2 modes: residual with a per-row affine (scale table Ps, shift folded into Pb)
     static constexpr int BMAX = AFFRES ? 1024 : 2048; // output rows with LDS-resident epilogue parameters
     static constexpr int TAB = BMAX * 4 * (AFFRES ? 2 : 1);
@@ -81,6 +81,8 @@ struct WsGeom {
 //         only (520 -> 420 MB of traffic per launch)                                 5: as 3 with the residual from planes
 //      6: as 3 with GELU: the inner skip of the noise-conditioned nets (fp32 residual, fp32 output for the conditional norm that
 //         follows; any K of this file - round 4 ran it on the packed tile engine at C = 512)
+//      7: measurement builds (-DACE_MEASUREMENT_SWITCHES): bias only, fp32 output - the inner skip's GEMM without its epilogue, for the
+//         fork experiment of profiles/r06_skip_fork.txt
 // Modes 0 / 1 (K <= 384, registers to spare): the epilogue of pixel tile t - 1 runs between the MFMAs of tile t.
 // H: contraction half of the calling wave (compile time, see conv_split.hip)
 template <int KSW, int NSTG, int MODE, int H>
@@ -88,7 +90,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     using G = WsGeom<KSW, NSTG, MODE>;
     constexpr int KH = G::KH, SLOT = G::SLOT, BMAX = G::BMAX, TAB = G::TAB, XCH = G::XCH, STP = G::STP;
     constexpr int PW = KSW / 2;             // 1-KiB pieces per wave per stage
-    constexpr bool GELU = MODE <= 1 || MODE == 6, RES = MODE != 1, PK = MODE != 3 && MODE != 5 && MODE != 6, F32 = G::F32, STATS = G::STATS, RSTATS = G::RSTATS;
+    constexpr bool GELU = MODE <= 1 || MODE == 6, RES = MODE != 1 && MODE != 7, PK = MODE != 3 && MODE != 5 && MODE != 6 && MODE != 7, F32 = G::F32, STATS = G::STATS, RSTATS = G::RSTATS;
     constexpr bool AFFRES = G::AFFRES, RPL = MODE == 4 || MODE == 5;   // RPL: the residual comes as planes
     constexpr bool INTER = MODE <= 1;       // epilogue of tile t - 1 between the MFMAs of tile t
     constexpr bool HOLD = KH < 24 || (MODE == 4 && ACE_WS_HOLD4);   // registers to hold the store data through a stage (else: stores retired first; holding them at K = 768 in mode 2 spills 22 VGPRs)
@@ -590,6 +592,9 @@ hipError_t launch_ws_k(const ConvStripArgs& a, int mode, hipStream_t s) {
     if (mode == 4) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 4>), grid, block, 0, s, a, pl);
     if (mode == 5) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 5>), grid, block, 0, s, a, pl);
     if (mode == 6) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 6>), grid, block, 0, s, a, pl);
+#ifdef ACE_MEASUREMENT_SWITCHES
+    if (mode == 7) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 7>), grid, block, 0, s, a, pl);
+#endif
     return hipGetLastError();
 }
 
@@ -647,6 +652,9 @@ hipError_t launch_conv_ws(const ConvStripArgs& a, hipStream_t s) {
     else if (a.act == ACT_NONE && res && f32 && !pk && !stats) mode = 3;
     else if (a.act == ACT_NONE && rpl && !f32 && pk && stats) mode = 4;
     else if (a.act == ACT_NONE && rpl && f32 && !pk && !stats) mode = 5;
+#ifdef ACE_MEASUREMENT_SWITCHES
+    else if (a.act == ACT_NONE && !res && !rpl && f32 && !pk && !stats) mode = 7;
+#endif
     if (mode < 0 || (pk && (!a.Clo || !a.cslot)) || (f32 && a.M > 1024)) return hipErrorInvalidValue;
     if (mode <= 1 && a.C > 384) return hipErrorInvalidValue;
     switch (a.C) {
