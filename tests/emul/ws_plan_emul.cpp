@@ -53,7 +53,7 @@ int main() {
                     for (int s = 0; s < S; ++s)
                         if (slot_rows[{q, s}] != 1) { printf("FAIL M %d HW %ld: slot %d slice %d gets %d partials\n", M, HW, q, s, slot_rows[{q, s}]); return 1; }
                 // balance: the busiest workgroup against the ideal share of 256 CUs (large fields only)
-                if (tiles >= 2000 && allow) {
+                if (tiles >= 2000 && (allow || pl.XG > 0)) {
                     const long ideal_num = (long)S * tiles, ideal_den = 256;
                     if (maxwork * ideal_den * worst_den > worst_num * ideal_num) { worst_num = maxwork * ideal_den; worst_den = ideal_num; }
                 }
