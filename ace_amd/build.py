@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libace_sfno.so")
 SOURCES = ["kernels.hip", "fft.hip", "strip.hip", "strip_fold.hip", "conv_ws.hip", "conv_wl.hip", "dhconv_strip.hip", "cln_mfma.hip", "physics.hip", "healpix.hip", "capi.hip", "tables.cpp"]
-HEADERS = ["kernels.h", "strip_common.h", "strip_pack.h", "ws_plan.h", "pack_frag.h", "dhconv_units.h", "small_fft.h", "tables.h", os.path.join("..", "..", "include", "ace_sfno.h")]
+HEADERS = ["kernels.h", "strip_common.h", "strip_pack.h", "ws_plan.h", "pack_frag.h", "dhconv_units.h", "tuning_guard.h", "small_fft.h", "tables.h", os.path.join("..", "..", "include", "ace_sfno.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
@@ -64,10 +64,17 @@ def _compile(hipcc: str, src: str, obj: str, extra, verbose: bool) -> None:
 def build(force: bool = False, verbose: bool = False, out: str = LIB, extra=(), objdir: str = OBJ) -> str:
     """Compile the HIP library for gfx950; returns the path of the .so.  `extra`: additional compiler flags (-D...) for a
     variant build, which then needs its own `out` and `objdir`."""
+    if out == LIB and extra:
+        raise ValueError("the shipped library is built with the default flags only; a variant (extra flags) needs its own `out` and `objdir`")
+    if extra and not any(f == "-DACE_MEASUREMENT_SWITCHES" for f in extra):
+        extra = list(extra) + ["-DACE_MEASUREMENT_SWITCHES"]   # csrc/tuning_guard.h: any -D of a tuning / ablation / trace macro has to say so
     if not force and out == LIB and not needs_build():
         return LIB
     hipcc = _hipcc()
     os.makedirs(objdir, exist_ok=True)
+    for stale in os.listdir(objdir):   # objects of sources that no longer exist (removed kernels) do not linger
+        if stale.endswith(".o") and stale[:-2] not in SOURCES:
+            os.remove(os.path.join(objdir, stale))
     ht = _header_time()
     jobs, objs = [], []
     for s in SOURCES:

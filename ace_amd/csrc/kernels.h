@@ -1,6 +1,8 @@
 // Launch interface of the gfx950 kernels (kernels.hip).  Internal to the library;
 // the public boundary is include/ace_sfno.h.
 #pragma once
+#include "tuning_guard.h"
+
 #include <hip/hip_runtime.h>
 
 #include <vector>

@@ -406,9 +406,16 @@ FDEV void fold_body(const LegStripArgs& p, char* smem, const int m, const int gr
     }
 }
 
+#ifdef ACE_LF_TRACE   // measurement builds (tools/trace_lf.py): per workgroup, wave 0: start / end (s_memtime), wavenumber, HW_ID, XCC
+__device__ unsigned long long lf_wg_span[2][4096][5];
+#endif
+
 template <int OUT, bool FULLN, int MODE>
 __global__ __launch_bounds__(256, 2) void legendre_fold_kernel(LegStripArgs p, int G) {
     __shared__ __attribute__((aligned(16))) char smem[FLDS_BYTES];
+#ifdef ACE_LF_TRACE
+    const unsigned long long lf_t0 = __builtin_amdgcn_s_memtime();
+#endif
     // workgroup b runs on XCD b % 8: deal the wavenumbers round-robin so that all groups of one m share an L2 and the
     // triangular load is even across XCDs; ascending m = heaviest first
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -422,6 +429,15 @@ __global__ __launch_bounds__(256, 2) void legendre_fold_kernel(LegStripArgs p, i
         case 6: fold_body<3, OUT, FULLN, MODE>(p, smem, m, grp, gm); break;
         default: break;
     }
+#ifdef ACE_LF_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned long long* e = lf_wg_span[MODE][blockIdx.x];
+        e[0] = lf_t0; e[1] = __builtin_amdgcn_s_memtime(); e[2] = (unsigned long long)m; e[3] = hwid; e[4] = xcc & 0xf;
+    }
+#endif
 }
 
 // The 0.25-degree form: one workgroup per CU (dynamic LDS: three units of up to 48 KiB), one wave per SIMD with the whole register
@@ -452,6 +468,10 @@ __global__ __launch_bounds__(256, 1) void legendre_fold_big_kernel(LegStripArgs 
 }
 
 }  // namespace
+
+#ifdef ACE_LF_TRACE
+extern "C" int ace_debug_lf_spans(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(lf_wg_span), sizeof(lf_wg_span)); }
+#endif
 
 bool legendre_fold_eligible(const LegStripArgs& a) {
     if (a.K < 1 || a.R < 1 || a.N < 1 || a.nbatch < 1 || (a.mode != 0 && a.mode != 1)) return false;

@@ -771,6 +771,69 @@ def test_quarter_degree_net_on_the_big_fold_kernel_vs_oracle(dev):
     assert_net_close(out, ref, NET_TOL)
 
 
+ROUTING_SWITCHES = [   # (environment, value): every run-time routing switch of DESIGN section 5 that no other test sets
+    ("ACE_NO_STRIP", "1"), ("ACE_NO_FOLD", "1"), ("ACE_NO_FFT", "1"), ("ACE_NO_DHCONV_STRIP", "1"), ("ACE_NO_ENC_WS", "1"), ("ACE_NO_ENC_PK", "1"),
+    ("ACE_FUSED_PACK", "0"), ("ACE_PLANES_STREAM", "0"), ("ACE_CONV_WS", "none"), ("ACE_CONV_WS", "skip,fc2"), ("ACE_CONV_WL", "0"),
+]
+
+
+@pytest.mark.parametrize("env,value", ROUTING_SWITCHES, ids=[f"{e}={v}" for e, v in ROUTING_SWITCHES])
+def test_every_routing_switch_against_the_oracle(dev, env, value, monkeypatch):
+    """The routing switches are read once per handle and select between gfx950 kernels that all have to give the reference's answer
+    (sfnonet.py:217-252 per block): a 3-block C = 128 net at 24 x 48 - a shape at which EVERY fast kernel is eligible (conv_ws /
+    conv_wl at K = 128, the 8 x 6 longitude FFT, the folded strip Legendre kernels, dhconv_strip, the planes-only residual stream,
+    rider workgroups, the encoder on conv_ws) - under each switch in turn against the fp64 oracle, batch 2, random norm gains."""
+    from oracle.sfno import SFNOConfig, SFNOOracle, init_state
+    cfg = SFNOConfig(in_chans=5, out_chans=4, img_shape=(24, 48), embed_dim=128, num_layers=3, operator_type="dhconv")
+    st = init_state(cfg, seed=21)
+    g = torch.Generator().manual_seed(22)
+    for k in st:
+        if "norm" in k:
+            st[k] = st[k] + 0.2 * torch.randn(st[k].shape, generator=g)
+    x = torch.randn(2, 5, 24, 48, generator=g)
+    ref = SFNOOracle(cfg, st, dtype=torch.float64).forward(x)
+    base = build_native_net(cfg, st, dev, "f16x3")
+    with torch.no_grad():
+        y0 = base(x.to(dev)).clone()
+    assert_net_close(y0, ref, NET_TOL)
+    monkeypatch.setenv(env, value)
+    net = build_native_net(cfg, st, dev, "f16x3")
+    out = torch.empty_like(y0)
+    with torch.no_grad():
+        y = net(x.to(dev)).clone()
+        net.forward_graph(x.to(dev), out)
+        torch.cuda.synchronize()
+    assert_net_close(y, ref, NET_TOL)
+    assert torch.equal(out, y)
+    assert rel_max(y, y0) <= 2e-6       # two routings of one arithmetic: rounding apart
+
+
+@pytest.mark.parametrize("env", ["ACE_NO_CLN_MFMA", "ACE_NO_CLN_PLANES"])
+def test_conditional_norm_routing_switches_against_the_oracle(dev, env, monkeypatch):
+    """ACE_NO_CLN_MFMA (statistics + apply passes) and ACE_NO_CLN_PLANES (single pass, fp32 out + a pack pass) at embed 256, where the
+    single-pass MFMA norm writing planes is the default (conditional_sfno/layers.py:245-318)."""
+    import ace_amd
+    from oracle.csfno import CSFNOConfig, CSFNOOracle
+    kwargs = dict(embed_dim=256, noise_embed_dim=8, noise_type="gaussian", num_layers=2, use_mlp=True, mlp_ratio=2.0, affine_norms=True,
+                  normalize_big_skip=True, filter_num_groups=1)
+    cfg = CSFNOConfig(in_chans=5, out_chans=4, img_shape=(16, 32), **kwargs)
+    monkeypatch.setenv(env, "1")
+    torch.manual_seed(11)
+    net = ace_amd.ModuleSelector(type="NoiseConditionedSFNO", config=dict(kwargs)).build(5, 4, ace_amd.DatasetInfo((16, 32))).torch_module
+    state = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    for k, v in state.items():
+        if v.ndim <= 1 or "W_scale" in k or "W_bias" in k:
+            state[k] = v + 0.1 * torch.randn(v.shape, generator=g)
+    net.load_state_dict(state, strict=True)
+    net.to(dev).set_precision("f16x3")
+    x = torch.randn(2, 5, 16, 32, generator=g)
+    noise = _csfno_noise(cfg, 2, 17)
+    with torch.no_grad():
+        y = net(x.to(dev), noise=noise.to(dev))
+    assert_net_close(y, CSFNOOracle(cfg, state, dtype=torch.float64).forward(x, noise=noise), NET_TOL)
+
+
 def test_graph_replay_matches_eager(dev, precision):
     from oracle.sfno import SFNOConfig, init_state
     cfg = SFNOConfig(in_chans=4, out_chans=4, img_shape=(24, 48), embed_dim=16, num_layers=2, operator_type="dhconv")
