@@ -157,8 +157,6 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
     issue_a(1); issue_b(bs[1], 1);
     issue_a(2); issue_b(bs[2], 2);
 
-    const float inv_a = ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_a)));
-    const float oscale = inv_a / p.bscale;
     const int key = (i >> 2) & 3;                 // swizzle key of this lane's fragment rows (rows i and i + 16 ... share it mod 4)
 
     // The operands of stage t + PB are requested WHILE stage t computes, one or two operations behind each group of six MFMAs
@@ -253,6 +251,10 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
     // first, the stores last and from the accumulator registers themselves, which nothing writes afterwards.  With the stores
     // first and their data in temporaries, 7 of 1000 forwards of the 1-degree network came out wrong (r02): a load issued
     // later returned into a register whose store had not read it yet.
+    // (the range slot is USED only here: consumed in the prologue, hipcc's wait for it - a vmcnt(0), the asm loads are invisible to its
+    // bookkeeping - sat behind the three stages of operand requests and cost every workgroup 8 - 16 k cycles before its first MFMA)
+    const float inv_a = ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_a)));
+    const float oscale = inv_a / p.bscale;
     float* E = p.E + (long)l * p.sE + (long)row0 * K2;
     float vmax = 0.f;
 #pragma unroll

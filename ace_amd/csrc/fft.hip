@@ -142,6 +142,9 @@ FDEV bool fft_unit_ride(int nride, int& cblk, int& lat, int& rid) {
 #ifndef ACE_FFT_FWD_WAVES
 #define ACE_FFT_FWD_WAVES 0
 #endif
+#ifndef ACE_FFT_FWD_PLN_WAVES
+#define ACE_FFT_FWD_PLN_WAVES 7   // planes-input forward kernel at W = 360: five 5-wave workgroups per CU need <= 72 registers
+#endif
 #ifndef ACE_FFT_QROWS
 #define ACE_FFT_QROWS 8    // channel rows per workgroup at W = 1440 (46 KiB of LDS per 8 rows)
 #endif
@@ -154,7 +157,7 @@ FDEV bool fft_unit_ride(int nride, int& cblk, int& lat, int& rid) {
 // FULLM: Mm == W / 2 + 1 (every wavenumber kept).  Then every output of a column is either stored or has the magnitude of a
 // stored entry (its Hermitian mirror), so the range maximum is the plain maximum over the column - no per-store selects.
 template <int N1, int N2, int R, bool PLN, bool FULLM>
-__global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? 7 : ACE_FFT_FWD_WAVES) : (N1 * N2 == 1440 && R == 8 ? 4 : 0)) void dft_forward_fft_kernel(DftArgs p) {
+__global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? ACE_FFT_FWD_PLN_WAVES : ACE_FFT_FWD_WAVES) : (N1 * N2 == 1440 && R == 8 ? 4 : 0)) void dft_forward_fft_kernel(DftArgs p) {
     constexpr int W = N1 * N2, H1 = N1 / 2 + 1, NT = R * N2;
     constexpr int PITCH = W + 4;     // 16-byte aligned rows; PITCH = 4 (mod 8): the 16 rows x 4 b of a wave's level-1 read hit 64 banks
     constexpr int K2N = N2 / 2 + 1;  // k = k1 + N1 k2 <= W / 2  =>  k2 <= N2 / 2
@@ -186,11 +189,25 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? 7 : ACE_FFT_FWD_WAV
     constexpr int NPF = (R * (W / 4) + NT - 1) / NT;   // 16-byte row pieces per thread
     const int rlast = (p.C - c0 < R ? p.C - c0 : R) - 1;   // ragged last channel block: its missing rows repeat the last one
 
-    // fused instance-norm affine of this thread's row in level 1 (one load pair per thread, applied in registers)
+    // fused instance-norm affine of this thread's row in level 1 (one load pair per thread, applied in registers).  The three small
+    // loads (scale, shift, range slot) are REQUESTED behind the rows' own loads: in front of them hipcc waited for the slot's value
+    // (a whole memory latency, its wave reduction needs it) before the first row request went out.
     const int r1 = tid % R, b1 = tid / R;
     const int cr = c0 + (r1 < rlast ? r1 : rlast);
-    float sc = p.sc ? p.sc[(long)b * p.C + cr] : 1.f;
-    const float sh = p.sc ? p.sh[(long)b * p.C + cr] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    using Tw = TwTab<N1, N2, false>;
+    float4 tw[Tw::CP / 2];                          // level-1 twiddles of this thread's b1: requested with them, used behind two barriers
+    constexpr bool TW_EARLY = Tw::CP / 2 <= 6;      // (the 40-point level 1 of W = 1440 has 11 of them: held from the top they spill)
+    auto load_tw = [&]() {
+        const float4* twp = reinterpret_cast<const float4*>(kTw<N1, N2, false>.v) + b1 * (Tw::CP / 2);
+#pragma unroll
+        for (int i = 0; i < Tw::CP / 2; ++i) tw[i] = twp[i];
+    };
+    auto load_affine = [&]() {
+        sc = p.sc ? p.sc[(long)b * p.C + cr] : 1.f;
+        sh = p.sc ? p.sh[(long)b * p.C + cr] : 0.f;
+        if constexpr (TW_EARLY) load_tw();
+    };
     if constexpr (PLN) {
         // the field arrives as P-format planes [C/8][H W][8] (hi | lo): an entry = 8 channels of one pixel, 16 bytes per plane;
         // this workgroup's R rows are R / 8 k-groups.  (hi + lo) / scale is the producer's 22-bit value, exactly.
@@ -199,8 +216,6 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? 7 : ACE_FFT_FWD_WAV
         const int kgmax = p.C / 8 - 1;
         const auto rsh = wide_rsrc(p.xhi + (long)b * p.sxp + (long)k * W * 8);
         const auto rsl = wide_rsrc(p.xlo + (long)b * p.sxp + (long)k * W * 8);
-        // the producer's power-of-two scale comes off in the level-1 affine (an exact scaling: same values as dividing here)
-        sc *= ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(slot_load(p.xslot + (tid & 63)))));
         u32x4 eh[NPE], el[NPE];
 #pragma unroll
         for (int q = 0; q < NPE; ++q) {
@@ -213,6 +228,10 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? 7 : ACE_FFT_FWD_WAV
                 el[q] = __builtin_amdgcn_raw_buffer_load_b128(rsl, off, 0, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        load_affine();
+        // the producer's power-of-two scale comes off in the level-1 affine (an exact scaling: same values as dividing here)
+        sc *= ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(slot_load(p.xslot + (tid & 63)))));
 #pragma unroll
         for (int q = 0; q < NPE; ++q) {
             const int idx = tid + q * NT;
@@ -241,6 +260,8 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? 7 : ACE_FFT_FWD_WAV
 #endif
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    load_affine();
 #pragma unroll
     for (int q = 0; q < NPF; ++q) {
         const int idx = tid + q * NT;
@@ -258,11 +279,7 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? (PLN ? 7 : ACE_FFT_FWD_WAV
         float xv[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) xv[a] = fmaf(xs[r1 * PITCH + N2 * a + b1], sc, sh);
-        using Tw = TwTab<N1, N2, false>;
-        float4 tw[Tw::CP / 2];
-        const float4* twp = reinterpret_cast<const float4*>(kTw<N1, N2, false>.v) + b1 * (Tw::CP / 2);
-#pragma unroll
-        for (int i = 0; i < Tw::CP / 2; ++i) tw[i] = twp[i];
+        if constexpr (!TW_EARLY) load_tw();
         __syncthreads();   // Z aliases the rows: every row value is in registers before any Z is written
         sfft::RFft<N1, v2f>::run([&](int a) { return xv[a]; }, [&](int k1, v2f y) {
             const v2f w = k1 % 2 ? v2f{tw[k1 / 2].z, tw[k1 / 2].w} : v2f{tw[k1 / 2].x, tw[k1 / 2].y};
@@ -374,6 +391,10 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_INV_WAVES : (N1 * 
     const int kb = k * p.Bt + b;
     const long HW = (long)p.H * W;
     const int rlast = (p.C - c0 < R ? p.C - c0 : R) - 1;
+    // the filter bias of this thread's row (step B's (b1, r) mapping has the same r = tid % R): requested here, used behind two
+    // barriers - loaded where it is used, every workgroup waited a memory latency for it in the middle of its life
+    const int crb = c0 + ((tid % R) < rlast ? (tid % R) : rlast);
+    const float bias = p.bias ? p.bias[crb] : 0.f;
 
     // ---- step A: thread (k1, r): the N2 inputs F[k1 + N1 k2] straight from memory (runs of R floats over r), N2-point inverse
     //      FFT, twiddle.  Which stored entry is F[k1 + N1 k2] is known per k2 at compile time: below N2/2 the entry itself (column
@@ -431,8 +452,6 @@ __global__ __launch_bounds__(R * N2, N1 * N2 == 360 ? ACE_FFT_INV_WAVES : (N1 * 
         for (int k1 = 0; k1 < H1; ++k1) u[k1] = Us[k1 * ZP + b1 * R + r];
         __syncthreads();   // the output rows alias U
         constexpr RootTab<N1> T1{};
-        const int cr = c0 + (r < rlast ? r : rlast);
-        const float bias = p.bias ? p.bias[cr] : 0.f;
         float* yr = ys + b1 * RP + r;                 // longitude N2 a + b1 of row r at yr[N2 a RP]
         float s0 = u[0].x + u[N1 / 2].x + bias, sh = u[0].x + ((N1 / 2) % 2 ? -u[N1 / 2].x : u[N1 / 2].x) + bias;
 #pragma unroll

@@ -73,7 +73,8 @@ if fn3(st) == 0:
         v = [st[64 * w + k] for k in range(64)]
         if not v[0]:
             continue
-        print(f"traced workgroup {w}: stage = issue | wait B | barrier | compute (ticks)")
+        b_ = 264 * w
+        print(f"traced workgroup {w} (block {b_}, rows {spans[6 * b_ + 3]}): kernel entry to the top of stage 0: {v[0] - spans[6 * b_]} ticks; stage = top | wait B | barrier | compute (ticks)")
         for t_ in range(12):
             a, b, c, d = v[4 * t_: 4 * t_ + 4]
             nxt = v[4 * t_ + 4] if t_ < 11 else v[48]
