@@ -48,6 +48,9 @@ constexpr int WS_OOBV = 0x7fffff00;   // buffer offset beyond every resource of 
 #ifndef ACE_WS_ABL
 #define ACE_WS_ABL 0     // measurement builds only (WRONG results), fc2 modes (NSTG == 2): bit 0 no epilogue (values, stores, statistics),
 #endif                   // bit 1 no store-retire wait before the next stage's pieces, bit 2 no residual loads, bit 3 no barrier / piece wait
+#ifndef ACE_WS_REARLY
+#define ACE_WS_REARLY 1   // fc2 modes with the residual as planes: its two loads per tile go out in the tile's first stage (see the loop)
+#endif
 #ifndef ACE_WS_VSPAN
 #define ACE_WS_VSPAN 8    // interleaved epilogue: its eight values are spread over the first VSPAN twelfths of the stage
 #endif
@@ -187,9 +190,12 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
         const int bl = pc >> 1, hf = pc & 1;
         const int hh = bl / KSW, jj = bl % KSW;
         const int J = hh * KH + q * KSW + jj;
-        int n = 32 * (tile0 + pt) + i;
-        n = n < p.HW ? n : p.HW - 1;
-        glds16((hf ? Xl : Xh) + ((long)(2 * J + g) * p.ldn + n) * 8, smem + (u & 1) * SLOT + pc * 1024);
+        // address = (uniform: plane, k-group pair 2 J, first pixel of the tile) + (lane: k-group parity g, pixel i - the last tile's
+        // missing pixels repeat its last one)
+        const int n0 = 32 * (tile0 + pt);
+        const int ic = i < p.HW - 1 - n0 ? i : p.HW - 1 - n0;
+        const unsigned lane_off = (unsigned)(g * (int)p.ldn + ic) * 16u;
+        glds16s((hf ? Xl : Xh) + ((long)(2 * J) * p.ldn + n0) * 8, lane_off, smem + (u & 1) * SLOT + pc * 1024);
     };
 #pragma unroll
     for (int k = 0; k < PW; ++k) piece(0, k);
@@ -419,6 +425,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
         static_for<0, NSTG>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             const int u = pt * NSTG + q;
+            if constexpr (MODE == 4) MT(16 * pt + 8 * q);            // (measurement builds: tools/trace_ws.py)
             if constexpr (!INTER && !(q == 0 && !HOLD)) {
 #pragma unroll
                 for (int k = 0; k < PW; ++k) piece(u + 1, k);
@@ -430,8 +437,10 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
                     ctx = tile_ctx(pt > 0 ? pt - 1 : 0, pt > 0);
                 } else {
                     if constexpr (!(ACE_WS_ABL & 1)) epilogue(pt > 0 ? pt - 1 : 0, pt > 0, eo);
+                    if constexpr (MODE == 4) MT(16 * pt + 1);
                     if constexpr (!HOLD) {   // no registers to hold the store data through the stage: retire the stores first
                         if constexpr (!(ACE_WS_ABL & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if constexpr (MODE == 4) MT(16 * pt + 2);
                         hold(eo);
 #pragma unroll
                         for (int k = 0; k < PW; ++k) piece(u + 1, k);
@@ -440,7 +449,12 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { v[r] = 0.f; if (ACC2) v2[r] = 0.f; }
             }
-            if constexpr (RES && q == NSTG - 1 && !(ACE_WS_ABL & 4)) load_residual(pt);
+            // the residual of the tile being computed: requested in its LAST stage - or, when it comes as planes (two registers sets that
+            // the epilogue above has just released) and the tile has two stages, already in the first: requested a stage before the
+            // wait that retires it, the 1.2 k cycles that wait took (tools/trace_ws.py) were the loads' latency
+            constexpr int RQ = (RPL && NSTG == 2 && ACE_WS_REARLY) ? 0 : NSTG - 1;
+            if constexpr (RES && q == RQ && !(ACE_WS_ABL & 4)) load_residual(pt);
+            if constexpr (MODE == 4) MT(16 * pt + 8 * q + 3);
             const unsigned sl = (unsigned)(size_t)(lds_cptr)(smem + (u & 1) * SLOT) + h * (KSW * 2048) + lane * 16;
             pipelined_steps<KSW, FDEPTH>(sl, [&](auto ss, const Frag& f) {
                 constexpr int st = decltype(ss)::value;
@@ -500,7 +514,9 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
                 *reinterpret_cast<f32x4*>(xw) = sa;
                 *reinterpret_cast<f32x4*>(xw + 1024) = sb;
             }
+            if constexpr (MODE == 4) MT(16 * pt + 8 * q + 4);
             if constexpr (!(ACE_WS_ABL & 8)) stage_top();
+            if constexpr (MODE == 4) MT(16 * pt + 8 * q + 5);
             if constexpr (INTER && RES) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) res[e] = resn[e];
@@ -622,6 +638,10 @@ hipError_t launch_pack_conv_frag(const float* W, long ldw, int O, int I, int ord
     hipLaunchKernelGGL(pack_conv_frag_kernel, dim3((unsigned)pack_frag_blocks(q), (unsigned)nsamples), dim3(256), 0, s, q);
     return hipGetLastError();
 }
+
+#ifdef ACE_X_TRACE   // measurement builds only (tools/trace_ws.py): this file's copy of the s_memtime stamps
+extern "C" int ace_debug_trace_ws(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mlp_trace), sizeof(mlp_trace)); }
+#endif
 
 // statistics partials per row the launch described by `a` writes (a.nstrips32 must be at least this)
 int conv_ws_stat_parts(const ConvStripArgs& a) {

@@ -45,6 +45,16 @@ MDEV void glds16(const void* gsrc, const char* lds_dst_uniform) {
                  : "v"(gsrc), "s"(addr)
                  : "memory", "m0");
 }
+// The same piece with the address split into a wave-uniform base (SGPR pair: which k-group, plane, tile - scalar arithmetic) and a
+// 32-bit lane offset that every piece of a tile shares: as one 64-bit lane address per piece the requests cost the wave eight vector
+// instructions each (two of them quarter rate) - 760 .. 1050 cycles in front of every 36-MFMA stage of fc2 (tools/trace_ws.py).
+MDEV void glds16s(const void* sbase_uniform, unsigned lane_off, const char* lds_dst_uniform) {
+    const unsigned addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cptr)lds_dst_uniform);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(lane_off), "s"(sbase_uniform), "s"(addr)
+                 : "memory", "m0");
+}
 MDEV float fast_erf(float x) {   // kernels.hip: max abs error 1.1e-7
     const float t = fminf(fabsf(x), 4.0f);
     float q = -1.150086973e-05f;
