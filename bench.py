@@ -323,11 +323,11 @@ def time_mode(stepper, precision, forcing_names, prog, dist, dev, K, Wm, graph, 
 
 
 # HBM bytes per launch and MFMA-busy from separate rocprofv3 --pmc passes (tools/pmc_collect.sh -> tools/pmc_to_profile.py ->
-# profiles/r05_pmc_traffic.json).  FETCH_SIZE / WRITE_SIZE in KB; gfx950 correction: 16-byte-per-lane streaming reads are
+# profiles/r06_pmc_traffic.json).  FETCH_SIZE / WRITE_SIZE in KB; gfx950 correction: 16-byte-per-lane streaming reads are
 # counted at half size (MI355X_MICROARCH.md "HBM").  The file carries the sha256 of the library the counters were taken on:
 # figures are attached to the bench line ONLY when that is the library being timed now (otherwise null + the reason).
-PMC_FILE = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")) if os.path.exists(f)),
-                os.path.join(ROOT, "profiles", "r05_pmc_traffic.json"))   # newest counter file; its build stamp decides whether it is used
+PMC_FILE = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json")) if os.path.exists(f)),
+                os.path.join(ROOT, "profiles", "r06_pmc_traffic.json"))   # newest counter file; its build stamp decides whether it is used
 
 
 def lib_sha256():
@@ -344,7 +344,7 @@ def measured_counters():
         with open(PMC_FILE) as f:
             d = json.load(f)
     except (OSError, ValueError):
-        return {}, "no counter file (profiles/r05_pmc_traffic.json)"
+        return {}, "no counter file (profiles/r06_pmc_traffic.json)"
     from ace_amd import build as _build
     if d.get("_lib_sha256") != lib_sha256() and d.get("_src_sha256") != _build.source_sha256():
         # neither the binary nor (hipcc output is not bit-reproducible: a rebuilt library differs) the kernel sources match
