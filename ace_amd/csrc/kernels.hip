@@ -2911,8 +2911,11 @@ hipError_t launch_instnorm_stats(const float* x, const float* gamma, const float
 // first version walked one side with a stride of 2 C Bt floats per lane: the reference's own `sht` benchmark, 1024 fields,
 // spent 1.1 of its 1.5 ms here).  TO_REF: entries with m > l are written as zeros without reading the internal buffer (the
 // triangular Legendre stage never writes them), so the standalone transform needs no memset of its scratch.
+// omax (from-reference direction, optional): atomicMax of the bit pattern of max |value| over the launch - the range of the
+// coefficients for the f16x3 Legendre stage, taken here instead of in a pass of its own over the converted tensor.
 template <bool TO_REF>
-__global__ __launch_bounds__(256) void spec_layout_kernel(const float* __restrict__ src, float* __restrict__ dst, int Bt, int C, int L, int Mm) {
+__global__ __launch_bounds__(256) void spec_layout_kernel(const float* __restrict__ src, float* __restrict__ dst, int Bt, int C, int L, int Mm,
+                                                          unsigned* omax) {
     __shared__ float tile[2][32][33];
     const long R = (long)L * Mm;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
@@ -2941,6 +2944,7 @@ __global__ __launch_bounds__(256) void spec_layout_kernel(const float* __restric
                 *reinterpret_cast<float2*>(dst + (((long)b * C + c) * R + r) * 2) = make_float2(tile[0][tx][ty + 8 * k], tile[1][tx][ty + 8 * k]);
         }
     } else {
+        float vmax = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = c0 + ty + 8 * k;
@@ -2949,6 +2953,19 @@ __global__ __launch_bounds__(256) void spec_layout_kernel(const float* __restric
             if (r < R && c < C) v = *reinterpret_cast<const float2*>(src + (((long)b * C + c) * R + r) * 2);
             tile[0][tx][ty + 8 * k] = v.x;
             tile[1][tx][ty + 8 * k] = v.y;
+            vmax = fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
+        }
+        if (omax) {   // one atomic per workgroup
+            __shared__ float red[4];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+            __syncthreads();
+            if (threadIdx.x == 0) {   // 32 k workgroups at the reference's benchmark size: the atomic only where it would raise the slot (64
+                const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));   // words in one line - unconditional, they serialise to 70 us)
+                unsigned* slot = omax + ((blockIdx.x + blockIdx.y) & (AMAX_SHARDS - 1));
+                if (__float_as_uint(m) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, __float_as_uint(m));
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -2972,13 +2989,14 @@ static inline unsigned grid_for(long total, int block) {
 hipError_t launch_spec_to_ref(const float* D, float* out, int Bt, int C, int L, int Mm, hipStream_t s) {
     const long R = (long)L * Mm;
     if ((R + 31) / 32 > 0x7fffffffL || (C + 31) / 32 > 65535 || Bt > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(spec_layout_kernel<true>, dim3((unsigned)((R + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)Bt), dim3(256), 0, s, D, out, Bt, C, L, Mm);
+    hipLaunchKernelGGL(spec_layout_kernel<true>, dim3((unsigned)((R + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)Bt), dim3(256), 0, s, D, out, Bt, C, L, Mm,
+                       static_cast<unsigned*>(nullptr));
     return hipGetLastError();
 }
-hipError_t launch_ref_to_spec(const float* in, float* E, int Bt, int C, int L, int Mm, hipStream_t s) {
+hipError_t launch_ref_to_spec(const float* in, float* E, int Bt, int C, int L, int Mm, hipStream_t s, unsigned* omax) {
     const long R = (long)L * Mm;
     if ((R + 31) / 32 > 0x7fffffffL || (C + 31) / 32 > 65535 || Bt > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(spec_layout_kernel<false>, dim3((unsigned)((R + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)Bt), dim3(256), 0, s, in, E, Bt, C, L, Mm);
+    hipLaunchKernelGGL(spec_layout_kernel<false>, dim3((unsigned)((R + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)Bt), dim3(256), 0, s, in, E, Bt, C, L, Mm, omax);
     return hipGetLastError();
 }
 
