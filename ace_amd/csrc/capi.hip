@@ -800,8 +800,8 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     if (c.in_chans <= 0 || c.out_chans <= 0 || c.embed_dim <= 0 || c.num_layers <= 0 || c.nlat < 2 || c.nlon < 2)
         return fail(ACE_ERR_INVALID, "non-positive dimension in ace_sfno_config");
     if (c.operator_type != 0 && c.operator_type != 1) return fail(ACE_ERR_INVALID, "Unsupported operator type");
-    if (c.normalization_layer < 0 || c.normalization_layer > 2)
-        return fail(ACE_ERR_INVALID, "normalization_layer must be 'none', 'instance_norm' or conditional layer norm");
+    if (c.normalization_layer < 0 || c.normalization_layer > 3)
+        return fail(ACE_ERR_INVALID, "normalization_layer must be 'none', 'instance_norm', conditional layer norm or 'layer_norm'");
     const bool cln = c.normalization_layer == 2;
     if (cln) {
         if (c.operator_type != 1) return fail(ACE_ERR_INVALID, "Only 'dhconv' operator_type is supported for NoiseConditionedSFNO models.");
@@ -850,6 +850,8 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string p = "blocks." + std::to_string(i) + ".";
         if (c.normalization_layer == 1) { add_weight(n.get(), p + "norm0.weight", C); add_weight(n.get(), p + "norm0.bias", C); }
+        // "layer_norm" (sfnonet.py:584-592): nn.LayerNorm over (H, W), its affine is a pair of (H, W) fields
+        if (c.normalization_layer == 3) { add_weight(n.get(), p + "norm0.weight", HW); add_weight(n.get(), p + "norm0.bias", HW); }
         auto add_cln = [&](const std::string& q, long ch) {   // ConditionalLayerNorm parameters in state_dict order
             if (c.noise_embed_dim > 0) {
                 add_weight(n.get(), q + "W_scale_2d.weight", ch * c.noise_embed_dim);
@@ -865,6 +867,7 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
         add_conv_weight(n.get(), p + "inner_skip.weight", (int)C, (int)C);
         add_weight(n.get(), p + "inner_skip.bias", C);
         if (c.normalization_layer == 1) { add_weight(n.get(), p + "norm1.weight", C); add_weight(n.get(), p + "norm1.bias", C); }
+        if (c.normalization_layer == 3) { add_weight(n.get(), p + "norm1.weight", HW); add_weight(n.get(), p + "norm1.bias", HW); }
         if (cln) add_cln(p + "norm1.", C);
         if (c.use_mlp) {
             add_conv_weight(n.get(), p + "mlp.fwd.0.weight", n->hid, (int)C);
@@ -1454,6 +1457,10 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     // NoiseConditionedSFNO: conditional layer norms are materialised in place (fp32) with their true max in the slot of
     // the instance-norm bound; the convolutions then run on the packed-operand engine (one pack pass per conv input)
     const bool cln = c.normalization_layer == 2;
+    // "layer_norm": nn.LayerNorm over (H, W) with an (H, W) affine (sfnonet.py:584-592) - a per-PIXEL affine does not fold into the
+    // consumers' weights, so it is materialised in place like the conditional norms (statistics + apply in one launch per norm,
+    // kernels.hip: spatial_layer_norm_kernel) and the convolutions run on the packed-operand engine
+    const bool lnrm = c.normalization_layer == 3;
     const float* skip_in = in;               // second source of the big-skip concat
     const unsigned* skip_in_slot = slot(0);
     // one conditional layer norm (layers.py:245-318): a single MFMA pass (cln_mfma.hip) where the shape allows it and the
@@ -1532,6 +1539,10 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             _Float16* P0 = reinterpret_cast<_Float16*>(n->P.p);
             ACE_TRY(cond_norm(h, h, p + "norm0.", C, slot(sb + 3), pk_ahead ? P0 : nullptr,
                               pk_ahead ? P0 + (size_t)n->Bmax * C * HW : nullptr, true, &n0_planes));
+            MARK(ST_NORM0);
+        }
+        if (lnrm) {   // x_norm = LayerNorm_(H, W)(h), in place
+            HIP_TRY(launch_spatial_layer_norm(h, W(p + "norm0.weight"), W(p + "norm0.bias"), 1e-6f, (long)B * C, HW, h, slot(sb + 3), s));
             MARK(ST_NORM0);
         }
         if (norm) {
@@ -1673,7 +1684,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         ConvW wskip = conv_weight(n, p + "inner_skip.weight", p + "inner_skip.bias");
         // B of the inner skip: the normalised block input (bound from the norm statistics) or, without a norm, the raw
         // block input; the spectrally round-tripped residual of mixed-grid blocks has no range slot -> fp32 engine
-        const unsigned* skip_max = scale_residual ? nullptr : ((norm || cln) ? slot(sb + 3) : hslot(i));
+        const unsigned* skip_max = scale_residual ? nullptr : ((norm || cln || lnrm) ? slot(sb + 3) : hslot(i));
         const bool skip_f16 = f16 && skip_max != nullptr;
         const bool pk = skip_f16 && packed_ok(n, C) && (!c.use_mlp || n->hid % 8 == 0);
         _Float16* Ph = reinterpret_cast<_Float16*>(n->P.p);
@@ -1863,6 +1874,10 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             ACE_TRY(cond_norm(n->T.p, n->T.p, p + "norm1.", C, slot(sb + 5), to_mlp ? Ph : nullptr, to_mlp ? Pl : nullptr, false, &n1_planes));
             MARK(ST_NORM1);
         }
+        if (lnrm) {
+            HIP_TRY(launch_spatial_layer_norm(n->T.p, W(p + "norm1.weight"), W(p + "norm1.bias"), 1e-6f, (long)B * C, HW, n->T.p, slot(sb + 5), s));
+            MARK(ST_NORM1);
+        }
         if (norm && !fused) {
             HIP_TRY(launch_instnorm_stats(n->T.p, W(p + "norm1.weight"), W(p + "norm1.bias"), 1e-6f, B, C, HW, sc1, sh1, s,
                                           slot(sb + 5)));
@@ -1877,7 +1892,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             const Weight& w1 = *n->weights[n->index.at(p + "mlp.fwd.0.weight")];
             const Weight& b1w = *n->weights[n->index.at(p + "mlp.fwd.0.bias")];
             const Weight& w2 = *n->weights[n->index.at(p + "mlp.fwd.2.weight")];
-            const unsigned* tmax = (norm || cln) ? slot(sb + 5) : slot(sb + 4);
+            const unsigned* tmax = (norm || cln || lnrm) ? slot(sb + 5) : slot(sb + 4);
             _Float16* Uh = reinterpret_cast<_Float16*>(n->U.p);
             _Float16* Ul = Uh + (size_t)n->Bmax * n->hid * HW;
             if (!n1_planes) ACE_TRY(pack_act(n, n->T.p, actB, C, a1, b1, tmax, Ph, Pl, B, s));
@@ -1903,7 +1918,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             ConvW wfc1 = conv_weight(n, p + "mlp.fwd.0.weight", p + "mlp.fwd.0.bias");
             if (a1 && !f16) ACE_TRY(fold(n, wfc1, n->hid, C, a1, b1, n->Wf1.p, n->bf1.p, B, s, &wfc1));
             ACE_TRY(conv(n, wfc1, n->T.p, actB, C, nullptr, 0, -1, n->U.p, n->hid, nullptr, 0, nullptr, nullptr, act, B, s,
-                         f16 ? a1 : nullptr, f16 ? b1 : nullptr, (norm || cln) ? slot(sb + 5) : slot(sb + 4), nullptr,
+                         f16 ? a1 : nullptr, f16 ? b1 : nullptr, (norm || cln || lnrm) ? slot(sb + 5) : slot(sb + 4), nullptr,
                          slot(sb + 6)));
             MARK(ST_MLP_FC1);
             ACE_TRY(conv(n, conv_weight(n, p + "mlp.fwd.2.weight", p + "mlp.fwd.2.bias"), n->U.p, (long)n->hid * HW,

@@ -98,6 +98,9 @@ hipError_t launch_csfno_weight_to_dense(const float* w, float* dense, int C, int
 // compact form for Gemm4Args::cplx: planes [l][2 (re | im)][Cin/8][Cout][8]
 hipError_t launch_pack_dhconv_f16c(const float* w, void* hi, void* lo, int Cin, int Cout, int L, float scale, hipStream_t s);
 hipError_t launch_zero_u32(unsigned* p, long n, hipStream_t s);
+// nn.LayerNorm over (H, W) with an (H, W) affine, per (sample, channel) plane (sfnonet.py:584-592); in place allowed
+hipError_t launch_spatial_layer_norm(const float* x, const float* gamma, const float* beta, float eps, long planes, long HW, float* y,
+                                     unsigned* omax, hipStream_t s);
 // max|x| of a plain tensor into a slot
 hipError_t launch_absmax(const float* x, long n, unsigned* omax, hipStream_t s);
 // fp32 matrix (rows x cols, pitch lds) -> fp16 hi/lo planes (pitch ldd halves, zero padded), values scaled by `scale`

@@ -3069,6 +3069,69 @@ hipError_t launch_expand_dhconv_weight(const float* w, float* wx, int Cin, int C
     return hipGetLastError();
 }
 
+// nn.LayerNorm over the two spatial dimensions, as the reference's "layer_norm" normalisation builds it (sfnonet.py:584-592:
+// normalized_shape = (H, W), eps 1e-6, elementwise affine of shape (H, W) shared by all channels): per (sample, channel) plane
+//     y[p] = (x[p] - mean) / sqrt(var + eps) * gamma[p] + beta[p]        (biased variance, fp64 sums in a fixed order)
+// One workgroup per plane, two passes (the second one's reads come from L2); in place allowed.  omax (optional): atomicMax of the bit
+// pattern of max |y| - the range slot of the packed convolutions that read y.
+__global__ __launch_bounds__(512) void spatial_layer_norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps, long HW, float* __restrict__ y,
+                                                                 unsigned* omax) {
+    const float* xp = x + (long)blockIdx.x * HW;
+    float* yp = y + (long)blockIdx.x * HW;
+    double s = 0.0, ss = 0.0;
+    for (long j = threadIdx.x; j < HW; j += blockDim.x) {
+        const double v = (double)xp[j];
+        s += v;
+        ss += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        ss += __shfl_down(ss, off, 64);
+    }
+    __shared__ double red[2][8];
+    __shared__ float stat[2], redm[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0.0, tss = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { ts += red[0][w]; tss += red[1][w]; }
+        const double mean = ts / (double)HW;
+        double var = tss / (double)HW - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        stat[0] = (float)rstd;
+        stat[1] = (float)(-mean * rstd);
+    }
+    __syncthreads();
+    const float a = stat[0], b = stat[1];
+    float vmax = 0.f;
+    for (long j = threadIdx.x; j < HW; j += blockDim.x) {
+        const float v = fmaf(fmaf(xp[j], a, b), gamma ? gamma[j] : 1.f, beta ? beta[j] : 0.f);
+        yp[j] = v;
+        vmax = fmaxf(vmax, fabsf(v));
+    }
+    if (omax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+        if (lane == 0) redm[wave] = vmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = 0.f;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, redm[w]);
+            atomicMax(omax + (blockIdx.x & (AMAX_SHARDS - 1)), __float_as_uint(m));
+        }
+    }
+}
+hipError_t launch_spatial_layer_norm(const float* x, const float* gamma, const float* beta, float eps, long planes, long HW, float* y,
+                                     unsigned* omax, hipStream_t s) {
+    if (planes < 1 || planes > 0x7fffffffL || HW < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(spatial_layer_norm_kernel, dim3((unsigned)planes), dim3(512), 0, s, x, gamma, beta, eps, HW, y, omax);
+    return hipGetLastError();
+}
+
 __global__ void rowaffine_add_kernel(const float* __restrict__ x, const float* __restrict__ sc,
                                      const float* __restrict__ sh, const float* __restrict__ r,
                                      const float* __restrict__ rsc, const float* __restrict__ rsh,

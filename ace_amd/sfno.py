@@ -28,7 +28,7 @@ from . import _lib
 from .registry import ModuleConfig, ModuleSelector
 
 _OPERATOR = {"diagonal": 0, "dhconv": 1}
-_NORM = {"none": 0, "instance_norm": 1}
+_NORM = {"none": 0, "instance_norm": 1, "layer_norm": 3}   # (2: the conditional layer norm of csfno.py)
 _ACT = {"gelu": 1, "relu": 2, "silu": 3}
 _ACT_LAYER = {"gelu": nn.GELU, "relu": nn.ReLU, "silu": nn.SiLU}
 _GRID = {"legendre-gauss": 0, "lobatto": 1, "equiangular": 2}
@@ -214,6 +214,9 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             def norm_layer():
                 return nn.InstanceNorm2d(num_features=self.embed_dim, eps=1e-6, affine=True,
                                          track_running_stats=False)
+        elif self.normalization_layer == "layer_norm":   # sfnonet.py:584-592: over (H, W), an (H, W) affine shared by the channels
+            def norm_layer():
+                return nn.LayerNorm(normalized_shape=(self.img_shape[0], self.img_shape[1]), eps=1e-6)
         else:
             norm_layer = nn.Identity
 

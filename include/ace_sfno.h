@@ -131,7 +131,9 @@ typedef struct ace_sfno_config {
     int scale_factor;             /* only 1 is supported */
     float hard_thresholding_fraction;
     int operator_type;            /* 0 = "diagonal", 1 = "dhconv" */
-    int normalization_layer;      /* 0 = "none", 1 = "instance_norm", 2 = conditional layer norm (NoiseConditionedSFNO) */
+    int normalization_layer;      /* 0 = "none", 1 = "instance_norm", 2 = conditional layer norm (NoiseConditionedSFNO),
+                                     3 = "layer_norm": nn.LayerNorm over (nlat, nlon), norm0 / norm1 weight and bias are (nlat, nlon) fields
+                                     (sfnonet.py:584-592) */
     int activation_function;      /* 1 = "gelu", 2 = "relu", 3 = "silu" */
     int use_mlp;
     float mlp_ratio;

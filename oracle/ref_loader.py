@@ -82,7 +82,8 @@ def load():
     thq.clenshaw_curtiss_weights = _as_t(_quad.clenshaw_curtiss_weights)
 
     def _precompute_legpoly(mmax, lmax, t, norm="ortho", inverse=False, csphase=True):
-        return _leg.precompute_legpoly(mmax, lmax, np.asarray(t), norm=norm, inverse=inverse, csphase=csphase)
+        # a copy: the oracle's table is a shared read-only array, the reference wraps what it gets in a tensor
+        return np.array(_leg.precompute_legpoly(mmax, lmax, np.asarray(t), norm=norm, inverse=inverse, csphase=csphase))
 
     thl._precompute_legpoly = _precompute_legpoly
 

@@ -78,6 +78,8 @@ class SFNOOracle:
         # sfnonet.py:593-601: InstanceNorm2d(eps=1e-6, affine=True, no running stats)
         if self.cfg.normalization_layer == "none":
             return x
+        if self.cfg.normalization_layer == "layer_norm":   # sfnonet.py:584-592: nn.LayerNorm((H, W), eps=1e-6), elementwise affine
+            return F.layer_norm(x, tuple(x.shape[-2:]), weight=self.p[prefix + ".weight"], bias=self.p[prefix + ".bias"], eps=1e-6)
         assert self.cfg.normalization_layer == "instance_norm"
         return F.instance_norm(x, weight=self.p[prefix + ".weight"], bias=self.p[prefix + ".bias"], eps=1e-6)
 
@@ -185,6 +187,10 @@ def init_state(cfg: SFNOConfig, seed: Optional[int] = 0) -> dict:
                 # non-trivial affine so the gamma/beta paths are exercised
                 st[p + nm + ".weight"] = 1.0 + 0.1 * torch.randn(C, generator=g)
                 st[p + nm + ".bias"] = 0.1 * torch.randn(C, generator=g)
+        elif cfg.normalization_layer == "layer_norm":
+            for nm in ("norm0", "norm1"):
+                st[p + nm + ".weight"] = 1.0 + 0.1 * torch.randn(H, W, generator=g)
+                st[p + nm + ".bias"] = 0.1 * torch.randn(H, W, generator=g)
         wshape = (C, C, L, 2) if cfg.operator_type == "dhconv" else (C, C, L, M, 2)
         st[p + "filter.filter.weight"] = scale * torch.randn(*wshape, generator=g)
         st[p + "filter.filter.bias"] = 0.01 * torch.randn(1, C, 1, 1, generator=g)

@@ -293,7 +293,9 @@ def test_modulus_sfnonet_golden(dev, precision):
 
 
 @pytest.mark.parametrize("name", ["gen_sfno_dhconv_12x24.pt", "gen_sfno_dhconv_equiangular_9x18.pt",
-                                  "gen_sfno_dhconv_180x360_c8.pt"])
+                                  "gen_sfno_dhconv_180x360_c8.pt",
+                                  # the "layer_norm" normalisation (sfnonet.py:584-592), make_golden_layer_norm.py
+                                  "gen_sfno_layer_norm_12x24.pt", "gen_sfno_layer_norm_equiangular_9x18.pt"])
 def test_dhconv_nets_vs_reference(dev, name, precision):
     from oracle.sfno import SFNOConfig, init_state
     d = load_golden(name)
@@ -304,6 +306,26 @@ def test_dhconv_nets_vs_reference(dev, name, precision):
     with torch.no_grad():
         y = net(x.to(dev))
     assert_net_close(y, d["y"], NET_TOL)
+
+
+@pytest.mark.parametrize("C,hw", [(128, (24, 48)), (40, (16, 32))])
+def test_layer_norm_nets_vs_oracle(dev, C, hw, precision):
+    """normalization_layer = "layer_norm" (sfnonet.py:584-592: nn.LayerNorm over (H, W), an (H, W) affine shared by the channels, in
+    front of the filter and of the MLP): materialised in place by spatial_layer_norm_kernel, the convolutions on the packed-operand
+    engine (C = 128) or the tile engines (C = 40) - 3 blocks, batch 2, random affines, against the fp64 oracle; graph replay = eager."""
+    from oracle.sfno import SFNOConfig, SFNOOracle, init_state
+    cfg = SFNOConfig(in_chans=5, out_chans=4, img_shape=hw, embed_dim=C, num_layers=3, operator_type="dhconv", normalization_layer="layer_norm")
+    st = init_state(cfg, seed=41)
+    x = torch.randn(2, 5, *hw, generator=torch.Generator().manual_seed(42))
+    ref = SFNOOracle(cfg, st, dtype=torch.float64).forward(x)
+    net = build_native_net(cfg, st, dev, precision)
+    out = torch.empty(2, 4, *hw, device=dev)
+    with torch.no_grad():
+        y = net(x.to(dev)).clone()
+        net.forward_graph(x.to(dev), out)
+        torch.cuda.synchronize()
+    assert_net_close(y, ref, NET_TOL)
+    assert torch.equal(out, y)
 
 
 @pytest.mark.parametrize("kw", [

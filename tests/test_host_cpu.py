@@ -138,6 +138,24 @@ def test_state_dict_matches_reference_names_at_ace2_shape():
     assert sum(v.numel() for v in sd.values()) == 455_831_552 + 0 or sum(v.numel() for v in sd.values()) > 4.5e8
 
 
+def test_layer_norm_state_dict_has_the_reference_shapes():
+    """normalization_layer = "layer_norm" (sfnonet.py:584-592): nn.LayerNorm over (H, W) - norm0 / norm1 carry (H, W) weights and
+    biases under the reference's names (the real reference net loads oracle.init_state's tensors strictly: make_golden_layer_norm.py)."""
+    import ace_amd
+    from oracle.sfno import SFNOConfig, init_state
+    with torch.device("meta"):
+        net = ace_amd.SphericalFourierNeuralOperatorNet(
+            params=ace_amd.SphericalFourierNeuralOperatorBuilder(embed_dim=16, num_layers=2, operator_type="dhconv", normalization_layer="layer_norm"),
+            in_chans=5, out_chans=7, img_shape=(12, 24))
+    sd = net.state_dict()
+    st = init_state(SFNOConfig(in_chans=5, out_chans=7, img_shape=(12, 24), embed_dim=16, num_layers=2, operator_type="dhconv",
+                               normalization_layer="layer_norm"), seed=0)
+    assert set(sd) == set(st)
+    for k, v in st.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    assert tuple(sd["blocks.1.norm1.weight"].shape) == (12, 24)
+
+
 def test_seeded_init_reproduces_reference_draw_order(golden_dir):
     """torch.manual_seed(0) + construction gives the reference's parameters bit for bit
     (fme/ace/models/modulus/test_sfnonet.py:13-36; state captured from the reference itself)."""

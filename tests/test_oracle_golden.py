@@ -95,7 +95,9 @@ def test_stepper_predict_golden(golden_dir):
 
 
 @pytest.mark.parametrize("name", ["gen_sfno_dhconv_12x24.pt", "gen_sfno_dhconv_equiangular_9x18.pt",
-                                  "gen_sfno_dhconv_180x360_c8.pt"])
+                                  "gen_sfno_dhconv_180x360_c8.pt",
+                                  # the "layer_norm" normalisation (sfnonet.py:584-592), make_golden_layer_norm.py
+                                  "gen_sfno_layer_norm_12x24.pt", "gen_sfno_layer_norm_equiangular_9x18.pt"])
 def test_dhconv_nets_vs_reference(golden_dir, name):
     d = _load(golden_dir, name)
     cfg = SFNOConfig(**{**d["cfg"], "img_shape": tuple(d["cfg"]["img_shape"])})
