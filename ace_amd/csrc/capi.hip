@@ -729,6 +729,12 @@ struct ace_sfno {
     ace_sfno_config cfg;
     int H = 0, W = 0, C = 0, L = 0, Mm = 0, hid = 0, Bmax = 1;
     long HW = 0;
+    // scale_factor != 1 (sfnonet.py:467-515): the blocks between the first filter's inverse transform and the last filter's work on
+    // the (nlat / sf) x (nlon / sf) Gauss-Legendre grid; hw_now is the resolution of the launches being enqueued (the 1x1-convolution
+    // helpers read it), HWs the inner one
+    mutable long hw_now = 0;
+    long HWs = 0;
+    int Hs = 0, Ws = 0;
     std::unique_ptr<ace_sht_plan> plan_lg, plan_data_own;
     ace_sht_plan* plan_data = nullptr;  // == plan_lg.get() when data_grid is legendre-gauss
     std::vector<std::unique_ptr<Weight>> weights;
@@ -796,7 +802,9 @@ static void add_conv_weight(ace_sfno* n, const std::string& name, int rows, int 
 extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     if (!cfg || !out) return fail(ACE_ERR_INVALID, "null argument");
     const ace_sfno_config& c = *cfg;
-    if (c.scale_factor != 1) return fail(ACE_ERR_INVALID, "scale_factor != 1 is not supported");
+    if (c.scale_factor < 1) return fail(ACE_ERR_INVALID, "scale_factor must be >= 1");
+    if (c.scale_factor != 1 && c.normalization_layer == 2)
+        return fail(ACE_ERR_INVALID, "scale_factor != 1 is not built for the noise-conditioned nets");
     if (c.in_chans <= 0 || c.out_chans <= 0 || c.embed_dim <= 0 || c.num_layers <= 0 || c.nlat < 2 || c.nlon < 2)
         return fail(ACE_ERR_INVALID, "non-positive dimension in ace_sfno_config");
     if (c.operator_type != 0 && c.operator_type != 1) return fail(ACE_ERR_INVALID, "Unsupported operator type");
@@ -822,15 +830,20 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     n->cfg = c;
     n->sw = read_switches();
     n->H = c.nlat; n->W = c.nlon; n->C = c.embed_dim; n->HW = (long)c.nlat * c.nlon;
+    n->hw_now = n->HW;
     n->Bmax = c.max_batch > 0 ? c.max_batch : 1;
-    // sfnonet.py:471-472
-    n->L = (int)(c.nlat * c.hard_thresholding_fraction);
-    n->Mm = (int)((c.nlon / 2 + 1) * c.hard_thresholding_fraction);
+    // sfnonet.py:467-472: the downscaled image and the modes kept
+    const int sf = c.scale_factor;
+    n->Hs = c.nlat / sf; n->Ws = c.nlon / sf; n->HWs = (long)n->Hs * n->Ws;
+    if (n->Hs < 1 || n->Ws < 2) return fail(ACE_ERR_INVALID, "scale_factor leaves no grid");
+    n->L = (int)(n->Hs * c.hard_thresholding_fraction);
+    n->Mm = (int)((n->Ws / 2 + 1) * c.hard_thresholding_fraction);
     if (n->L < 1 || n->Mm < 1) return fail(ACE_ERR_INVALID, "hard_thresholding_fraction leaves no modes");
     n->hid = (int)(c.embed_dim * c.mlp_ratio);
 
-    ACE_TRY(plan_build(c.nlat, c.nlon, n->L, n->Mm, GRID_LEGENDRE_GAUSS, n->plan_lg, c.precision == 1));
-    if (c.data_grid == GRID_LEGENDRE_GAUSS) {
+    // trans / itrans on the inner Gauss-Legendre grid; trans_down / itrans_up on the data grid (sfnonet.py:498-515)
+    ACE_TRY(plan_build(n->Hs, n->Ws, n->L, n->Mm, GRID_LEGENDRE_GAUSS, n->plan_lg, c.precision == 1));
+    if (c.data_grid == GRID_LEGENDRE_GAUSS && sf == 1) {
         n->plan_data = n->plan_lg.get();
     } else {
         ACE_TRY(plan_build(c.nlat, c.nlon, n->L, n->Mm, (Grid)c.data_grid, n->plan_data_own, c.precision == 1));
@@ -851,7 +864,9 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
         const std::string p = "blocks." + std::to_string(i) + ".";
         if (c.normalization_layer == 1) { add_weight(n.get(), p + "norm0.weight", C); add_weight(n.get(), p + "norm0.bias", C); }
         // "layer_norm" (sfnonet.py:584-592): nn.LayerNorm over (H, W), its affine is a pair of (H, W) fields
-        if (c.normalization_layer == 3) { add_weight(n.get(), p + "norm0.weight", HW); add_weight(n.get(), p + "norm0.bias", HW); }
+        const long hw_n0 = i == 0 ? HW : n->HWs;                                  // sfnonet.py:616-623: norm0 sees the block's input grid,
+        const long hw_n1 = (i == 0 || i + 1 < c.num_layers) ? n->HWs : HW;        // norm1 its output grid (a first block's: the inner one)
+        if (c.normalization_layer == 3) { add_weight(n.get(), p + "norm0.weight", hw_n0); add_weight(n.get(), p + "norm0.bias", hw_n0); }
         auto add_cln = [&](const std::string& q, long ch) {   // ConditionalLayerNorm parameters in state_dict order
             if (c.noise_embed_dim > 0) {
                 add_weight(n.get(), q + "W_scale_2d.weight", ch * c.noise_embed_dim);
@@ -867,7 +882,7 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
         add_conv_weight(n.get(), p + "inner_skip.weight", (int)C, (int)C);
         add_weight(n.get(), p + "inner_skip.bias", C);
         if (c.normalization_layer == 1) { add_weight(n.get(), p + "norm1.weight", C); add_weight(n.get(), p + "norm1.bias", C); }
-        if (c.normalization_layer == 3) { add_weight(n.get(), p + "norm1.weight", HW); add_weight(n.get(), p + "norm1.bias", HW); }
+        if (c.normalization_layer == 3) { add_weight(n.get(), p + "norm1.weight", hw_n1); add_weight(n.get(), p + "norm1.bias", hw_n1); }
         if (cln) add_cln(p + "norm1.", C);
         if (c.use_mlp) {
             add_conv_weight(n.get(), p + "mlp.fwd.0.weight", n->hid, (int)C);
@@ -1210,13 +1225,13 @@ static int conv(const ace_sfno* n, const ConvW& cw, const float* in, long in_bst
     g.bsc = bsc; g.bsh = bsh; g.sbs = bsc ? cin : 0;
     g.omax = omax;
     g.A = cw.w; g.lda = cw.pitch; g.sA = cw.sw; g.a_kpad = cw.pitch;
-    g.B = in; g.ldb = n->HW; g.sB = in_bstride;
-    g.B2 = in2; g.ldb2 = n->HW; g.sB2 = in2_bstride; g.K1 = in2 ? K1 : -1;
-    g.C = out; g.ldc = n->HW; g.sC = (long)cout * n->HW;
+    g.B = in; g.ldb = n->hw_now; g.sB = in_bstride;
+    g.B2 = in2; g.ldb2 = n->hw_now; g.sB2 = in2_bstride; g.K1 = in2 ? K1 : -1;
+    g.C = out; g.ldc = n->hw_now; g.sC = (long)cout * n->hw_now;
     g.bias = cw.bias; g.sbias = cw.sbias;
-    g.R = R; g.ldr = n->HW; g.sR = r_bstride;
+    g.R = R; g.ldr = n->hw_now; g.sR = r_bstride;
     g.rsc = rsc; g.rsh = rsh; g.srs = rsc ? cout : 0;
-    g.M = cout; g.N = (int)n->HW; g.K = cin; g.nbatch = batch; g.act = act;
+    g.M = cout; g.N = (int)n->hw_now; g.K = cin; g.nbatch = batch; g.act = act;
     if (n->cfg.precision == 1 && cw.hi && cw.sw == 0 && bmax && gemm_f16x3_eligible(g)) {
         // compensated fp16 with the B scale derived in-kernel from max|B| (slot written by B's producer)
         if (g.act == ACT_GELU) g.act = ACT_GELU_FAST;  // the epilogue is on the critical path of this engine
@@ -1241,12 +1256,12 @@ static int fold(const ace_sfno* n, const ConvW& cw, int O, int I, const float* a
 // f16x3 "v4": 1x1 convolution whose input already is in P format (fp16 hi/lo planes [cin/8][HW][8] per sample, scaled
 // from the bound in `in_slot`).  Output: fp32 (+ omax) and/or P-format planes for the next convolution.
 static bool packed_ok(const ace_sfno* n, int cin) {
-    return !n->sw.no_pk && n->cfg.precision == 1 && n->P.p && cin % 8 == 0 && n->HW % 4 == 0;
+    return !n->sw.no_pk && n->cfg.precision == 1 && n->P.p && cin % 8 == 0 && n->hw_now % 4 == 0;
 }
 static int pack_act(const ace_sfno* n, const float* x, long x_bs, int cin, const float* sc, const float* sh,
                     const unsigned* slot, void* hi, void* lo, int batch, hipStream_t s) {
-    HIP_TRY(launch_pack_pformat(x, n->HW, x_bs, cin, (int)n->HW, batch, sc, sh, sc ? cin : 0, slot, hi, lo, n->HW,
-                                (long)cin * n->HW, s));
+    HIP_TRY(launch_pack_pformat(x, n->hw_now, x_bs, cin, (int)n->hw_now, batch, sc, sh, sc ? cin : 0, slot, hi, lo, n->hw_now,
+                                (long)cin * n->hw_now, s));
     return ACE_OK;
 }
 static int conv_pk(const ace_sfno* n, const Weight& w, const float* bias, const void* bhi, const void* blo, int cin,
@@ -1257,13 +1272,13 @@ static int conv_pk(const ace_sfno* n, const Weight& w, const float* bias, const 
     a.Ahi = static_cast<const _Float16*>((const void*)w.thi.p); a.Alo = static_cast<const _Float16*>((const void*)w.tlo.p);
     a.lda = w.pitch; a.sA = 0; a.ascale = w.ascale; a.a_tiled = 1;
     a.Bhi = static_cast<const _Float16*>(bhi); a.Blo = static_cast<const _Float16*>(blo);
-    a.ldn = n->HW; a.sB = (long)cin * n->HW; a.bmax = in_slot;
-    a.C = out; a.ldc = n->HW; a.sC = (long)cout * n->HW; a.omax = omax;
-    a.Chi = static_cast<_Float16*>(ohi); a.Clo = static_cast<_Float16*>(olo); a.ldnc = n->HW; a.sCp = (long)cout * n->HW;
+    a.ldn = n->hw_now; a.sB = (long)cin * n->hw_now; a.bmax = in_slot;
+    a.C = out; a.ldc = n->hw_now; a.sC = (long)cout * n->hw_now; a.omax = omax;
+    a.Chi = static_cast<_Float16*>(ohi); a.Clo = static_cast<_Float16*>(olo); a.ldnc = n->hw_now; a.sCp = (long)cout * n->hw_now;
     a.cw = w.winf; a.cb = cb; a.cslot = cslot;
     a.bias = bias; a.sbias = 0;
-    a.R = R; a.ldr = n->HW; a.sR = r_bs; a.rsc = rsc; a.rsh = rsh; a.srs = rsc ? cout : 0;
-    a.M = cout; a.N = (int)n->HW; a.K = cin; a.nbatch = batch;
+    a.R = R; a.ldr = n->hw_now; a.sR = r_bs; a.rsc = rsc; a.rsh = rsh; a.srs = rsc ? cout : 0;
+    a.M = cout; a.N = (int)n->hw_now; a.K = cin; a.nbatch = batch;
     a.act = act == ACT_GELU ? ACT_GELU_FAST : act;
     HIP_TRY(launch_gemm_f16x3_packed(a, s));
     return ACE_OK;
@@ -1293,14 +1308,14 @@ static int conv_pk2(const ace_sfno* n, const PkOpts& o, int batch, hipStream_t s
     }
     a.lda = o.w->pitch; a.a_tiled = 1;
     a.Bhi = static_cast<const _Float16*>(o.bhi); a.Blo = static_cast<const _Float16*>(o.blo);
-    a.ldn = n->HW; a.sB = (long)o.cin * n->HW; a.bmax = o.in_slot;
-    a.C = o.out; a.ldc = n->HW; a.sC = (long)o.cout * n->HW; a.omax = o.omax;
-    a.Chi = static_cast<_Float16*>(o.ohi); a.Clo = static_cast<_Float16*>(o.olo); a.ldnc = n->HW; a.sCp = (long)o.cout * n->HW;
+    a.ldn = n->hw_now; a.sB = (long)o.cin * n->hw_now; a.bmax = o.in_slot;
+    a.C = o.out; a.ldc = n->hw_now; a.sC = (long)o.cout * n->hw_now; a.omax = o.omax;
+    a.Chi = static_cast<_Float16*>(o.ohi); a.Clo = static_cast<_Float16*>(o.olo); a.ldnc = n->hw_now; a.sCp = (long)o.cout * n->hw_now;
     a.cw = o.w->winf; a.cb = o.cb; a.cslot = o.cslot; a.cinb = o.cinb; a.rmax = o.rmax;
     a.part = reinterpret_cast<float4*>(o.part);
     a.bias = o.bias; a.sbias = o.sbias;
-    a.R = o.R; a.ldr = n->HW; a.sR = o.r_bs; a.rsc = o.rsc; a.rsh = o.rsh; a.srs = o.rsc ? o.cout : 0;
-    a.M = o.cout; a.N = (int)n->HW; a.K = o.cin; a.nbatch = batch;
+    a.R = o.R; a.ldr = n->hw_now; a.sR = o.r_bs; a.rsc = o.rsc; a.rsh = o.rsh; a.srs = o.rsc ? o.cout : 0;
+    a.M = o.cout; a.N = (int)n->hw_now; a.K = o.cin; a.nbatch = batch;
     a.act = o.act == ACT_GELU ? ACT_GELU_FAST : o.act;
     HIP_TRY(launch_gemm_f16x3_packed(a, s));
     return ACE_OK;
@@ -1353,9 +1368,10 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                         const float* noise = nullptr) {
     const ace_sfno_config& c = n->cfg;
     const int C = n->C, Cin = c.in_chans, act = c.activation_function;
-    const long HW = n->HW;
+    long HW = n->HW;                 // resolution of the launches being enqueued: the data grid, or (scale_factor != 1, between the
+    n->hw_now = HW;                  // first filter's inverse transform and the last one's) the inner grid - see the blocks
     const long N2 = (long)B * 2 * C;
-    const long actB = (long)C * HW;  // per-sample stride of a C-channel activation
+    long actB = (long)C * HW;        // per-sample stride of a C-channel activation
     auto W = [&](const std::string& name) { return n->w(name); };
     // dynamic-range slots of the f16x3 engine (AMAX_SHARDS words each): 0 network input, 1..7 encoder/decoder hidden,
     // 8 + i block input h_i, 16 + 12 i + {0 X, 1 D, 2 E, 3 N0, 4 T, 5 N1, 6 U, 7 Y, 8 folded skip weight, 9 folded fc1 weight}
@@ -1676,6 +1692,9 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
         MARK(ST_LEGENDRE_INV);
         ACE_TRY(run_dft_inverse(inv, n->X.p, W(p + "filter.filter.bias"), n->Y.p, B, C, s, slot(sb + 7)));
         MARK(ST_DFT_INV);
+        // everything behind the filter works on ITS output grid (sfnonet.py:217-252: the skips, norm1 and the MLP see what the
+        // inverse transform produced) - the inner grid after the first block of a scale_factor != 1 net, the data grid after the last
+        HW = (long)inv.nlat * inv.nlon; actB = (long)C * HW; n->hw_now = HW;
 #ifdef ACE_MEASUREMENT_SWITCHES
         if (forked) { HIP_TRY(hipEventRecord(n->ev_join, n->side_stream)); HIP_TRY(hipStreamWaitEvent(s, n->ev_join, 0)); }
 #endif

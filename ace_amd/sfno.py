@@ -96,11 +96,11 @@ class FourierNeuralOperatorBlock(nn.Module):
 
     def __init__(self, embed_dim, modes_lat, modes_lon, operator_type, mlp_ratio, act_layer, norm_layer, use_mlp):
         super().__init__()
-        self.norm0 = norm_layer()
+        self.norm0 = norm_layer[0]()
         self.filter = SpectralFilterLayer(embed_dim, modes_lat, modes_lon, operator_type)
         self.inner_skip = nn.Conv2d(embed_dim, embed_dim, 1, 1)
         self.act_layer = act_layer()
-        self.norm1 = norm_layer()
+        self.norm1 = norm_layer[1]()
         if use_mlp:
             self.mlp = MLP(embed_dim, int(embed_dim * mlp_ratio), act_layer)
         self.outer_skip = nn.Identity()
@@ -182,8 +182,8 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             raise ValueError(f"Unsupported operator type f{self.operator_type}")
         if self.factorization is not None or self.separable:
             raise NotImplementedError("factorized / separable spectral weights are not implemented")
-        if self.scale_factor != 1 or self.residual_filter_factor != 1:
-            raise NotImplementedError("scale_factor / residual_filter_factor != 1 are not implemented")
+        if self.residual_filter_factor != 1:
+            raise NotImplementedError("residual_filter_factor != 1 is not implemented")
         if self.normalization_layer not in _NORM:
             raise NotImplementedError(f"Error, normalization {self.normalization_layer} not implemented.")
         if self.activation_function not in _ACT:
@@ -214,17 +214,28 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             def norm_layer():
                 return nn.InstanceNorm2d(num_features=self.embed_dim, eps=1e-6, affine=True,
                                          track_running_stats=False)
-        elif self.normalization_layer == "layer_norm":   # sfnonet.py:584-592: over (H, W), an (H, W) affine shared by the channels
-            def norm_layer():
+            norm_layer0 = norm_layer1 = norm_layer
+        elif self.normalization_layer == "layer_norm":   # sfnonet.py:584-592: over a whole grid, an affine of that shape shared by the channels
+            def norm_layer0():      # on the data grid
                 return nn.LayerNorm(normalized_shape=(self.img_shape[0], self.img_shape[1]), eps=1e-6)
+
+            def norm_layer1():      # on the inner (img_shape // scale_factor) grid
+                return nn.LayerNorm(normalized_shape=(self.h, self.w), eps=1e-6)
         else:
-            norm_layer = nn.Identity
+            norm_layer0 = norm_layer1 = nn.Identity
+
+        def block_norms(i):         # sfnonet.py:616-623: a first block sees (data, inner), a last one (inner, data), the others (inner, inner)
+            if i == 0:
+                return norm_layer0, norm_layer1
+            if i == self.num_layers - 1:
+                return norm_layer1, norm_layer0
+            return norm_layer1, norm_layer1
 
         self.blocks = nn.ModuleList(
             [
                 FourierNeuralOperatorBlock(self.embed_dim, modes_lat, modes_lon, self.operator_type, mlp_ratio,
-                                           act_layer, norm_layer, self.use_mlp)
-                for _ in range(self.num_layers)
+                                           act_layer, block_norms(i), self.use_mlp)
+                for i in range(self.num_layers)
             ]
         )
 

@@ -188,9 +188,11 @@ def init_state(cfg: SFNOConfig, seed: Optional[int] = 0) -> dict:
                 st[p + nm + ".weight"] = 1.0 + 0.1 * torch.randn(C, generator=g)
                 st[p + nm + ".bias"] = 0.1 * torch.randn(C, generator=g)
         elif cfg.normalization_layer == "layer_norm":
+            # sfnonet.py:616-623: norm0 on the block's input grid, norm1 on its output grid (a first block's: the inner one)
+            shapes = {"norm0": (H, W) if i == 0 else (h, w), "norm1": (h, w) if (i == 0 or i + 1 < cfg.num_layers) else (H, W)}
             for nm in ("norm0", "norm1"):
-                st[p + nm + ".weight"] = 1.0 + 0.1 * torch.randn(H, W, generator=g)
-                st[p + nm + ".bias"] = 0.1 * torch.randn(H, W, generator=g)
+                st[p + nm + ".weight"] = 1.0 + 0.1 * torch.randn(*shapes[nm], generator=g)
+                st[p + nm + ".bias"] = 0.1 * torch.randn(*shapes[nm], generator=g)
         wshape = (C, C, L, 2) if cfg.operator_type == "dhconv" else (C, C, L, M, 2)
         st[p + "filter.filter.weight"] = scale * torch.randn(*wshape, generator=g)
         st[p + "filter.filter.bias"] = 0.01 * torch.randn(1, C, 1, 1, generator=g)

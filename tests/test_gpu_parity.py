@@ -328,6 +328,42 @@ def test_layer_norm_nets_vs_oracle(dev, C, hw, precision):
     assert torch.equal(out, y)
 
 
+@pytest.mark.parametrize("case", ["sf2_3blocks", "sf2_2blocks", "sf2_1block", "sf3_equiangular", "sf2_layer_norm", "sf2_diagonal_no_norm"])
+def test_scale_factor_nets_vs_reference(dev, case, precision):
+    """scale_factor != 1 (sfnonet.py:467-515; the filter's residual round trip, s2convolutions.py:165-172) against outputs of the REAL
+    reference net (tests/golden/make_golden_scale_factor.py): the first block goes from the data grid to the inner Gauss-Legendre grid,
+    the last one back, one to three blocks, instance / layer / no norm, dhconv and diagonal filters."""
+    from oracle.sfno import SFNOConfig, init_state
+    d = load_golden("gen_sfno_scale_factor.pt")[case]
+    cfg = SFNOConfig(**{**d["cfg"], "img_shape": tuple(d["cfg"]["img_shape"])})
+    state = init_state(cfg, seed=d["seed"])
+    x = torch.randn(d["batch"], cfg.in_chans, *cfg.img_shape, generator=torch.Generator().manual_seed(d["seed"] + 1000))
+    net = build_native_net(cfg, state, dev, precision)
+    with torch.no_grad():
+        y = net(x.to(dev))
+    assert_net_close(y, d["y"], NET_TOL)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(num_layers=2), dict(normalization_layer="layer_norm"), dict(data_grid="equiangular", scale_factor=3)])
+def test_scale_factor_wide_nets_vs_oracle(dev, kw, precision):
+    """scale_factor 2 / 3 at C = 128 on 48 x 96 (inner grid 24 x 48 / 16 x 32): the middle blocks run the fused packed-operand path with
+    its fast kernels on the inner grid, the first and the last block the mixed-grid path - batch 2, four blocks, against the fp64
+    oracle (itself exact against the real reference: test_oracle_golden.py::test_scale_factor_nets_vs_reference); graph = eager."""
+    from oracle.sfno import SFNOConfig, SFNOOracle, init_state
+    cfg = SFNOConfig(**{**dict(in_chans=5, out_chans=4, img_shape=(48, 96), embed_dim=128, num_layers=4, operator_type="dhconv", scale_factor=2), **kw})
+    st = init_state(cfg, seed=71)
+    x = torch.randn(2, 5, 48, 96, generator=torch.Generator().manual_seed(72))
+    ref = SFNOOracle(cfg, st, dtype=torch.float64).forward(x)
+    net = build_native_net(cfg, st, dev, precision)
+    out = torch.empty(2, 4, 48, 96, device=dev)
+    with torch.no_grad():
+        y = net(x.to(dev)).clone()
+        net.forward_graph(x.to(dev), out)
+        torch.cuda.synchronize()
+    assert_net_close(y, ref, NET_TOL)
+    assert torch.equal(out, y)
+
+
 @pytest.mark.parametrize("kw", [
     dict(normalization_layer="none"), dict(use_mlp=False), dict(big_skip=False, pos_embed=False),
     dict(activation_function="silu", encoder_layers=2), dict(hard_thresholding_fraction=0.6),

@@ -110,6 +110,18 @@ def test_dhconv_nets_vs_reference(golden_dir, name):
     assert dataclasses.asdict(cfg)["operator_type"] == "dhconv"
 
 
+@pytest.mark.parametrize("case", ["sf2_3blocks", "sf2_2blocks", "sf2_1block", "sf3_equiangular", "sf2_layer_norm", "sf2_diagonal_no_norm"])
+def test_scale_factor_nets_vs_reference(golden_dir, case):
+    """scale_factor != 1 (sfnonet.py:467-515): outputs of the REAL reference net (tests/golden/make_golden_scale_factor.py)."""
+    d = _load(golden_dir, "gen_sfno_scale_factor.pt")[case]
+    cfg = SFNOConfig(**{**d["cfg"], "img_shape": tuple(d["cfg"]["img_shape"])})
+    state = init_state(cfg, seed=d["seed"])
+    assert sum(checksum(v) for v in state.values()) == pytest.approx(d["state_checksum"], rel=1e-12)
+    x = torch.randn(d["batch"], cfg.in_chans, *cfg.img_shape, generator=torch.Generator().manual_seed(d["seed"] + 1000))
+    assert checksum(x) == pytest.approx(d["x_checksum"], rel=1e-12)
+    torch.testing.assert_close(SFNOOracle(cfg, state)(x), d["y"])
+
+
 def test_legendre_tables_against_scipy_spherical_harmonics():
     """An INDEPENDENT pin of the oracle's Legendre tables at the full sizes (the torch-harmonics arithmetic they restate is not
     in the reference tree, and the reference's own goldens hold it at 9 x 18 / 12 x 24 only): the orthonormal associated Legendre
