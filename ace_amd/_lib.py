@@ -24,6 +24,7 @@ class AceSfnoConfig(ctypes.Structure):
         ("mlp_ratio", c_float), ("encoder_layers", c_int), ("pos_embed", c_int), ("big_skip", c_int),
         ("data_grid", c_int), ("max_batch", c_int), ("precision", c_int),
         ("noise_embed_dim", c_int), ("affine_norms", c_int), ("normalize_big_skip", c_int), ("filter_num_groups", c_int),
+        ("residual_filter_factor", c_int),
     ]
 
 

@@ -750,6 +750,10 @@ struct ace_sfno {
     DevBuf P;  // f16x3: a C-channel activation as P-format fp16 hi/lo planes (input of the packed-operand GEMM)
     DevBuf cln_stats;    // conditional layer norm: per-pixel mean | rstd
     DevBuf inN;          // conditional layer norm of the network input (normalize_big_skip)
+    // residual_filter_factor > 1 (sfnonet.py:473-497): exact-fp32 plan on the data grid with lmax = nlat / r, mmax = nlon / r / 2 + 1,
+    // its scratch and the band-limited copy of the network input the decoder's big skip reads
+    std::unique_ptr<ace_sht_plan> plan_res;
+    DevBuf resX, resD, inF;
     DevBuf P2;           // second one: the block input h as written by the previous block's fc2 epilogue
     DevBuf part;         // per-strip row statistics from the GEMM epilogues (fused instance norm), two tensors
     DevBuf Wp0, Wp1;     // folded (norm affine) skip / fc1 weights as tiled fp16 planes, per sample
@@ -803,8 +807,9 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     if (!cfg || !out) return fail(ACE_ERR_INVALID, "null argument");
     const ace_sfno_config& c = *cfg;
     if (c.scale_factor < 1) return fail(ACE_ERR_INVALID, "scale_factor must be >= 1");
-    if (c.scale_factor != 1 && c.normalization_layer == 2)
-        return fail(ACE_ERR_INVALID, "scale_factor != 1 is not built for the noise-conditioned nets");
+    if ((c.scale_factor != 1 || c.residual_filter_factor > 1) && c.normalization_layer == 2)
+        return fail(ACE_ERR_INVALID, "scale_factor / residual_filter_factor != 1 are not built for the noise-conditioned nets");
+    if (c.residual_filter_factor < 0) return fail(ACE_ERR_INVALID, "residual_filter_factor must be >= 1");
     if (c.in_chans <= 0 || c.out_chans <= 0 || c.embed_dim <= 0 || c.num_layers <= 0 || c.nlat < 2 || c.nlon < 2)
         return fail(ACE_ERR_INVALID, "non-positive dimension in ace_sfno_config");
     if (c.operator_type != 0 && c.operator_type != 1) return fail(ACE_ERR_INVALID, "Unsupported operator type");
@@ -848,6 +853,16 @@ extern "C" int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** out) {
     } else {
         ACE_TRY(plan_build(c.nlat, c.nlon, n->L, n->Mm, (Grid)c.data_grid, n->plan_data_own, c.precision == 1));
         n->plan_data = n->plan_data_own.get();
+    }
+
+    if (c.residual_filter_factor > 1 && c.big_skip) {
+        const int rl = c.nlat / c.residual_filter_factor, rm = c.nlon / c.residual_filter_factor / 2 + 1;
+        if (rl < 1 || rm < 1) return fail(ACE_ERR_INVALID, "residual_filter_factor leaves no modes");
+        ACE_TRY(plan_build(c.nlat, c.nlon, rl, rm, (Grid)c.data_grid, n->plan_res, false));
+        const size_t n2 = (size_t)n->Bmax * 2 * c.in_chans;
+        HIP_TRY(n->resX.alloc(((size_t)rm * c.nlat + LEG_STRIP_SLACK_ROWS) * n2));
+        HIP_TRY(n->resD.alloc(((size_t)rl + LEG_STRIP_SLACK_ROWS) * rm * n2));
+        HIP_TRY(n->inF.alloc((size_t)n->Bmax * c.in_chans * n->HW));
     }
 
     // parameters in the reference's state_dict order
@@ -1032,6 +1047,8 @@ extern "C" long ace_sfno_workspace_size(const ace_sfno* n, int batch) {
     };
     plan_bytes(n->plan_lg.get());
     plan_bytes(n->plan_data_own.get());
+    plan_bytes(n->plan_res.get());
+    for (const DevBuf* b : {&n->resX, &n->resD, &n->inF}) add(*b);
     return (long)(fl * sizeof(float));
 }
 
@@ -1517,6 +1534,15 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
                                        n->cln_stats.p, y, B, Cc, c.noise_embed_dim, HW, s, omax));
         return ACE_OK;
     };
+    if (n->plan_res) {   // residual = residual_filter_up(residual_filter_down(x)) (sfnonet.py:715-716), exact fp32; its range into slot 7
+        const long NR = (long)B * 2 * Cin;
+        ACE_TRY(run_dft_forward(*n->plan_res, in, nullptr, nullptr, n->resX.p, B, Cin, s));
+        ACE_TRY(run_legendre_forward(*n->plan_res, n->resX.p, n->resD.p, NR, s));
+        ACE_TRY(run_legendre_inverse(*n->plan_res, n->resD.p, n->resX.p, NR, s));
+        ACE_TRY(run_dft_inverse(*n->plan_res, n->resX.p, nullptr, n->inF.p, B, Cin, s, slot(7)));
+        skip_in = n->inF.p;
+        skip_in_slot = slot(7);
+    }
     if (cln && c.big_skip && c.normalize_big_skip) {
         ACE_TRY(cond_norm(in, n->inN.p, "norm_big_skip.", Cin, slot(7)));
         skip_in = n->inN.p;

@@ -182,8 +182,8 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             raise ValueError(f"Unsupported operator type f{self.operator_type}")
         if self.factorization is not None or self.separable:
             raise NotImplementedError("factorized / separable spectral weights are not implemented")
-        if self.residual_filter_factor != 1:
-            raise NotImplementedError("residual_filter_factor != 1 is not implemented")
+        if self.residual_filter_factor < 1 or self.scale_factor < 1:
+            raise ValueError("scale_factor and residual_filter_factor must be >= 1")
         if self.normalization_layer not in _NORM:
             raise NotImplementedError(f"Error, normalization {self.normalization_layer} not implemented.")
         if self.activation_function not in _ACT:
@@ -285,6 +285,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             mlp_ratio=float(self.mlp_ratio), encoder_layers=self.encoder_layers,
             pos_embed=int(hasattr(self, "pos_embed")), big_skip=int(self.big_skip),
             data_grid=_GRID[self.data_grid], max_batch=max_batch, precision=_PRECISION[self.precision],
+            residual_filter_factor=int(self.residual_filter_factor),
         )
 
     def set_precision(self, precision: str):

@@ -128,7 +128,8 @@ typedef struct ace_sfno_config {
     int in_chans, out_chans;      /* n_in_channels, n_out_channels of ModuleConfig.build */
     int nlat, nlon;               /* dataset_info.img_shape */
     int embed_dim, num_layers;
-    int scale_factor;             /* only 1 is supported */
+    int scale_factor;             /* >= 1: the blocks between the first filter's inverse transform and the last one's forward transform
+                                     work on the (nlat / sf) x (nlon / sf) Gauss-Legendre grid (sfnonet.py:467-515) */
     float hard_thresholding_fraction;
     int operator_type;            /* 0 = "diagonal", 1 = "dhconv" */
     int normalization_layer;      /* 0 = "none", 1 = "instance_norm", 2 = conditional layer norm (NoiseConditionedSFNO),
@@ -149,6 +150,8 @@ typedef struct ace_sfno_config {
     int affine_norms;             /* elementwise gamma/beta in the layer norms */
     int normalize_big_skip;       /* conditional layer norm on the big-skip input */
     int filter_num_groups;        /* groups of the spectral filter (weight (G, L, C/G, C/G, 2)); >= 1 */
+    int residual_filter_factor;   /* 0 / 1: none; r > 1: the big skip's input is band-limited on the data grid to lmax = nlat / r,
+                                     mmax = nlon / r / 2 + 1 (sfnonet.py:473-497, 715-716) */
 } ace_sfno_config;
 
 int ace_sfno_create(const ace_sfno_config* cfg, ace_sfno** net);

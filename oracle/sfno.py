@@ -54,7 +54,6 @@ _ACT = {"gelu": F.gelu, "relu": F.relu, "silu": F.silu}
 class SFNOOracle:
     def __init__(self, cfg: SFNOConfig, state: dict, dtype=torch.float32):
         assert cfg.spectral_transform == "sht" and cfg.filter_type == "linear"
-        assert cfg.residual_filter_factor == 1
         self.cfg = cfg
         self.dtype = dtype
         self.p = {k.removeprefix("module."): v.detach().to("cpu").to(dtype) for k, v in state.items()
@@ -67,6 +66,11 @@ class SFNOOracle:
         modes_lon = int((self.w // 2 + 1) * cfg.hard_thresholding_fraction)
         # sfnonet.py:498-515
         kw = dict(lmax=modes_lat, mmax=modes_lon, dtype=dtype)
+        # sfnonet.py:473-497: the big skip's input is band-limited on the data grid when residual_filter_factor != 1
+        if cfg.residual_filter_factor != 1:
+            rl, rm = int(H // cfg.residual_filter_factor), int(W // cfg.residual_filter_factor // 2 + 1)
+            self.residual_filter_down = RealSHT(H, W, lmax=rl, mmax=rm, grid=cfg.data_grid, dtype=dtype)
+            self.residual_filter_up = InverseRealSHT(H, W, lmax=rl, mmax=rm, grid=cfg.data_grid, dtype=dtype)
         self.trans_down = RealSHT(H, W, grid=cfg.data_grid, **kw)
         self.itrans_up = InverseRealSHT(H, W, grid=cfg.data_grid, **kw)
         self.trans = RealSHT(self.h, self.w, grid="legendre-gauss", **kw)
@@ -135,6 +139,8 @@ class SFNOOracle:
         # sfnonet.py:713-749
         x = x.detach().to("cpu").to(self.dtype)
         residual = x
+        if self.cfg.residual_filter_factor != 1:   # sfnonet.py:715-716
+            residual = self.residual_filter_up(self.residual_filter_down(x))
         x = self._mlp_stack(x, "encoder")
         if self.cfg.pos_embed:
             x = x + self.p["pos_embed"]

@@ -61,7 +61,8 @@ def build_native_net(cfg, state, device="cuda", precision=None):
 
     d = dataclasses.asdict(cfg)
     params = types.SimpleNamespace(
-        operator_type=d["operator_type"], scale_factor=d["scale_factor"], embed_dim=d["embed_dim"],
+        operator_type=d["operator_type"], scale_factor=d["scale_factor"], residual_filter_factor=d["residual_filter_factor"],
+        embed_dim=d["embed_dim"],
         num_layers=d["num_layers"], hard_thresholding_fraction=d["hard_thresholding_fraction"],
         normalization_layer=d["normalization_layer"], use_mlp=d["use_mlp"],
         activation_function=d["activation_function"], encoder_layers=d["encoder_layers"],

@@ -328,7 +328,8 @@ def test_layer_norm_nets_vs_oracle(dev, C, hw, precision):
     assert torch.equal(out, y)
 
 
-@pytest.mark.parametrize("case", ["sf2_3blocks", "sf2_2blocks", "sf2_1block", "sf3_equiangular", "sf2_layer_norm", "sf2_diagonal_no_norm"])
+@pytest.mark.parametrize("case", ["sf2_3blocks", "sf2_2blocks", "sf2_1block", "sf3_equiangular", "sf2_layer_norm", "sf2_diagonal_no_norm",
+                                  "rff2", "rff2_sf2", "rff3_sf3_equiangular"])
 def test_scale_factor_nets_vs_reference(dev, case, precision):
     """scale_factor != 1 (sfnonet.py:467-515; the filter's residual round trip, s2convolutions.py:165-172) against outputs of the REAL
     reference net (tests/golden/make_golden_scale_factor.py): the first block goes from the data grid to the inner Gauss-Legendre grid,
@@ -344,7 +345,8 @@ def test_scale_factor_nets_vs_reference(dev, case, precision):
     assert_net_close(y, d["y"], NET_TOL)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(num_layers=2), dict(normalization_layer="layer_norm"), dict(data_grid="equiangular", scale_factor=3)])
+@pytest.mark.parametrize("kw", [dict(), dict(num_layers=2), dict(normalization_layer="layer_norm"), dict(data_grid="equiangular", scale_factor=3),
+                                dict(residual_filter_factor=2), dict(residual_filter_factor=3, scale_factor=1)])
 def test_scale_factor_wide_nets_vs_oracle(dev, kw, precision):
     """scale_factor 2 / 3 at C = 128 on 48 x 96 (inner grid 24 x 48 / 16 x 32): the middle blocks run the fused packed-operand path with
     its fast kernels on the inner grid, the first and the last block the mixed-grid path - batch 2, four blocks, against the fp64

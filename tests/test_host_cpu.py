@@ -179,10 +179,17 @@ def test_unsupported_options_are_rejected():
         Net(params=None, filter_type="non-linear", img_shape=(6, 12))
     with pytest.raises(ValueError):
         Net(params=None, operator_type="block-diagonal", img_shape=(6, 12))
-    with pytest.raises(NotImplementedError):
-        Net(params=None, scale_factor=2, img_shape=(6, 12))
+    with pytest.raises(ValueError):
+        Net(params=None, scale_factor=0, img_shape=(6, 12))
     with pytest.raises(ValueError):
         Net(params=None, activation_function="tanh", img_shape=(6, 12))
+    # built since round 6 (sfnonet.py:467-515, 584-592): the reference's names and shapes
+    net = Net(params=None, scale_factor=2, residual_filter_factor=2, normalization_layer="layer_norm", img_shape=(12, 24), embed_dim=8, num_layers=3,
+              in_chans=2, out_chans=2)
+    sd = net.state_dict()
+    assert tuple(sd["blocks.0.norm0.weight"].shape) == (12, 24) and tuple(sd["blocks.0.norm1.weight"].shape) == (6, 12)
+    assert tuple(sd["blocks.1.norm0.weight"].shape) == (6, 12) and tuple(sd["blocks.2.norm1.bias"].shape) == (12, 24)
+    assert tuple(sd["blocks.1.filter.filter.weight"].shape) == (8, 8, 6, 7, 2) and tuple(sd["pos_embed"].shape) == (1, 8, 12, 24)   # "diagonal": (L, M) of the inner grid
 
 
 # ----------------------------------------------------------------------------- packer / normaliser / step bookkeeping

@@ -110,7 +110,8 @@ def test_dhconv_nets_vs_reference(golden_dir, name):
     assert dataclasses.asdict(cfg)["operator_type"] == "dhconv"
 
 
-@pytest.mark.parametrize("case", ["sf2_3blocks", "sf2_2blocks", "sf2_1block", "sf3_equiangular", "sf2_layer_norm", "sf2_diagonal_no_norm"])
+@pytest.mark.parametrize("case", ["sf2_3blocks", "sf2_2blocks", "sf2_1block", "sf3_equiangular", "sf2_layer_norm", "sf2_diagonal_no_norm",
+                                  "rff2", "rff2_sf2", "rff3_sf3_equiangular"])
 def test_scale_factor_nets_vs_reference(golden_dir, case):
     """scale_factor != 1 (sfnonet.py:467-515): outputs of the REAL reference net (tests/golden/make_golden_scale_factor.py)."""
     d = _load(golden_dir, "gen_sfno_scale_factor.pt")[case]
