@@ -2071,6 +2071,8 @@ extern "C" int ace_sfno_forward_conditioned_timed(ace_sfno* n, const float* in, 
 
 extern "C" int ace_sfno_set_taps(ace_sfno* n, int enable) {
     if (!n) return fail(ACE_ERR_INVALID, "null argument");
+    if (enable && n->cfg.scale_factor != 1)   // the taps are (batch, C, nlat, nlon) copies: the inner blocks of such a net live on another grid
+        return fail(ACE_ERR_STATE, "per-block taps are not available for scale_factor != 1");
     if (enable && n->taps.empty()) {
         n->taps = std::vector<DevBuf>(n->cfg.num_layers + 1);
         for (auto& t : n->taps) HIP_TRY(t.alloc((size_t)n->Bmax * n->C * n->HW));
