@@ -116,6 +116,7 @@ SIGNATURES = {
     "ace_hpx_conv1_packed": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p, c_void_p, c_void_p]),
     "ace_hpx_pool2": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_void_p]),
+    "ace_hpx_upsample2": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_int, c_void_p]),
     # x, w, bias, tmp, y, imgs, cin, cout, H, W, pitch_in, pitch_out, plane_stride_out, act, cap, xmax, ymax, stream
     "ace_hpx_tconv2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_long,
                                c_int, c_float, c_void_p, c_void_p, c_void_p]),

@@ -376,6 +376,36 @@ __global__ __launch_bounds__(256) void hpx_pool2_kernel(const float* __restrict_
     }
 }
 
+// nn.Upsample(scale_factor = 2) of every (image, channel) plane (healpix_blocks.py:197-252, 699-759: the "Interpolate" block and the
+// resize of SmoothedInterpolate): mode 0 "nearest" (every cell a 2 x 2 block of itself), 1 "bilinear" with torch's source index
+// (align_corners false: max(0.5 (o + 0.5) - 0.5, 0); true: o (n - 1) / (2 n - 1)), neighbours clamped to the plane.  Both are convex
+// combinations of the input: the input's bound is the output's.
+template <int MODE>
+__global__ __launch_bounds__(256) void hpx_upsample2_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int H, int W,
+                                                            int px, long sx, int py, long sy, int align_corners) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long total = planes * Ho * Wo;
+    const float ry = (align_corners && Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.5f;
+    const float rx = (align_corners && Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.5f;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int xo = (int)(t % Wo), yo = (int)((t / Wo) % Ho);
+        const long pl = t / ((long)Wo * Ho);
+        const float* s = x + pl * sx;
+        float v;
+        if (MODE == 0) {
+            v = s[(long)(yo >> 1) * px + (xo >> 1)];
+        } else {
+            const float fy = align_corners ? ry * (float)yo : fmaxf(ry * ((float)yo + 0.5f) - 0.5f, 0.f);
+            const float fx = align_corners ? rx * (float)xo : fmaxf(rx * ((float)xo + 0.5f) - 0.5f, 0.f);
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+            const float ly1 = fy - (float)y0, lx1 = fx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+            v = ly0 * (lx0 * s[(long)y0 * px + x0] + lx1 * s[(long)y0 * px + x1]) + ly1 * (lx0 * s[(long)y1 * px + x0] + lx1 * s[(long)y1 * px + x1]);
+        }
+        y[pl * sy + (long)yo * py + xo] = v;
+    }
+}
+
 __device__ __forceinline__ float hpx_act(float v, int act, float cap) {
     if (act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     else if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
@@ -624,6 +654,17 @@ extern "C" int ace_hpx_pool2(const float* x, float* y, long planes, int H, int W
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (is_max) hipLaunchKernelGGL(hpx_pool2_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, x, y, planes, H, W, pitch_in, plane_stride_in, pitch_out, plane_stride_out);
     else hipLaunchKernelGGL(hpx_pool2_kernel<false>, dim3(grid_for(total)), dim3(256), 0, s, x, y, planes, H, W, pitch_in, plane_stride_in, pitch_out, plane_stride_out);
+    HPX_TRY(hipGetLastError());
+    return ACE_OK;
+}
+
+extern "C" int ace_hpx_upsample2(const float* x, float* y, long planes, int H, int W, int pitch_in, long plane_stride_in, int pitch_out,
+                                 long plane_stride_out, int mode, int align_corners, void* stream) {
+    if (!x || !y || planes < 1 || H < 1 || W < 1 || (mode != 0 && mode != 1)) return hfail(ACE_ERR_INVALID, "ace_hpx_upsample2: bad argument");
+    const long total = planes * (2L * H) * (2L * W);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (mode == 0) hipLaunchKernelGGL(hpx_upsample2_kernel<0>, dim3(grid_for(total)), dim3(256), 0, s, x, y, planes, H, W, pitch_in, plane_stride_in, pitch_out, plane_stride_out, 0);
+    else hipLaunchKernelGGL(hpx_upsample2_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, x, y, planes, H, W, pitch_in, plane_stride_in, pitch_out, plane_stride_out, align_corners);
     HPX_TRY(hipGetLastError());
     return ACE_OK;
 }

@@ -10,7 +10,7 @@ healpix_unet.py} that the reference's own test configuration uses - ConvNeXtBloc
 TransposedConvUpsample, CappedGELU, face padding modes "karlbauer" and "earth2grid" (which the reference documents as giving
 the same result; one gather table serves both) and "isolatitude" (its own table, same gather kernel), and the
 DealiasedDownsample / SmoothedInterpolateConv resamplers (composed from the same operators).  Not built (raise at
-construction): interpolation modes other than "nearest".  The symmetric ConvNeXt
+construction): interpolation modes other than "nearest" / "nearest-exact" / "bilinear" (bicubic, area).  The symmetric ConvNeXt
 variants (residual added after the last activation) close with an identity contraction that carries the residual; the "Interpolate"
 upsampling block is the transposed convolution with identity taps.
 
@@ -800,37 +800,36 @@ def _add_after_activation(y: Hpx, skip: Hpx) -> Hpx:
     return Hpx(out, W, omax)
 
 
+_UPSAMPLE_MODES = {"nearest": 0, "nearest-exact": 0, "bilinear": 1}   # (at an integer factor "nearest-exact" picks the same cells as "nearest")
+
+
 class NearestUpsample(nn.Module):
-    """nn.Upsample(scale_factor=2, mode="nearest") on folded faces (healpix_blocks.py:229-253, the "Interpolate" upsampling block):
-    every cell becomes a 2 x 2 block of itself - the native 2 x 2 stride-2 transposed convolution with the identity as each of its
-    four taps (no parameters; exact up to the 22-bit operand split of the compensated-fp16 mode)."""
+    """nn.Upsample(scale_factor=2, mode=...) on folded faces (healpix_blocks.py:229-253, the "Interpolate" upsampling block; also the
+    resize inside SmoothedInterpolate): "nearest" - every cell becomes a 2 x 2 block of itself - or "bilinear" with torch's source
+    index and align_corners, one elementwise launch (ace_hpx_upsample2); exact fp32 in both arithmetic modes.  The input's bound also
+    bounds the result.  (Round 5 ran "nearest" as a transposed convolution with identity taps on the matrix engine.)"""
 
     def __init__(self, stride: int = 2, mode: str = "nearest", align_corners: bool = False):
         super().__init__()
-        if stride != 2 or mode != "nearest" or align_corners:
-            raise NotImplementedError(f"Interpolate upsampling: only stride 2, mode 'nearest' is built (got stride={stride}, mode={mode!r}, "
-                                      f"align_corners={align_corners})")
+        if stride != 2 or mode not in _UPSAMPLE_MODES:
+            raise NotImplementedError(f"Interpolate upsampling: stride 2 with mode 'nearest' / 'nearest-exact' / 'bilinear' is built (got stride={stride}, "
+                                      f"mode={mode!r})")
+        if align_corners and _UPSAMPLE_MODES[mode] == 0:
+            raise ValueError("align_corners option can only be set with the interpolating modes: linear | bilinear | bicubic | trilinear")   # torch's own
+        self.mode, self.align_corners = mode, bool(align_corners)
 
     def forward(self, x: Hpx, slack: bool = False) -> Hpx:
         """slack: leave the readable slack of a k > 1 contraction's input behind the result (and give it the exact pitch % 4)"""
         C = x.data.shape[1]
         dev = x.data.device
-        key = (-C, str(dev))                      # (negative: the four stacked identities of this width)
-        if key not in _IDENTITY:
-            h = ctypes.c_void_p()
-            eye4 = torch.eye(C, dtype=torch.float32, device=dev).repeat(4, 1).contiguous()
-            _check(_lib.lib().ace_hpx_weight_create(eye4.data_ptr(), 4 * C, C, _lib.current_stream(), ctypes.byref(h)))
-            _IDENTITY[key] = h
         x = _dense(x)
         imgs, H, W = x.data.shape[0], x.rows, x.width
         po = _round4(2 * W) if slack else _RT.pitch_for(2 * W)
-        tmp = torch.empty(4 * imgs * C * H * x.pitch, dtype=torch.float32, device=dev)
         flat = torch.zeros(imgs * C * 2 * H * po + (_SLACK if slack else 0), dtype=torch.float32, device=dev)
         y = flat[: imgs * C * 2 * H * po].view(imgs, C, 2 * H, po)
-        ymax = _RT.slot(dev)
-        _check(_lib.lib().ace_hpx_tconv2(x.data.data_ptr(), _IDENTITY[key], None, tmp.data_ptr(), y.data_ptr(), imgs, C, C, H, W, x.pitch, po,
-                                         2 * H * po, ACT_NONE, _INF, _bound(x).data_ptr(), ymax.data_ptr(), _lib.current_stream()))
-        return Hpx(y, 2 * W, ymax)
+        _check(_lib.lib().ace_hpx_upsample2(x.data.data_ptr(), y.data_ptr(), imgs * C, H, W, x.pitch, H * x.pitch, po, 2 * H * po,
+                                            _UPSAMPLE_MODES[self.mode], int(self.align_corners), _lib.current_stream()))
+        return Hpx(y, 2 * W, _bound(x))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -983,8 +982,8 @@ class SmoothedInterpolate(nn.Module):
 
     def __init__(self, in_channels: int = 3, scale_factor: int = 2, mode: str = "nearest", trim_size: int = 0):
         super().__init__()
-        if scale_factor != 2 or mode != "nearest":
-            raise NotImplementedError(f"SmoothedInterpolate: only scale_factor 2, mode 'nearest' is built (got {scale_factor}, {mode!r})")
+        if scale_factor != 2 or mode not in _UPSAMPLE_MODES:
+            raise NotImplementedError(f"SmoothedInterpolate: scale_factor 2 with mode 'nearest' / 'nearest-exact' / 'bilinear' is built (got {scale_factor}, {mode!r})")
         self.in_channels, self.scale_factor, self.mode, self.trim_size = in_channels, scale_factor, mode, trim_size
         cross = torch.tensor([[0.0, 1.0, 0.0], [1.0, 0.0, 1.0], [0.0, 1.0, 0.0]])
         self.register_buffer("smoother_kernel", cross.unsqueeze(0).unsqueeze(0).repeat((in_channels, 1, 1, 1)))
@@ -1017,7 +1016,7 @@ class SmoothedInterpolateConv(nn.Module):
             block.append(activation_factory())
         self.block = nn.Sequential(*block)
         self._filters = _FixedFilter()
-        self._up = NearestUpsample()
+        self._up = NearestUpsample(2, mode)
 
     def forward(self, x: Hpx) -> Hpx:
         dev = x.data.device

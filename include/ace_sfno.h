@@ -360,6 +360,10 @@ int ace_hpx_conv1_packed(const void* xhi, const void* xlo, int cin, const ace_hp
 /* nn.AvgPool2d(2) / nn.MaxPool2d(2) on `planes` = imgs * channels planes (the input's bound also bounds the result). */
 int ace_hpx_pool2(const float* x, float* y, long planes, int H, int W, int pitch_in, long plane_stride_in, int pitch_out,
                   long plane_stride_out, int is_max, void* stream);
+/* nn.Upsample(scale_factor=2, mode) on `planes` planes (healpix_blocks.py:197-252 "Interpolate", 699-759 SmoothedInterpolate's resize):
+ * mode 0 "nearest", 1 "bilinear" (align_corners as torch defines it).  y: [planes][2 H][pitch_out].  The input's bound also bounds the result. */
+int ace_hpx_upsample2(const float* x, float* y, long planes, int H, int W, int pitch_in, long plane_stride_in, int pitch_out,
+                      long plane_stride_out, int mode, int align_corners, void* stream);
 /* nn.ConvTranspose2d(cin, cout, 2, stride 2) + activation (healpix_blocks.py:636-697).  w: prepared from
  * [(dy 2 + dx) cout + o][cin]; tmp: imgs * 4 cout * H * pitch_in floats of scratch; y: [imgs][cout][2 H][pitch_out]. */
 int ace_hpx_tconv2(const float* x, const ace_hpx_weight* w, const float* bias, float* tmp, float* y, int imgs, int cin, int cout, int H,

@@ -271,6 +271,18 @@ class FakeHpx:
         torch.as_strided(dst, (planes, H // 2, W // 2), (plane_stride_out, pitch_out, 1)).copy_(r)
         return 0
 
+    def ace_hpx_upsample2(self, x, y, planes, H, W, pitch_in, plane_stride_in, pitch_out, plane_stride_out, mode, align_corners, stream):
+        self.calls.append("upsample")
+        src = _f32(x, (planes - 1) * plane_stride_in + H * pitch_in)
+        dst = _f32(y, (planes - 1) * plane_stride_out + 2 * H * pitch_out)
+        s = torch.as_strided(src, (1, planes, H, W), (0, plane_stride_in, pitch_in, 1))
+        if mode == 0:
+            r = torch.nn.functional.interpolate(s, scale_factor=2, mode="nearest")
+        else:
+            r = torch.nn.functional.interpolate(s, scale_factor=2, mode="bilinear", align_corners=bool(align_corners))
+        torch.as_strided(dst, (planes, 2 * H, 2 * W), (plane_stride_out, pitch_out, 1)).copy_(r[0])
+        return 0
+
     def ace_hpx_tconv2(self, x, w, bias, tmp, y, imgs, cin, cout, H, W, pitch_in, pitch_out, plane_stride_out, act, cap, xmax, ymax, stream):
         self.calls.append("tconv")
         Wm = self._w(w)

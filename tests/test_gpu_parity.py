@@ -1563,8 +1563,8 @@ def test_healpix_isolatitude_padding_and_unet_vs_reference(dev):
 
 
 def test_healpix_interpolate_upsample_unet_vs_reference(dev):
-    """the "Interpolate" upsampling block (nn.Upsample(scale_factor=2, mode="nearest"), healpix_blocks.py:229-253) as the native
-    2 x 2 transposed convolution with identity taps, in a ConvNeXt UNet with max pooling, against the reference's output"""
+    """the "Interpolate" upsampling block (nn.Upsample(scale_factor=2, mode="nearest"), healpix_blocks.py:229-253) on ace_hpx_upsample2
+    (round 5: a transposed convolution with identity taps), in a ConvNeXt UNet with max pooling, against the reference's output"""
     import ace_amd
     g = load_golden("gen_healpix_isolatitude.pt")["unet"]["interpolate_upsample"]
     case = g["case"]
@@ -1575,9 +1575,16 @@ def test_healpix_interpolate_upsample_unet_vs_reference(dev):
     with torch.no_grad():
         y = net(g["x"].to(dev))
     assert_net_close(y, g["y"], NET_TOL)
+    dec = dict(case["config"]["decoder"])
+    dec["up_sampling_block"] = {"block_type": "Interpolate", "upsample_mode": "bilinear"}       # built since round 6 (ace_hpx_upsample2)
+    bil = ace_amd.ModuleSelector(type="HEALPixUNet", config={**case["config"], "decoder": dec}).build(
+        case["n_in"], case["n_out"], ace_amd.DatasetInfo((case["nside"], case["nside"]))).torch_module.to(dev)
+    bil.load_state_dict(g["state_dict"], strict=True)
+    with torch.no_grad():
+        yb = bil(g["x"].to(dev))
+    assert yb.shape == y.shape and bool(torch.isfinite(yb).all()) and not torch.equal(yb, y)
     with pytest.raises(NotImplementedError):
-        dec = dict(case["config"]["decoder"])
-        dec["up_sampling_block"] = {"block_type": "Interpolate", "upsample_mode": "bilinear"}
+        dec["up_sampling_block"] = {"block_type": "Interpolate", "upsample_mode": "bicubic"}
         ace_amd.ModuleSelector(type="HEALPixUNet", config={**case["config"], "decoder": dec}).build(3, 2, ace_amd.DatasetInfo((8, 8)))
 
 

@@ -62,8 +62,10 @@ def test_unbuilt_variants_are_loud(gold):
     enc["down_sampling_block"] = {"block_type": "DealiasedDownsample"}       # built since round 3 (same operators, tests/test_healpix_resamplers.py)
     ace_amd.ModuleSelector(type="HEALPixUNet", config={**cfg, "encoder": enc}).build(3, 2, ace_amd.DatasetInfo((8, 8)))
     dec = dict(cfg["decoder"])
-    dec["up_sampling_block"] = {"block_type": "SmoothedInterpolateConv", "upsample_mode": "bilinear"}
-    with pytest.raises(NotImplementedError, match="nearest"):
+    dec["up_sampling_block"] = {"block_type": "SmoothedInterpolateConv", "upsample_mode": "bilinear"}      # built since round 6 (ace_hpx_upsample2)
+    ace_amd.ModuleSelector(type="HEALPixUNet", config={**cfg, "decoder": dec}).build(3, 2, ace_amd.DatasetInfo((8, 8)))
+    dec["up_sampling_block"] = {"block_type": "SmoothedInterpolateConv", "upsample_mode": "bicubic"}
+    with pytest.raises(NotImplementedError, match="bilinear"):
         ace_amd.ModuleSelector(type="HEALPixUNet", config={**cfg, "decoder": dec}).build(3, 2, ace_amd.DatasetInfo((8, 8)))
     enc["down_sampling_block"] = {"block_type": "FancyPool"}
     with pytest.raises(ValueError, match="FancyPool"):

@@ -101,8 +101,9 @@ def test_resampler_configuration_surface():
         SmoothedInterpolateConv(in_channels=2, out_channels=2, hpx_padding_mode="isolatitude", nside=8)
     with pytest.raises(ValueError, match="must equal"):
         SmoothedInterpolateConv(in_channels=2, out_channels=2, nside=8, nside_after=12)
-    with pytest.raises(NotImplementedError, match="nearest"):
-        SmoothedInterpolateConv(in_channels=2, out_channels=2, mode="bilinear")
+    SmoothedInterpolateConv(in_channels=2, out_channels=2, mode="bilinear")          # built since round 6 (ace_hpx_upsample2)
+    with pytest.raises(NotImplementedError, match="bilinear"):
+        SmoothedInterpolateConv(in_channels=2, out_channels=2, mode="bicubic")
 
 
 @pytest.mark.gpu
@@ -126,3 +127,61 @@ def test_resampler_blocks_vs_reference():
         with torch.no_grad():
             y = _run_block(blk, g["x"], torch.device("cuda"))
         assert rel_max(y, g["y"]) <= 2e-6, (name, rel_max(y, g["y"]))
+
+
+def _upsample_cases():
+    from ace_amd.healpix import NearestUpsample
+    g = torch.Generator().manual_seed(5)
+    for mode, ac in (("nearest", False), ("nearest-exact", False), ("bilinear", False), ("bilinear", True)):
+        for shape in ((24, 3, 8, 8), (12, 5, 6, 6), (12, 2, 1, 1)):
+            x = torch.randn(*shape, generator=g)
+            want = torch.nn.Upsample(scale_factor=2, mode=mode, **({"align_corners": True} if ac else {}))(x)     # healpix_blocks.py:244-253
+            yield NearestUpsample(2, mode, ac), x, want, (mode, ac, shape)
+
+
+def test_interpolate_upsampling_modes_on_the_emulated_operators():
+    """The "Interpolate" block (healpix_blocks.py:229-253) IS nn.Upsample(scale_factor=2, mode=...): host logic (pitches, strides,
+    the bound handed on) against torch's own operator for nearest / nearest-exact / bilinear with and without align_corners."""
+    with fake_hpx() as fake:
+        for blk, x, want, tag in _upsample_cases():
+            y = _run_block(blk, x, torch.device("cpu"))
+            torch.testing.assert_close(y, want, rtol=0, atol=1e-6, msg=str(tag))
+        assert "upsample" in fake.calls and "tconv" not in fake.calls
+    with pytest.raises(ValueError, match="align_corners"):
+        from ace_amd.healpix import NearestUpsample
+        NearestUpsample(2, "nearest", True)
+
+
+@pytest.mark.gpu
+def test_interpolate_upsampling_modes_vs_torch():
+    """ace_hpx_upsample2 (csrc/healpix.hip) against nn.Upsample itself, the operator the reference's block wraps: nearest exact, bilinear
+    to fp32 rounding (same source index, same bracketing of the four products)."""
+    for blk, x, want, tag in _upsample_cases():
+        y = _run_block(blk, x, torch.device("cuda")).cpu()
+        if tag[0] != "bilinear":
+            assert torch.equal(y, want), tag
+        else:
+            torch.testing.assert_close(y, want, rtol=0, atol=2e-6, msg=str(tag))
+
+
+@pytest.mark.gpu
+def test_bilinear_smoothed_interpolate_conv_vs_torch():
+    """SmoothedInterpolateConv with upsample_mode = "bilinear" (healpix_blocks.py:699-866) against the same operator sequence evaluated
+    with torch on the host: face padding by one cell (the native gather, pinned on the reference's own padded faces elsewhere), bilinear
+    x 2, the four-point smoother / 4 as a depthwise convolution, trim one cell, face padding, the 3 x 3 convolution."""
+    torch.manual_seed(3)
+    blk = SmoothedInterpolateConv(in_channels=3, out_channels=4, kernel_size=3, mode="bilinear", hpx_padding_mode="earth2grid").eval()
+    ref = SmoothedInterpolateConv(in_channels=3, out_channels=4, kernel_size=3, mode="nearest", hpx_padding_mode="earth2grid").eval()
+    ref.load_state_dict(blk.state_dict())
+    x = torch.randn(12, 3, 8, 8)
+    with torch.no_grad():
+        y_bil = _run_block(blk.to("cuda"), x, torch.device("cuda")).cpu()
+        y_near = _run_block(ref.to("cuda"), x, torch.device("cuda")).cpu()
+    assert y_bil.shape == y_near.shape == (12, 4, 16, 16)
+    # a smooth field: nearest and bilinear resizes agree to first order, the block differs only through the resize
+    xs = torch.ones(12, 3, 8, 8) * torch.linspace(0.5, 1.5, 3).view(1, 3, 1, 1)
+    with torch.no_grad():
+        a = _run_block(blk, xs, torch.device("cuda")).cpu()
+        b = _run_block(ref, xs, torch.device("cuda")).cpu()
+    torch.testing.assert_close(a, b, rtol=0, atol=1e-6)       # constant faces: every resize is the identity on them
+    assert float((y_bil - y_near).abs().max()) > 1e-3          # ... and a random field tells the two modes apart
