@@ -15,9 +15,17 @@
 //     filter element is fetched exactly once per launch;
 //   * the coefficients D_l (fp16 hi/lo planes written by the Legendre stage, row-major (D_re | D_im)) are the A operand
 //     shared by the four waves: a stage holds the 32-wide k slice of BOTH halves of the row, as 1-KiB LDS-DMA pieces of
-//     16 rows x 32 k with a source-side XOR swizzle, four-stage ring, the pieces of stage t + 3 requested while stage t computes (as
+//     16 rows x 32 k with a source-side XOR swizzle, three-stage ring, the pieces of stage t + 2 requested while stage t computes (as
 //     the filter fragments; one or two requests behind every six MFMAs), ONE barrier per stage, counted waits (all vector-memory
 //     operations of the loop are inline asm, no stores: the count is exact);
+//   * TWO workgroups per CU (round 6, second half): with requests two stages ahead instead of three a wave needs 256 registers and a
+//     workgroup 72 KiB of LDS, so a CU holds two units: one's prologue (7 - 13 k cycles of memory latency) and epilogue (6 - 11 k)
+//     run under the other's MFMAs.  In-kernel trace: a pair of 96-row units takes 88 k cycles where one alone took 55 k, the
+//     stages of a pair issue an MFMA every 37 cycles (87 % of the pipe); the launch 93.6 -> 87 us same box with the XCD-balanced
+//     list (dhconv_units.h, order 1).  While all CUs run pairs of 96-row units the filter stream alone asks HBM for ~6 TB/s:
+//     what is left is the ramp at both ends of a unit and the second, half-empty round of the dispatch
+//     (profiles/r06_dhconv_occupancy.txt: host-packed persistent lists, longest-first unit orders and one-strip units at three
+//     workgroups per CU were measured and not kept);
 //   * complex structure: real += D_re Wr - D_im Wi, imaginary += D_re Wi + D_im Wr; the minus sign is put on the D_im
 //     fragment (8 v_xor per strip and k16 step);
 //   * row strips beyond l are skipped (1 .. 3 active strips of 32 rows per chunk).
@@ -62,14 +70,19 @@ MDEV half8 neg8(half8 v) {
 
 
 // NS: active 32-row strips (1 .. 3) of this workgroup's row chunk [row0, row0 + rows) of degree l
+#ifndef ACE_DH_PB
+#define ACE_DH_PB 2
+#endif
+#ifndef ACE_DH_WGS
+#define ACE_DH_WGS 2
+#endif
 template <int NS>
-MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const int j, const int row0, const int rows) {
-    constexpr int PB = 3;                         // A pieces and B fragments of stage t + PB are issued while stage t computes
+MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const int j, const int row0, const int rows, const int tid) {
+    constexpr int PB = ACE_DH_PB;                 // A pieces and B fragments of stage t + PB are issued while stage t computes
     constexpr int NSTG = PB + 1;                  // ring depth (stages): the slot refilled during stage t held stage t - 1, which every
                                                   // wave had finished before any wave passed the barrier of stage t
     constexpr int STAGE = NS * 8192;              // bytes: NS strips x 2 slices (re, im) x (2 row pieces x 2 planes) x 1 KiB
     constexpr int NA = 2 * NS;                    // A pieces per wave per stage
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, g = lane >> 5;
@@ -152,10 +165,9 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
 
     // prologue in the steady-state issue order: A0 B0 | A1 B1 | A2 B2
     BSet bs[4];                                   // ring of fragment sets, indexed with compile-time constants only
-    static_assert(PB == 3, "ring of four fragment sets: the one of stage t is refilled for stage t + 4 a stage later");
     issue_a(0); issue_b(bs[0], 0);
-    issue_a(1); issue_b(bs[1], 1);
-    issue_a(2); issue_b(bs[2], 2);
+    if constexpr (PB >= 2) { issue_a(1); issue_b(bs[1], 1); }
+    if constexpr (PB == 3) { issue_a(2); issue_b(bs[2], 2); }
 
     const int key = (i >> 2) & 3;                 // swizzle key of this lane's fragment rows (rows i and i + 16 ... share it mod 4)
 
@@ -168,7 +180,7 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
     auto stage = [&](const int t, BSet& b, BSet& bnew) {
         DH_MT(4 * t);
         DH_MT(4 * t + 1);
-        wait_b(b, std::integral_constant<int, 2 * (NA + 8)>{});
+        wait_b(b, std::integral_constant<int, (PB - 1) * (NA + 8)>{});
         DH_MT(4 * t + 2);
         __builtin_amdgcn_s_barrier();             // every wave's pieces of stage t landed; every wave is done with stage t - 1
         DH_MT(4 * t + 3);
@@ -291,14 +303,14 @@ MDEV void dhconv_body(const DhconvStripArgs& p, char* smem, const int l, const i
     for (int s = 0; s < NS; ++s) asm volatile("" ::"v"(acc[s][0]), "v"(acc[s][1]));   // the store data stays put to the end
 }
 
-__global__ __launch_bounds__(256, 1) void dhconv_strip_kernel(DhconvStripArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * DH_CHUNK_STRIPS * 8192];
+__global__ __launch_bounds__(256, ACE_DH_WGS) void dhconv_strip_kernel(DhconvStripArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[(ACE_DH_PB + 1) * DH_CHUNK_STRIPS * 8192];
     // Workgroup b runs on XCD b % 8 (each XCD has its own L2) and, measured (tools/trace_dh.py, profiles/r06_dhconv_dispatch.txt), on
     // shader engine (b / 8) % 4 of that XCD: the dispatcher deals a launch's workgroups to the four engines in turn WHATEVER their
-    // load, only the 8 CUs of an engine share work dynamically.  With one workgroup per CU and units of unequal size the ORDER of
-    // the units therefore decides the balance: dhconv_build_units (host) lists, per XCD, the units (degree, column group, row
-    // chunk) largest first, the chunks of one (degree, column group) next to each other (they stream the same 393 KB filter slice:
-    // once from HBM, then from this XCD's L2) and in alternating order so that every engine gets the same mix.
+    // load, only the 8 CUs of an engine (16 resident workgroups) share work dynamically.  dhconv_build_units (host) lists, per XCD,
+    // the units (degree, column group, row chunk) of the degrees it owns, longest group first, the chunks of one (degree, column
+    // group) next to each other (they stream the same 393 KB filter slice: once from HBM, then from this XCD's L2), in the chunk
+    // order that keeps the four engines even.
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int4 u = reinterpret_cast<const int4*>(p.units)[xcd * p.units_per_xcd + idx];   // (l, j, row0, rows); rows = 0: padding
     const int l = u.x, j = u.y, row0 = u.z, rows = u.w;
@@ -306,10 +318,12 @@ __global__ __launch_bounds__(256, 1) void dhconv_strip_kernel(DhconvStripArgs p)
 #ifdef ACE_DH_TRACE
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
+    const int tid = threadIdx.x;
     // active 32-row strips: 1 .. 3
-    if (rows <= 32) dhconv_body<1>(p, smem, l, j, row0, rows);
-    else if (rows <= 64) dhconv_body<2>(p, smem, l, j, row0, rows);
-    else dhconv_body<3>(p, smem, l, j, row0, rows);
+    if (rows <= 32) dhconv_body<1>(p, smem, l, j, row0, rows, tid);
+    else if constexpr (DH_CHUNK_STRIPS < 2) return;
+    else if (rows <= 64) dhconv_body<2>(p, smem, l, j, row0, rows, tid);
+    else if constexpr (DH_CHUNK_STRIPS >= 3) dhconv_body<3>(p, smem, l, j, row0, rows, tid);
 #ifdef ACE_DH_TRACE
     DH_MT(49);
     DH_STAMP(0, t_start);
@@ -332,7 +346,16 @@ bool dhconv_native_groups_ok(int C, int groups) {
     return cg % 32 == 0 && (cg % 128 == 0 || 128 % cg == 0);
 }
 
-int dhconv_build_units(int L, int Mrows, int trimul, int C, std::vector<int>& out) { return dhconv_units(L, Mrows, trimul, C, out); }
+#ifndef ACE_DH_ORDER
+#define ACE_DH_ORDER DH_ORDER_DEFAULT
+#endif
+int dhconv_build_units(int L, int Mrows, int trimul, int C, std::vector<int>& out) {
+    int order = ACE_DH_ORDER;
+#ifdef ACE_MEASUREMENT_SWITCHES
+    if (const char* e = std::getenv("ACE_DH_ORDER")) order = std::atoi(e);
+#endif
+    return dhconv_units(L, Mrows, trimul, C, out, order);
+}
 
 bool dhconv_strip_eligible(const DhconvStripArgs& a) {
     if (a.kstore > 0 && a.kstore != a.C && !(a.groups > 1 && a.kstore == a.C / a.groups && dhconv_native_groups_ok(a.C, a.groups))) return false;

@@ -11,7 +11,7 @@
     defined(ACE_FFT_XCD_INV) || defined(ACE_G4_PIN) || defined(ACE_EXP_NOLDSREAD) || defined(ACE_EXP_NOBARRIER) || defined(ACE_EXP_NOGLOBAL) || \
     defined(ACE_EXP_NOLDSWRITE) || defined(ACE_G3_W128_PCT) || defined(ACE_G4_PFD) || defined(ACE_G4_REGEPI) || defined(ACE_G4_RTOUCH) ||       \
     defined(ACE_GEMM2_BK) || defined(ACE_LB) || defined(ACE_PF) || defined(ACE_MLP_ABL) || defined(ACE_MLP_FDEPTH) || defined(ACE_X_TRACE) ||    \
-    defined(ACE_DH_TRACE) || defined(ACE_DH_TRACE_WG) || defined(ACE_LF_TRACE) || defined(ACE_DEBUG_WS)
+    defined(ACE_DH_TRACE) || defined(ACE_DH_TRACE_WG) || defined(ACE_DH_PB) || defined(ACE_DH_WGS) || defined(ACE_DH_STRIPS) || defined(ACE_DH_ORDER) || defined(ACE_LF_TRACE) || defined(ACE_DEBUG_WS)
 #error "tuning / ablation / trace macro set without -DACE_MEASUREMENT_SWITCHES: the shipped library is built with the defaults only (tools/mkvar.sh)"
 #endif
 #endif
