@@ -289,8 +289,9 @@ static int run_legendre_forward(const ace_sht_plan& pl, const float* X, float* D
     return ACE_OK;
 }
 // X[m][k][n2] = sum_{l>=m} pt[m][k][l] E[l][m][n2]   (sht_fix.py:208-219), batched over m
+// dry: decide the route (pl.route[1]) without launching anything
 static int run_legendre_inverse(const ace_sht_plan& pl, const float* E, float* X, long N2, hipStream_t s,
-                                const unsigned* emax = nullptr) {
+                                const unsigned* emax = nullptr, bool dry = false) {
     GemmArgs g;
     g.A = pl.pt.p; g.lda = pl.Lp; g.sA = (long)pl.nlat * pl.Lp;
     g.B = E; g.ldb = (long)pl.mmax * N2; g.sB = N2;
@@ -308,18 +309,19 @@ static int run_legendre_inverse(const ace_sht_plan& pl, const float* E, float* X
             LegStripArgs f = a;
             f.A = reinterpret_cast<const _Float16*>(pl.pt_ffrag.p); f.tile_off = reinterpret_cast<const int*>(pl.pt_foff.p);
             if (legendre_fold_eligible(f)) {
-                HIP_TRY(launch_legendre_fold(f, s));
+                if (!dry) HIP_TRY(launch_legendre_fold(f, s));
                 pl.route[1] = fold_route(f);
                 return ACE_OK;
             }
         }
         if (pl.strip && legendre_strip_eligible(a)) {
-            HIP_TRY(launch_legendre_strip(a, s));
+            if (!dry) HIP_TRY(launch_legendre_strip(a, s));
             pl.route[1] = 1;
             return ACE_OK;
         }
     }
     pl.route[1] = 0;
+    if (dry) return ACE_OK;
     if (pl.f16 && emax && gemm_f16x3_eligible(g)) {
         HIP_TRY(launch_gemm_f16x3(g, pl.pt_hi.p, pl.pt_lo.p, pl.pt_scale, 1.f, s, emax, nullptr));
         return ACE_OK;
@@ -390,7 +392,9 @@ extern "C" int ace_sht_inverse(ace_sht_plan* p, const float* coeffs, float* x, i
         emax = reinterpret_cast<unsigned*>(p->slots.p);   // of its own over the converted tensor, 45 us at the reference's benchmark size)
         HIP_TRY(launch_zero_u32(emax, 2 * AMAX_SHARDS, s));
     }
-    HIP_TRY(launch_ref_to_spec(coeffs, p->D.p, 1, n, p->lmax, p->mmax, s, emax));
+    // the strip kernels are exactly triangular: the converter then neither reads nor writes the entries with m > l (half the tensor)
+    ACE_TRY(run_legendre_inverse(*p, p->D.p, p->X.p, N2, s, emax, true));
+    HIP_TRY(launch_ref_to_spec(coeffs, p->D.p, 1, n, p->lmax, p->mmax, s, emax, p->route[1] != 0));
     ACE_TRY(run_legendre_inverse(*p, p->D.p, p->X.p, N2, s, emax));
     ACE_TRY(run_dft_inverse(*p, p->X.p, nullptr, x, 1, n, s));
     return ACE_OK;

@@ -344,7 +344,8 @@ hipError_t launch_cond_layer_norm(const float* x, const float* noise, const floa
 
 // layout converters between the internal spectral layout and the reference's (n, L, M) complex64
 hipError_t launch_spec_to_ref(const float* D, float* out, int Bt, int C, int L, int Mm, hipStream_t s);
-hipError_t launch_ref_to_spec(const float* in, float* E, int Bt, int C, int L, int Mm, hipStream_t s, unsigned* omax = nullptr);
+// triangular_consumer: the scratch is read by an exactly triangular kernel only (entries with m > l may stay unwritten)
+hipError_t launch_ref_to_spec(const float* in, float* E, int Bt, int C, int L, int Mm, hipStream_t s, unsigned* omax = nullptr, bool triangular_consumer = false);
 
 // "diagonal" operator (contractions.py:169-180): E[l][m][b][:, o] = sum_i D[l][m][b][:, i] * w[i][o][l][m] (complex)
 hipError_t launch_contract_diagonal(const float* D, const float* w, float* E, int Bt, int Cin, int Cout, int L, int Mm,

@@ -2915,7 +2915,7 @@ hipError_t launch_instnorm_stats(const float* x, const float* gamma, const float
 // coefficients for the f16x3 Legendre stage, taken here instead of in a pass of its own over the converted tensor.
 template <bool TO_REF>
 __global__ __launch_bounds__(256) void spec_layout_kernel(const float* __restrict__ src, float* __restrict__ dst, int Bt, int C, int L, int Mm,
-                                                          unsigned* omax) {
+                                                          unsigned* omax, int tri) {
     __shared__ float tile[2][32][33];
     const long R = (long)L * Mm;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
@@ -2944,13 +2944,22 @@ __global__ __launch_bounds__(256) void spec_layout_kernel(const float* __restric
                 *reinterpret_cast<float2*>(dst + (((long)b * C + c) * R + r) * 2) = make_float2(tile[0][tx][ty + 8 * k], tile[1][tx][ty + 8 * k]);
         }
     } else {
+        // Entries with m > l are never used by a synthesis (their Legendre values are zero): they are not read.  `tri` < 0: the
+        // consumer is one of the exactly triangular strip kernels, which never touch them - a tile that lies wholly above the
+        // diagonal is skipped, the others leave them unwritten; otherwise they are written as zeros (the tile engines read whole
+        // k-tiles of the scratch and 0 x garbage is not 0).  The range maximum is over the used entries only.
+        const bool exact = tri < 0;
+        {
+            const long l0 = r0 / Mm, m0 = r0 % Mm;
+            if (exact && m0 > l0 && m0 + 32 <= Mm) return;   // 32 consecutive r of one degree, all above the diagonal
+        }
         float vmax = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = c0 + ty + 8 * k;
             const long r = r0 + tx;
             float2 v = make_float2(0.f, 0.f);
-            if (r < R && c < C) v = *reinterpret_cast<const float2*>(src + (((long)b * C + c) * R + r) * 2);
+            if (r < R && c < C && (int)(r % Mm) <= (int)(r / Mm)) v = *reinterpret_cast<const float2*>(src + (((long)b * C + c) * R + r) * 2);
             tile[0][tx][ty + 8 * k] = v.x;
             tile[1][tx][ty + 8 * k] = v.y;
             vmax = fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
@@ -2972,7 +2981,7 @@ __global__ __launch_bounds__(256) void spec_layout_kernel(const float* __restric
         for (int k = 0; k < 4; ++k) {
             const long r = r0 + ty + 8 * k;
             const int c = c0 + tx;
-            if (r < R && c < C) {
+            if (r < R && c < C && (!exact || (int)(r % Mm) <= (int)(r / Mm))) {
                 float* p = dst + (r * Bt + b) * 2 * C + c;
                 p[0] = tile[0][ty + 8 * k][tx];
                 p[C] = tile[1][ty + 8 * k][tx];
@@ -2990,13 +2999,13 @@ hipError_t launch_spec_to_ref(const float* D, float* out, int Bt, int C, int L, 
     const long R = (long)L * Mm;
     if ((R + 31) / 32 > 0x7fffffffL || (C + 31) / 32 > 65535 || Bt > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL(spec_layout_kernel<true>, dim3((unsigned)((R + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)Bt), dim3(256), 0, s, D, out, Bt, C, L, Mm,
-                       static_cast<unsigned*>(nullptr));
+                       static_cast<unsigned*>(nullptr), 0);
     return hipGetLastError();
 }
-hipError_t launch_ref_to_spec(const float* in, float* E, int Bt, int C, int L, int Mm, hipStream_t s, unsigned* omax) {
+hipError_t launch_ref_to_spec(const float* in, float* E, int Bt, int C, int L, int Mm, hipStream_t s, unsigned* omax, bool triangular_consumer) {
     const long R = (long)L * Mm;
     if ((R + 31) / 32 > 0x7fffffffL || (C + 31) / 32 > 65535 || Bt > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(spec_layout_kernel<false>, dim3((unsigned)((R + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)Bt), dim3(256), 0, s, in, E, Bt, C, L, Mm, omax);
+    hipLaunchKernelGGL(spec_layout_kernel<false>, dim3((unsigned)((R + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)Bt), dim3(256), 0, s, in, E, Bt, C, L, Mm, omax, triangular_consumer ? -1 : 0);
     return hipGetLastError();
 }
 
