@@ -56,6 +56,11 @@ constexpr int WS_OOBV = 0x7fffff00;   // buffer offset beyond every resource of 
 #endif
 
 
+#ifndef ACE_WS_MINMAX
+#define ACE_WS_MINMAX 0   // 1: the statistics epilogues also track a row's running minimum / maximum (rounds 3-6: the norm finaliser's bound came
+#endif                    // from them; it now comes from the variance - kernels.hip: instnorm_finalize_kernel - and the records carry +-3e38 there)
+constexpr bool WS_MINMAX = ACE_WS_MINMAX != 0;
+
 // v_min_f32 / v_max_f32 as single instructions: hipcc puts a canonicalising `v_max x, x` in front of fminf / fmaxf on a computed value
 __device__ __forceinline__ float raw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float raw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -287,9 +292,11 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
                 const bool ok = c.vo_p != WS_OOBV;   // a stored pixel of a live tile
                 rsm[e] += ok ? val : 0.f;
                 rsq[e] = ok ? fmaf(val, val, rsq[e]) : rsq[e];
-                const float lo_ = raw_min(rmn[e], val), hi_ = raw_max(rmx[e], val);
-                rmn[e] = ok ? lo_ : rmn[e];
-                rmx[e] = ok ? hi_ : rmx[e];
+                if constexpr (WS_MINMAX) {
+                    const float lo_ = raw_min(rmn[e], val), hi_ = raw_max(rmx[e], val);
+                    rmn[e] = ok ? lo_ : rmn[e];
+                    rmx[e] = ok ? hi_ : rmx[e];
+                }
             }
             if (PK) {
                 const float xs = val * cscale;
@@ -312,24 +319,30 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
                 for (int cc = 0; cc < 8; ++cc) {
                     const float x = cc < 4 ? a[cc & 3] : b[cc & 3];
                     const bool ok = 8 * cq + cc < c.ncols_ok;
-                    const float xs_ = ok ? x : 0.f, xm_ = ok ? x : __builtin_nanf("");      // two selects: 0 for the sums, NaN for min / max
+                    const float xs_ = ok ? x : 0.f;                                         // 0 is neutral for the sums
                     sm += xs_;
                     sq = fmaf(xs_, xs_, sq);
-                    mn = raw_min(mn, xm_);
-                    mx = raw_max(mx, xm_);
+                    if constexpr (WS_MINMAX) {
+                        const float xm_ = ok ? x : __builtin_nanf("");                      // a NaN for min / max
+                        mn = raw_min(mn, xm_);
+                        mx = raw_max(mx, xm_);
+                    }
                 }
 #pragma unroll
                 for (int off = 16; off <= 32; off <<= 1) {
                     sm += __shfl_xor(sm, off, 64);
                     sq += __shfl_xor(sq, off, 64);
-                    mn = raw_min(mn, __shfl_xor(mn, off, 64));
-                    mx = raw_max(mx, __shfl_xor(mx, off, 64));
+                    if constexpr (WS_MINMAX) {
+                        mn = raw_min(mn, __shfl_xor(mn, off, 64));
+                        mx = raw_max(mx, __shfl_xor(mx, off, 64));
+                    }
                 }
                 // ONE partial per workgroup and row instead of one per 32-pixel tile (r03: the norm finaliser read 2025 partials per
                 // channel, 6 KiB apart, and took 10 us): the row's running statistics live in LDS, always updated by the same lane
                 if (c.vo_s != WS_OOBV) {
                     f32x4 acc = Lacc[ln];
-                    acc[0] += sm; acc[1] += sq; acc[2] = raw_min(acc[2], mn); acc[3] = raw_max(acc[3], mx);
+                    acc[0] += sm; acc[1] += sq;
+                    if constexpr (WS_MINMAX) { acc[2] = raw_min(acc[2], mn); acc[3] = raw_max(acc[3], mx); }
                     Lacc[ln] = acc;
                 }
             }
@@ -358,12 +371,16 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
             if (RSTATS) {
                 const bool ok = c.vo_p != WS_OOBV;   // a stored pixel of a live tile
                 // two selects instead of four: 0 is neutral for the sums, a NaN for v_min_f32 / v_max_f32 (they return the other operand)
-                const float vs = ok ? val : 0.f, vm = ok ? val : __builtin_nanf("");
+                const float vs = ok ? val : 0.f;
                 rsm[e] += vs;
                 rsq[e] = fmaf(vs, vs, rsq[e]);
-                rmn[e] = raw_min(rmn[e], vm);
-                rmx[e] = raw_max(rmx[e], vm);
-                asm volatile("" : "+v"(rsm[e]), "+v"(rsq[e]), "+v"(rmn[e]), "+v"(rmx[e]));
+                if constexpr (WS_MINMAX) {
+                    const float vm = ok ? val : __builtin_nanf("");
+                    rmn[e] = raw_min(rmn[e], vm);
+                    rmx[e] = raw_max(rmx[e], vm);
+                    asm volatile("" : "+v"(rmn[e]), "+v"(rmx[e]));
+                }
+                asm volatile("" : "+v"(rsm[e]), "+v"(rsq[e]));
             }
             asm volatile("" : "+v"(gst.val));
         } else {
@@ -536,8 +553,10 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
             for (int off = 1; off <= 16; off <<= 1) {
                 rsm[e] += __shfl_xor(rsm[e], off, 64);
                 rsq[e] += __shfl_xor(rsq[e], off, 64);
-                rmn[e] = fminf(rmn[e], __shfl_xor(rmn[e], off, 64));
-                rmx[e] = fmaxf(rmx[e], __shfl_xor(rmx[e], off, 64));
+                if constexpr (WS_MINMAX) {
+                    rmn[e] = fminf(rmn[e], __shfl_xor(rmn[e], off, 64));
+                    rmx[e] = fmaxf(rmx[e], __shfl_xor(rmx[e], off, 64));
+                }
             }
         // lanes 0 and 32 hold rows row0 + 8 g + e; part[(sample, slot) x M + row], slot = part_q of this workgroup
         const auto rsG = __builtin_amdgcn_make_buffer_rsrc(p.part + ((long)smp * p.nstrips32 + part_q) * p.M, 0, p.M * 16, 0x00020000);

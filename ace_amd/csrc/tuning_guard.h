@@ -6,7 +6,7 @@
 #pragma once
 #if !defined(ACE_MEASUREMENT_SWITCHES)
 #if defined(ACE_WL_ABL) || defined(ACE_WL_D) || defined(ACE_WL_WAVES) || defined(ACE_WS_ABL) || defined(ACE_WS_ACC2) || defined(ACE_WS_FD4) || \
-    defined(ACE_WS_FINE) || defined(ACE_WS_HOLD4) || defined(ACE_WS_VSPAN) || defined(ACE_WS_REARLY) || defined(ACE_FFT_ABL) || defined(ACE_FFT_FWD_WAVES) || defined(ACE_FFT_FWD_PLN_WAVES) ||            \
+    defined(ACE_WS_FINE) || defined(ACE_WS_HOLD4) || defined(ACE_WS_VSPAN) || defined(ACE_WS_REARLY) || defined(ACE_WS_MINMAX) || defined(ACE_FFT_ABL) || defined(ACE_FFT_FWD_WAVES) || defined(ACE_FFT_FWD_PLN_WAVES) ||            \
     defined(ACE_FFT_INV_ROWS) || defined(ACE_FFT_INV_WAVES) || defined(ACE_FFT_QROWS) || defined(ACE_FFT_ROWS) || defined(ACE_FFT_XCD) ||       \
     defined(ACE_FFT_XCD_INV) || defined(ACE_G4_PIN) || defined(ACE_EXP_NOLDSREAD) || defined(ACE_EXP_NOBARRIER) || defined(ACE_EXP_NOGLOBAL) || \
     defined(ACE_EXP_NOLDSWRITE) || defined(ACE_G3_W128_PCT) || defined(ACE_G4_PFD) || defined(ACE_G4_REGEPI) || defined(ACE_G4_RTOUCH) ||       \
