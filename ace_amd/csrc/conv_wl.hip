@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
 #pragma unroll
         for (int r = 0; r < 16; ++r) prev[t][r] = 0.f;
     int prev_vo = WL_OOBV;
-    GeluStage gst = {0.f, 0.f, 0.f, 0.f};
+    GeluStage gst = {0.f, 0.f, 0.f};
     half8 hh, ll;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { hh[e] = (_Float16)0.f; ll[e] = (_Float16)0.f; }
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
         constexpr int v = k / 4, ch = k % 4, t = v / 16, q = (v % 16) / 8, e = v % 8;
         if constexpr (ch == 0) {
             gelu_stage0(gst, fmaf(prev[t][8 * q + e], s_acc, bias_next));
-            asm volatile("" : "+v"(gst.val), "+v"(gst.u), "+v"(gst.t));     // pinned to this slot (pure arithmetic would
+            asm volatile("" : "+v"(gst.val), "+v"(gst.t));                // pinned to this slot (pure arithmetic would
         } else if constexpr (ch == 1) {                                    //  otherwise sink to its last use)
             gelu_stage1(gst);
             constexpr int vn = (v + 1) % (16 * RT);                          // bias of the next value, one value ahead

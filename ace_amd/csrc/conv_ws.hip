@@ -350,7 +350,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     };
     // quarter `ch` of value e (GELU modes): 0 scale / bias / residual + first GELU stage, 1 second stage, 2 last stage +
     // statistics, 3 hi / lo split
-    GeluStage gst = {0.f, 0.f, 0.f, 0.f};
+    GeluStage gst = {0.f, 0.f, 0.f};
     // bias of the value about to be finished: read from the LDS table one value ahead (in the previous value's polynomial
     // quarter), so that no LDS latency sits in front of an MFMA
     float bias_next = INTER ? Pb[row0 + 8 * g] : 0.f;
@@ -360,7 +360,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
             float val = fmaf(own[e] + (e < 4 ? pa[e & 3] : pb[e & 3]), s_acc, bias_next);
             if (RES) val = val + res[e];
             gelu_stage0(gst, val);
-            asm volatile("" : "+v"(gst.val), "+v"(gst.u), "+v"(gst.t));   // pinned to this slot (pure arithmetic would otherwise
+            asm volatile("" : "+v"(gst.val), "+v"(gst.t));   // pinned to this slot (pure arithmetic would otherwise
         } else if constexpr (ch == 1) {                                  //  sink to its last use)
             gelu_stage1(gst);
             bias_next = Pb[row0 + 8 * c.g + ((e + 1) & 7)];

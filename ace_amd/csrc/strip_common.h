@@ -69,36 +69,38 @@ MDEV float fast_erf(float x) {   // kernels.hip: max abs error 1.1e-7
     q = q * t;
     return copysignf(1.0f - __builtin_amdgcn_exp2f(-q), x);
 }
-// The same GELU in three stages (identical operations in identical order), for epilogues that are spread over an MFMA stream
-// a few instructions at a time: gfx950 hides vector-ALU work behind matrix work only when the two alternate in ONE wave's
-// instruction stream, about 6 VALU per MFMA (profiles/r03_mfma_valu_overlap_probe.txt)
-struct GeluStage { float val, u, t, q; };
+// GELU(v) = v / 2 (1 + erf(v / sqrt 2)) with the 1 / sqrt 2 folded into the fit's coefficients (c_k / 2^(k / 2): q is the same function of
+// |v| / sqrt 2; max abs error of the GELU unchanged, tools/fit_fast_erf.py --gelu) - one multiplication and one register per value less
+// than erf(v * 0.7071).  In three stages (identical operations in identical order wherever it is used), for epilogues that are spread
+// over an MFMA stream a few instructions at a time: gfx950 hides vector-ALU work behind matrix work only when the two alternate in ONE
+// wave's instruction stream, about 6 VALU per MFMA (profiles/r03_mfma_valu_overlap_probe.txt)
+struct GeluStage { float val, t, q; };
 MDEV void gelu_stage0(GeluStage& g, float val) {
-    g.val = val * 0.5f;                          // h = x / 2: the result is fma(h, erf, h)
-    g.u = val * 0.70710678118654752440f;
-    g.t = fminf(fabsf(g.u), 4.0f);
+    g.val = val;
+    g.t = fminf(fabsf(val), 5.65685424949238f);  // erf(4) rounds to 1
 }
 MDEV void gelu_stage1(GeluStage& g) {
-    float q = -1.150086973e-05f;
-    q = fmaf(q, g.t, 1.518900972e-04f);
-    q = fmaf(q, g.t, -8.436889620e-04f);
-    q = fmaf(q, g.t, 2.264559502e-03f);
-    q = fmaf(q, g.t, -7.151089812e-05f);
-    q = fmaf(q, g.t, -2.773463540e-02f);
-    q = fmaf(q, g.t, 1.483123451e-01f);
-    q = fmaf(q, g.t, 9.184418917e-01f);
-    q = fmaf(q, g.t, 1.627907395e+00f);
+    float q = -5.082714551e-07f;
+    q = fmaf(q, g.t, 9.493131074e-06f);
+    q = fmaf(q, g.t, -7.457227184e-05f);
+    q = fmaf(q, g.t, 2.830699377e-04f);
+    q = fmaf(q, g.t, -1.264146067e-05f);
+    q = fmaf(q, g.t, -6.933658849e-03f);
+    q = fmaf(q, g.t, 5.243633315e-02f);
+    q = fmaf(q, g.t, 4.592209458e-01f);
+    q = fmaf(q, g.t, 1.151104331e+00f);
     g.q = q;
 }
 MDEV float gelu_stage2(const GeluStage& g) {
     const float q = g.q * g.t;
-    const float erf = copysignf(1.0f - __builtin_amdgcn_exp2f(-q), g.u);
-    return fmaf(g.val, erf, g.val);              // x / 2 (1 + erf): one instruction and one rounding less than 0.5 x (1 + erf)
+    const float erf = copysignf(1.0f - __builtin_amdgcn_exp2f(-q), g.val);
+    const float h = g.val * 0.5f;
+    return fmaf(h, erf, h);                      // x / 2 (1 + erf): one instruction and one rounding less than 0.5 x (1 + erf)
 }
 
 template <int ACT>
 MDEV float act_fn(float v) {
-    if (ACT == ACT_GELU_FAST || ACT == ACT_GELU) { const float h = 0.5f * v; return fmaf(h, fast_erf(v * 0.70710678118654752440f), h); }
+    if (ACT == ACT_GELU_FAST || ACT == ACT_GELU) { GeluStage g; gelu_stage0(g, v); gelu_stage1(g); return gelu_stage2(g); }
     if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
     if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
     return v;

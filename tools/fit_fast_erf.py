@@ -32,3 +32,18 @@ if __name__ == "__main__":
         r = (r.astype(np.float64) * t.astype(np.float64) + np.float64(c[k])).astype(np.float32)
     y = np.copysign((np.float32(1) - np.exp2(-r.astype(np.float64)).astype(np.float32)).astype(np.float32), xs)
     print("max abs err", np.abs(y - erf(xs)).max())
+    # --gelu: the coefficients of strip_common.h's gelu_stage1: q as a function of |v| = sqrt 2 t (c_k / 2^(k / 2)), and the error
+    # of GELU(v) = v / 2 (1 + erf(v / sqrt 2)) evaluated that way in float32
+    import sys
+    if "--gelu" in sys.argv:
+        d = np.array([np.float32(float(c[k]) * 2.0 ** (-k / 2.0)) for k in range(len(c))])
+        print("gelu:", ", ".join("%.9ef" % v for v in d[:0:-1]))
+        v = np.linspace(-8, 8, 2000001)
+        t = np.minimum(np.abs(v), T * np.sqrt(2.0)).astype(np.float32)
+        r = np.full_like(t, d[-1])
+        for k in range(len(d) - 2, 0, -1):
+            r = (r * t + d[k]).astype(np.float32)
+        r = (r * t).astype(np.float32)
+        e = np.copysign(np.float32(1) - np.exp2(-r).astype(np.float32), v).astype(np.float32)
+        h = (v.astype(np.float32) * np.float32(0.5)).astype(np.float32)
+        print("gelu max abs err", np.abs((h * e + h).astype(np.float64) - 0.5 * v * (1 + erf(v / np.sqrt(2.0)))).max())
