@@ -188,19 +188,28 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     //      Piece pc = (block pc / 2 of the stage: half hh, k-step jj; plane pc % 2): lane (i, g) fetches k-group 2 J + g, pixel i
     const _Float16* Xh = p.Xhi + (long)smp * p.sX;
     const _Float16* Xl = p.Xlo + (long)smp * p.sX;
+    const unsigned smem_lds = lds_addr_of(smem);
+    // wave-uniform part of a piece's address that does not change from stage to stage: plane and k-group pair of (wave, k); the
+    // stage adds ONE 64-bit offset (its contraction segment q, its pixel tile) that all pieces of the stage share
+    const _Float16* pbase[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+        const int pc = wave + 8 * k;
+        const int bl = pc >> 1, hf = pc & 1;
+        const int hh = bl / KSW, jj = bl % KSW;
+        pbase[k] = (hf ? Xl : Xh) + (long)(2 * (hh * KH + jj)) * p.ldn * 8;
+    }
     auto piece = [&](int u, int k) {
         const int uu = u < NU ? u : NU - 1;
         const int pt = uu / NSTG, q = uu % NSTG;
         const int pc = wave + 8 * k;
-        const int bl = pc >> 1, hf = pc & 1;
-        const int hh = bl / KSW, jj = bl % KSW;
-        const int J = hh * KH + q * KSW + jj;
         // address = (uniform: plane, k-group pair 2 J, first pixel of the tile) + (lane: k-group parity g, pixel i - the last tile's
         // missing pixels repeat its last one)
         const int n0 = 32 * (tile0 + pt);
         const int ic = i < p.HW - 1 - n0 ? i : p.HW - 1 - n0;
         const unsigned lane_off = (unsigned)(g * (int)p.ldn + ic) * 16u;
-        glds16s((hf ? Xl : Xh) + ((long)(2 * J) * p.ldn + n0) * 8, lane_off, smem + (u & 1) * SLOT + pc * 1024);
+        const long stage_off = ((long)(2 * q * KSW) * p.ldn + n0) * 8;
+        glds16a(pbase[k] + stage_off, lane_off, smem_lds + (unsigned)((u & 1) * SLOT + pc * 1024));
     };
 #pragma unroll
     for (int k = 0; k < PW; ++k) piece(0, k);

@@ -55,6 +55,15 @@ MDEV void glds16s(const void* sbase_uniform, unsigned lane_off, const char* lds_
                  : "v"(lane_off), "s"(sbase_uniform), "s"(addr)
                  : "memory", "m0");
 }
+// ... with the LDS destination as a byte address (lds_addr_of(smem) + offset): the generic -> LDS pointer conversion of the char* forms
+// above carries a null check (s_cmp_lg_u64 + s_cselect) that hipcc repeats for every piece - four scalar instructions per piece
+MDEV unsigned lds_addr_of(const char* p) { return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cptr)p); }
+MDEV void glds16a(const void* sbase_uniform, unsigned lane_off, unsigned lds_addr_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(lane_off), "s"(sbase_uniform), "s"(lds_addr_uniform)
+                 : "memory", "m0");
+}
 MDEV float fast_erf(float x) {   // kernels.hip: max abs error 1.1e-7
     const float t = fminf(fabsf(x), 4.0f);
     float q = -1.150086973e-05f;
@@ -91,11 +100,15 @@ MDEV void gelu_stage1(GeluStage& g) {
     q = fmaf(q, g.t, 1.151104331e+00f);
     g.q = q;
 }
+// v / 2 (1 + erf) = (v + |v| - |v| erfc(|v| / sqrt 2)) / 2 with erfc = 2^-q: an addition, a multiply-add and a multiplication where
+// 1 - 2^-q, the copy of the sign, v / 2 and the multiply-add were four (max abs error 4.8e-7 on [-8, 8] against 6.5e-7; NaN and +Inf
+// propagate, the tail beyond the fit's range is -t erfc(4) / 2 = -4e-8 instead of 0: tools/fit_fast_erf.py --gelu)
+// (the planes' power-of-two scale does not belong into the 1 / 2: hipcc already folds it into the v_fma_mix conversions of the split,
+// and without the multiplication in front of them it falls back to cvt / cvt / sub / cvt / perm: measured on the ISA, +2.5 per value)
 MDEV float gelu_stage2(const GeluStage& g) {
     const float q = g.q * g.t;
-    const float erf = copysignf(1.0f - __builtin_amdgcn_exp2f(-q), g.val);
-    const float h = g.val * 0.5f;
-    return fmaf(h, erf, h);                      // x / 2 (1 + erf): one instruction and one rounding less than 0.5 x (1 + erf)
+    const float s = g.val + fabsf(g.val);
+    return 0.5f * fmaf(-g.t, __builtin_amdgcn_exp2f(-q), s);
 }
 
 template <int ACT>

@@ -44,6 +44,8 @@ if __name__ == "__main__":
         for k in range(len(d) - 2, 0, -1):
             r = (r * t + d[k]).astype(np.float32)
         r = (r * t).astype(np.float32)
-        e = np.copysign(np.float32(1) - np.exp2(-r).astype(np.float32), v).astype(np.float32)
-        h = (v.astype(np.float32) * np.float32(0.5)).astype(np.float32)
-        print("gelu max abs err", np.abs((h * e + h).astype(np.float64) - 0.5 * v * (1 + erf(v / np.sqrt(2.0)))).max())
+        # gelu_stage2: (v + |v| - t 2^-q) / 2, the multiply-add rounded once
+        v32 = v.astype(np.float32)
+        s = (v32 + np.abs(v32)).astype(np.float32)
+        inner = (s.astype(np.float64) - t.astype(np.float64) * np.exp2(-r).astype(np.float32).astype(np.float64)).astype(np.float32)
+        print("gelu max abs err", np.abs((inner * np.float32(0.5)).astype(np.float64) - 0.5 * v * (1 + erf(v / np.sqrt(2.0)))).max())
