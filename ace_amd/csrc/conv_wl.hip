@@ -175,9 +175,7 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
         for (int r = 0; r < 16; ++r) prev[t][r] = 0.f;
     int prev_vo = WL_OOBV;
     GeluStage gst = {0.f, 0.f, 0.f};
-    half8 hh, ll;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { hh[e] = (_Float16)0.f; ll[e] = (_Float16)0.f; }
+    unsigned hh[4] = {0u, 0u, 0u, 0u}, ll[4] = {0u, 0u, 0u, 0u};   // the P entry being assembled: fp16 hi / lo of rows 8 g + e, packed
     float bias_next = Pb[8 * g];
     // quarter `ch` of value v = 16 t + 8 q + e of the finished tile (gfx950 hides vector-ALU work behind matrix work only when
     // the two alternate in ONE wave's instruction stream, ~6 VALU per MFMA: profiles/r03_mfma_valu_overlap_probe.txt)
@@ -196,16 +194,12 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
             gst.val = gelu_stage2(gst);
             asm volatile("" : "+v"(gst.val));
         } else {
-            const float xs = gst.val * cscale;
-            const _Float16 a16 = (_Float16)xs;
-            hh[e] = a16;
-            ll[e] = (_Float16)(xs - (float)a16);
+            split_put<e>(hh, ll, cscale, gst.val);
             if constexpr (e == 7) {   // the entry is complete: k-group 4 T + 2 q (+ g in the lane part of the offset)
                 const int soff = (4 * (slice * RT + t) + 2 * q) * p.HW * 16;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hh), rsH, prev_vo, soff, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ll), rsL, prev_vo, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{hh[0], hh[1], hh[2], hh[3]}, rsH, prev_vo, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{ll[0], ll[1], ll[2], ll[3]}, rsL, prev_vo, soff, 0);
             }
-            asm volatile("" : "+v"(hh), "+v"(ll));
         }
     };
     constexpr int NCH = 4 * 16 * RT;     // chunks per tile

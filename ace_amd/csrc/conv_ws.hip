@@ -246,7 +246,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     u32x4 rph = {0u, 0u, 0u, 0u}, rpl = rph;   // RPL: the residual's P entry (hi, lo) of the tile being finished
     f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
     struct EpiOut {                        // data registers of the epilogue's stores (held until the stores retired)
-        half8 hh8, ll8;
+        unsigned hh[4], ll[4];             // the P entry being assembled: fp16 hi / lo of the eight rows, packed (split_put)
         float vals[8];
         f32x4 stv;
     };
@@ -261,7 +261,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { own[e] = 0.f; res[e] = 0.f; resn[e] = 0.f; eo.vals[e] = 0.f; }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { eo.hh8[e] = eo.ll8[e] = (_Float16)0.f; }
+    for (int e = 0; e < 4; ++e) { eo.hh[e] = 0u; eo.ll[e] = 0u; }
     eo.stv = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto tile_ctx = [&](const int pt, const bool live) {   // live = false: every store of the tile suppressed
@@ -278,6 +278,13 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     auto epi_item = [&](auto kc, const TileCtx& c, EpiOut& o) {
         constexpr int k = decltype(kc)::value;
         const int i = c.i, g = c.g;
+        if constexpr (k == 0 && PK) {
+            // a NEW entry: split_put modifies the words in place, and the words of the tile before may still be the data of stores in
+            // flight (held through a stage, `hold`) - defining them afresh lets the allocator keep those where they are (with the
+            // in-place chain alone the 0.25-degree net came out wrong in its last rows: the stores read the next tile's values)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) asm volatile("" : "=v"(o.hh[d]), "=v"(o.ll[d]));
+        }
         if constexpr (k < 8) {
             constexpr int e = k;
             const int row = row0 + 8 * g + e;
@@ -307,16 +314,11 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
                     rmx[e] = ok ? hi_ : rmx[e];
                 }
             }
-            if (PK) {
-                const float xs = val * cscale;
-                const _Float16 a16 = (_Float16)xs;
-                o.hh8[e] = a16;
-                o.ll8[e] = (_Float16)(xs - (float)a16);
-            }
+            if (PK) split_put<e>(o.hh, o.ll, cscale, val);
         } else {
             if (PK) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.hh8), rsH, c.vo_p, c.n0 * 16, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.ll8), rsL, c.vo_p, c.n0 * 16, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{o.hh[0], o.hh[1], o.hh[2], o.hh[3]}, rsH, c.vo_p, c.n0 * 16, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{o.ll[0], o.ll[1], o.ll[2], o.ll[3]}, rsL, c.vo_p, c.n0 * 16, 0);
             }
             if (STATS && !RSTATS) {
                 // lane (r = lane & 15, cq = lane >> 4) reduces columns 8 cq .. 8 cq + 7 of row r; the four quarters meet in two exchanges
@@ -393,11 +395,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
             }
             asm volatile("" : "+v"(gst.val));
         } else {
-            const float xs = gst.val * cscale;
-            const _Float16 a16 = (_Float16)xs;
-            o.hh8[e] = a16;
-            o.ll8[e] = (_Float16)(xs - (float)a16);
-            asm volatile("" : "+v"(o.hh8), "+v"(o.ll8));
+            split_put<e>(o.hh, o.ll, cscale, gst.val);
         }
     };
     auto epilogue = [&](const int pt, const bool live, EpiOut& o) {   // all of it at once
@@ -405,7 +403,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
         static_for<0, 9>([&](auto kc) { epi_item(kc, c, o); });
     };
     auto hold = [&](EpiOut& o) {           // gfx950 store-data rule (profiles/r02_store_data_hazard.txt)
-        if constexpr (PK) asm volatile("" ::"v"(o.hh8), "v"(o.ll8));
+        if constexpr (PK) asm volatile("" ::"v"(o.hh[0]), "v"(o.hh[1]), "v"(o.hh[2]), "v"(o.hh[3]), "v"(o.ll[0]), "v"(o.ll[1]), "v"(o.ll[2]), "v"(o.ll[3]));
         if constexpr (F32) asm volatile("" ::"v"(o.vals[0]), "v"(o.vals[1]), "v"(o.vals[2]), "v"(o.vals[3]), "v"(o.vals[4]), "v"(o.vals[5]), "v"(o.vals[6]), "v"(o.vals[7]));
     };
     auto load_residual = [&](int pt) {     // rows of pixel tile pt this wave will finish -> resn (retired by the next stage-top wait)

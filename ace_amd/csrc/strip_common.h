@@ -111,6 +111,24 @@ MDEV float gelu_stage2(const GeluStage& g) {
     return 0.5f * fmaf(-g.t, __builtin_amdgcn_exp2f(-q), s);
 }
 
+// hi / lo split of value E (0 .. 7) of a P entry, straight into the entry's packed words: H[E / 2], L[E / 2] get fp16(cs v) and
+// fp16(cs v - hi) in their low (E even) or high (E odd) half, the other half is preserved.  The arithmetic is the one hipcc emits
+// for `h = (_Float16)(cs * v); l = (_Float16)(cs * v - (float)h)` (v_fma_mix: the product is never rounded to fp32) - but written
+// through half8 element inserts it costs 3.5 instructions per value (even values go through a temporary and a v_bfi each), here 2.5.
+// Pinned where it stands (volatile): these ride in MFMA streams a few instructions at a time.
+template <int E>
+MDEV void split_put(unsigned (&H)[4], unsigned (&L)[4], const float cs, const float v) {
+    constexpr int d = E >> 1;
+    if constexpr ((E & 1) == 0) {
+        asm volatile("v_fma_mixlo_f16 %0, %2, %3, 0\n\tv_fma_mixlo_f16 %1, %2, %3, -%0 op_sel_hi:[0,0,1]" : "+v"(H[d]), "+v"(L[d]) : "v"(cs), "v"(v));
+    } else {
+        unsigned tmp;   // the high half written by v_fma_mixhi is not read back in the next instruction: its hi goes through a temporary
+        asm volatile("v_fma_mixlo_f16 %2, %3, %4, 0\n\tv_fma_mixhi_f16 %0, %3, %4, 0\n\tv_fma_mixhi_f16 %1, %3, %4, -%2 op_sel_hi:[0,0,1]"
+                     : "+v"(H[d]), "+v"(L[d]), "=&v"(tmp)
+                     : "v"(cs), "v"(v));
+    }
+}
+
 template <int ACT>
 MDEV float act_fn(float v) {
     if (ACT == ACT_GELU_FAST || ACT == ACT_GELU) { GeluStage g; gelu_stage0(g, v); gelu_stage1(g); return gelu_stage2(g); }

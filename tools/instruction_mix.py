@@ -14,7 +14,7 @@ from ace_amd import build  # noqa: E402
 
 HOT = {   # source -> substrings of the demangled kernel names to report
     "conv_ws.hip": ["conv_ws_kernel<12, 1, 0>", "conv_ws_kernel<12, 1, 2>", "conv_ws_kernel<12, 2, 4>", "conv_ws_kernel<12, 2, 5>"],
-    "conv_wl.hip": ["conv_wl_kernel<24, 3, 4>", "conv_wl_kernel<32, 2, 4>"],
+    "conv_wl.hip": ["conv_wl_kernel<24, 3, 4, true>", "conv_wl_kernel<32, 2, 4, false>"],
     "dhconv_strip.hip": ["dhconv_strip_kernel"],
     "strip_fold.hip": ["legendre_fold_kernel<0, true, 1>", "legendre_fold_kernel<1, true, 0>", "legendre_fold_big_kernel"],
     "fft.hip": ["dft_forward_fft_kernel<20, 18, 16, true, true>", "dft_inverse_fft_kernel<20, 18, 32, false>"],
