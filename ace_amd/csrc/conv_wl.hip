@@ -161,6 +161,9 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
     const _Float16* Xh = p.Xhi + (long)smp * p.sX;
     const _Float16* Xl = p.Xlo + (long)smp * p.sX;
     const int pbytes = p.M * p.HW * 2;
+    const int xbytes = p.C * (int)p.ldn * 2;     // one input plane: C / 8 k-groups x ldn entries of 16 bytes
+    const auto rsXh = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Xh), 0, xbytes, 0x00020000);
+    const auto rsXl = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Xl), 0, xbytes, 0x00020000);
     const auto rsH = __builtin_amdgcn_make_buffer_rsrc(p.Chi + (long)smp * p.sCp, 0, pbytes, 0x00020000);
     const auto rsL = __builtin_amdgcn_make_buffer_rsrc(p.Clo + (long)smp * p.sCp, 0, pbytes, 0x00020000);
     const char* aw = smem + lane * 16;
@@ -221,9 +224,10 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
         int n = 32 * tile + i;
         const bool nok = n < p.HW;
         n = nok ? n : p.HW - 1;
-        const _Float16* bh0 = Xh + ((long)g * p.ldn + n) * 8;     // k-group 2 j + g of k-step j: + 2 j ldn entries
-        const _Float16* bl0 = Xl + ((long)g * p.ldn + n) * 8;
-        const long kstep = (long)2 * p.ldn * 8;
+        // k-group 2 j + g of k-step j: lane part (g ldn + n) entries of 16 bytes, k-step part 2 j ldn entries - through buffer
+        // descriptors, the k-step as the SCALAR offset (as 64-bit lane addresses every load cost a v_lshl_add_u64: one per value)
+        const int bvo = (g * (int)p.ldn + n) * 16;
+        const int kstep = 2 * (int)p.ldn * 16;
         f32x16 acc[RT];
 #pragma unroll
         for (int t = 0; t < RT; ++t)
@@ -232,8 +236,8 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
         half8 bh[D], bl[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            bh[d] = *reinterpret_cast<const half8*>(bh0 + d * kstep);
-            bl[d] = *reinterpret_cast<const half8*>(bl0 + d * kstep);
+            bh[d] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsXh, bvo, d * kstep, 0));
+            bl[d] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsXl, bvo, d * kstep, 0));
         }
         // A fragments double-buffered by hand and scheduling barriers: left alone, hipcc hoists all the LDS reads of the
         // unrolled loop to the top (554 VGPRs spilled in the first version)
@@ -268,8 +272,8 @@ __global__ __launch_bounds__(64 * WL_WAVES) void conv_wl_kernel(ConvStripArgs p,
                 constexpr int t = decltype(tc)::value;
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][t], ch, acc[t], 0, 0, 0);
                 if constexpr (t == RT - 1 && j + D < KS && !(ACE_WL_ABL & 2)) {   // this k-step's B registers are free: the fragment of step j + D
-                    bh[j % D] = *reinterpret_cast<const half8*>(bh0 + (j + D) * kstep);
-                    bl[j % D] = *reinterpret_cast<const half8*>(bl0 + (j + D) * kstep);
+                    bh[j % D] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsXh, bvo, (j + D) * kstep, 0));
+                    bl[j % D] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsXl, bvo, (j + D) * kstep, 0));
                 }
                 slot(std::integral_constant<int, MPS * j + 2 * RT + t>{});
             });
