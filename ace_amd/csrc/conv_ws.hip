@@ -138,6 +138,8 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     const unsigned raw_r = p.rmax ? slot_load(p.rmax + lane) : 0u;
     const unsigned raw_p = (RPL && p.rslot) ? slot_load(p.rslot + lane) : 0u;
 
+    // scale of the residual planes (a power of two), undone in the residual's scale table (RPL) - exact
+    const float inv_r = RPL ? ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_p))) : 1.f;
     {   // epilogue parameters of this sample -> LDS
         const float* b = p.bias + (long)smp * p.sbias;
         const float* rsc = (AFFRES && p.rsc) ? p.rsc + (long)smp * p.srs : nullptr;
@@ -147,7 +149,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
             const int r = tid + 512 * k;
             if (r < p.M) {
                 Pb[r] = b[r] + (rsh ? rsh[r] : 0.f);
-                if (AFFRES) Ps[r] = rsc ? rsc[r] : 1.f;
+                if (AFFRES) Ps[r] = (rsc ? rsc[r] : 1.f) * inv_r;
             }
         }
     }
@@ -155,7 +157,6 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     const float inv_x = ldexpf(1.0f, -pow2_exponent_for(xbound));
     const float inv_a = p.aslot ? ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_a))) : 1.0f / p.ascale;
     const float s_acc = inv_x * inv_a;
-    const float inv_r = RPL ? ldexpf(1.0f, -pow2_exponent_for(wave_max_bits(raw_p))) : 1.f;   // scale of the residual planes, undone
     float cscale = 1.f;
     if (PK) {   // bound of this launch's output, identical in every workgroup; the consumer reads it from cslot
         const float inb = p.cinb ? wave_max_bits(raw_c) : xbound;
@@ -292,7 +293,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
             if (RES) {
                 if constexpr (RPL) {   // rows row0 + 8 g + e of this pixel = ONE P entry: (hi + lo) / scale
                     const half8 rh8 = __builtin_bit_cast(half8, rph), rl8 = __builtin_bit_cast(half8, rpl);
-                    val = fmaf(((float)rh8[e] + (float)rl8[e]) * inv_r, Ps[row], val);
+                    val = fmaf((float)rl8[e], Ps[row], fmaf((float)rh8[e], Ps[row], val));   // two v_fma_mix (the table carries 1 / scale)
                 } else {
                     val = AFFRES ? fmaf(resn[e], Ps[row], val) : val + res[e];   // light epilogues consume the fetched rows in place
                 }
