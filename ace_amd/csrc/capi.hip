@@ -1406,6 +1406,9 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     if (c.num_layers + 8 > 16) { /* block-input slots 8..15 are shared cyclically for deep nets */ }
     auto hslot = [&](int i) { return slot(8 + (i % 8)); };
 
+    // Residual stream as planes only (see the block loop): the condition is needed by the encoder already
+    const bool stream_ok = n->sw.planes_stream && f16 && !n->taps_on && n->plan_data == n->plan_lg.get() && C % 16 == 0 &&
+                           !n->plan_lg->sw.no_fft && dft_fft_has_width(n->W);
     // ---- encoder (sfnonet.py:721-733): [conv+bias, act] x encoder_layers, conv (no bias), + pos_embed
     const float* cur = in;
     long cur_bs = (long)Cin * HW;
@@ -1451,7 +1454,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
     // The last encoder convolution (C -> C, no bias, + pos_embed) on the weight-stationary strip kernel when block 0 takes the
     // packed path: its epilogue then writes h0 as fp32 AND as P-format planes with the row statistics of norm0, so block 0
     // starts like every other block (no pack pass, no statistics pass over h0).
-    bool enc_planes = false;
+    bool enc_planes = false, enc_planes_only = false;
     int enc_nparts = 0;          // statistics partials per row the last encoder convolution wrote
     {
         const Weight& we = *n->weights[n->index.at("encoder." + std::to_string(2 * c.encoder_layers) + ".weight")];
@@ -1470,7 +1473,14 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
             k.A = reinterpret_cast<const _Float16*>(we.frag0.p); k.sA = 0; k.ascale = we.ascale;
             k.bias = n->zero_c.p; k.sbias = 0;
             k.R = W("pos_embed"); k.sR = 0;
-            k.Cf = h; k.sCf = actB;
+            // fp32 copy of h0: only where something reads it - with the residual stream as planes (stream_ok below) block 0 takes its
+            // input from the planes everywhere (longitude FFT, inner skip, outer-skip residual) and the 100 MB write is dropped
+            // (block 0 is on the fused path here - block0_fused above - and its fc2 must be the conv_ws one, whose residual comes from the planes)
+            if (stream_ok && c.num_layers >= 1) {
+                const Weight& w2b0 = *n->weights[n->index.at("blocks.0.mlp.fwd.2.weight")];
+                enc_planes_only = w2b0.frag0.p && C <= 1024 && conv_ws_eligible(n->hid, C, HW, 2, n->sw.conv_ws_roles);
+            }
+            if (!enc_planes_only) { k.Cf = h; k.sCf = actB; }
             k.Chi = Hh; k.Clo = Hl; k.sCp = (long)C * HW; k.cslot = hslot(0);
             k.cw = we.winf; k.cb = 0.f; k.rmax = reinterpret_cast<const unsigned*>(n->pe_slot.p);
             k.C = C; k.M = C; k.HW = (int)HW; k.nbatch = B; k.act = ACT_NONE;
@@ -1565,9 +1575,7 @@ static int forward_impl(ace_sfno* n, const float* in, float* out, int B, hipStre
 
     // Residual stream as planes only: once a block's fc2 (conv_ws mode 4) has written h' as P-format planes, the next block reads
     // them everywhere - longitude FFT, inner skip, outer-skip residual - and no fp32 copy of h' exists (fc2: 520 -> 420 MB).
-    const bool stream_ok = n->sw.planes_stream && f16 && !n->taps_on && n->plan_data == n->plan_lg.get() && C % 16 == 0 &&
-                           !n->plan_lg->sw.no_fft && dft_fft_has_width(n->W);
-    bool h_planes_only = false;
+    bool h_planes_only = enc_planes && enc_planes_only;   // the encoder wrote h0 as planes only (implies stream_ok)
     // ---- blocks (sfnonet.py:217-252)
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string p = "blocks." + std::to_string(i) + ".";

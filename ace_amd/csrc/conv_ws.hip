@@ -69,7 +69,7 @@ template <int KSW, int NSTG, int MODE>
 struct WsGeom {
     static constexpr int KH = KSW * NSTG;          // k16-steps per wave: its half of the contraction
     static constexpr int SLOT = 2 * KSW * 2048;    // one stage of activation fragments, both halves
-    static constexpr bool F32 = MODE == 2 || MODE == 3 || MODE == 5 || MODE == 6 || MODE == 7, STATS = MODE == 0 || MODE == 2 || MODE == 4;
+    static constexpr bool F32 = MODE == 2 || MODE == 3 || MODE == 5 || MODE == 6 || MODE == 7, STATS = MODE == 0 || MODE == 2 || MODE == 4 || MODE == 8;
     static constexpr bool AFFRES = MODE >= 2;      // fc2 modes: residual with a per-row affine (scale table Ps, shift folded into Pb)
     static constexpr int BMAX = AFFRES ? 1024 : 2048; // output rows with LDS-resident epilogue parameters
     static constexpr int TAB = BMAX * 4 * (AFFRES ? 2 : 1);
@@ -87,6 +87,7 @@ struct WsGeom {
 //      3: fc2, last block (fp32 output, optional range maximum)
 //      4: as 2 with the residual read from P-format planes and NO fp32 output: the residual stream of the blocks exists as planes
 //         only (520 -> 420 MB of traffic per launch)                                 5: as 3 with the residual from planes
+//      8: as 2 without the fp32 output: the encoder's last convolution when block 0 reads its input as planes everywhere (round 6)
 //      6: as 3 with GELU: the inner skip of the noise-conditioned nets (fp32 residual, fp32 output for the conditional norm that
 //         follows; any K of this file - round 4 ran it on the packed tile engine at C = 512)
 //      7: measurement builds (-DACE_MEASUREMENT_SWITCHES): bias only, fp32 output - the inner skip's GEMM without its epilogue, for the
@@ -442,7 +443,7 @@ MDEV void conv_ws_body(const ConvStripArgs& p, char* smem, const WsPlan pl) {
     f32x16 v, v2;   // v2: second accumulator of the ACC2 form (the MFMA stream alternates v, v2, v, v2, ...)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { v[r] = 0.f; v2[r] = 0.f; }
-    constexpr int FDEPTH = (MODE == 2 && KH == 24) ? 0 : ((MODE == 4 && KH == 24) ? ACE_WS_FD4 : 1);   // fragment read-ahead; 0 where the registers are gone (K = 768 + planes + statistics)
+    constexpr int FDEPTH = (MODE == 2 && KH == 24) ? 0 : (((MODE == 4 || MODE == 8) && KH == 24) ? ACE_WS_FD4 : 1);   // fragment read-ahead; 0 where the registers are gone (K = 768 + planes + statistics)
     // Loop body = one stage followed by the wait + barrier that opens the next (stage 0 was opened by the prologue); an
     // asm-loaded register still in flight is never live across the back edge (hipcc believes the value is there and may copy it).
     constexpr int VSPAN = ACE_WS_VSPAN * KSW / 12 > 0 ? ACE_WS_VSPAN * KSW / 12 : 1;   // interleaved epilogue: the eight values over the first VSPAN k-steps, the stores right after
@@ -631,6 +632,7 @@ hipError_t launch_ws_k(const ConvStripArgs& a, int mode, hipStream_t s) {
         return hipErrorInvalidValue;
     }
     if (mode == 2) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 2>), grid, block, 0, s, a, pl);
+    if (mode == 8) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 8>), grid, block, 0, s, a, pl);
     if (mode == 3) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 3>), grid, block, 0, s, a, pl);
     if (mode == 4) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 4>), grid, block, 0, s, a, pl);
     if (mode == 5) hipLaunchKernelGGL((conv_ws_kernel<KSW, NSTG, 5>), grid, block, 0, s, a, pl);
@@ -696,6 +698,7 @@ hipError_t launch_conv_ws(const ConvStripArgs& a, hipStream_t s) {
     else if (gelu && res && f32 && !pk && !stats) mode = 6;
     else if (gelu && !res && pk && !stats && !f32) mode = 1;
     else if (a.act == ACT_NONE && res && f32 && pk && stats) mode = 2;
+    else if (a.act == ACT_NONE && res && !f32 && pk && stats) mode = 8;
     else if (a.act == ACT_NONE && res && f32 && !pk && !stats) mode = 3;
     else if (a.act == ACT_NONE && rpl && !f32 && pk && stats) mode = 4;
     else if (a.act == ACT_NONE && rpl && f32 && !pk && !stats) mode = 5;
