@@ -63,7 +63,8 @@ def stage_model(C=384, H=180, W=360, L=180, M=181, hid=768, cin=44, cout=50):
         # re-packing of the norm-folded fc1 weight for norm1); no pass over an activation (fp32 mode: one pass, 99.5 MB)
         "norm0_stats": (8 * tiles * C, tiles * C * 16 + 4 * C * 4),
         "norm1_stats": (8 * groups * C + 2 * hid * C, groups * C * 16 + 2 * hid * C * 4 + 4 * C * 4),
-        "encoder": (2 * (cin * C + C * C) * H * W, cin * H * W * 4 + 4 * act),
+        # (moved: input + hidden planes written and read + h0 as planes; the fp32 copy of h0 is no longer written - conv_ws mode 8)
+        "encoder": (2 * (cin * C + C * C) * H * W, cin * H * W * 4 + 4 * act, cin * H * W * 4 + 3 * act),
         "decoder": (2 * ((C + cin) * C + C * cout) * H * W, 3 * act + (cin + cout) * H * W * 4),
     }
     return {k: (v if len(v) == 3 else (v[0], v[1], v[1])) for k, v in f.items()}

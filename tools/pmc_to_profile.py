@@ -27,7 +27,7 @@ RULES = [  # (regex on kernel key, stage, reads are wide (x2 correction applies)
     (r"^gemm3_f16x3_kernel<2, 2, false, true, false>", "decoder", True),
     (r"^gemm3_f16x3_kernel<2, 2, false, false, false>", "decoder", True),        # round 4: the decoder's first convolution only (the encoder's runs on gemm4)
     (r"^gemm4_f16x3_kernel<2, 2, false, true>", "encoder(first convolution)", True),
-    (r"^conv_ws_kernel<12, 1, 2>", "encoder", True),                              # round 4: last encoder convolution (the first one: gemm4 <2,2>)
+    (r"^conv_ws_kernel<12, 1, [28]>", "encoder", True),                            # round 4: last encoder convolution (the first one: gemm4 <2,2>)
 ]
 out = {"_source": src, "_lib_sha256": sha, "_src_sha256": src_sha, "_note": "per-launch means over the dispatches of 2 eager forwards; separate rocprofv3 --pmc passes "
        "(FETCH_SIZE | WRITE_SIZE TCC_HIT TCC_MISS | SQ busy | SQ insts), never combined with API traces"}
